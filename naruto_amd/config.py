@@ -1,0 +1,108 @@
+"""Co-SLAM-level configuration for the mapping hot path.
+
+The hot path reads its hyper-parameters from a Co-SLAM yaml dict
+(reference: configs/Replica/replica_coslam.yaml, configs/Replica/office0/coslam.yaml, loaded by
+src/utils/config_utils.py:28-76 with ``inherit_from``).  ``load_config`` keeps that file format so an
+existing config tree can be pointed at unchanged; ``office0_config`` / ``mp3d_large_config`` /
+``unit_cube_config`` carry the shipped values for the benchmark workloads, because the reference's
+config files do not travel to the GPU box.
+"""
+
+from __future__ import annotations
+
+import copy
+import os
+from typing import Dict, Optional
+
+import yaml
+
+
+def update_recursive(dst: Dict, src: Dict) -> None:
+    for key, val in src.items():
+        if isinstance(val, dict):
+            node = dst.get(key)
+            if not isinstance(node, dict):
+                node = {}
+                dst[key] = node
+            update_recursive(node, val)
+        else:
+            dst[key] = val
+
+
+def load_config(path: str, default_path: Optional[str] = None, root: Optional[str] = None) -> Dict:
+    """yaml with ``inherit_from`` chains (same semantics as the reference loader).
+
+    ``inherit_from`` entries are resolved relative to ``root`` (default: the current directory, which
+    is how the reference resolves them -- it is always run from the repo root)."""
+    with open(path, "r") as fh:
+        special = yaml.full_load(fh) or {}
+    parent = special.get("inherit_from")
+    if parent is not None:
+        if root is not None and not os.path.isabs(parent):
+            parent = os.path.join(root, parent)
+        cfg = load_config(parent, default_path, root)
+    elif default_path is not None:
+        with open(default_path, "r") as fh:
+            cfg = yaml.full_load(fh) or {}
+    else:
+        cfg = {}
+    update_recursive(cfg, special)
+    return cfg
+
+
+_REPLICA_BASE = {
+    "dataset": "replica",
+    "data": {"downsample": 1, "sc_factor": 1, "translation": 0, "num_workers": 4},
+    "mapping": {
+        "sample": 2048, "first_mesh": True, "iters": 10, "lr_embed": 0.01, "lr_decoder": 0.01,
+        "lr_rot": 0.001, "lr_trans": 0.001, "keyframe_every": 5, "map_every": 5, "n_pixels": 0.05,
+        "first_iters": 200, "optim_cur": True, "min_pixels_cur": 100, "map_accum_step": 1,
+        "pose_accum_step": 5, "map_wait_step": 0, "filter_depth": True, "active_ray": False,
+    },
+    "grid": {"enc": "HashGrid", "tcnn_encoding": True, "hash_size": 16, "voxel_color": 0.08,
+             "voxel_sdf": 0.02, "oneGrid": True},
+    "pos": {"enc": "OneBlob", "n_bins": 16},
+    "decoder": {"geo_feat_dim": 15, "hidden_dim": 32, "num_layers": 2, "num_layers_color": 2,
+                "hidden_dim_color": 32, "tcnn_network": False, "pred_uncert": False, "uncert_grid": True},
+    "cam": {"H": 680, "W": 1200, "fx": 600.0, "fy": 600.0, "cx": 599.5, "cy": 339.5,
+            "png_depth_scale": 6553.5, "crop_edge": 0, "near": 0, "far": 5, "depth_trunc": 100.0},
+    "training": {
+        "rgb_weight": 5.0, "depth_weight": 0.1, "sdf_weight": 1000, "fs_weight": 10,
+        "uncert_weight": 0.005, "eikonal_weight": 0, "smooth_weight": 0.000001, "smooth_pts": 32,
+        "smooth_vox": 0.1, "smooth_margin": 0.05, "n_samples_d": 32, "range_d": 0.1, "n_range_d": 11,
+        "n_importance": 0, "perturb": 1, "white_bkgd": False, "trunc": 0.1, "rot_rep": "axis_angle",
+        "rgb_missing": 0.05,
+    },
+    "mesh": {"resolution": 512, "render_color": False, "vis": 500, "voxel_eval": 0.05, "voxel_final": 0.02},
+}
+
+
+def _with_bound(bound, **training_overrides) -> Dict:
+    cfg = copy.deepcopy(_REPLICA_BASE)
+    cfg["mapping"]["bound"] = [list(map(float, b)) for b in bound]
+    cfg["mapping"]["marching_cubes_bound"] = [list(map(float, b)) for b in bound]
+    cfg["training"].update(training_overrides)
+    return cfg
+
+
+def office0_config(**training_overrides) -> Dict:
+    """Replica office0 (configs/Replica/office0/coslam.yaml:3 over replica_coslam.yaml)."""
+    return _with_bound([[-2.2, 2.6], [-3.4, 2.1], [-1.4, 2.0]], **training_overrides)
+
+
+def mp3d_large_config(**training_overrides) -> Dict:
+    """Largest shipped MP3D volume (configs/MP3D/YmJkqBEsHnH/coslam.yaml:3); the MP3D base yaml
+    equals the Replica one on every hot-path key."""
+    cfg = _with_bound([[-16.2, 4.1], [-5.5, 1.3], [-0.5, 6.0]], **training_overrides)
+    cfg["dataset"] = "mp3d"
+    return cfg
+
+
+def unit_cube_config(desired_resolution: int = 1024, hash_size: int = 16, **training_overrides) -> Dict:
+    """Synthetic unit-cube volume for the HBM-stress configuration (BASELINE.json configs[4]).
+    ``voxel_sdf > 10`` is Co-SLAM's way to give the finest resolution directly."""
+    cfg = _with_bound([[0.0, 1.0], [0.0, 1.0], [0.0, 1.0]], **training_overrides)
+    cfg["grid"]["voxel_sdf"] = desired_resolution
+    cfg["grid"]["hash_size"] = hash_size
+    cfg["cam"]["far"] = 1.0
+    return cfg

@@ -1,0 +1,182 @@
+/*
+ * naruto_hip.h -- C ABI of libnaruto_hip.so: NARUTO's neural-implicit mapping / uncertainty hot path
+ * (Co-SLAM-derived joint hash grid + OneBlob + two tiny MLPs, SDF-weighted compositing, uncertainty
+ * aggregation, mapping losses) as hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * The reference has no FFI: its seam is the Python attribute surface of one nn.Module
+ * (reference src/slam/coslam/coslam.py:65).  Each entry point below names
+ * the reference code it replaces.  Conventions:
+ *   - every pointer is a DEVICE pointer to fp32 data unless it says "host";
+ *   - nothing here allocates, frees, synchronises or throws; work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the legacy default stream);
+ *   - return value 0 = ok, negative = error (naruto_last_error() gives the text);
+ *   - gradients are ACCUMULATED (+=) into the buffers of NarutoGrads, so the caller zeroes them
+ *     (this is what torch's .grad accumulation needs, reference coslam.py:368-399);
+ *   - a NarutoField handle is immutable after creation and may be shared by streams/threads.
+ */
+#ifndef NARUTO_HIP_H
+#define NARUTO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NARUTO_MAX_LEVELS 16
+#define NARUTO_OK 0
+#define NARUTO_ERR_INVALID (-22)      /* bad argument / unsupported configuration */
+#define NARUTO_ERR_LAUNCH (-5)        /* HIP launch failure */
+
+typedef struct NarutoField NarutoField;
+
+/* Static description of the scene representation (reference: JointEncodingNaruto.__init__,
+ * scene_rep.py:26-36; Co-SLAM get_encoder / tcnn HashGrid config; decoder.py:82-97). */
+typedef struct NarutoFieldDesc {
+    uint32_t n_levels;            /* tcnn n_levels; this build supports 16                      */
+    uint32_t n_features;          /* tcnn n_features_per_level; this build supports 2           */
+    uint32_t log2_hashmap_size;   /* config grid.hash_size                                      */
+    uint32_t base_resolution;     /* 16                                                         */
+    float    per_level_scale;     /* exp2(log2(desired_res / base_res) / (n_levels-1))           */
+    uint32_t n_bins;              /* OneBlob bins per input dim; this build supports 16          */
+    uint32_t hidden_dim;          /* SDF net hidden width; this build supports 32                */
+    uint32_t geo_feat_dim;        /* this build supports 15                                      */
+    uint32_t hidden_dim_color;    /* this build supports 32                                      */
+    uint32_t uncert_dims[3];      /* uncertainty voxel grid [Nx,Ny,Nz] (scene_rep.py:49-56)      */
+    float    bbox_min[3];         /* config mapping.bound[:,0]                                   */
+    float    bbox_max[3];         /* config mapping.bound[:,1]                                   */
+    float    trunc;               /* training.trunc                                              */
+    float    sc_factor;           /* data.sc_factor                                              */
+    int32_t  white_bkgd;          /* training.white_bkgd                                         */
+} NarutoFieldDesc;
+
+/* Learnable parameters, in the reference's own layouts (state_dict tensors):
+ *   table        embed_fn.params                         [n_entries * 2]
+ *   uncert_grid  uncert_grid                             [Nx, Ny, Nz]
+ *   sdf_w0       decoder.sdf_net.model.0.weight          [32, 80]  (in = 32 hash feats ++ 48 OneBlob)
+ *   sdf_w1       decoder.sdf_net.model.2.weight          [16, 32]  (out = sdf ++ 15 geo feats)
+ *   col_w0       decoder.color_net.model.0.weight        [32, 63]  (in = 48 OneBlob ++ 15 geo feats)
+ *   col_w1       decoder.color_net.model.2.weight        [3, 32]                                   */
+typedef struct NarutoParams {
+    const float* table;
+    const float* uncert_grid;
+    const float* sdf_w0;
+    const float* sdf_w1;
+    const float* col_w0;
+    const float* col_w1;
+} NarutoParams;
+
+typedef struct NarutoGrads {       /* same shapes; any pointer may be NULL = "not needed" */
+    float* table;
+    float* uncert_grid;
+    float* sdf_w0;
+    float* sdf_w1;
+    float* col_w0;
+    float* col_w1;
+} NarutoGrads;
+
+/* Where the M query points come from.  Either x != NULL: already-normalised points [M,3]
+ * (query_sdf / query_color_sdf, scene_rep.py:98-148), or rays: M = n_rays * n_samples points
+ * o + d * z, normalised by the bounding box (run_network [Co-SLAM], called at scene_rep.py:183-184). */
+typedef struct NarutoPoints {
+    const float* x;          /* [M,3] or NULL            */
+    const float* rays_o;     /* [n_rays,3]               */
+    const float* rays_d;     /* [n_rays,3]               */
+    const float* z_vals;     /* [n_rays,n_samples]       */
+    uint32_t     n_samples;
+} NarutoPoints;
+
+const char* naruto_last_error(void);
+int naruto_version(void);
+
+int  naruto_field_create(const NarutoFieldDesc* desc, NarutoField** out);
+void naruto_field_destroy(NarutoField* f);
+/* Level tables the library derived (tcnn GridEncodingTemplated constructor): host arrays of
+ * n_levels (scale, resolution, size) and n_levels+1 (offset, in entries). */
+int  naruto_field_levels(const NarutoField* f, float* scale, uint32_t* resolution, uint32_t* size, uint32_t* offset);
+uint64_t naruto_field_n_entries(const NarutoField* f);
+
+/* A1 -- depth sampling, scene_rep.py:158-180.  target_d may be NULL (then n_samples uniform depths,
+ * scene_rep.py:171-173); rand [n_rays,S] may be NULL (perturb == 0).  S = n_samples_d + n_range_d
+ * (or n_range_d if n_samples_d == 0, or n_samples if target_d == NULL).  z_vals [n_rays,S]. */
+int naruto_sample_z(uint32_t n_rays, const float* target_d, float near_, float far_, uint32_t n_samples_d,
+                    uint32_t n_range_d, float range_d, uint32_t n_samples, const float* rand,
+                    float* z_vals, void* stream);
+
+/* A3 alone -- embed_fn(x): query_sdf(embed=True), scene_rep.py:109-111.  feat [M,32] level-major. */
+int naruto_hash_encode_fwd(const NarutoField* f, uint32_t M, const float* x, const float* table,
+                           float* feat, void* stream);
+/* its backward (tcnn HashGrid backward): d_table += scatter(d_feat). */
+int naruto_hash_encode_bwd(const NarutoField* f, uint32_t M, const float* x, const float* d_feat,
+                           float* d_table, void* stream);
+
+/* A2-A5 fused -- calc_embedding + embedpos_fn + decoder (scene_rep.py:58-64,132-148, decoder.py:29-41,
+ * 99-116).  Outputs (any may be NULL):
+ *   raw        [M,5]  (r,g,b pre-sigmoid, sdf, uncert_raw)            -- query_color_sdf / run_network
+ *   sdf_uncert [M,2]  (sdf, uncert_raw); colour net skipped when raw==NULL -- query_sdf(return_uncert)
+ *   geo        [M,15]                                                  -- query_sdf(return_geo)
+ *   feat_save  [16,M,2] hash features kept for naruto_query_bwd (training only)                    */
+int naruto_query_fwd(const NarutoField* f, const NarutoParams* p, uint32_t M, const NarutoPoints* pts,
+                     float* raw, float* sdf_uncert, float* geo, float* feat_save, void* stream);
+
+/* Backward of naruto_query_fwd (autograd of the above through nn.Linear / tcnn / grid_sample).
+ * d_raw [M,5] required; d_geo [M,15] optional (NULL = 0).  feat_save from the forward call.
+ * workspace: naruto_query_bwd_workspace(M) bytes, contents undefined on entry and exit. */
+size_t naruto_query_bwd_workspace(const NarutoField* f, uint32_t M);
+int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, const NarutoPoints* pts,
+                     const float* feat_save, const float* d_raw, const float* d_geo,
+                     const NarutoGrads* g, void* workspace, void* stream);
+
+/* A6+A7 -- sdf2weights [Co-SLAM] + raw2outputs (scene_rep.py:66-96).  Outputs (any may be NULL):
+ * rgb [N,3], disp [N], acc [N], weights [N,S], depth [N], depth_var [N], uncert_map [N]. */
+int naruto_composite_fwd(const NarutoField* f, uint32_t n_rays, uint32_t S, const float* raw,
+                         const float* z_vals, float* rgb, float* disp, float* acc, float* weights,
+                         float* depth, float* depth_var, float* uncert_map, void* stream);
+/* Backward: cotangents of the outputs (any may be NULL = 0) -> d_raw [N,S,5].
+ * accumulate != 0 adds into d_raw instead of overwriting it. */
+int naruto_composite_bwd(const NarutoField* f, uint32_t n_rays, uint32_t S, const float* raw,
+                         const float* z_vals, const float* d_rgb, const float* d_disp, const float* d_acc,
+                         const float* d_weights, const float* d_depth, const float* d_depth_var,
+                         const float* d_uncert_map, float* d_raw, int accumulate, void* stream);
+
+/* A8 -- the mapping losses of JointEncodingNaruto.forward (scene_rep.py:246-285 + Co-SLAM
+ * get_sdf_loss/get_masks).  Three steps so that data-parallel ranks can all-reduce the sums in
+ * between (the loss weights depend on GLOBAL sample counts):
+ *   1. naruto_loss_sums     : this rank's rays -> sums[NARUTO_LOSS_NSUMS] (fp64, device)
+ *   2. (optional) all-reduce of sums over ranks: SUM for every slot except slot
+ *      NARUTO_LOSS_SLOT_MINUNCERT which is a MIN
+ *   3. naruto_loss_finalize : sums (+ total ray count over all ranks) -> losses[8] =
+ *      {rgb_loss, depth_loss, sdf_loss, fs_loss, psnr, uncert_loss, min(uncert_map), n_valid_depth}
+ * workspace: naruto_loss_workspace(n_rays) bytes. */
+#define NARUTO_LOSS_NSUMS 16
+#define NARUTO_LOSS_SLOT_MINUNCERT 9
+size_t naruto_loss_workspace(uint32_t n_rays);
+int naruto_loss_sums(const NarutoField* f, uint32_t n_rays, uint32_t S, const float* raw, const float* z_vals,
+                     const float* rgb, const float* depth, const float* uncert_map, const float* target_rgb,
+                     const float* target_d, float depth_trunc, float rgb_missing, double* sums,
+                     void* workspace, void* stream);
+int naruto_loss_finalize(const double* sums, uint64_t n_rays_total, uint32_t S, float* losses, void* stream);
+/* Backward of the whole loss block down to d_raw [N,S,5] (composite backward fused in):
+ * loss_grad [6] = d(total)/d{rgb_loss, depth_loss, sdf_loss, fs_loss, psnr(ignored), uncert_loss},
+ * device array (e.g. the weights of get_loss_from_ret, coslam.py:154-174). */
+int naruto_loss_bwd(const NarutoField* f, uint32_t n_rays, uint32_t S, const float* raw, const float* z_vals,
+                    const float* target_rgb, const float* target_d, float depth_trunc, float rgb_missing,
+                    const double* sums, uint64_t n_rays_total, const float* loss_grad, float* d_raw,
+                    void* stream);
+
+/* A10 helper -- one fused Adam step over a flat fp32 buffer (torch.optim.Adam semantics incl. L2
+ * weight_decay, reference coslam.py:409-419); step is the 1-based step count. */
+int naruto_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n,
+                     float lr, float beta1, float beta2, float eps, float weight_decay, uint32_t step,
+                     void* stream);
+
+/* Hardware self-checks used by the GPU tests: the MFMA / permlane layouts the kernels rely on.
+ * out: device buffer of 64*16 floats; returns 0 and fills out (see tests/test_gpu_intrinsics.py). */
+int naruto_debug_mfma_layout(const float* a, const float* b, float* out, void* stream);
+int naruto_debug_permlane_swap(const float* v0, const float* v1, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NARUTO_HIP_H */

@@ -1,0 +1,126 @@
+"""ctypes binding of libnaruto_hip.so (C ABI: include/naruto_hip.h).
+
+This is the ONLY compute backend of the package: if the shared library has not been built the import
+fails loudly -- there is no PyTorch / CPU fallback for the hot path.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List, Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnaruto_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ["naruto_api.hip", "naruto_field.hip", "naruto_render.hip", "naruto_common.h"]
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "naruto_hip.h")
+
+MAX_LEVELS = 16
+LOSS_NSUMS = 16
+LOSS_SLOT_MINUNCERT = 9
+
+
+class NarutoFieldDesc(C.Structure):
+    _fields_ = [
+        ("n_levels", C.c_uint32), ("n_features", C.c_uint32), ("log2_hashmap_size", C.c_uint32),
+        ("base_resolution", C.c_uint32), ("per_level_scale", C.c_float), ("n_bins", C.c_uint32),
+        ("hidden_dim", C.c_uint32), ("geo_feat_dim", C.c_uint32), ("hidden_dim_color", C.c_uint32),
+        ("uncert_dims", C.c_uint32 * 3), ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3),
+        ("trunc", C.c_float), ("sc_factor", C.c_float), ("white_bkgd", C.c_int32),
+    ]
+
+
+class NarutoParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("table", "uncert_grid", "sdf_w0", "sdf_w1", "col_w0", "col_w1")]
+
+
+class NarutoGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("table", "uncert_grid", "sdf_w0", "sdf_w1", "col_w0", "col_w1")]
+
+
+class NarutoPoints(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("rays_o", C.c_void_p), ("rays_d", C.c_void_p), ("z_vals", C.c_void_p),
+                ("n_samples", C.c_uint32)]
+
+
+def build_command(out: str = LIB_PATH) -> List[str]:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    return [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
+            os.path.join(CSRC, "naruto_api.hip"), "-o", out]
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [HEADER]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if force or needs_build():
+        cmd = build_command()
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_V, _U32, _U64, _F, _I = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_int
+
+# name -> (restype, argtypes); every symbol include/naruto_hip.h declares
+SIGNATURES = {
+    "naruto_last_error": (C.c_char_p, []),
+    "naruto_version": (_I, []),
+    "naruto_field_create": (_I, [C.POINTER(NarutoFieldDesc), C.POINTER(_V)]),
+    "naruto_field_destroy": (None, [_V]),
+    "naruto_field_levels": (_I, [_V, C.POINTER(_F), C.POINTER(_U32), C.POINTER(_U32), C.POINTER(_U32)]),
+    "naruto_field_n_entries": (_U64, [_V]),
+    "naruto_sample_z": (_I, [_U32, _V, _F, _F, _U32, _U32, _F, _U32, _V, _V, _V]),
+    "naruto_hash_encode_fwd": (_I, [_V, _U32, _V, _V, _V, _V]),
+    "naruto_hash_encode_bwd": (_I, [_V, _U32, _V, _V, _V, _V]),
+    "naruto_query_fwd": (_I, [_V, C.POINTER(NarutoParams), _U32, C.POINTER(NarutoPoints), _V, _V, _V, _V, _V]),
+    "naruto_query_bwd_workspace": (C.c_size_t, [_V, _U32]),
+    "naruto_query_bwd": (_I, [_V, C.POINTER(NarutoParams), _U32, C.POINTER(NarutoPoints), _V, _V, _V,
+                              C.POINTER(NarutoGrads), _V, _V]),
+    "naruto_composite_fwd": (_I, [_V, _U32, _U32, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V]),
+    "naruto_composite_bwd": (_I, [_V, _U32, _U32, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _I, _V]),
+    "naruto_loss_workspace": (C.c_size_t, [_U32]),
+    "naruto_loss_sums": (_I, [_V, _U32, _U32, _V, _V, _V, _V, _V, _V, _V, _F, _F, _V, _V, _V]),
+    "naruto_loss_finalize": (_I, [_V, _U64, _U32, _V, _V]),
+    "naruto_loss_bwd": (_I, [_V, _U32, _U32, _V, _V, _V, _V, _F, _F, _V, _U64, _V, _V, _V]),
+    "naruto_adam_step": (_I, [_V, _V, _V, _V, _U64, _F, _F, _F, _F, _F, _U32, _V]),
+    "naruto_debug_mfma_layout": (_I, [_V, _V, _V, _V]),
+    "naruto_debug_permlane_swap": (_I, [_V, _V, _V, _V]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). There is no fallback path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class NarutoError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().naruto_last_error().decode("utf-8", "replace")
+        raise NarutoError(f"{what or 'libnaruto_hip'} failed ({rc}): {msg}")

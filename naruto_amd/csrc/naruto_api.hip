@@ -1,0 +1,341 @@
+// extern "C" entry points of libnaruto_hip.so (see include/naruto_hip.h for the contract).
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "naruto_field.hip"
+#include "naruto_render.hip"
+
+using namespace naruto;
+
+struct NarutoField {
+    NarutoFieldDesc desc;
+    LevelTab lt;
+    UncertTab ut;
+    BoxTab bt;
+    uint32_t offset[NARUTO_MAX_LEVELS + 1];
+    uint64_t n_entries;
+    int n_cu;
+};
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(NARUTO_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return NARUTO_OK;
+}
+
+PointSrc make_points(const NarutoPoints* pts) {
+    PointSrc ps;
+    ps.x = pts->x;
+    ps.rays_o = pts->rays_o;
+    ps.rays_d = pts->rays_d;
+    ps.z_vals = pts->z_vals;
+    ps.S = pts->n_samples ? pts->n_samples : 1u;
+    return ps;
+}
+
+int check_points(const NarutoPoints* pts) {
+    if (pts == nullptr) return fail(NARUTO_ERR_INVALID, "points: NULL");
+    if (pts->x == nullptr && (pts->rays_o == nullptr || pts->rays_d == nullptr || pts->z_vals == nullptr || pts->n_samples == 0))
+        return fail(NARUTO_ERR_INVALID, "points: give x, or rays_o + rays_d + z_vals + n_samples");
+    return NARUTO_OK;
+}
+
+uint32_t cu_count(const NarutoField* f) { return f->n_cu > 0 ? (uint32_t)f->n_cu : 256u; }
+
+constexpr uint32_t kBwdMaxBlocks = 256;     // one 145 KB-LDS block per CU
+
+}  // namespace
+
+extern "C" {
+
+const char* naruto_last_error(void) { return g_err; }
+int naruto_version(void) { return 1; }
+
+int naruto_field_create(const NarutoFieldDesc* d, NarutoField** out) {
+    if (d == nullptr || out == nullptr) return fail(NARUTO_ERR_INVALID, "create: NULL argument");
+    if (d->n_levels != kLevels || d->n_features != 2)
+        return fail(NARUTO_ERR_INVALID, "create: this build supports n_levels=16, n_features=2 (got %u, %u)", d->n_levels, d->n_features);
+    if (d->n_bins != kBins || d->hidden_dim != kHidden || d->hidden_dim_color != kHidden || d->geo_feat_dim != kGeo)
+        return fail(NARUTO_ERR_INVALID, "create: this build supports n_bins=16, hidden_dim=32, hidden_dim_color=32, geo_feat_dim=15");
+    if (d->log2_hashmap_size < 4 || d->log2_hashmap_size > 28) return fail(NARUTO_ERR_INVALID, "create: log2_hashmap_size out of range");
+    if (d->uncert_dims[0] == 0 || d->uncert_dims[1] == 0 || d->uncert_dims[2] == 0) return fail(NARUTO_ERR_INVALID, "create: empty uncert grid");
+    if (!(d->trunc > 0.0f)) return fail(NARUTO_ERR_INVALID, "create: trunc must be > 0");
+    NarutoField* f = new (std::nothrow) NarutoField;
+    if (f == nullptr) return fail(NARUTO_ERR_INVALID, "create: out of memory");
+    f->desc = *d;
+    // tcnn GridEncodingTemplated constructor: per-level scale / resolution / size / offset
+    const float log2_pls = std::log2(d->per_level_scale);
+    uint64_t offset = 0;
+    f->lt.hashed = 0;
+    for (uint32_t l = 0; l < d->n_levels; ++l) {
+        const float scale = exp2f((float)l * log2_pls) * (float)d->base_resolution - 1.0f;
+        const uint32_t res = (uint32_t)ceilf(scale) + 1u;
+        const uint32_t max_params = 0xFFFFFFFFu / 2u;
+        const double dense = (double)res * (double)res * (double)res;
+        uint64_t params = powf((float)res, 3.0f) > (float)max_params ? (uint64_t)max_params : (uint64_t)dense;
+        params = (params + 7u) / 8u * 8u;
+        const uint64_t cap = 1ull << d->log2_hashmap_size;
+        if (params > cap) params = cap;
+        // grid_index(): the spatial hash is used iff the level's size is smaller than res^3
+        const bool hashed = (double)params < dense;
+        if (hashed) f->lt.hashed |= 1u << l;
+        f->lt.scale[l] = scale;
+        f->lt.res[l] = res;
+        f->lt.size[l] = (uint32_t)params;
+        f->lt.off[l] = (uint32_t)offset;
+        f->offset[l] = (uint32_t)offset;
+        offset += params;
+        if (offset > 0x7FFFFFFFull) { delete f; return fail(NARUTO_ERR_INVALID, "create: hash table too large for 32-bit entry offsets"); }
+    }
+    f->offset[d->n_levels] = (uint32_t)offset;
+    f->n_entries = offset;
+    f->ut.D = (int32_t)d->uncert_dims[0];
+    f->ut.H = (int32_t)d->uncert_dims[1];
+    f->ut.W = (int32_t)d->uncert_dims[2];
+    for (int i = 0; i < 3; ++i) {
+        f->bt.bmin[i] = d->bbox_min[i];
+        f->bt.bext[i] = d->bbox_max[i] - d->bbox_min[i];
+    }
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) f->n_cu = cus;
+    else { f->n_cu = 0; (void)hipGetLastError(); }
+    *out = f;
+    return NARUTO_OK;
+}
+
+void naruto_field_destroy(NarutoField* f) { delete f; }
+
+int naruto_field_levels(const NarutoField* f, float* scale, uint32_t* resolution, uint32_t* size, uint32_t* offset) {
+    if (f == nullptr) return fail(NARUTO_ERR_INVALID, "levels: NULL field");
+    for (uint32_t l = 0; l < f->desc.n_levels; ++l) {
+        if (scale) scale[l] = f->lt.scale[l];
+        if (resolution) resolution[l] = f->lt.res[l];
+        if (size) size[l] = f->lt.size[l];
+        if (offset) offset[l] = f->offset[l];
+    }
+    if (offset) offset[f->desc.n_levels] = f->offset[f->desc.n_levels];
+    return NARUTO_OK;
+}
+
+uint64_t naruto_field_n_entries(const NarutoField* f) { return f ? f->n_entries : 0; }
+
+int naruto_sample_z(uint32_t n_rays, const float* target_d, float near_, float far_, uint32_t n_samples_d, uint32_t n_range_d,
+                    float range_d, uint32_t n_samples, const float* rand, float* z_vals, void* stream) {
+    if (z_vals == nullptr) return fail(NARUTO_ERR_INVALID, "sample_z: NULL output");
+    if (n_rays == 0) return NARUTO_OK;
+    uint32_t nu, nr;
+    if (target_d != nullptr) { nu = n_samples_d; nr = n_range_d; }
+    else { nu = n_samples; nr = 0; }
+    const uint32_t S = nu + nr;
+    if (S < 2 || S > (uint32_t)kMaxSamples) return fail(NARUTO_ERR_INVALID, "sample_z: need 2 <= samples per ray <= %d (got %u)", kMaxSamples, S);
+    if (target_d != nullptr && nr < 2) return fail(NARUTO_ERR_INVALID, "sample_z: n_range_d must be >= 2");
+    if (target_d != nullptr && nu == 1) return fail(NARUTO_ERR_INVALID, "sample_z: n_samples_d must be 0 or >= 2");
+    hipLaunchKernelGGL(k_sample_z, dim3(n_rays), dim3(64), 0, (hipStream_t)stream, n_rays, target_d, near_, far_, nu, nr, range_d, rand, z_vals);
+    return check_launch("sample_z");
+}
+
+int naruto_hash_encode_fwd(const NarutoField* f, uint32_t M, const float* x, const float* table, float* feat, void* stream) {
+    if (f == nullptr || x == nullptr || table == nullptr || feat == nullptr) return fail(NARUTO_ERR_INVALID, "hash_encode_fwd: NULL argument");
+    if (M == 0) return NARUTO_OK;
+    hipLaunchKernelGGL(k_hash_encode_fwd, dim3((M + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, f->lt, x,
+                       reinterpret_cast<const float2*>(table), M, feat);
+    return check_launch("hash_encode_fwd");
+}
+
+int naruto_hash_encode_bwd(const NarutoField* f, uint32_t M, const float* x, const float* d_feat, float* d_table, void* stream) {
+    if (f == nullptr || x == nullptr || d_feat == nullptr || d_table == nullptr) return fail(NARUTO_ERR_INVALID, "hash_encode_bwd: NULL argument");
+    if (M == 0) return NARUTO_OK;
+    PointSrc ps{};
+    ps.x = x;
+    ps.S = 1;
+    hipLaunchKernelGGL(k_hash_scatter, dim3((M + 255u) / 256u, kLevels), dim3(256), 0, (hipStream_t)stream, f->lt, f->bt, ps, M, d_feat,
+                       (size_t)kFeat, (size_t)2, d_table);
+    return check_launch("hash_encode_bwd");
+}
+
+int naruto_query_fwd(const NarutoField* f, const NarutoParams* p, uint32_t M, const NarutoPoints* pts, float* raw, float* sdf_uncert,
+                     float* geo, float* feat_save, void* stream) {
+    if (f == nullptr || p == nullptr) return fail(NARUTO_ERR_INVALID, "query_fwd: NULL argument");
+    if (p->table == nullptr || p->uncert_grid == nullptr || p->sdf_w0 == nullptr || p->sdf_w1 == nullptr)
+        return fail(NARUTO_ERR_INVALID, "query_fwd: NULL parameter");
+    if (int rc = check_points(pts)) return rc;
+    if (M == 0) return NARUTO_OK;
+    const bool color = raw != nullptr;
+    if (color && (p->col_w0 == nullptr || p->col_w1 == nullptr)) return fail(NARUTO_ERR_INVALID, "query_fwd: colour net parameters missing");
+    if (!color && sdf_uncert == nullptr && geo == nullptr && feat_save == nullptr) return fail(NARUTO_ERR_INVALID, "query_fwd: no output requested");
+    NarutoParams pp = *p;
+    if (!color) { pp.col_w0 = p->sdf_w0; pp.col_w1 = p->sdf_w0; }       // staged but unused; keep the loads in bounds
+    const uint32_t n_tiles = (M + 63u) / 64u;
+    uint32_t blocks = (n_tiles + 3u) / 4u;
+    const uint32_t cap = cu_count(f) * 4u;
+    if (blocks > cap) blocks = cap;
+    const PointSrc ps = make_points(pts);
+    if (color)
+        hipLaunchKernelGGL(k_query_fwd<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, f->lt, f->ut, f->bt, pp, ps, M, raw, sdf_uncert, geo, feat_save);
+    else
+        hipLaunchKernelGGL(k_query_fwd<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, f->lt, f->ut, f->bt, pp, ps, M, raw, sdf_uncert, geo, feat_save);
+    return check_launch("query_fwd");
+}
+
+size_t naruto_query_bwd_workspace(const NarutoField* f, uint32_t M) {
+    (void)f;
+    return (size_t)kLevels * 2u * sizeof(float) * (size_t)M + (size_t)kBwdMaxBlocks * kAccFloats * sizeof(float);
+}
+
+int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, const NarutoPoints* pts, const float* feat_save,
+                     const float* d_raw, const float* d_geo, const NarutoGrads* g, void* workspace, void* stream) {
+    if (f == nullptr || p == nullptr || g == nullptr || feat_save == nullptr || d_raw == nullptr || workspace == nullptr)
+        return fail(NARUTO_ERR_INVALID, "query_bwd: NULL argument");
+    if (p->table == nullptr || p->uncert_grid == nullptr || p->sdf_w0 == nullptr || p->sdf_w1 == nullptr || p->col_w0 == nullptr || p->col_w1 == nullptr)
+        return fail(NARUTO_ERR_INVALID, "query_bwd: NULL parameter");
+    if (int rc = check_points(pts)) return rc;
+    if (M == 0) return NARUTO_OK;
+    float* d_feat = reinterpret_cast<float*>(workspace);
+    float* partials = d_feat + (size_t)kLevels * 2u * (size_t)M;
+    const uint32_t n_tiles = (M + 31u) / 32u;
+    uint32_t blocks = (n_tiles + 3u) / 4u;
+    uint32_t cap = cu_count(f);
+    if (cap > kBwdMaxBlocks) cap = kBwdMaxBlocks;
+    if (blocks > cap) blocks = cap;
+    const PointSrc ps = make_points(pts);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BwdLds)) != hipSuccess)
+            return fail(NARUTO_ERR_LAUNCH, "query_bwd: cannot reserve %zu bytes of LDS: %s", sizeof(BwdLds), hipGetErrorString(hipGetLastError()));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_query_bwd, dim3(blocks), dim3(256), sizeof(BwdLds), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, ps, M, feat_save, d_raw,
+                       d_geo, d_feat, g->uncert_grid, partials);
+    if (int rc = check_launch("query_bwd")) return rc;
+    if (g->sdf_w0 || g->sdf_w1 || g->col_w0 || g->col_w1) {
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((kAccFloats + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, blocks, *g);
+        if (int rc = check_launch("wgrad_reduce")) return rc;
+    }
+    if (g->table != nullptr) {
+        hipLaunchKernelGGL(k_hash_scatter, dim3((M + 255u) / 256u, kLevels), dim3(256), 0, (hipStream_t)stream, f->lt, f->bt, ps, M, d_feat, (size_t)2,
+                           (size_t)2 * (size_t)M, g->table);
+        if (int rc = check_launch("hash_scatter")) return rc;
+    }
+    return NARUTO_OK;
+}
+
+int naruto_composite_fwd(const NarutoField* f, uint32_t n_rays, uint32_t S, const float* raw, const float* z_vals, float* rgb, float* disp,
+                         float* acc, float* weights, float* depth, float* depth_var, float* uncert_map, void* stream) {
+    if (f == nullptr || raw == nullptr || z_vals == nullptr) return fail(NARUTO_ERR_INVALID, "composite_fwd: NULL argument");
+    if (S < 1 || S > (uint32_t)kMaxSamples) return fail(NARUTO_ERR_INVALID, "composite_fwd: samples per ray must be in [1, %d]", kMaxSamples);
+    if (n_rays == 0) return NARUTO_OK;
+    hipLaunchKernelGGL(k_composite_fwd, dim3((n_rays + kRaysPerBlock - 1) / kRaysPerBlock), dim3(64 * kRaysPerBlock), 0, (hipStream_t)stream, n_rays, S,
+                       f->desc.trunc, f->desc.sc_factor, f->desc.white_bkgd, raw, z_vals, rgb, disp, acc, weights, depth, depth_var, uncert_map);
+    return check_launch("composite_fwd");
+}
+
+int naruto_composite_bwd(const NarutoField* f, uint32_t n_rays, uint32_t S, const float* raw, const float* z_vals, const float* d_rgb,
+                         const float* d_disp, const float* d_acc, const float* d_weights, const float* d_depth, const float* d_depth_var,
+                         const float* d_uncert_map, float* d_raw, int accumulate, void* stream) {
+    if (f == nullptr || raw == nullptr || z_vals == nullptr || d_raw == nullptr) return fail(NARUTO_ERR_INVALID, "composite_bwd: NULL argument");
+    if (S < 1 || S > (uint32_t)kMaxSamples) return fail(NARUTO_ERR_INVALID, "composite_bwd: samples per ray must be in [1, %d]", kMaxSamples);
+    if (n_rays == 0) return NARUTO_OK;
+    CompositeCot cot{d_rgb, d_disp, d_acc, d_weights, d_depth, d_depth_var, d_uncert_map};
+    LossArgs la{};
+    hipLaunchKernelGGL(k_composite_bwd<false>, dim3((n_rays + kRaysPerBlock - 1) / kRaysPerBlock), dim3(64 * kRaysPerBlock), 0, (hipStream_t)stream,
+                       n_rays, S, f->desc.trunc, f->desc.sc_factor, f->desc.white_bkgd, raw, z_vals, cot, la, d_raw, accumulate);
+    return check_launch("composite_bwd");
+}
+
+size_t naruto_loss_workspace(uint32_t n_rays) { return (size_t)n_rays * 16u * sizeof(float); }
+
+int naruto_loss_sums(const NarutoField* f, uint32_t n_rays, uint32_t S, const float* raw, const float* z_vals, const float* rgb, const float* depth,
+                     const float* uncert_map, const float* target_rgb, const float* target_d, float depth_trunc, float rgb_missing, double* sums,
+                     void* workspace, void* stream) {
+    if (f == nullptr || raw == nullptr || z_vals == nullptr || rgb == nullptr || depth == nullptr || uncert_map == nullptr || target_rgb == nullptr ||
+        target_d == nullptr || sums == nullptr || workspace == nullptr)
+        return fail(NARUTO_ERR_INVALID, "loss_sums: NULL argument");
+    if (n_rays == 0) return fail(NARUTO_ERR_INVALID, "loss_sums: no rays");
+    float* terms = reinterpret_cast<float*>(workspace);
+    hipLaunchKernelGGL(k_loss_terms, dim3((n_rays + kRaysPerBlock - 1) / kRaysPerBlock), dim3(64 * kRaysPerBlock), 0, (hipStream_t)stream, n_rays, S,
+                       f->desc.trunc * f->desc.sc_factor, raw, z_vals, rgb, depth, uncert_map, target_rgb, target_d, depth_trunc, rgb_missing, terms);
+    if (int rc = check_launch("loss_terms")) return rc;
+    hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(256), 0, (hipStream_t)stream, terms, n_rays, sums);
+    return check_launch("loss_reduce");
+}
+
+int naruto_loss_finalize(const double* sums, uint64_t n_rays_total, uint32_t S, float* losses, void* stream) {
+    if (sums == nullptr || losses == nullptr || n_rays_total == 0 || S == 0) return fail(NARUTO_ERR_INVALID, "loss_finalize: bad argument");
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, n_rays_total, S, losses);
+    return check_launch("loss_finalize");
+}
+
+int naruto_loss_bwd(const NarutoField* f, uint32_t n_rays, uint32_t S, const float* raw, const float* z_vals, const float* target_rgb,
+                    const float* target_d, float depth_trunc, float rgb_missing, const double* sums, uint64_t n_rays_total, const float* loss_grad,
+                    float* d_raw, void* stream) {
+    if (f == nullptr || raw == nullptr || z_vals == nullptr || target_rgb == nullptr || target_d == nullptr || sums == nullptr || loss_grad == nullptr ||
+        d_raw == nullptr)
+        return fail(NARUTO_ERR_INVALID, "loss_bwd: NULL argument");
+    if (S < 1 || S > (uint32_t)kMaxSamples) return fail(NARUTO_ERR_INVALID, "loss_bwd: samples per ray must be in [1, %d]", kMaxSamples);
+    if (n_rays == 0) return NARUTO_OK;
+    CompositeCot cot{};
+    LossArgs la{target_rgb, target_d, sums, loss_grad, n_rays_total, depth_trunc, rgb_missing, f->desc.trunc * f->desc.sc_factor};
+    hipLaunchKernelGGL(k_composite_bwd<true>, dim3((n_rays + kRaysPerBlock - 1) / kRaysPerBlock), dim3(64 * kRaysPerBlock), 0, (hipStream_t)stream,
+                       n_rays, S, f->desc.trunc, f->desc.sc_factor, f->desc.white_bkgd, raw, z_vals, cot, la, d_raw, 0);
+    return check_launch("loss_bwd");
+}
+
+int naruto_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, uint32_t step, void* stream) {
+    if (param == nullptr || grad == nullptr || exp_avg == nullptr || exp_avg_sq == nullptr) return fail(NARUTO_ERR_INVALID, "adam_step: NULL argument");
+    if (n == 0) return NARUTO_OK;
+    if (step == 0) return fail(NARUTO_ERR_INVALID, "adam_step: step is 1-based");
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+    uint64_t blocks = (n + 255u) / 256u;
+    if (blocks > 2048u) blocks = 2048u;
+    hipLaunchKernelGGL(k_adam, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
+                       weight_decay, bc1, bc2_sqrt);
+    return check_launch("adam_step");
+}
+
+// ---- hardware layout probes (tests/test_gpu_intrinsics.py) ---------------------------------------
+__global__ void k_debug_mfma(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out) {
+    const int lane = threadIdx.x;
+    f32x16 c = zero16();
+    c = mfma32(a[lane], b[lane], c);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[lane * 16 + r] = c[r];
+}
+
+__global__ void k_debug_swap(const float* __restrict__ v0, const float* __restrict__ v1, float* __restrict__ out) {
+    const int lane = threadIdx.x;
+    float a = v0[lane], b = v1[lane];
+    swap32(a, b);
+    out[lane] = a;
+    out[64 + lane] = b;
+}
+
+int naruto_debug_mfma_layout(const float* a, const float* b, float* out, void* stream) {
+    if (a == nullptr || b == nullptr || out == nullptr) return fail(NARUTO_ERR_INVALID, "debug_mfma_layout: NULL argument");
+    hipLaunchKernelGGL(k_debug_mfma, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, out);
+    return check_launch("debug_mfma_layout");
+}
+
+int naruto_debug_permlane_swap(const float* v0, const float* v1, float* out, void* stream) {
+    if (v0 == nullptr || v1 == nullptr || out == nullptr) return fail(NARUTO_ERR_INVALID, "debug_permlane_swap: NULL argument");
+    hipLaunchKernelGGL(k_debug_swap, dim3(1), dim3(64), 0, (hipStream_t)stream, v0, v1, out);
+    return check_launch("debug_permlane_swap");
+}
+
+}  // extern "C"

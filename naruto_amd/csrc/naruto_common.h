@@ -1,0 +1,243 @@
+// Shared device helpers for the gfx950 kernels of libnaruto_hip.so.
+// Wave = 64 lanes everywhere; no other target is supported.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/naruto_hip.h"
+
+namespace naruto {
+
+constexpr int kLevels = 16;       // hash levels (L)
+constexpr int kFeat = 32;         // L * F
+constexpr int kBins = 16;         // OneBlob bins / dim
+constexpr int kPos = 48;          // 3 * kBins
+constexpr int kHidden = 32;       // both MLPs
+constexpr int kGeo = 15;
+constexpr int kOut = 16;          // sdf + geo
+constexpr int kInSdf = kFeat + kPos;   // 80
+constexpr int kInCol = kPos + kGeo;    // 63
+constexpr uint32_t kPrime1 = 2654435761u;
+constexpr uint32_t kPrime2 = 805459861u;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Per-level tables, passed to kernels by value (SGPR-resident).
+struct LevelTab {
+    float scale[kLevels];
+    uint32_t res[kLevels];
+    uint32_t off[kLevels];       // in entries (float2)
+    uint32_t size[kLevels];      // entries in the level
+    uint32_t hashed;             // bit l set: level l uses the spatial hash (size is 2^T)
+};
+
+struct UncertTab {
+    int32_t D, H, W;             // uncert_grid is [D=Nx][H=Ny][W=Nz]
+};
+
+struct BoxTab {
+    float bmin[3];
+    float bext[3];               // bmax - bmin (fp32 subtraction, as torch does)
+};
+
+struct PointSrc {
+    const float* x;
+    const float* rays_o;
+    const float* rays_d;
+    const float* z_vals;
+    uint32_t S;
+};
+
+// ---------------------------------------------------------------------------------------------
+// point m -> normalised coordinates.  rays: p = o + d*z (separately rounded mul and add, as the
+// reference's eager torch ops), then (p - bmin) / (bmax - bmin)   [Co-SLAM run_network].
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_point(const PointSrc& ps, const BoxTab& bt, uint32_t m, float& x, float& y, float& z) {
+    if (ps.x) {
+        x = ps.x[3 * (size_t)m + 0];
+        y = ps.x[3 * (size_t)m + 1];
+        z = ps.x[3 * (size_t)m + 2];
+    } else {
+        const uint32_t n = m / ps.S;
+        const float t = ps.z_vals[m];
+        const float px = __fadd_rn(ps.rays_o[3 * n + 0], __fmul_rn(ps.rays_d[3 * n + 0], t));
+        const float py = __fadd_rn(ps.rays_o[3 * n + 1], __fmul_rn(ps.rays_d[3 * n + 1], t));
+        const float pz = __fadd_rn(ps.rays_o[3 * n + 2], __fmul_rn(ps.rays_d[3 * n + 2], t));
+        x = __fdiv_rn(__fsub_rn(px, bt.bmin[0]), bt.bext[0]);
+        y = __fdiv_rn(__fsub_rn(py, bt.bmin[1]), bt.bext[1]);
+        z = __fdiv_rn(__fsub_rn(pz, bt.bmin[2]), bt.bext[2]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One hash-grid level: 8 corner indices + trilinear weights (tcnn kernel_grid / grid_index /
+// pos_fract, linear interpolation, coherent prime hash).  Weight order is tcnn's:
+// w = ((1 * wx') * wy') * wz', corners enumerated with bit0 = x, bit1 = y, bit2 = z.
+// ---------------------------------------------------------------------------------------------
+template <int T>
+__device__ __forceinline__ void hash_corners(const LevelTab& lt, float x, float y, float z, uint32_t (&idx)[8], float (&w)[8]) {
+    const float scale = lt.scale[T];
+    const uint32_t res = lt.res[T];
+    const uint32_t size = lt.size[T];
+    const float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
+    const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+    const uint32_t gx = (uint32_t)(int)fx, gy = (uint32_t)(int)fy, gz = (uint32_t)(int)fz;
+    const float wx = px - fx, wy = py - fy, wz = pz - fz;
+    const float ux = 1.0f - wx, uy = 1.0f - wy, uz = 1.0f - wz;
+    if ((lt.hashed >> T) & 1u) {
+        const uint32_t mask = size - 1u;
+        const uint32_t hy0 = gy * kPrime1, hy1 = hy0 + kPrime1;
+        const uint32_t hz0 = gz * kPrime2, hz1 = hz0 + kPrime2;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const uint32_t cx = gx + (uint32_t)(c & 1);
+            idx[c] = (cx ^ ((c & 2) ? hy1 : hy0) ^ ((c & 4) ? hz1 : hz0)) & mask;
+        }
+    } else {
+        const uint32_t r2 = res * res;
+        const uint32_t base = gx + gy * res + gz * r2;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            uint32_t i = base + (uint32_t)(c & 1) + ((c & 2) ? res : 0u) + ((c & 4) ? r2 : 0u);
+            if (i >= size) i %= size;     // only out-of-box / wrap-around corners take this path
+            idx[c] = i;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        w[c] = ((c & 1) ? wx : ux) * ((c & 2) ? wy : uy) * ((c & 4) ? wz : uz);
+    }
+}
+
+template <int T>
+__device__ __forceinline__ float2 hash_level(const LevelTab& lt, const float2* __restrict__ table, float x, float y, float z) {
+    uint32_t idx[8];
+    float w[8];
+    hash_corners<T>(lt, x, y, z, idx, w);
+    const float2* __restrict__ tl = table + lt.off[T];
+    float2 v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = tl[idx[c]];
+    float2 acc = make_float2(0.0f, 0.0f);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        acc.x = fmaf(w[c], v[c].x, acc.x);
+        acc.y = fmaf(w[c], v[c].y, acc.y);
+    }
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Uncertainty voxel grid: F.grid_sample(uncert_grid[None,None], (x*2-1)[None,None,None],
+// align_corners=False, zeros padding) -- reference scene_rep.py:61-62.  grid_sample's (x,y,z)
+// index (W,H,D) = (Nz,Ny,Nx): coordinate 0 walks the LAST axis (the reference's x<->z quirk).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void uncert_corners(const UncertTab& ut, float x, float y, float z, int32_t (&idx)[8], float (&w)[8]) {
+    const float gx = x * 2.0f - 1.0f, gy = y * 2.0f - 1.0f, gz = z * 2.0f - 1.0f;
+    const float ix = ((gx + 1.0f) * (float)ut.W - 1.0f) * 0.5f;
+    const float iy = ((gy + 1.0f) * (float)ut.H - 1.0f) * 0.5f;
+    const float iz = ((gz + 1.0f) * (float)ut.D - 1.0f) * 0.5f;
+    const float fx0 = floorf(ix), fy0 = floorf(iy), fz0 = floorf(iz);
+    const float fx = ix - fx0, fy = iy - fy0, fz = iz - fz0;
+    // clamp before the int conversion so that far-out-of-box points cannot overflow
+    const int x0 = (int)fminf(fmaxf(fx0, -2.0f), (float)ut.W + 1.0f);
+    const int y0 = (int)fminf(fmaxf(fy0, -2.0f), (float)ut.H + 1.0f);
+    const int z0 = (int)fminf(fmaxf(fz0, -2.0f), (float)ut.D + 1.0f);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int xi = x0 + (c & 1), yi = y0 + ((c >> 1) & 1), zi = z0 + ((c >> 2) & 1);
+        const bool ok = (xi >= 0) & (xi < ut.W) & (yi >= 0) & (yi < ut.H) & (zi >= 0) & (zi < ut.D);
+        idx[c] = ok ? ((zi * ut.H + yi) * ut.W + xi) : -1;
+        w[c] = ((c & 1) ? fx : 1.0f - fx) * ((c & 2) ? fy : 1.0f - fy) * ((c & 4) ? fz : 1.0f - fz);
+    }
+}
+
+__device__ __forceinline__ float uncert_sample(const UncertTab& ut, const float* __restrict__ grid, float x, float y, float z) {
+    int32_t idx[8];
+    float w[8];
+    uncert_corners(ut, x, y, z, idx, w);
+    float acc = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float v = idx[c] >= 0 ? grid[idx[c]] : 0.0f;
+        acc = fmaf(v, w[c], acc);
+    }
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// OneBlob (tcnn one_blob_subwarp_aligned + quartic_cdf, 16 bins): e[b] = cdf3(right_b) - cdf3(left_b),
+// cdf3(t) = C(t) + C(t-1) + C(t+1), C(v) = clamp(15/16 u (1 - 2/3 u^2 + 1/5 u^4) + 1/2, 0, 1), u = 16 v.
+// C saturates for |u| >= 1, so two of the three terms are exactly 0 or 1:
+//   cdf3(t) = C(t - r) + 1 + r,   r = clamp(rint(t), -1, 1).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float oneblob_cdf3(float t) {
+    const float r = fminf(fmaxf(rintf(t), -1.0f), 1.0f);
+    const float u = (t - r) * 16.0f;
+    const float u2 = u * u;
+    const float u4 = u2 * u2;
+    const float p = (15.0f / 16.0f) * u * (1.0f - (2.0f / 3.0f) * u2 + (1.0f / 5.0f) * u4) + 0.5f;
+    return fminf(fmaxf(p, 0.0f), 1.0f) + (1.0f + r);
+}
+
+__device__ __forceinline__ void oneblob16(float x, float (&e)[kBins]) {
+    float c[kBins];
+#pragma unroll
+    for (int b = 0; b < kBins; ++b) c[b] = oneblob_cdf3((float)b * (1.0f / 16.0f) - x);
+#pragma unroll
+    for (int b = 0; b < kBins - 1; ++b) e[b] = c[b + 1] - c[b];
+    e[kBins - 1] = (c[0] + 1.0f) - c[kBins - 1];
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA / cross-lane primitives (layouts verified on hardware by naruto_debug_* + tests).
+//   mfma32: D[i][j] += sum_k A[i][k] B[k][j], 32x32x2 fp32 (exact fp32 fma chain).
+//     A operand: lane l holds A[i = l&31][k = l>>5];  B operand: lane l holds B[k = l>>5][j = l&31];
+//     C/D: lane l, reg r holds D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
+//   swap32(a, b): lanes 32..63 of a <-> lanes 0..31 of b.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void swap32(float& a, float& b) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+
+// row index held by (reg r, half hh) of a 32x32 MFMA result
+__host__ __device__ constexpr int crow(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 v;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = 0.0f;
+    return v;
+}
+
+// wave-local LDS hand-off: LDS ops of one wave execute in order; this only stops the compiler
+// from moving LDS accesses across the point and drains outstanding LDS traffic.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+}  // namespace naruto

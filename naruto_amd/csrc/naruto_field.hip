@@ -1,0 +1,478 @@
+// Field kernels: hash-grid gather + OneBlob + the two tiny MLPs, forward and backward.
+//
+// Execution shape (gfx950).  The MLPs run on the matrix cores in the TRANSPOSED formulation
+//     Out^T[unit, point] = W[unit, in] . In^T[in, point]
+// with v_mfma_f32_32x32x2_f32 (exact fp32 fma chain): points sit on lanes (32 per MFMA tile), units on
+// accumulator registers split over the two half-waves.  The B operand wants lane (j, k) = (l&31, l>>5)
+// to hold input 2t+k of point j, and the C/D layout of one layer IS that B layout for the next layer
+// up to a fixed permutation of the K order -- which is free, because the weight (A) operands are staged
+// into LDS already permuted.  Activations therefore never leave registers on the forward / dgrad path.
+//
+//   forward : one wave = 64 points.  Every lane owns one point for the table gathers (8-byte gathers,
+//             128 per point); one v_permlane32_swap per hash level turns "(f0,f1) of my point" into the
+//             B operands of the two 32-point MFMA tiles (A = lanes 0..31, B = lanes 32..63).
+//   backward: one wave = 32 points (no gathers there: the hash features were saved by the forward as
+//             [16][M][2], so lane (j,k) loads component k of point j directly).  Weight gradients are
+//             dW = G^T . X with the POINT index as the MFMA K dimension; that needs [point][unit]
+//             operands, staged through a per-wave LDS tile.  dW tiles are summed into a per-block LDS
+//             image (ds_add_f32), written once per block to a partials buffer and reduced by
+//             k_wgrad_reduce in a fixed order.
+//
+// Reference behaviour replaced: JointEncodingNaruto.query_color_sdf / query_sdf / calc_embedding
+// (reference src/slam/coslam/model/scene_rep.py:58-64,98-148), SDFNetNaruto / ColorSDFNet_v2_Naruto
+// (src/slam/coslam/model/decoder.py:29-41,99-116), tcnn HashGrid + OneBlob, Co-SLAM ColorNet, and the
+// autograd of all of them.
+
+#include <type_traits>
+
+#include "naruto_common.h"
+
+namespace naruto {
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS images of the weights in MFMA A-operand order: entry [t][lane] is what lane
+// (i = lane&31, k = lane>>5) feeds to the t-th MFMA of that layer.
+// ------------------------------------------------------------------------------------------------
+struct FwdLds {
+    float s0[40 * 64];     // sdf layer 0: t<16 hash-feature pairs (2t,2t+1); t>=16 OneBlob pairs
+    float c0p[24 * 64];    // colour layer 0, OneBlob part
+    float s1[16 * 64];     // sdf layer 1: K pair t = hidden units crow(t,0), crow(t,1)
+    float c0g[8 * 64];     // colour layer 0, geo part: K pair r = sdf-net outputs crow(r,0), crow(r,1)
+    float c1[3 * 16 * 2];  // colour layer 1 (VALU): [c][r][hh] = col_w1[c][crow(r,hh)]
+};
+
+__device__ __forceinline__ void stage_fwd_weights(FwdLds& L, const NarutoParams& p, int tid, int nthreads) {
+    for (int e = tid; e < 40 * 64; e += nthreads) {
+        const int t = e >> 6, l = e & 63, i = l & 31, kk = l >> 5;
+        const int col = t < 16 ? 2 * t + kk : kFeat + 2 * (t - 16) + kk;
+        L.s0[e] = p.sdf_w0[i * kInSdf + col];
+    }
+    for (int e = tid; e < 24 * 64; e += nthreads) {
+        const int t = e >> 6, l = e & 63, i = l & 31, kk = l >> 5;
+        L.c0p[e] = p.col_w0[i * kInCol + 2 * t + kk];
+    }
+    for (int e = tid; e < 16 * 64; e += nthreads) {
+        const int t = e >> 6, l = e & 63, i = l & 31, kk = l >> 5;
+        L.s1[e] = i < kOut ? p.sdf_w1[i * kHidden + crow(t, kk)] : 0.0f;
+    }
+    for (int e = tid; e < 8 * 64; e += nthreads) {
+        const int r = e >> 6, l = e & 63, i = l & 31, kk = l >> 5;
+        const int row = crow(r, kk);                      // sdf-net output row 0..15; row 0 is the sdf
+        L.c0g[e] = row >= 1 ? p.col_w0[i * kInCol + kPos + row - 1] : 0.0f;
+    }
+    for (int e = tid; e < 3 * 16 * 2; e += nthreads) {
+        const int c = e / 32, r = (e >> 1) & 15, hh = e & 1;
+        L.c1[e] = p.col_w1[c * kHidden + crow(r, hh)];
+    }
+}
+
+template <bool COLOR>
+__global__ __launch_bounds__(256) void k_query_fwd(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps,
+                                                   uint32_t M, float* __restrict__ raw, float* __restrict__ sdf_uncert,
+                                                   float* __restrict__ geo, float* __restrict__ feat_save) {
+    __shared__ FwdLds L;
+    stage_fwd_weights(L, p, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hh = lane >> 5, j = lane & 31;
+    const uint32_t n_tiles = (M + 63u) / 64u;
+    const float2* __restrict__ table = reinterpret_cast<const float2*>(p.table);
+    float2* __restrict__ feat_out = reinterpret_cast<float2*>(feat_save);
+    for (uint32_t tile = blockIdx.x * 4u + wave; tile < n_tiles; tile += gridDim.x * 4u) {
+        const uint32_t m_raw = tile * 64u + lane;
+        const bool valid = m_raw < M;
+        const uint32_t m = valid ? m_raw : M - 1u;       // padding lanes redo the last point, stores masked
+        float x, y, z;
+        load_point(ps, bt, m, x, y, z);
+        const float u = uncert_sample(ut, p.uncert_grid, x, y, z);
+
+        f32x16 hA = zero16(), hB = zero16(), cA = zero16(), cB = zero16();
+        static_for<0, kLevels>([&](auto tc) {
+            constexpr int T = decltype(tc)::value;
+            const float2 f = hash_level<T>(lt, table, x, y, z);
+            if (feat_out != nullptr && valid) feat_out[(size_t)T * M + m] = f;
+            const float a = L.s0[T * 64 + lane];
+            float b0 = f.x, b1 = f.y;
+            swap32(b0, b1);                      // b0: tile A operand, b1: tile B operand
+            hA = mfma32(a, b0, hA);
+            hB = mfma32(a, b1, hB);
+        });
+        static_for<0, 3>([&](auto dc) {
+            constexpr int D = decltype(dc)::value;
+            float e[kBins];
+            oneblob16(D == 0 ? x : (D == 1 ? y : z), e);
+            static_for<0, 8>([&](auto qc) {
+                constexpr int Q = decltype(qc)::value;
+                constexpr int P = D * 8 + Q;
+                float b0 = e[2 * Q], b1 = e[2 * Q + 1];
+                swap32(b0, b1);
+                const float as = L.s0[(16 + P) * 64 + lane];
+                hA = mfma32(as, b0, hA);
+                hB = mfma32(as, b1, hB);
+                if constexpr (COLOR) {
+                    const float ac = L.c0p[P * 64 + lane];
+                    cA = mfma32(ac, b0, cA);
+                    cB = mfma32(ac, b1, cB);
+                }
+            });
+        });
+        // sdf layer 1 on relu(h): K pair t = (reg t of the low half, reg t of the high half)
+        f32x16 oA = zero16(), oB = zero16();
+        static_for<0, 16>([&](auto tc) {
+            constexpr int T = decltype(tc)::value;
+            const float a = L.s1[T * 64 + lane];
+            oA = mfma32(a, fmaxf(hA[T], 0.0f), oA);
+            oB = mfma32(a, fmaxf(hB[T], 0.0f), oB);
+        });
+        // this lane's own sdf: output row 0 lives in reg 0 of the low half of each tile
+        float sdf = oA[0], sdf_b = oB[0];
+        swap32(sdf, sdf_b);
+        if (geo != nullptr) {
+            const uint32_t mA = tile * 64u + j, mB = mA + 32u;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int row = crow(r, hh);
+                if (row >= 1) {
+                    if (mA < M) geo[(size_t)mA * kGeo + row - 1] = oA[r];
+                    if (mB < M) geo[(size_t)mB * kGeo + row - 1] = oB[r];
+                }
+            }
+        }
+        if (sdf_uncert != nullptr && valid) reinterpret_cast<float2*>(sdf_uncert)[m] = make_float2(sdf, u);
+        if constexpr (COLOR) {
+            static_for<0, 8>([&](auto rc) {
+                constexpr int R = decltype(rc)::value;
+                const float a = L.c0g[R * 64 + lane];
+                cA = mfma32(a, oA[R], cA);
+                cB = mfma32(a, oB[R], cB);
+            });
+            float rgb[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float pa = 0.0f, pb = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float w = L.c1[(c * 16 + r) * 2 + hh];
+                    pa = fmaf(w, fmaxf(cA[r], 0.0f), pa);
+                    pb = fmaf(w, fmaxf(cB[r], 0.0f), pb);
+                }
+                swap32(pa, pb);                  // lanes<32: (A lo, A hi); lanes>=32: (B lo, B hi)
+                rgb[c] = pa + pb;
+            }
+            if (raw != nullptr && valid) {
+                float* o = raw + (size_t)m * 5;
+                o[0] = rgb[0]; o[1] = rgb[1]; o[2] = rgb[2]; o[3] = sdf; o[4] = u;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stand-alone hash encode (query_sdf(embed=True), Co-SLAM smoothness()) and the table scatter.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hash_encode_fwd(LevelTab lt, const float* __restrict__ x, const float2* __restrict__ table,
+                                                         uint32_t M, float* __restrict__ feat) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const float px = x[3 * (size_t)m], py = x[3 * (size_t)m + 1], pz = x[3 * (size_t)m + 2];
+    float2* out = reinterpret_cast<float2*>(feat + (size_t)m * kFeat);
+    static_for<0, kLevels>([&](auto tc) {
+        constexpr int T = decltype(tc)::value;
+        out[T] = hash_level<T>(lt, table, px, py, pz);
+    });
+}
+
+template <int T>
+__device__ __forceinline__ void scatter_level(const LevelTab& lt, float x, float y, float z, float2 g, float* __restrict__ d_table) {
+    uint32_t idx[8];
+    float w[8];
+    hash_corners<T>(lt, x, y, z, idx, w);
+    float* tl = d_table + 2 * (size_t)lt.off[T];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        unsafeAtomicAdd(tl + 2 * (size_t)idx[c], w[c] * g.x);          // global_atomic_add_f32
+        unsafeAtomicAdd(tl + 2 * (size_t)idx[c] + 1, w[c] * g.y);
+    }
+}
+
+// One thread per (point, level); blockIdx.y = level, so the atomics of concurrently running blocks
+// stay within one or two levels' slices of the table (<= 512 KB each: L2-resident).  d_feat is
+// addressed through (stride_m, stride_l) so that both [M,32] row-major (autograd of hash_encode) and
+// the [16][M][2] layout written by k_query_bwd can be consumed.
+__global__ __launch_bounds__(256) void k_hash_scatter(LevelTab lt, BoxTab bt, PointSrc ps, uint32_t M, const float* __restrict__ d_feat,
+                                                      size_t stride_m, size_t stride_l, float* __restrict__ d_table) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float x, y, z;
+    load_point(ps, bt, m, x, y, z);
+    const int level = blockIdx.y;
+    const float2 g = *reinterpret_cast<const float2*>(d_feat + (size_t)m * stride_m + (size_t)level * stride_l);
+    if (g.x == 0.0f && g.y == 0.0f) return;
+    switch (level) {
+#define NARUTO_CASE(T) case T: scatter_level<T>(lt, x, y, z, g, d_table); break;
+        NARUTO_CASE(0) NARUTO_CASE(1) NARUTO_CASE(2) NARUTO_CASE(3) NARUTO_CASE(4) NARUTO_CASE(5) NARUTO_CASE(6) NARUTO_CASE(7)
+        NARUTO_CASE(8) NARUTO_CASE(9) NARUTO_CASE(10) NARUTO_CASE(11) NARUTO_CASE(12) NARUTO_CASE(13) NARUTO_CASE(14) NARUTO_CASE(15)
+#undef NARUTO_CASE
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of k_query_fwd<true>.
+// ------------------------------------------------------------------------------------------------
+constexpr int kStageLd = 97;   // row stride (floats) of the per-wave [32][96] input stage: odd => conflict-free
+constexpr int kGradLd = 33;    // row stride of the per-wave [32][32] stages
+// per-block dW image, 32x32 tiles (row = output unit of the layer, col = input column):
+//   0..2 dW(sdf_w0): stage cols 0..31 | 32..63 | 64..95   (80 real columns, 80..95 discarded)
+//   3    dW(sdf_w1): rows < 16 valid
+//   4..5 dW(col_w0): stage cols 32..63 (OneBlob 0..31) | 64..95 (OneBlob 32..47 ++ sdf-net outputs 0..15)
+//   6    dW(col_w1): rows < 3 valid
+constexpr int kAccTiles = 7;
+constexpr int kAccFloats = kAccTiles * 1024;
+
+struct BwdLds {
+    FwdLds f;
+    float s0T[16 * 64];   // dgrad sdf0 -> feats:   A[i=feat][K pair t]       = sdf_w0[crow(t,k)][i]
+    float s1T[8 * 64];    // dgrad sdf1 -> hidden:  A[i=hidden][K pair r]     = sdf_w1[crow(r,k)][i]
+    float c0gT[16 * 64];  // dgrad col0 -> sdf-net outputs: A[i=out row][K pair t] = col_w0[crow(t,k)][48+i-1]
+    float acc[kAccFloats];
+    float xs[4][32 * kStageLd];   // per wave: layer inputs  [point][feat32 | oneblob48 | sdf-net out16]
+    float ga[4][32 * kGradLd];    // per wave: "G" operand stage [point][32]
+    float gb[4][32 * kGradLd];    // per wave: activation stage  [point][32]
+};
+
+__device__ __forceinline__ void stage_bwd_weights(BwdLds& L, const NarutoParams& p, int tid, int nthreads) {
+    stage_fwd_weights(L.f, p, tid, nthreads);
+    for (int e = tid; e < 16 * 64; e += nthreads) {
+        const int t = e >> 6, l = e & 63, i = l & 31, kk = l >> 5;
+        L.s0T[e] = p.sdf_w0[crow(t, kk) * kInSdf + i];
+    }
+    for (int e = tid; e < 8 * 64; e += nthreads) {
+        const int r = e >> 6, l = e & 63, i = l & 31, kk = l >> 5;
+        L.s1T[e] = p.sdf_w1[crow(r, kk) * kHidden + i];        // crow(r,kk) in 0..15 for r<8
+    }
+    for (int e = tid; e < 16 * 64; e += nthreads) {
+        const int t = e >> 6, l = e & 63, i = l & 31, kk = l >> 5;
+        L.c0gT[e] = (i >= 1 && i < kOut) ? p.col_w0[crow(t, kk) * kInCol + kPos + i - 1] : 0.0f;
+    }
+    for (int e = tid; e < kAccFloats; e += nthreads) L.acc[e] = 0.0f;
+}
+
+// C-layout tile (units on regs/halves, points on lanes) -> [point][unit] stage
+__device__ __forceinline__ void stage_ctile(float* __restrict__ buf, int ld, int col0, const f32x16& t, int j, int hh) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) buf[j * ld + col0 + crow(r, hh)] = t[r];
+}
+
+// one 32x32 dW tile over this wave's 32 points: D[i][c] = sum_pt G[pt][i] * X[pt][c0 + c]
+__device__ __forceinline__ void wgrad_tile(const float* __restrict__ gbuf, int gld, const float* __restrict__ xbuf, int xld, int c0,
+                                           float* __restrict__ acc_tile, int lane) {
+    const int i = lane & 31, kk = lane >> 5;
+    f32x16 d = zero16();
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int pt = 2 * t + kk;
+        d = mfma32(gbuf[pt * gld + i], xbuf[pt * xld + c0 + i], d);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) unsafeAtomicAdd(&acc_tile[crow(r, kk) * 32 + i], d[r]);     // ds_add_f32
+}
+
+__global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps, uint32_t M,
+                                                   const float* __restrict__ feat_save, const float* __restrict__ d_raw,
+                                                   const float* __restrict__ d_geo, float* __restrict__ d_feat,
+                                                   float* __restrict__ d_uncert_grid, float* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    BwdLds& L = *reinterpret_cast<BwdLds*>(smem_raw);
+    stage_bwd_weights(L, p, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hh = lane >> 5, j = lane & 31;
+    const uint32_t n_tiles = (M + 31u) / 32u;
+    float* __restrict__ xs = L.xs[wave];
+    float* __restrict__ ga = L.ga[wave];
+    float* __restrict__ gb = L.gb[wave];
+    for (uint32_t tile = blockIdx.x * 4u + wave; tile < n_tiles; tile += gridDim.x * 4u) {
+        // lanes j and j+32 both work on point tile*32 + j; hh selects the K-pair component
+        const uint32_t m_raw = tile * 32u + j;
+        const bool valid = m_raw < M;
+        const uint32_t m = valid ? m_raw : M - 1u;
+        float x, y, z;
+        load_point(ps, bt, m, x, y, z);
+        float g_rgb[3], g_sdf, g_unc;
+        {
+            const float* g = d_raw + (size_t)m * 5;     // padding lanes: zero cotangent => zero contribution
+            g_rgb[0] = valid ? g[0] : 0.0f; g_rgb[1] = valid ? g[1] : 0.0f; g_rgb[2] = valid ? g[2] : 0.0f;
+            g_sdf = valid ? g[3] : 0.0f;
+            g_unc = valid ? g[4] : 0.0f;
+        }
+        // uncertainty grid: raw[...,4] is the trilinear sample itself (the decoder passes it through)
+        if (d_uncert_grid != nullptr && hh == 0 && g_unc != 0.0f) {
+            int32_t ui[8];
+            float uw[8];
+            uncert_corners(ut, x, y, z, ui, uw);
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (ui[c] >= 0) unsafeAtomicAdd(d_uncert_grid + ui[c], uw[c] * g_unc);
+        }
+        // ---- recompute the forward from the saved hash features; stage layer-0 inputs [point][0..79]
+        f32x16 h = zero16(), c = zero16();
+        static_for<0, kLevels>([&](auto tc) {
+            constexpr int T = decltype(tc)::value;
+            const float b = feat_save[((size_t)T * M + m) * 2 + hh];
+            xs[j * kStageLd + 2 * T + hh] = valid ? b : 0.0f;
+            h = mfma32(L.f.s0[T * 64 + lane], b, h);
+        });
+        static_for<0, 3>([&](auto dc) {
+            constexpr int D = decltype(dc)::value;
+            float e[kBins];
+            oneblob16(D == 0 ? x : (D == 1 ? y : z), e);
+            static_for<0, 8>([&](auto qc) {
+                constexpr int Q = decltype(qc)::value;
+                constexpr int P = D * 8 + Q;
+                const float b = hh ? e[2 * Q + 1] : e[2 * Q];
+                xs[j * kStageLd + kFeat + 2 * P + hh] = valid ? b : 0.0f;
+                h = mfma32(L.f.s0[(16 + P) * 64 + lane], b, h);
+                c = mfma32(L.f.c0p[P * 64 + lane], b, c);
+            });
+        });
+        f32x16 o = zero16();
+        static_for<0, 16>([&](auto tc) {
+            constexpr int T = decltype(tc)::value;
+            o = mfma32(L.f.s1[T * 64 + lane], fmaxf(h[T], 0.0f), o);
+        });
+        static_for<0, 8>([&](auto rc) {
+            constexpr int R = decltype(rc)::value;
+            c = mfma32(L.f.c0g[R * 64 + lane], o[R], c);
+        });
+        // sdf-net outputs -> stage columns 80..95 (colour layer-0 inputs); padding points -> 0
+#pragma unroll
+        for (int r = 0; r < 8; ++r) xs[j * kStageLd + 80 + crow(r, hh)] = valid ? o[r] : 0.0f;
+
+        // ---- colour layer 1 backward (VALU): d_c = relu'(c) * (col_w1^T . d_rgb)
+        f32x16 dcv, cact;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) a = fmaf(L.f.c1[(q * 16 + r) * 2 + hh], g_rgb[q], a);
+            dcv[r] = c[r] > 0.0f ? a : 0.0f;
+            cact[r] = fmaxf(c[r], 0.0f);
+        }
+        // ---- dW(col_w1)[q][i] = sum_pt d_rgb[q] * relu(c)[i]   (tile 6; G rows q<3 read from d_raw)
+        stage_ctile(gb, kGradLd, 0, cact, j, hh);
+        wave_lds_sync();
+        {
+            const int i = lane & 31;
+            f32x16 d = zero16();
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const uint32_t pt = tile * 32u + 2 * t + hh;
+                const float gv = (i < 3 && pt < M) ? d_raw[(size_t)pt * 5 + i] : 0.0f;
+                d = mfma32(gv, gb[(2 * t + hh) * kGradLd + i], d);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) unsafeAtomicAdd(&L.acc[6 * 1024 + crow(r, hh) * 32 + i], d[r]);
+        }
+        // ---- dW(col_w0) = d_c^T . [OneBlob48 | out16]   (tiles 4, 5)
+        stage_ctile(ga, kGradLd, 0, dcv, j, hh);
+        wave_lds_sync();
+        wgrad_tile(ga, kGradLd, xs, kStageLd, 32, &L.acc[4 * 1024], lane);
+        wgrad_tile(ga, kGradLd, xs, kStageLd, 64, &L.acc[5 * 1024], lane);
+        // ---- dgrad colour layer 0 -> sdf-net outputs (rows 1..15 = geo features)
+        f32x16 dov = zero16();
+        static_for<0, 16>([&](auto tc) {
+            constexpr int T = decltype(tc)::value;
+            dov = mfma32(L.c0gT[T * 64 + lane], dcv[T], dov);
+        });
+        if (d_geo != nullptr && valid) {          // external cotangent of geo (query_sdf(return_geo=True))
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int row = crow(r, hh);
+                if (row >= 1) dov[r] += d_geo[(size_t)m * kGeo + row - 1];
+            }
+        }
+        if (hh == 0) dov[0] += g_sdf;             // row 0 is the sdf: its direct cotangent
+        // ---- dW(sdf_w1)[o][i] = sum_pt d_out[o] * relu(h)[i]   (tile 3; rows >= 16 of d_out are exact zeros)
+        {
+            f32x16 hact;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hact[r] = fmaxf(h[r], 0.0f);
+            wave_lds_sync();
+            stage_ctile(gb, kGradLd, 0, hact, j, hh);
+            stage_ctile(ga, kGradLd, 0, dov, j, hh);
+            wave_lds_sync();
+            wgrad_tile(ga, kGradLd, gb, kGradLd, 0, &L.acc[3 * 1024], lane);
+        }
+        // ---- dgrad sdf layer 1 -> hidden, masked by ReLU
+        f32x16 dh = zero16();
+        static_for<0, 8>([&](auto rc) {
+            constexpr int R = decltype(rc)::value;
+            dh = mfma32(L.s1T[R * 64 + lane], dov[R], dh);
+        });
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh[r] = h[r] > 0.0f ? dh[r] : 0.0f;
+        // ---- dW(sdf_w0) = d_h^T . [feat32 | OneBlob48 | (16 discarded)]   (tiles 0..2)
+        wave_lds_sync();
+        stage_ctile(ga, kGradLd, 0, dh, j, hh);
+        wave_lds_sync();
+        wgrad_tile(ga, kGradLd, xs, kStageLd, 0, &L.acc[0 * 1024], lane);
+        wgrad_tile(ga, kGradLd, xs, kStageLd, 32, &L.acc[1 * 1024], lane);
+        wgrad_tile(ga, kGradLd, xs, kStageLd, 64, &L.acc[2 * 1024], lane);
+        wave_lds_sync();
+        // ---- dgrad sdf layer 0 -> hash features
+        f32x16 df = zero16();
+        static_for<0, 16>([&](auto tc) {
+            constexpr int T = decltype(tc)::value;
+            df = mfma32(L.s0T[T * 64 + lane], dh[T], df);
+        });
+        // reg 4q+e of half hh is feature e + 8q + 4hh  => level (e>>1) + 4q + 2hh, component e&1
+        if (valid) {
+            float2* __restrict__ dfo = reinterpret_cast<float2*>(d_feat);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    const int level = e2 + 4 * q + 2 * hh;
+                    dfo[(size_t)level * M + m] = make_float2(df[4 * q + 2 * e2], df[4 * q + 2 * e2 + 1]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float* __restrict__ out = partials + (size_t)blockIdx.x * kAccFloats;
+    for (int e = threadIdx.x; e < kAccFloats; e += blockDim.x) out[e] = L.acc[e];
+}
+
+// partials [n_blocks][7][32][32] -> += into the four weight gradients, fixed summation order
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partials, uint32_t n_blocks, NarutoGrads g) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= kAccFloats) return;
+    float s = 0.0f;
+    for (uint32_t b = 0; b < n_blocks; ++b) s += partials[(size_t)b * kAccFloats + e];
+    const int tile = e >> 10, row = (e >> 5) & 31, col = e & 31;
+    if (tile <= 2) {
+        const int c = tile * 32 + col;
+        if (c < kInSdf && g.sdf_w0) g.sdf_w0[row * kInSdf + c] += s;
+    } else if (tile == 3) {
+        if (row < kOut && g.sdf_w1) g.sdf_w1[row * kHidden + col] += s;
+    } else if (tile == 4) {
+        if (g.col_w0) g.col_w0[row * kInCol + col] += s;                       // OneBlob 0..31
+    } else if (tile == 5) {
+        if (g.col_w0) {
+            if (col < 16) g.col_w0[row * kInCol + 32 + col] += s;               // OneBlob 32..47
+            else if (col >= 17) g.col_w0[row * kInCol + kPos + (col - 17)] += s;  // out row col-16 >= 1 -> geo col-17
+        }
+    } else {
+        if (row < 3 && g.col_w1) g.col_w1[row * kHidden + col] += s;
+    }
+}
+
+}  // namespace naruto

@@ -1,0 +1,440 @@
+// Per-ray kernels: depth sampling, SDF-weighted compositing + uncertainty aggregation (forward and
+// backward), the mapping losses, fused Adam.  One wave (64 lanes) per ray; samples are strided over the
+// lanes and per-ray scans / reductions are wave-level (DPP shuffles), never block-level.
+//
+// Reference behaviour replaced: JointEncodingNaruto.render_rays z sampling (reference
+// src/slam/coslam/model/scene_rep.py:158-180), raw2outputs (:66-96), forward losses (:246-285),
+// Co-SLAM sdf2weights / get_masks / get_sdf_loss, torch.optim.Adam (coslam.py:409-419).
+
+#include "naruto_common.h"
+
+namespace naruto {
+
+constexpr int kMaxSamples = 1024;      // per-ray samples the per-wave LDS scratch is sized for
+constexpr int kRaysPerBlock = 4;       // 4 waves per block, one ray each
+
+// torch.linspace (aten RangeFactoriesKernel.cpp): symmetric two-sided formula
+__device__ __forceinline__ float linspace_at(float start, float end, uint32_t steps, uint32_t i) {
+    const float step = __fdiv_rn(__fsub_rn(end, start), (float)(steps - 1u));
+    if (i < steps / 2u) return __fadd_rn(start, __fmul_rn(step, (float)i));
+    return __fsub_rn(end, __fmul_rn(step, (float)(steps - i - 1u)));
+}
+
+// ------------------------------------------------------------------------------------------------
+// A1: z_vals = sort(cat(linspace(near, far, nu), z_samples)), z_samples = linspace(-r, r, nr) + d, or
+// linspace(near, far, nr) where d <= 0; then the stratified jitter.  Both lists are already sorted, so the
+// "sort" is a rank computation (merge), not a sort.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_sample_z(uint32_t n_rays, const float* __restrict__ target_d, float near_, float far_,
+                                                 uint32_t nu, uint32_t nr, float range_d, const float* __restrict__ rand,
+                                                 float* __restrict__ z_vals) {
+    __shared__ float zs[kMaxSamples];
+    const uint32_t n = blockIdx.x;
+    const uint32_t S = nu + nr;
+    const int lane = threadIdx.x;
+    if (target_d == nullptr) {
+        for (uint32_t s = lane; s < S; s += 64) zs[s] = linspace_at(near_, far_, S, s);     // S == n_samples, nr == 0
+    } else {
+        const float d = target_d[n];
+        const bool use_near_far = !(d > 0.0f);           // rows with target_d <= 0 (NaN also lands here)
+        auto range_val = [&](uint32_t k) {
+            return use_near_far ? linspace_at(near_, far_, nr, k) : __fadd_rn(linspace_at(-range_d, range_d, nr, k), d);
+        };
+        for (uint32_t s = lane; s < S; s += 64) {
+            if (s < nu) {                                 // uniform element: rank = i + #{R < U[i]}
+                const float v = linspace_at(near_, far_, nu, s);
+                uint32_t rank = s;
+                for (uint32_t k = 0; k < nr; ++k) rank += range_val(k) < v ? 1u : 0u;
+                zs[rank] = v;
+            } else {                                      // near-surface element: rank = k + #{U <= R[k]}
+                const uint32_t k = s - nu;
+                const float v = range_val(k);
+                uint32_t rank = k;
+                for (uint32_t i = 0; i < nu; ++i) rank += linspace_at(near_, far_, nu, i) <= v ? 1u : 0u;
+                zs[rank] = v;
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t s = lane; s < S; s += 64) {
+        float v = zs[s];
+        if (rand != nullptr) {
+            const float lo = s == 0 ? zs[0] : 0.5f * (zs[s] + zs[s - 1]);
+            const float up = s == S - 1 ? zs[S - 1] : 0.5f * (zs[s + 1] + zs[s]);
+            v = __fadd_rn(lo, __fmul_rn(__fsub_rn(up, lo), rand[(size_t)n * S + s]));
+        }
+        z_vals[(size_t)n * S + s] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Shared per-ray compositing core.  Works on this wave's ray; sdf / z / raw live in per-wave LDS.
+// ------------------------------------------------------------------------------------------------
+struct RayScratch {
+    float sdf[kMaxSamples];
+    float z[kMaxSamples];
+};
+
+__device__ __forceinline__ float softplus_(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float softplus_grad_(float x) {
+    if (x > 20.0f) return 1.0f;
+    const float e = expf(x);
+    return e / (e + 1.0f);
+}
+__device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+struct RayWeights {
+    float z_min;      // depth of the first sign change (z[0] if none)
+    float t_eps;      // sum(mask * bell) + 1e-8
+    float limit;      // z_min + sc_factor * trunc
+};
+
+__device__ __forceinline__ float bell(float sdf, float trunc) { return sigmoid_(sdf / trunc) * sigmoid_(-sdf / trunc); }
+
+// sdf2weights [Co-SLAM]: first index i with sdf[i]*sdf[i+1] < 0 (argmax of a 0/1 mask: 0 when there is none)
+__device__ __forceinline__ RayWeights ray_weights(const RayScratch& rs, uint32_t S, float trunc, float sc_factor, int lane) {
+    uint32_t first = 0xFFFFFFFFu;
+    for (uint32_t s = lane; s + 1 < S; s += 64) {
+        if (rs.sdf[s] * rs.sdf[s + 1] < 0.0f) { first = s; break; }     // lane-local first; strided => global min below
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) first = min(first, (uint32_t)__shfl_xor((int)first, o, 64));
+    RayWeights rw;
+    rw.z_min = rs.z[first == 0xFFFFFFFFu ? 0u : first];
+    rw.limit = rw.z_min + sc_factor * trunc;
+    float t = 0.0f;
+    for (uint32_t s = lane; s < S; s += 64) t += rs.z[s] < rw.limit ? bell(rs.sdf[s], trunc) : 0.0f;
+    rw.t_eps = wave_sum(t) + 1e-8f;
+    return rw;
+}
+
+__device__ __forceinline__ void load_ray(RayScratch& rs, const float* __restrict__ raw, const float* __restrict__ z_vals, uint32_t n,
+                                         uint32_t S, int lane) {
+    for (uint32_t s = lane; s < S; s += 64) {
+        rs.sdf[s] = raw[((size_t)n * S + s) * 5 + 3];
+        rs.z[s] = z_vals[(size_t)n * S + s];
+    }
+    wave_lds_sync();
+}
+
+struct RayOut {
+    float rgb[3], depth, acc, depth_var, uncert, disp;
+};
+
+__device__ __forceinline__ RayOut ray_composite(const RayScratch& rs, const RayWeights& rw, const float* __restrict__ raw, uint32_t n,
+                                                uint32_t S, float trunc, int white_bkgd, float* __restrict__ weights_out, int lane) {
+    float r = 0.0f, g = 0.0f, b = 0.0f, dep = 0.0f, acc = 0.0f, unc = 0.0f;
+    for (uint32_t s = lane; s < S; s += 64) {
+        const float z = rs.z[s];
+        const float w = (z < rw.limit ? bell(rs.sdf[s], trunc) : 0.0f) / rw.t_eps;
+        const float* p = raw + ((size_t)n * S + s) * 5;
+        r = fmaf(w, sigmoid_(p[0]), r);
+        g = fmaf(w, sigmoid_(p[1]), g);
+        b = fmaf(w, sigmoid_(p[2]), b);
+        dep = fmaf(w, z, dep);
+        acc += w;
+        unc = fmaf(w * w, softplus_(p[4]) + 0.01f, unc);
+        if (weights_out != nullptr) weights_out[(size_t)n * S + s] = w;
+    }
+    RayOut o;
+    o.rgb[0] = wave_sum(r); o.rgb[1] = wave_sum(g); o.rgb[2] = wave_sum(b);
+    o.depth = wave_sum(dep);
+    o.acc = wave_sum(acc);
+    o.uncert = wave_sum(unc);
+    float var = 0.0f;
+    for (uint32_t s = lane; s < S; s += 64) {
+        const float z = rs.z[s];
+        const float w = (z < rw.limit ? bell(rs.sdf[s], trunc) : 0.0f) / rw.t_eps;
+        const float dz = z - o.depth;
+        var = fmaf(w, dz * dz, var);
+    }
+    o.depth_var = wave_sum(var);
+    const float q = o.depth / o.acc;
+    const float qq = (q != q) ? q : fmaxf(1e-10f, q);       // torch.max propagates NaN (0/0 on empty rays)
+    o.disp = 1.0f / qq;
+    if (white_bkgd) {
+        o.rgb[0] += 1.0f - o.acc; o.rgb[1] += 1.0f - o.acc; o.rgb[2] += 1.0f - o.acc;
+    }
+    return o;
+}
+
+__global__ __launch_bounds__(64 * kRaysPerBlock) void k_composite_fwd(uint32_t n_rays, uint32_t S, float trunc, float sc_factor,
+                                                                      int white_bkgd, const float* __restrict__ raw,
+                                                                      const float* __restrict__ z_vals, float* __restrict__ rgb,
+                                                                      float* __restrict__ disp, float* __restrict__ acc,
+                                                                      float* __restrict__ weights, float* __restrict__ depth,
+                                                                      float* __restrict__ depth_var, float* __restrict__ uncert_map) {
+    __shared__ RayScratch scratch[kRaysPerBlock];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n = blockIdx.x * kRaysPerBlock + wave;
+    if (n >= n_rays) return;
+    RayScratch& rs = scratch[wave];
+    load_ray(rs, raw, z_vals, n, S, lane);
+    const RayWeights rw = ray_weights(rs, S, trunc, sc_factor, lane);
+    const RayOut o = ray_composite(rs, rw, raw, n, S, trunc, white_bkgd, weights, lane);
+    if (lane == 0) {
+        if (rgb) { rgb[3 * (size_t)n] = o.rgb[0]; rgb[3 * (size_t)n + 1] = o.rgb[1]; rgb[3 * (size_t)n + 2] = o.rgb[2]; }
+        if (disp) disp[n] = o.disp;
+        if (acc) acc[n] = o.acc;
+        if (depth) depth[n] = o.depth;
+        if (depth_var) depth_var[n] = o.depth_var;
+        if (uncert_map) uncert_map[n] = o.uncert;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A8 forward: per-ray loss terms -> workspace [n_rays][16] -> fp64 sums[16]
+//  0 sum (w rgb - w tgt)^2        1 sum_valid (D - d)^2      2 n_valid
+//  3 sum front (sdf - 1)^2        4 n_fs                      5 sum sdf_mask (z + sdf*tr - d)^2   6 n_sdf
+//  7 sum_valid 1/(2(u+1e-9))      8 sum_valid log(u+1e-9)     9 min u (all rays)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool depth_valid(float d, float depth_trunc) { return d > 0.0f && d < depth_trunc; }
+// scene_rep.py:249-250 writes rgb_missing into a BOOL tensor: invalid-depth rays keep weight 1 unless rgb_missing == 0
+__device__ __forceinline__ float rgb_weight(bool valid, float rgb_missing) { return valid ? 1.0f : (rgb_missing != 0.0f ? 1.0f : 0.0f); }
+
+__global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_terms(uint32_t n_rays, uint32_t S, float trunc_sc, const float* __restrict__ raw,
+                                                                   const float* __restrict__ z_vals, const float* __restrict__ rgb,
+                                                                   const float* __restrict__ depth, const float* __restrict__ uncert_map,
+                                                                   const float* __restrict__ target_rgb, const float* __restrict__ target_d,
+                                                                   float depth_trunc, float rgb_missing, float* __restrict__ terms) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n = blockIdx.x * kRaysPerBlock + wave;
+    if (n >= n_rays) return;
+    const float td = target_d[n];
+    const bool valid = depth_valid(td, depth_trunc);
+    const float dm = td > 0.0f ? 1.0f : 0.0f;
+    float fs = 0.0f, nfs = 0.0f, sl = 0.0f, nsdf = 0.0f;
+    for (uint32_t s = lane; s < S; s += 64) {
+        const float z = z_vals[(size_t)n * S + s];
+        const float sdf = raw[((size_t)n * S + s) * 5 + 3];
+        const float front = z < (td - trunc_sc) ? 1.0f : 0.0f;
+        const float back = z > (td + trunc_sc) ? 1.0f : 0.0f;
+        const float sm = (1.0f - front) * (1.0f - back) * dm;
+        const float a = sdf * front - front;
+        fs = fmaf(a, a, fs);
+        nfs += front;
+        const float c = (z + sdf * trunc_sc) * sm - td * sm;
+        sl = fmaf(c, c, sl);
+        nsdf += sm != 0.0f ? 1.0f : 0.0f;
+    }
+    fs = wave_sum(fs); nfs = wave_sum(nfs); sl = wave_sum(sl); nsdf = wave_sum(nsdf);
+    if (lane == 0) {
+        const float w = rgb_weight(valid, rgb_missing);
+        float s0 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float e = rgb[3 * (size_t)n + c] * w - target_rgb[3 * (size_t)n + c] * w;
+            s0 = fmaf(e, e, s0);
+        }
+        const float D = depth[n], u = uncert_map[n];
+        float* t = terms + (size_t)n * 16;
+        t[0] = s0;
+        t[1] = valid ? (D - td) * (D - td) : 0.0f;
+        t[2] = valid ? 1.0f : 0.0f;
+        t[3] = fs; t[4] = nfs; t[5] = sl; t[6] = nsdf;
+        t[7] = valid ? 1.0f / (2.0f * (u + 1e-9f)) : 0.0f;
+        t[8] = valid ? logf(u + 1e-9f) : 0.0f;
+        t[9] = u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_loss_reduce(const float* __restrict__ terms, uint32_t n_rays, double* __restrict__ sums) {
+    __shared__ double part[4][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double acc[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[k] = k == 9 ? 1e300 : 0.0;
+    for (uint32_t n = threadIdx.x; n < n_rays; n += 256) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[k] += (double)terms[(size_t)n * 16 + k];
+        const double u = (double)terms[(size_t)n * 16 + 9];
+        acc[9] = (u < acc[9] || u != u) ? u : acc[9];
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        double v = acc[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double other = __shfl_xor(v, o, 64);
+            v = k == 9 ? ((other < v || other != other) ? other : v) : v + other;
+        }
+        if (lane == 0) part[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const int k = threadIdx.x;
+        double v = 0.0;
+        if (k < 9) v = part[0][k] + part[1][k] + part[2][k] + part[3][k];
+        else if (k == 9) {
+            v = part[0][9];
+            for (int w = 1; w < 4; ++w) v = (part[w][9] < v || part[w][9] != part[w][9]) ? part[w][9] : v;
+        }
+        sums[k] = v;
+    }
+}
+
+struct LossScalars {
+    float inv_3n, inv_ns, nv, fs_w, sdf_w, mean_a, mean_e;
+};
+
+__device__ __forceinline__ LossScalars loss_scalars(const double* __restrict__ sums, uint64_t n_total, uint32_t S) {
+    LossScalars k;
+    const double N = (double)n_total;
+    k.inv_3n = (float)(1.0 / (3.0 * N));
+    k.inv_ns = (float)(1.0 / (N * (double)S));
+    k.nv = (float)sums[2];
+    const float nfs = (float)sums[4], nsdf = (float)sums[6];
+    const float ns = nfs + nsdf;
+    k.fs_w = 1.0f - nfs / ns;
+    k.sdf_w = 1.0f - nsdf / ns;
+    k.mean_a = (float)(sums[7] / sums[2]);
+    k.mean_e = (float)(sums[1] / sums[2]);
+    return k;
+}
+
+__global__ void k_loss_finalize(const double* __restrict__ sums, uint64_t n_total, uint32_t S, float* __restrict__ losses) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const LossScalars k = loss_scalars(sums, n_total, S);
+    const float rgb_loss = (float)sums[0] * k.inv_3n;
+    const float depth_loss = (float)(sums[1] / sums[2]);            // mean over an empty selection is NaN, as in torch
+    const float fs_loss = (float)sums[3] * k.inv_ns * k.fs_w;
+    const float sdf_loss = (float)sums[5] * k.inv_ns * k.sdf_w;
+    const float psnr = -10.0f * logf(rgb_loss) / logf(10.0f);
+    const float uncert_loss = k.mean_a * k.mean_e + 0.5f * (float)(sums[8] / sums[2]);
+    losses[0] = rgb_loss; losses[1] = depth_loss; losses[2] = sdf_loss; losses[3] = fs_loss;
+    losses[4] = psnr; losses[5] = uncert_loss; losses[6] = (float)sums[9]; losses[7] = (float)sums[2];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Composite backward.  LOSS = true: the output cotangents come from the loss block (scene_rep.py:246-285)
+// and the direct sdf terms of get_sdf_loss are added; LOSS = false: cotangents are given by the caller.
+// ------------------------------------------------------------------------------------------------
+struct CompositeCot {
+    const float* d_rgb; const float* d_disp; const float* d_acc; const float* d_weights;
+    const float* d_depth; const float* d_depth_var; const float* d_uncert_map;
+};
+struct LossArgs {
+    const float* target_rgb; const float* target_d; const double* sums; const float* loss_grad;
+    uint64_t n_total; float depth_trunc, rgb_missing, trunc_sc;
+};
+
+template <bool LOSS>
+__global__ __launch_bounds__(64 * kRaysPerBlock) void k_composite_bwd(uint32_t n_rays, uint32_t S, float trunc, float sc_factor, int white_bkgd,
+                                                                      const float* __restrict__ raw, const float* __restrict__ z_vals,
+                                                                      CompositeCot cot, LossArgs la, float* __restrict__ d_raw, int accumulate) {
+    __shared__ RayScratch scratch[kRaysPerBlock];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n = blockIdx.x * kRaysPerBlock + wave;
+    if (n >= n_rays) return;
+    RayScratch& rs = scratch[wave];
+    load_ray(rs, raw, z_vals, n, S, lane);
+    const RayWeights rw = ray_weights(rs, S, trunc, sc_factor, lane);
+    const RayOut o = ray_composite(rs, rw, raw, n, S, trunc, 0, nullptr, lane);     // rgb WITHOUT the white background term
+
+    float g_rgb[3] = {0.0f, 0.0f, 0.0f}, g_depth = 0.0f, g_acc = 0.0f, g_var = 0.0f, g_unc = 0.0f, g_disp = 0.0f;
+    float td = 0.0f, dm = 0.0f, c_fs = 0.0f, c_sdf = 0.0f;
+    if constexpr (LOSS) {
+        const LossScalars k = loss_scalars(la.sums, la.n_total, S);
+        td = la.target_d[n];
+        const bool valid = depth_valid(td, la.depth_trunc);
+        dm = td > 0.0f ? 1.0f : 0.0f;
+        const float w = rgb_weight(valid, la.rgb_missing);
+        const float G_rgb = la.loss_grad[0], G_depth = la.loss_grad[1], G_sdf = la.loss_grad[2], G_fs = la.loss_grad[3],
+                    G_unc = la.loss_grad[5];
+        const float wb = white_bkgd ? 1.0f - o.acc : 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g_rgb[c] = G_rgb * 2.0f * w * w * ((o.rgb[c] + wb) - la.target_rgb[3 * (size_t)n + c]) * k.inv_3n;
+        if (valid) {
+            const float e = o.depth - td;
+            const float u = o.uncert + 1e-9f;
+            g_depth = (G_depth + G_unc * k.mean_a) * 2.0f * e / k.nv;
+            g_unc = G_unc * (0.5f / u - k.mean_e * 0.5f / (u * u)) / k.nv;
+        }
+        c_fs = G_fs * k.fs_w * 2.0f * k.inv_ns;
+        c_sdf = G_sdf * k.sdf_w * 2.0f * k.inv_ns;
+    } else {
+        if (cot.d_rgb) { g_rgb[0] = cot.d_rgb[3 * (size_t)n]; g_rgb[1] = cot.d_rgb[3 * (size_t)n + 1]; g_rgb[2] = cot.d_rgb[3 * (size_t)n + 2]; }
+        if (cot.d_depth) g_depth = cot.d_depth[n];
+        if (cot.d_acc) g_acc = cot.d_acc[n];
+        if (cot.d_depth_var) g_var = cot.d_depth_var[n];
+        if (cot.d_uncert_map) g_unc = cot.d_uncert_map[n];
+        if (cot.d_disp) g_disp = cot.d_disp[n];
+    }
+    if (white_bkgd) g_acc -= g_rgb[0] + g_rgb[1] + g_rgb[2];          // rgb_map += 1 - acc
+    // disp = acc / depth where depth/acc > 1e-10, constant otherwise
+    float gd_depth = 0.0f, gd_acc = 0.0f;
+    if (g_disp != 0.0f) {
+        const float q = o.depth / o.acc;
+        if (q > 1e-10f) { gd_depth = -g_disp * o.acc / (o.depth * o.depth); gd_acc = g_disp / o.depth; }
+    }
+    // pass 1: gw_i (cotangent of the normalised weight) and sum_i gw_i w_i
+    float dot = 0.0f;
+    for (uint32_t s = lane; s < S; s += 64) {
+        const float z = rs.z[s];
+        const float w = (z < rw.limit ? bell(rs.sdf[s], trunc) : 0.0f) / rw.t_eps;
+        const float* p = raw + ((size_t)n * S + s) * 5;
+        const float dz = z - o.depth;
+        float gw = g_rgb[0] * sigmoid_(p[0]) + g_rgb[1] * sigmoid_(p[1]) + g_rgb[2] * sigmoid_(p[2]);
+        gw += (g_depth + gd_depth) * z + (g_acc + gd_acc);
+        gw += g_unc * 2.0f * w * (softplus_(p[4]) + 0.01f);
+        gw += g_var * (dz * dz - 2.0f * z * (o.depth - o.depth * o.acc));
+        if (!LOSS && cot.d_weights) gw += cot.d_weights[(size_t)n * S + s];
+        dot = fmaf(gw, w, dot);
+    }
+    dot = wave_sum(dot);
+    // pass 2: write d_raw
+    for (uint32_t s = lane; s < S; s += 64) {
+        const float z = rs.z[s];
+        const float sdf = rs.sdf[s];
+        const float m = z < rw.limit ? 1.0f : 0.0f;
+        const float sg = sigmoid_(sdf / trunc);
+        const float bl = sg * sigmoid_(-sdf / trunc);
+        const float w = m * bl / rw.t_eps;
+        const float* p = raw + ((size_t)n * S + s) * 5;
+        const float c0 = sigmoid_(p[0]), c1 = sigmoid_(p[1]), c2 = sigmoid_(p[2]);
+        const float dz = z - o.depth;
+        float gw = g_rgb[0] * c0 + g_rgb[1] * c1 + g_rgb[2] * c2;
+        gw += (g_depth + gd_depth) * z + (g_acc + gd_acc);
+        gw += g_unc * 2.0f * w * (softplus_(p[4]) + 0.01f);
+        gw += g_var * (dz * dz - 2.0f * z * (o.depth - o.depth * o.acc));
+        if (!LOSS && cot.d_weights) gw += cot.d_weights[(size_t)n * S + s];
+        const float dbell = bl * (1.0f - 2.0f * sg) / trunc;
+        float g_s = m * dbell / rw.t_eps * (gw - dot);
+        if constexpr (LOSS) {
+            const float front = z < (td - la.trunc_sc) ? 1.0f : 0.0f;
+            const float back = z > (td + la.trunc_sc) ? 1.0f : 0.0f;
+            const float sm = (1.0f - front) * (1.0f - back) * dm;
+            g_s += c_fs * front * (sdf * front - front);
+            g_s += c_sdf * sm * ((z + sdf * la.trunc_sc) * sm - td * sm) * la.trunc_sc;
+        }
+        float* q = d_raw + ((size_t)n * S + s) * 5;
+        const float o0 = g_rgb[0] * w * c0 * (1.0f - c0), o1 = g_rgb[1] * w * c1 * (1.0f - c1), o2 = g_rgb[2] * w * c2 * (1.0f - c2);
+        const float o4 = g_unc * w * w * softplus_grad_(p[4]);
+        if (accumulate) { q[0] += o0; q[1] += o1; q[2] += o2; q[3] += g_s; q[4] += o4; }
+        else { q[0] = o0; q[1] = o1; q[2] = o2; q[3] = g_s; q[4] = o4; }
+    }
+}
+
+template __global__ void k_composite_bwd<true>(uint32_t, uint32_t, float, float, int, const float*, const float*, CompositeCot, LossArgs, float*, int);
+template __global__ void k_composite_bwd<false>(uint32_t, uint32_t, float, float, int, const float*, const float*, CompositeCot, LossArgs, float*, int);
+
+// ------------------------------------------------------------------------------------------------
+// Fused Adam (torch.optim.Adam, amsgrad off): one pass over p, g, m, v.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                              uint64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+    const float step_size = lr / bc1;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        const float pi = p[i];
+        if (wd != 0.0f) gi = fmaf(wd, pi, gi);
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);            // torch: exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - step_size * (mi / denom);
+    }
+}
+
+}  // namespace naruto

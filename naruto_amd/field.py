@@ -1,0 +1,274 @@
+"""NarutoFieldHIP: drop-in for the reference's ``JointEncodingNaruto`` (reference
+src/slam/coslam/model/scene_rep.py:25-287), the ``nn.Module`` that ``CoSLAMNaruto`` instantiates at
+src/slam/coslam/coslam.py:65 -- same constructor, same method names / argument meaning / return
+dicts, same parameter and state_dict names, but every operator runs as hand-written HIP kernels from
+libnaruto_hip.so.  There is no PyTorch fallback: tensors must live on the GPU.
+
+Attribute surface kept: forward, render_rays, raw2outputs, sdf2weights,
+query_sdf, query_color, query_color_sdf, run_network, calc_embedding-free fused path,
+get_uncert_grid, embed_fn / embedpos_fn / decoder / color_net / sdf_net sub-modules, uncert_grid.
+"""
+
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class _HashGridEncoding(nn.Module):
+    """Holds ``params`` like ``tcnn.Encoding`` does (state_dict key ``embed_fn.params``); callable."""
+
+    def __init__(self, owner: "NarutoFieldHIP", n_params: int, n_output_dims: int):
+        super().__init__()
+        self.params = nn.Parameter((torch.rand(n_params) * 2 - 1) * 1e-4)      # tcnn: U(-1e-4, 1e-4)
+        self.n_output_dims = n_output_dims
+        object.__setattr__(self, "_owner", owner)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return ops.hash_encode(self._owner._handle(), x.reshape(-1, 3), self.params)
+
+
+class _OneBlobEncoding(nn.Module):
+    """Parameter-free; exists so that ``embedpos_fn.params`` (empty) appears in the state_dict as with tcnn.
+    The encoding itself is fused into the query kernels."""
+
+    def __init__(self, n_bins: int):
+        super().__init__()
+        self.params = nn.Parameter(torch.zeros(0))
+        self.n_bins = n_bins
+        self.n_output_dims = 3 * n_bins
+
+    def forward(self, x):
+        raise NotImplementedError("OneBlob is evaluated inside the fused query kernels; use query_sdf / query_color_sdf")
+
+
+class _Mlp(nn.Module):
+    """Weight holder with the reference's module path ``.model.{0,2}.weight`` (bias-free Linear, ReLU, Linear)."""
+
+    def __init__(self, d_in: int, d_hidden: int, d_out: int):
+        super().__init__()
+        self.model = nn.Sequential(nn.Linear(d_in, d_hidden, bias=False), nn.ReLU(inplace=True),
+                                   nn.Linear(d_hidden, d_out, bias=False))
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("the MLPs are evaluated inside the fused query kernels")
+
+
+class _Decoder(nn.Module):
+    def __init__(self, in_sdf: int, in_col: int, hidden: int, hidden_col: int, geo: int):
+        super().__init__()
+        self.color_net = _Mlp(in_col, hidden_col, 3)
+        self.sdf_net = _Mlp(in_sdf, hidden, 1 + geo)
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("the decoder is evaluated inside the fused query kernels")
+
+
+class NarutoFieldHIP(nn.Module):
+    N_LEVELS, N_FEATURES, BASE_RESOLUTION = 16, 2, 16        # Co-SLAM get_encoder defaults
+
+    def __init__(self, config: Dict, bound_box: torch.Tensor):
+        super().__init__()
+        self.config = config
+        self.bounding_box = bound_box
+        dec, grid = config['decoder'], config['grid']
+        if not grid.get('oneGrid', True):
+            raise NotImplementedError("oneGrid=False (separate colour grid) is not shipped by the reference configs")
+        if dec.get('tcnn_network', False) or dec.get('pred_uncert', False) or not dec.get('uncert_grid', False):
+            raise NotImplementedError("supported decoder: tcnn_network=False, pred_uncert=False, uncert_grid=True")
+        if config['training'].get('n_importance', 0) > 0:
+            raise NotImplementedError("n_importance > 0 cannot run in the reference either (scene_rep.py:204)")
+        if 'hash' not in grid['enc'].lower() or 'blob' not in config['pos']['enc'].lower():
+            raise NotImplementedError("supported encodings: HashGrid + OneBlob")
+        self.get_resolution()
+        self.per_level_scale = float(np.exp2(np.log2(self.resolution_sdf / self.BASE_RESOLUTION) / (self.N_LEVELS - 1)))
+        self._uncert_dims = None
+        self._handles: Dict = {}
+        n_params = self._make_handle((1, 1, 1)).n_params
+        self.input_ch = self.N_LEVELS * self.N_FEATURES
+        self.input_ch_pos = 3 * config['pos']['n_bins']
+        self.embedpos_fn = _OneBlobEncoding(config['pos']['n_bins'])
+        self.embed_fn = _HashGridEncoding(self, n_params, self.input_ch)
+        self.decoder = _Decoder(self.input_ch + self.input_ch_pos, self.input_ch_pos + dec['geo_feat_dim'],
+                                dec['hidden_dim'], dec['hidden_dim_color'], dec['geo_feat_dim'])
+        # the reference re-registers the two nets at top level (batchify(fn, None) returns the module itself)
+        self.color_net = self.decoder.color_net
+        self.sdf_net = self.decoder.sdf_net
+        self.act_uncertainty = nn.Softplus()
+        self.process_group = None            # set by enable_data_parallel()
+        self.n_rays_total = 0
+        self.strict_assert = False
+        self._pending_min_uncert = None
+
+    # ------------------------------------------------------------------ construction helpers
+    def get_resolution(self):
+        """Co-SLAM JointEncoding.get_resolution."""
+        dim_max = (self.bounding_box[:, 1] - self.bounding_box[:, 0]).max()
+        g = self.config['grid']
+        self.resolution_sdf = g['voxel_sdf'] if g['voxel_sdf'] > 10 else int(dim_max / g['voxel_sdf'])
+        self.resolution_color = g['voxel_color'] if g['voxel_color'] > 10 else int(dim_max / g['voxel_color'])
+
+    def _make_handle(self, uncert_dims) -> ops.FieldHandle:
+        key = tuple(int(v) for v in uncert_dims)
+        h = self._handles.get(key)
+        if h is None:
+            bb = self.bounding_box.detach().float().cpu()
+            tr = self.config['training']
+            h = ops.FieldHandle(n_levels=self.N_LEVELS, n_features=self.N_FEATURES,
+                                log2_hashmap_size=self.config['grid']['hash_size'], base_resolution=self.BASE_RESOLUTION,
+                                per_level_scale=self.per_level_scale, n_bins=self.config['pos']['n_bins'],
+                                hidden_dim=self.config['decoder']['hidden_dim'], geo_feat_dim=self.config['decoder']['geo_feat_dim'],
+                                hidden_dim_color=self.config['decoder']['hidden_dim_color'], uncert_dims=key,
+                                bbox_min=bb[:, 0].tolist(), bbox_max=bb[:, 1].tolist(), trunc=tr['trunc'],
+                                sc_factor=self.config['data']['sc_factor'], white_bkgd=tr['white_bkgd'])
+            self._handles[key] = h
+        return h
+
+    def _handle(self) -> ops.FieldHandle:
+        if getattr(self, "uncert_grid", None) is None:
+            raise RuntimeError("uncert_grid is not initialised: call get_uncert_grid(voxel_size) first "
+                               "(reference coslam.py:240-243)")
+        return self._make_handle(tuple(self.uncert_grid.shape))
+
+    def get_uncert_grid(self, voxel_size):
+        """scene_rep.py:49-56 (on the module's device instead of the hard-coded "cuda")."""
+        bb = self.bounding_box
+        Nx = round((bb[0, 1] - bb[0, 0]).item() / voxel_size + 0.0005) + 1
+        Ny = round((bb[1, 1] - bb[1, 0]).item() / voxel_size + 0.0005) + 1
+        Nz = round((bb[2, 1] - bb[2, 0]).item() / voxel_size + 0.0005) + 1
+        dev = self.embed_fn.params.device
+        self.uncert_grid = torch.nn.parameter.Parameter(torch.ones([Nx, Ny, Nz], device=dev).float() * 3)
+        self.cache_uncert = np.zeros([Nx, Ny, Nz], dtype=np.float32)
+        return self.uncert_grid
+
+    def enable_data_parallel(self, group, n_rays_total: int = 0):
+        """Ray-sharded data parallelism (naruto_amd.parallel): loss sums are all-reduced over ``group``."""
+        self.process_group = group
+        self.n_rays_total = n_rays_total
+
+    def _params(self) -> Dict[str, torch.Tensor]:
+        return {"table": self.embed_fn.params, "uncert_grid": self.uncert_grid,
+                "sdf_w0": self.decoder.sdf_net.model[0].weight, "sdf_w1": self.decoder.sdf_net.model[2].weight,
+                "col_w0": self.decoder.color_net.model[0].weight, "col_w1": self.decoder.color_net.model[2].weight}
+
+    # ------------------------------------------------------------------ A6/A7
+    def sdf2weights(self, sdf, z_vals, args=None):
+        raw = torch.zeros(*sdf.shape, 5, dtype=torch.float32, device=sdf.device)
+        raw[..., 3] = sdf
+        return ops.composite(self._handle(), raw, z_vals)[3]
+
+    def raw2outputs(self, raw, z_vals, white_bkgd=False):
+        """-> rgb_map, disp_map, acc_map, weights, depth_map, depth_var, uncert_map (scene_rep.py:66-96)."""
+        if bool(white_bkgd) != bool(self.config['training']['white_bkgd']):
+            raise NotImplementedError("white_bkgd is fixed by config['training']['white_bkgd'] in this build")
+        return ops.composite(self._handle(), raw, z_vals)
+
+    # ------------------------------------------------------------------ A9
+    def query_sdf(self, query_points, return_geo=False, embed=False, return_uncert=False):
+        """scene_rep.py:98-130.  query_points [..., 3], already normalised to the unit cube."""
+        lead = list(query_points.shape[:-1])
+        flat = torch.reshape(query_points, [-1, query_points.shape[-1]])
+        if embed:
+            e = ops.hash_encode(self._handle(), flat, self.embed_fn.params)
+            return torch.reshape(e, lead + [e.shape[-1]])
+        out = ops.field_query(self._handle(), self._params(), x=flat, color=False, want_geo=return_geo)
+        su, geo = (out if return_geo else (out, None))
+        sdf = su if return_uncert else su[:, 0]
+        sdf = torch.reshape(sdf, lead + ([2] if return_uncert else []))
+        if not return_geo:
+            return sdf
+        return sdf, torch.reshape(geo, lead + [geo.shape[-1]])
+
+    def query_color_sdf(self, query_points):
+        """scene_rep.py:132-148: -> raw [M,5] = (rgb pre-sigmoid, sdf, uncert_raw)."""
+        flat = torch.reshape(query_points, [-1, query_points.shape[-1]])
+        return ops.field_query(self._handle(), self._params(), x=flat, color=True)
+
+    def query_color(self, query_points):
+        """Co-SLAM JointEncoding.query_color."""
+        return torch.sigmoid(self.query_color_sdf(query_points)[..., :3])
+
+    def run_network(self, inputs):
+        """Co-SLAM JointEncoding.run_network: world-space points [..., 3] -> raw [..., 5]."""
+        flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
+        bb = self.bounding_box.to(flat)
+        flat = (flat - bb[:, 0]) / (bb[:, 1] - bb[:, 0])
+        out = ops.field_query(self._handle(), self._params(), x=flat, color=True)
+        return torch.reshape(out, list(inputs.shape[:-1]) + [out.shape[-1]])
+
+    # ------------------------------------------------------------------ A1 + render
+    def _sample_z(self, rays_o, target_d, rand=None):
+        tr, cam = self.config['training'], self.config['cam']
+        n_rays = rays_o.shape[0]
+        if target_d is not None:
+            n_range, n_unif, n_samples = tr['n_range_d'], tr['n_samples_d'], 0
+        else:
+            n_range, n_unif, n_samples = 0, 0, tr['n_samples']        # KeyError with shipped configs, as in the reference
+        S = n_unif + n_range if target_d is not None else n_samples
+        if tr['perturb'] > 0. and rand is None:
+            rand = torch.rand(n_rays, S, device=rays_o.device)
+        if not tr['perturb'] > 0.:
+            rand = None
+        return ops.sample_z(n_rays, target_d, float(cam['near']), float(cam['far']), n_unif, n_range, float(tr['range_d']),
+                            n_samples, rand, device=rays_o.device)
+
+    def render_rays(self, rays_o, rays_d, target_d=None, rand=None):
+        """scene_rep.py:150-225.  ``rand`` (optional, [N,S]) replaces the jitter draw for reproducible tests."""
+        z_vals = self._sample_z(rays_o, target_d, rand)
+        raw = ops.field_query(self._handle(), self._params(), rays_o=rays_o, rays_d=rays_d, z_vals=z_vals, color=True)
+        raw = raw.reshape(z_vals.shape[0], z_vals.shape[1], 5)
+        rgb_map, disp_map, acc_map, weights, depth_map, depth_var, uncert_map = ops.composite(self._handle(), raw, z_vals)
+        return {'rgb': rgb_map, 'depth': depth_map, 'disp_map': disp_map, 'acc_map': acc_map, 'depth_var': depth_var,
+                'z_vals': z_vals, 'raw': raw, 'uncert_map': uncert_map}
+
+    # ------------------------------------------------------------------ A8
+    def check_asserts(self):
+        """The reference asserts ``uncert_map.min() > 0`` inside forward (scene_rep.py:280), which costs a
+        device sync per iteration.  Here the value is produced on the device and checked lazily: at the next
+        forward (one iteration late) or on demand; ``strict_assert = True`` restores the in-line check."""
+        if self._pending_min_uncert is not None:
+            v = float(self._pending_min_uncert.item())
+            self._pending_min_uncert = None
+            assert v > 0, "uncert_map.min() > 0 violated (scene_rep.py:280)"
+
+    def forward(self, rays_o, rays_d, target_rgb, target_d, global_step=0, rand=None):
+        """scene_rep.py:227-287."""
+        if not self.training:
+            return self.render_rays(rays_o, rays_d, target_d=target_d, rand=rand)
+        self.check_asserts()
+        cfg = self.config
+        z_vals = self._sample_z(rays_o, target_d, rand)
+        raw = ops.field_query(self._handle(), self._params(), rays_o=rays_o, rays_d=rays_d, z_vals=z_vals, color=True)
+        raw = raw.reshape(z_vals.shape[0], z_vals.shape[1], 5)
+        rgb, depth, _disp, _acc, _var, _um, losses = ops.render_loss(
+            self._handle(), raw, z_vals, target_rgb, target_d, cfg['cam']['depth_trunc'], cfg['training']['rgb_missing'],
+            group=self.process_group, n_rays_total=self.n_rays_total)
+        self._pending_min_uncert = losses[6].detach()
+        if self.strict_assert:
+            self.check_asserts()
+        return {"rgb": rgb, "depth": depth, "rgb_loss": losses[0], "depth_loss": losses[1], "sdf_loss": losses[2],
+                "fs_loss": losses[3], "psnr": losses[4].detach(), "uncert_loss": losses[5]}
+
+
+def get_map_volumes(query_fn, bounding_box: torch.Tensor, voxel_size: float):
+    """Planner query path (reference src/slam/coslam/coslam_utils.py:58-97): dense lattice -> [uncert_vol,
+    sdf_vol] as numpy.  The reference's discarded ``embed=True`` pass (coslam_utils.py:86-87) is skipped."""
+    ts = []
+    for i in range(3):
+        lo, hi = float(bounding_box[i, 0]), float(bounding_box[i, 1])
+        n = round((hi - lo) / voxel_size + 0.0005)                        # Co-SLAM getVoxels
+        ts.append(torch.linspace(lo, hi, n + 1))
+    q = torch.stack(torch.meshgrid(*ts, indexing='ij'), -1).to(torch.float32).to(bounding_box.device)
+    q = (q - bounding_box[:, 0]) / (bounding_box[:, 1] - bounding_box[:, 0])
+    with torch.no_grad():
+        su = query_fn(q, embed=False, return_uncert=True)
+        sdf, uncert = su[..., 0], su[..., 1]
+        uncert_map = torch.nn.functional.softplus(uncert) + 0.01
+        mask = (sdf >= 0) * (sdf < 0.5)
+        uncert_map[torch.logical_not(mask)] = 0
+    return [uncert_map.cpu().numpy().copy(), sdf.cpu().numpy().copy()]

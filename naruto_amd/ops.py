@@ -1,0 +1,356 @@
+"""torch-facing operators over the C ABI: tensor checks, stream plumbing and autograd wiring.
+
+Every operator launches hand-written HIP kernels from libnaruto_hip.so on torch's CURRENT stream; torch
+is used for memory, streams and autograd bookkeeping only.  Mapping to the reference (paths under
+/root/reference): see include/naruto_hip.h and DESIGN.md.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import NarutoFieldDesc, NarutoGrads, NarutoParams, NarutoPoints, check
+
+PARAM_NAMES = ("table", "uncert_grid", "sdf_w0", "sdf_w1", "col_w0", "col_w1")
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a tensor on the GPU (the hot path has no CPU implementation), got {t.device}")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class FieldHandle:
+    """Owns one NarutoField* (immutable description of the scene representation)."""
+
+    def __init__(self, *, n_levels=16, n_features=2, log2_hashmap_size=16, base_resolution=16, per_level_scale,
+                 n_bins=16, hidden_dim=32, geo_feat_dim=15, hidden_dim_color=32, uncert_dims, bbox_min, bbox_max,
+                 trunc, sc_factor, white_bkgd=False):
+        lib = _lib.load()
+        d = NarutoFieldDesc()
+        d.n_levels, d.n_features, d.log2_hashmap_size = n_levels, n_features, log2_hashmap_size
+        d.base_resolution, d.per_level_scale, d.n_bins = base_resolution, float(per_level_scale), n_bins
+        d.hidden_dim, d.geo_feat_dim, d.hidden_dim_color = hidden_dim, geo_feat_dim, hidden_dim_color
+        for i in range(3):
+            d.uncert_dims[i] = int(uncert_dims[i])
+            d.bbox_min[i] = float(bbox_min[i])
+            d.bbox_max[i] = float(bbox_max[i])
+        d.trunc, d.sc_factor, d.white_bkgd = float(trunc), float(sc_factor), int(bool(white_bkgd))
+        self.desc = d
+        self._h = C.c_void_p()
+        check(lib.naruto_field_create(C.byref(d), C.byref(self._h)), "naruto_field_create")
+        self.n_levels = n_levels
+        self.n_entries = int(lib.naruto_field_n_entries(self._h))
+        self.n_params = self.n_entries * n_features
+        self.uncert_dims = tuple(int(v) for v in uncert_dims)
+
+    @property
+    def ptr(self) -> C.c_void_p:
+        return self._h
+
+    def levels(self):
+        lib = _lib.load()
+        L = self.n_levels
+        scale = (C.c_float * L)()
+        res = (C.c_uint32 * L)()
+        size = (C.c_uint32 * L)()
+        off = (C.c_uint32 * (L + 1))()
+        check(lib.naruto_field_levels(self._h, scale, res, size, off), "naruto_field_levels")
+        return list(scale), list(res), list(size), list(off)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                _lib.load().naruto_field_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+
+def _params_struct(params: Dict[str, torch.Tensor]) -> NarutoParams:
+    s = NarutoParams()
+    for n in PARAM_NAMES:
+        setattr(s, n, _p(params.get(n)))
+    return s
+
+
+def _points_struct(x, rays_o, rays_d, z_vals) -> Tuple[NarutoPoints, int]:
+    s = NarutoPoints()
+    if x is not None:
+        s.x = _p(x)
+        return s, x.shape[0]
+    s.rays_o, s.rays_d, s.z_vals = _p(rays_o), _p(rays_d), _p(z_vals)
+    s.n_samples = z_vals.shape[1]
+    return s, z_vals.shape[0] * z_vals.shape[1]
+
+
+# ---------------------------------------------------------------------------------------------------
+# A1
+# ---------------------------------------------------------------------------------------------------
+def sample_z(n_rays: int, target_d: Optional[torch.Tensor], near: float, far: float, n_samples_d: int, n_range_d: int,
+             range_d: float, n_samples: int = 0, rand: Optional[torch.Tensor] = None, device=None) -> torch.Tensor:
+    lib = _lib.load()
+    if target_d is not None:
+        target_d = _f32c(target_d, "target_d").reshape(-1)
+        device = target_d.device
+        S = n_samples_d + n_range_d
+    else:
+        S = n_samples
+    z = torch.empty(n_rays, S, dtype=torch.float32, device=device)
+    if rand is not None:
+        rand = _f32c(rand, "rand")
+        assert rand.shape == (n_rays, S)
+    with torch.cuda.device(z.device):
+        check(lib.naruto_sample_z(n_rays, _p(target_d), near, far, n_samples_d, n_range_d, range_d, n_samples, _p(rand),
+                                  _p(z), _stream()), "naruto_sample_z")
+    return z
+
+
+# ---------------------------------------------------------------------------------------------------
+# A3 alone: embed_fn(x)
+# ---------------------------------------------------------------------------------------------------
+class _HashEncode(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, handle: FieldHandle, x: torch.Tensor, table: torch.Tensor):
+        lib = _lib.load()
+        x = _f32c(x, "x")
+        table = _f32c(table, "table")
+        M = x.shape[0]
+        feat = torch.empty(M, 32, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            check(lib.naruto_hash_encode_fwd(handle.ptr, M, _p(x), _p(table), _p(feat), _stream()), "naruto_hash_encode_fwd")
+        ctx.handle = handle
+        ctx.save_for_backward(x, table)
+        return feat
+
+    @staticmethod
+    def backward(ctx, d_feat):
+        lib = _lib.load()
+        x, table = ctx.saved_tensors
+        d_table = None
+        if ctx.needs_input_grad[2]:
+            d_feat = _f32c(d_feat, "d_feat")
+            d_table = torch.zeros_like(table)
+            with torch.cuda.device(x.device):
+                check(lib.naruto_hash_encode_bwd(ctx.handle.ptr, x.shape[0], _p(x), _p(d_feat), _p(d_table), _stream()),
+                      "naruto_hash_encode_bwd")
+        return None, None, d_table
+
+
+def hash_encode(handle: FieldHandle, x: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+    return _HashEncode.apply(handle, x, table)
+
+
+# ---------------------------------------------------------------------------------------------------
+# A2-A5 fused
+# ---------------------------------------------------------------------------------------------------
+class _FieldQuery(torch.autograd.Function):
+    """raw (or sdf_uncert) [, geo] = field(points).  Gradients flow to the six parameter tensors only
+    (the reference never differentiates w.r.t. the query points: tracking is disabled in every config)."""
+
+    @staticmethod
+    def forward(ctx, handle, color, want_geo, x, rays_o, rays_d, z_vals, table, uncert_grid, sdf_w0, sdf_w1, col_w0, col_w1):
+        lib = _lib.load()
+        params = {"table": table, "uncert_grid": uncert_grid, "sdf_w0": sdf_w0, "sdf_w1": sdf_w1, "col_w0": col_w0,
+                  "col_w1": col_w1}
+        params = {k: _f32c(v, k) for k, v in params.items()}
+        if x is not None:
+            x = _f32c(x, "x")
+            dev = x.device
+        else:
+            rays_o, rays_d, z_vals = _f32c(rays_o, "rays_o"), _f32c(rays_d, "rays_d"), _f32c(z_vals, "z_vals")
+            dev = z_vals.device
+        pts, M = _points_struct(x, rays_o, rays_d, z_vals)
+        need_grad = any(ctx.needs_input_grad[7:])
+        out = torch.empty(M, 5 if color else 2, dtype=torch.float32, device=dev)
+        geo = torch.empty(M, 15, dtype=torch.float32, device=dev) if want_geo else None
+        feat = torch.empty(16, M, 2, dtype=torch.float32, device=dev) if need_grad else None
+        ps = _params_struct(params)
+        with torch.cuda.device(dev):
+            check(lib.naruto_query_fwd(handle.ptr, C.byref(ps), M, C.byref(pts), _p(out) if color else None,
+                                       None if color else _p(out), _p(geo), _p(feat), _stream()), "naruto_query_fwd")
+        ctx.handle, ctx.color, ctx.want_geo, ctx.M = handle, color, want_geo, M
+        ctx.has_x = x is not None
+        if need_grad:
+            ctx.save_for_backward(feat, *(t for t in (x, rays_o, rays_d, z_vals) if t is not None),
+                                  *(params[k] for k in PARAM_NAMES))
+        if want_geo:
+            return out, geo
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out, d_geo=None):
+        lib = _lib.load()
+        saved = ctx.saved_tensors
+        feat = saved[0]
+        if ctx.has_x:
+            x, rays_o, rays_d, z_vals = saved[1], None, None, None
+            rest = saved[2:]
+        else:
+            x = None
+            rays_o, rays_d, z_vals = saved[1:4]
+            rest = saved[4:]
+        params = dict(zip(PARAM_NAMES, rest))
+        M = ctx.M
+        dev = feat.device
+        d_out = _f32c(d_out, "d_out") if d_out is not None else None
+        if ctx.color:
+            d_raw = d_out if d_out is not None else torch.zeros(M, 5, dtype=torch.float32, device=dev)
+        else:
+            d_raw = torch.zeros(M, 5, dtype=torch.float32, device=dev)
+            if d_out is not None:
+                d_raw[:, 3:5] = d_out
+        if d_geo is not None:
+            d_geo = _f32c(d_geo, "d_geo")
+        grads = {}
+        for i, n in enumerate(PARAM_NAMES):
+            grads[n] = torch.zeros_like(params[n]) if ctx.needs_input_grad[7 + i] else None
+        gs = NarutoGrads()
+        for n in PARAM_NAMES:
+            setattr(gs, n, _p(grads[n]))
+        ps = _params_struct(params)
+        pts, _ = _points_struct(x, rays_o, rays_d, z_vals)
+        with torch.cuda.device(dev):
+            ws_bytes = lib.naruto_query_bwd_workspace(ctx.handle.ptr, M)
+            ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
+            check(lib.naruto_query_bwd(ctx.handle.ptr, C.byref(ps), M, C.byref(pts), _p(feat), _p(d_raw), _p(d_geo),
+                                       C.byref(gs), _p(ws), _stream()), "naruto_query_bwd")
+        return (None, None, None, None, None, None, None) + tuple(grads[n] for n in PARAM_NAMES)
+
+
+def field_query(handle: FieldHandle, params: Dict[str, torch.Tensor], *, x=None, rays_o=None, rays_d=None, z_vals=None,
+                color: bool = True, want_geo: bool = False):
+    return _FieldQuery.apply(handle, color, want_geo, x, rays_o, rays_d, z_vals, *(params[n] for n in PARAM_NAMES))
+
+
+# ---------------------------------------------------------------------------------------------------
+# A6 + A7
+# ---------------------------------------------------------------------------------------------------
+class _Composite(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, handle, raw, z_vals):
+        lib = _lib.load()
+        raw, z_vals = _f32c(raw, "raw"), _f32c(z_vals, "z_vals")
+        N, S = z_vals.shape
+        dev = raw.device
+        rgb = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        disp, acc, depth, depth_var, um = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(5))
+        weights = torch.empty(N, S, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.naruto_composite_fwd(handle.ptr, N, S, _p(raw), _p(z_vals), _p(rgb), _p(disp), _p(acc), _p(weights),
+                                           _p(depth), _p(depth_var), _p(um), _stream()), "naruto_composite_fwd")
+        ctx.handle = handle
+        ctx.save_for_backward(raw, z_vals)
+        return rgb, disp, acc, weights, depth, depth_var, um
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_disp, d_acc, d_weights, d_depth, d_depth_var, d_um):
+        lib = _lib.load()
+        raw, z_vals = ctx.saved_tensors
+        N, S = z_vals.shape
+        cots = [None if g is None else _f32c(g, "cotangent") for g in (d_rgb, d_disp, d_acc, d_weights, d_depth, d_depth_var, d_um)]
+        d_raw = torch.empty_like(raw)
+        with torch.cuda.device(raw.device):
+            check(lib.naruto_composite_bwd(ctx.handle.ptr, N, S, _p(raw), _p(z_vals), *(_p(c) for c in cots), _p(d_raw), 0,
+                                           _stream()), "naruto_composite_bwd")
+        return None, d_raw, None
+
+
+def composite(handle: FieldHandle, raw: torch.Tensor, z_vals: torch.Tensor):
+    """-> rgb_map, disp_map, acc_map, weights, depth_map, depth_var, uncert_map (raw2outputs order)."""
+    return _Composite.apply(handle, raw, z_vals)
+
+
+# ---------------------------------------------------------------------------------------------------
+# A8: composite + losses in one autograd node
+# ---------------------------------------------------------------------------------------------------
+class _RenderLoss(torch.autograd.Function):
+    """(raw, z_vals, targets) -> render outputs + losses[8].
+
+    losses = [rgb_loss, depth_loss, sdf_loss, fs_loss, psnr, uncert_loss, min(uncert_map), n_valid_depth].
+    ``group``: optional torch.distributed process group; the loss sums are all-reduced over it so every
+    rank normalises by the GLOBAL ray / sample counts (data-parallel ray sharding);
+    ``n_rays_total``: rays over all ranks (0 = this rank's count x world size)."""
+
+    @staticmethod
+    def forward(ctx, handle, raw, z_vals, target_rgb, target_d, depth_trunc, rgb_missing, group, n_rays_total):
+        lib = _lib.load()
+        raw, z_vals = _f32c(raw, "raw"), _f32c(z_vals, "z_vals")
+        target_rgb, target_d = _f32c(target_rgb, "target_rgb"), _f32c(target_d, "target_d").reshape(-1)
+        N, S = z_vals.shape
+        dev = raw.device
+        rgb = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        disp, acc, depth, depth_var, um = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(5))
+        sums = torch.empty(_lib.LOSS_NSUMS, dtype=torch.float64, device=dev)
+        losses = torch.empty(8, dtype=torch.float32, device=dev)
+        n_total = N
+        with torch.cuda.device(dev):
+            st = _stream()
+            check(lib.naruto_composite_fwd(handle.ptr, N, S, _p(raw), _p(z_vals), _p(rgb), _p(disp), _p(acc), None, _p(depth),
+                                           _p(depth_var), _p(um), st), "naruto_composite_fwd")
+            ws = torch.empty(lib.naruto_loss_workspace(N) // 4, dtype=torch.float32, device=dev)
+            check(lib.naruto_loss_sums(handle.ptr, N, S, _p(raw), _p(z_vals), _p(rgb), _p(depth), _p(um), _p(target_rgb),
+                                       _p(target_d), depth_trunc, rgb_missing, _p(sums), _p(ws), st), "naruto_loss_sums")
+            if group is not None:
+                from . import parallel
+                parallel.allreduce_loss_sums(sums, group)
+                n_total = int(n_rays_total) if n_rays_total else N * parallel.world_size(group)
+            check(lib.naruto_loss_finalize(_p(sums), n_total, S, _p(losses), st), "naruto_loss_finalize")
+        ctx.handle, ctx.depth_trunc, ctx.rgb_missing, ctx.n_total = handle, depth_trunc, rgb_missing, n_total
+        ctx.save_for_backward(raw, z_vals, target_rgb, target_d, sums)
+        ctx.mark_non_differentiable(disp, acc, depth_var, um)
+        return rgb, depth, disp, acc, depth_var, um, losses
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_depth, _d_disp, _d_acc, _d_var, _d_um, d_losses):
+        lib = _lib.load()
+        raw, z_vals, target_rgb, target_d, sums = ctx.saved_tensors
+        N, S = z_vals.shape
+        dev = raw.device
+        d_raw = torch.empty_like(raw)
+        if d_losses is None:
+            d_losses = torch.zeros(8, dtype=torch.float32, device=dev)
+        d_losses = _f32c(d_losses, "d_losses")
+        with torch.cuda.device(dev):
+            st = _stream()
+            check(lib.naruto_loss_bwd(ctx.handle.ptr, N, S, _p(raw), _p(z_vals), _p(target_rgb), _p(target_d), ctx.depth_trunc,
+                                      ctx.rgb_missing, _p(sums), ctx.n_total, _p(d_losses), _p(d_raw), st), "naruto_loss_bwd")
+            if d_rgb is not None or d_depth is not None:       # someone differentiated the rendered rgb / depth too
+                d_rgb = None if d_rgb is None else _f32c(d_rgb, "d_rgb")
+                d_depth = None if d_depth is None else _f32c(d_depth, "d_depth")
+                check(lib.naruto_composite_bwd(ctx.handle.ptr, N, S, _p(raw), _p(z_vals), _p(d_rgb), None, None, None, _p(d_depth),
+                                               None, None, _p(d_raw), 1, st), "naruto_composite_bwd")
+        return None, d_raw, None, None, None, None, None, None, None
+
+
+def render_loss(handle: FieldHandle, raw, z_vals, target_rgb, target_d, depth_trunc: float, rgb_missing: float, group=None,
+                n_rays_total: int = 0):
+    return _RenderLoss.apply(handle, raw, z_vals, target_rgb, target_d, float(depth_trunc), float(rgb_missing), group,
+                             int(n_rays_total))
+
+
+# ---------------------------------------------------------------------------------------------------
+# A10 helper
+# ---------------------------------------------------------------------------------------------------
+def adam_step_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, *, lr: float,
+               betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, step: int) -> None:
+    lib = _lib.load()
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+    with torch.cuda.device(param.device):
+        check(lib.naruto_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, betas[0], betas[1], eps,
+                                   weight_decay, step, _stream()), "naruto_adam_step")

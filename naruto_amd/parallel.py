@@ -1,0 +1,96 @@
+"""Data-parallel mapping over the GPUs of one node: ray-batch sharding, one process per GPU.
+
+The reference is single-process / single-GPU (reference scripts/naruto/run_replica.sh:14); the only
+parallelism the path offers is over independent rays.  Every rank holds a full
+replica of the parameters (hash table 6.5 MB, MLPs, uncertainty grid) and its own Adam state; one mapping
+iteration exchanges exactly two things over RCCL (torch.distributed backend "nccl" on ROCm):
+
+  1. the 16-slot fp64 vector of loss sums, BETWEEN forward and backward -- the mapping losses are
+     normalised by GLOBAL counts (n_fs, n_sdf, n_valid, N: Co-SLAM get_masks, scene_rep.py:246-285), so
+     each rank must scale its cotangents by the global denominators;
+  2. the gradients, as ONE flat fp32 buffer (1 729 400 floats for office0), summed.
+
+With (1) in place the sum over ranks of the per-rank gradients equals the single-process gradient of the
+whole batch, so every rank then takes the identical Adam step (no parameter broadcast).
+
+The functions here are backend-agnostic (they work on CPU tensors over gloo as well), which is what the
+world_size-2 CPU tests exercise.
+"""
+
+from __future__ import annotations
+
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+LOSS_SLOT_MINUNCERT = 9
+
+
+def world_size(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank(group=None) -> int:
+    return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+
+
+def shard_bounds(n_items: int, rank_: int, world: int) -> Tuple[int, int]:
+    """Contiguous split of n_items over ranks; the first (n_items % world) ranks get one extra item."""
+    base, extra = divmod(n_items, world)
+    lo = rank_ * base + min(rank_, extra)
+    return lo, lo + base + (1 if rank_ < extra else 0)
+
+
+def shard_rays(tensors: Sequence[torch.Tensor], rank_: int, world: int) -> List[torch.Tensor]:
+    lo, hi = shard_bounds(tensors[0].shape[0], rank_, world)
+    return [t[lo:hi] for t in tensors]
+
+
+def allreduce_loss_sums(sums: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place all-reduce of the loss sums: SUM everywhere except the min(uncert_map) slot (MIN)."""
+    if world_size(group) == 1:
+        return sums
+    mn = sums[LOSS_SLOT_MINUNCERT].clone()
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=group)
+    sums[LOSS_SLOT_MINUNCERT] = mn
+    return sums
+
+
+def allreduce_grads(params: Iterable[torch.nn.Parameter], group=None, flat: Optional[torch.Tensor] = None) -> None:
+    """Sum the .grad of all parameters over ranks through one flat bucket (one collective per step)."""
+    if world_size(group) == 1:
+        return
+    ps = [p for p in params if p.grad is not None]
+    if not ps:
+        return
+    n = sum(p.grad.numel() for p in ps)
+    if flat is None or flat.numel() != n or flat.device != ps[0].grad.device:
+        flat = torch.empty(n, dtype=ps[0].grad.dtype, device=ps[0].grad.device)
+    off = 0
+    for p in ps:
+        k = p.grad.numel()
+        flat[off:off + k].copy_(p.grad.reshape(-1))
+        off += k
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for p in ps:
+        k = p.grad.numel()
+        p.grad.copy_(flat[off:off + k].view_as(p.grad))
+        off += k
+
+
+def init_from_env(backend: Optional[str] = None):
+    """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
+    import os
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return None
+    if not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend=backend)
+    return dist.group.WORLD

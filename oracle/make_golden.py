@@ -228,11 +228,11 @@ def case_composite_edges(name, seed):
         res["out_" + k] = a.detach().numpy()
     # gradient of a fixed linear functional of the outputs wrt raw
     cot = {k: rs.normal(size=tuple(a.shape)).astype(np.float32) for k, a in zip(names, outs)}
-    cot["disp_map"] *= 0.0                                  # 1/x blows up on near-empty rays; not differentiated in use
-    cot["weights"] *= 0.0
-    cot["acc_map"] *= 0.0
-    cot["depth_var"] *= 0.0
-    total = sum((torch.from_numpy(cot[k]) * a).sum() for k, a in zip(names, outs))
+    # the cotangents the reference's losses produce: rgb, depth, uncert_map.  (disp is NaN on the empty
+    # ray -- 0/0 -- and must not enter the functional at all: 0 * NaN poisons autograd.)
+    for k in ("disp_map", "weights", "acc_map", "depth_var"):
+        cot[k] *= 0.0
+    total = sum((torch.from_numpy(cot[k]) * a).sum() for k, a in zip(names, outs) if k in ("rgb", "depth", "uncert_map"))
     total.backward()
     res["grad_raw"] = rt.grad.numpy()
     for k in names:

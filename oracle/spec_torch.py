@@ -33,6 +33,8 @@ What is restated, and where it comes from (paths under /root/reference):
 
 from __future__ import annotations
 
+import ctypes
+import ctypes.util
 import math
 from typing import Dict, Optional
 
@@ -40,6 +42,13 @@ import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+# tcnn derives the level tables with the C float functions std::log2(float) / exp2f / ceilf; use the very
+# same libm entry points so that the restatement does not depend on numpy's own exp2 rounding.
+_libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+for _fn in ("exp2f", "log2f", "ceilf"):
+    getattr(_libm, _fn).restype = ctypes.c_float
+    getattr(_libm, _fn).argtypes = [ctypes.c_float]
 
 # tiny-cuda-nn coherent_prime_hash primes (grid.h) -- first is 1 for memory coherence
 HASH_PRIMES = (1, 2654435761, 805459861)
@@ -60,13 +69,13 @@ class HashGridMeta:
         self.base_resolution = int(base_resolution)
         # tcnn reads per_level_scale into a float and takes std::log2 of that float
         self.per_level_scale = np.float32(per_level_scale)
-        self.log2_per_level_scale = np.float32(np.log2(self.per_level_scale))
+        self.log2_per_level_scale = np.float32(_libm.log2f(float(self.per_level_scale)))
         scales, ress, sizes, offsets = [], [], [], [0]
         for lvl in range(self.n_levels):
             # grid_scale(): exp2f(level * log2_pls) * base - 1
-            scale = np.float32(np.exp2(np.float32(lvl) * self.log2_per_level_scale)
+            scale = np.float32(np.float32(_libm.exp2f(float(np.float32(lvl) * self.log2_per_level_scale)))
                                * np.float32(self.base_resolution) - np.float32(1.0))
-            res = int(math.ceil(float(scale))) + 1            # grid_resolution()
+            res = int(_libm.ceilf(float(scale))) + 1          # grid_resolution()
             max_params = (2 ** 32 - 1) // 2
             dense = res ** 3
             params = max_params if float(res) ** 3 > float(max_params) else dense
@@ -120,7 +129,8 @@ def hash_encode(x: torch.Tensor, table: torch.Tensor, meta: HashGridMeta) -> tor
     outs = []
     for lvl in range(meta.n_levels):
         scale = float(meta.scale[lvl])
-        pos = x * scale + 0.5                       # fmaf(scale, x, 0.5f)
+        # fmaf(scale, x, 0.5f): product and sum are exact in fp64, one rounding to fp32
+        pos = (x.double() * scale + 0.5).to(x.dtype)
         g = torch.floor(pos)
         w = pos - g                                 # fractional part, identity interpolation
         gi = g.to(torch.int64) & U32                # (uint32_t)(int)floorf

@@ -75,7 +75,7 @@ def test_sample_z(gpu, n_samples_d, perturb):
                       rand=None if rand is None else torch.from_numpy(rand))
     got = ops.sample_z(n, torch.from_numpy(td).to(gpu), 0.0, 5.0, n_samples_d, 11, 0.1,
                        rand=None if rand is None else torch.from_numpy(rand).to(gpu))
-    H.assert_close(got, want, 2e-6, "z_vals")
+    H.assert_close(got, want, 2e-6, "z_vals", rel=5e-7)
     if perturb == 0:
         assert bool((got[:, 1:] >= got[:, :-1]).all()), "z_vals must be sorted"
 
@@ -125,7 +125,7 @@ def test_hash_encode_vs_oracle(gpu, kind):
     scale, res, size, off = m._handle().levels()
     assert np.array_equal(np.asarray(res), ora.meta.resolution) and np.array_equal(np.asarray(size), ora.meta.size)
     assert np.array_equal(np.asarray(off), ora.meta.offset)
-    np.testing.assert_allclose(np.asarray(scale), ora.meta.scale, rtol=3e-7)
+    assert np.array_equal(np.asarray(scale, np.float32), ora.meta.scale)
     rs = np.random.RandomState(5)
     x = np.concatenate([rs.uniform(0, 1, size=(3000, 3)), rs.uniform(-0.7, 1.7, size=(1000, 3)),
                         np.array([[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5], [1, 0, 1]])]).astype(np.float32)
@@ -147,7 +147,8 @@ def test_composite_edges_golden(gpu):
     names = ("rgb", "disp_map", "acc_map", "weights", "depth", "depth_var", "uncert_map")
     for k, o in zip(names, outs):
         H.assert_close(o, g["out_" + k], TOL_OUT, f"composite.{k}", rel=1e-5)
-    total = sum((torch.from_numpy(g["cot_" + k]).to(gpu) * o).sum() for k, o in zip(names, outs))
+    total = sum((torch.from_numpy(g["cot_" + k]).to(gpu) * o).sum() for k, o in zip(names, outs)
+                if k in ("rgb", "depth", "uncert_map"))
     total.backward()
     grad_close(raw.grad, g["grad_raw"], "composite.grad_raw")
 
@@ -328,7 +329,7 @@ def test_full_size_properties(gpu):
     pts = t["rays_o"][:, None, :] + t["rays_d"][:, None, :] * r1["z_vals"][..., None]
     with torch.no_grad():
         raw2 = m.run_network(pts)
-    H.assert_close(raw2, r1["raw"], 2e-5, "run_network(pts) vs fused ray path")
+    H.assert_close(raw2, r1["raw"], TOL_OUT, "run_network(pts) vs fused ray path")
     # splitting the batch changes nothing (bitwise): tiles are independent
     with torch.no_grad():
         a = m.query_color_sdf(pts.reshape(-1, 3)[:100000])

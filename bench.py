@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rendered rays/s of one NARUTO mapping iteration ("train step") on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): Replica office_0 volume, 2048 rays x 128 samples per GPU, hash grid
+L=16 F=2 T=2^16, MLPs 2x32, uncertainty grid on; synthetic rays (seeded), random-init weights.
+One step = the iteration body of the reference's global_BA (reference src/slam/coslam/coslam.py:361-399):
+zero_grad -> forward (z sampling with jitter, hash gather, MLPs, compositing, uncertainty aggregation,
+five losses + smoothness term) -> backward -> Adam on decoder + hash table (+ uncertainty-grid Adam every
+5th iteration).  N > 1: one process per GPU, every rank renders its own 2048-ray shard of a 2048*N batch
+(weak scaling), the loss sums and the flat gradient are all-reduced over RCCL.
+
+Prints ONE JSON line on rank 0 (see the driver contract) with two extra objects:
+  roofline     -- the dominant kernel's algorithmic rate against the roof that bounds it, from HIP events on
+                  the launch stream around K launches of that kernel (the per-kernel table is in "kernels");
+  cpu_baseline -- the oracle's (CPU PyTorch restatement, oracle/spec_torch.py) identical mapping iteration on
+                  this host's cores, on a bounded sample.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from naruto_amd import config as C  # noqa: E402
+from naruto_amd import parallel, synthetic as syn  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP32_MFMA_PEAK_TF = 157.3      # v_mfma_f32_32x32x2_f32 peak = fp32 vector peak
+
+
+def workload(name: str):
+    if name == "office0_2048x128":
+        return C.office0_config(perturb=1.0, n_samples_d=117), 2048
+    if name == "office0_2048x43":
+        return C.office0_config(perturb=1.0), 2048
+    if name == "mp3d_2048x256":
+        return C.mp3d_large_config(perturb=1.0, n_samples_d=245), 2048
+    if name == "office0_8192x43":
+        return C.office0_config(perturb=1.0), 8192
+    raise SystemExit(f"unknown workload {name}")
+
+
+def events_ms(fn, iters: int) -> float:
+    """Average duration of fn() in ms, HIP events on the current (= launch) stream."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def kernel_table(tr, rays, cfg, iters: int):
+    """Per-kernel average durations + algorithmic work, each measured alone on the launch stream."""
+    import ctypes as CT
+    from naruto_amd import _lib, ops
+    lib = _lib.load()
+    m = tr.model
+    h = m._handle()
+    dev = rays["rays_o"].device
+    N = rays["rays_o"].shape[0]
+    trc, cam = cfg["training"], cfg["cam"]
+    S = trc["n_samples_d"] + trc["n_range_d"]
+    M = N * S
+    rand = torch.rand(N, S, device=dev)
+    z = ops.sample_z(N, rays["target_d"], float(cam["near"]), float(cam["far"]), trc["n_samples_d"], trc["n_range_d"],
+                     float(trc["range_d"]), rand=rand)
+    params = {k: v.detach() for k, v in m._params().items()}
+    ps = ops._params_struct(params)
+    pts, _ = ops._points_struct(None, rays["rays_o"], rays["rays_d"], z)
+    raw = torch.empty(M, 5, device=dev)
+    feat = torch.empty(16, M, 2, device=dev)
+    st = lambda: ops._stream()
+    p = ops._p
+    rows = []
+
+    def add(name, fn, bytes_, flops, bound):
+        ms = events_ms(fn, iters)
+        rows.append({"kernel": name, "ms": round(ms, 5), "alg_bytes": int(bytes_), "alg_flops": int(flops),
+                     "GBps": round(bytes_ / ms / 1e6, 1), "TFLOPs": round(flops / ms / 1e9, 3), "bound": bound})
+
+    # algorithmic work per sample: 16 levels x 8 corners x 8 B gathered + 32 B uncert corners
+    gather = 16 * 8 * 8 + 32
+    mlp_fwd = 2 * (80 * 32 + 32 * 16 + 63 * 32 + 32 * 3)          # 10 368 FLOP
+    add("k_sample_z", lambda: _lib.check(lib.naruto_sample_z(N, p(rays["target_d"]), float(cam["near"]), float(cam["far"]),
+        trc["n_samples_d"], trc["n_range_d"], float(trc["range_d"]), 0, p(rand), p(z), st())), N * S * 8 + N * 4, 0, "hbm")
+    add("k_query_fwd<color>", lambda: _lib.check(lib.naruto_query_fwd(h.ptr, CT.byref(ps), M, CT.byref(pts), p(raw), None, None,
+        p(feat), st())), M * (gather + 4 + 20 + 128) + N * 24, M * mlp_fwd, "hbm")
+    rgb = torch.empty(N, 3, device=dev)
+    outs = [torch.empty(N, device=dev) for _ in range(5)]
+    add("k_composite_fwd", lambda: _lib.check(lib.naruto_composite_fwd(h.ptr, N, S, p(raw), p(z), p(rgb), p(outs[0]), p(outs[1]), None,
+        p(outs[2]), p(outs[3]), p(outs[4]), st())), M * 24 + N * 32, 0, "hbm")
+    sums = torch.empty(16, dtype=torch.float64, device=dev)
+    ws = torch.empty(N * 16, device=dev)
+    tgt, td = rays["target_rgb"], rays["target_d"].reshape(-1)
+    add("k_loss_terms+reduce", lambda: _lib.check(lib.naruto_loss_sums(h.ptr, N, S, p(raw), p(z), p(rgb), p(outs[2]), p(outs[4]), p(tgt), p(td),
+        float(cam["depth_trunc"]), float(trc["rgb_missing"]), p(sums), p(ws), st())), M * 8 + N * 100, 0, "hbm")
+    gl = torch.tensor([trc["rgb_weight"], trc["depth_weight"], trc["sdf_weight"], trc["fs_weight"], 0.0, trc["uncert_weight"]],
+                      dtype=torch.float32, device=dev)
+    d_raw = torch.empty(M, 5, device=dev)
+    add("k_composite_bwd<loss>", lambda: _lib.check(lib.naruto_loss_bwd(h.ptr, N, S, p(raw), p(z), p(tgt), p(td), float(cam["depth_trunc"]),
+        float(trc["rgb_missing"]), p(sums), N, p(gl), p(d_raw), st())), M * 44 + N * 20, 0, "hbm")
+    grads = {k: torch.zeros_like(v) for k, v in params.items()}
+    gs = _lib.NarutoGrads()
+    for k, v in grads.items():
+        setattr(gs, k, p(v))
+    wsb = torch.empty(lib.naruto_query_bwd_workspace(h.ptr, M) // 4, device=dev)
+    # the three kernels of naruto_query_bwd, split by giving each call only the outputs one kernel produces
+    gs_mlp = _lib.NarutoGrads()
+    for k in ("uncert_grid", "sdf_w0", "sdf_w1", "col_w0", "col_w1"):
+        setattr(gs_mlp, k, p(grads[k]))
+    mlp_bwd_flops = M * 2 * (5184 + (15 * 32 + 16 * 32 + 32 * 32 + 3 * 32) + 5184)    # recompute + dgrad + wgrad
+    add("k_query_bwd+k_wgrad_reduce", lambda: _lib.check(lib.naruto_query_bwd(h.ptr, CT.byref(ps), M, CT.byref(pts), p(feat), p(d_raw), None,
+        CT.byref(gs_mlp), p(wsb), st())), M * (128 + 20 + 128 + 4) + N * 24, mlp_bwd_flops, "mfma")
+    t_mlp = rows[-1]["ms"]
+    ms_all = events_ms(lambda: _lib.check(lib.naruto_query_bwd(h.ptr, CT.byref(ps), M, CT.byref(pts), p(feat), p(d_raw), None, CT.byref(gs),
+                                                               p(wsb), st())), iters)
+    sc_bytes = M * (16 * 8 * 2 * 8 + 128 + 4)          # 256 fp32 atomic read-modify-writes + d_feat + point
+    ms_sc = max(ms_all - t_mlp, 1e-6)
+    rows.append({"kernel": "k_hash_scatter", "ms": round(ms_sc, 5), "alg_bytes": int(sc_bytes), "alg_flops": 0,
+                 "GBps": round(sc_bytes / ms_sc / 1e6, 1), "TFLOPs": 0.0, "bound": "hbm"})
+    return rows
+
+
+def cpu_baseline(cfg, n_rays: int, iters: int):
+    """The oracle's mapping iteration (CPU PyTorch), same body, on a bounded sample."""
+    from oracle import spec_torch as S
+    torch.manual_seed(0)
+    bbox = torch.tensor(cfg["mapping"]["bound"], dtype=torch.float32)
+    ora = S.OracleField(cfg, bbox, 0.1)
+    g1, g2 = ora.param_groups()
+    o_map = torch.optim.Adam(g1, betas=(0.9, 0.99))
+    o_unc = torch.optim.Adam(g2, lr=1)
+    rays = {k: torch.from_numpy(v) for k, v in syn.random_rays(n_rays, cfg["mapping"]["bound"], seed=0).items()}
+    trc = cfg["training"]
+    ora.train()
+
+    def step(i):
+        o_map.zero_grad()
+        ret = ora.forward(rays["rays_o"], rays["rays_d"], rays["target_rgb"], rays["target_d"])
+        sm = S.smoothness(ora, trc["smooth_pts"], trc["smooth_vox"], trc["smooth_margin"], torch.rand(3), torch.rand(3))
+        S.total_loss(ret, trc, smooth_term=sm).backward()
+        o_map.step()
+        if (i + 1) % 5 == 0:
+            o_unc.step()
+            o_unc.zero_grad()
+
+    step(0)
+    t0 = time.perf_counter()
+    for i in range(iters):
+        step(i + 1)
+    dt = (time.perf_counter() - t0) / iters
+    S_tot = trc["n_samples_d"] + trc["n_range_d"]
+    return {"value": round(n_rays / dt, 1), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{iters} mapping iterations of {n_rays} rays x {S_tot} samples after 1 warm-up (oracle/spec_torch.py, "
+                      f"forward+losses+smoothness+backward+Adam), {dt * 1e3:.0f} ms/iter"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="office0_2048x128")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernels", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=4)
+    args = ap.parse_args()
+
+    group = parallel.init_from_env("nccl") if args.gpus > 1 else None
+    world, rank = parallel.world_size(group), parallel.rank(group)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE is {world}"
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    cfg, n_rays = workload(args.workload)
+    from naruto_amd.trainer import MappingTrainer
+    torch.manual_seed(0)                                     # identical replicas on every rank
+    tr = MappingTrainer(cfg, torch.tensor(cfg["mapping"]["bound"], dtype=torch.float32), dev, 0.1, group=group)
+    n_total = n_rays * world
+    all_rays = syn.random_rays(n_total, cfg["mapping"]["bound"], seed=0)
+    lo, hi = parallel.shard_bounds(n_total, rank, world)
+    rays = {k: torch.from_numpy(v[lo:hi]).to(dev) for k, v in all_rays.items()}
+
+    def step():
+        tr.step(rays["rays_o"], rays["rays_d"], rays["target_rgb"], rays["target_d"], smooth=True, n_rays_total=n_total)
+
+    for _ in range(args.warmup):
+        step()
+    tr.model.check_asserts()
+    if group is not None:
+        torch.distributed.barrier(group)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if group is not None:
+        torch.distributed.barrier(group)
+    dt = time.perf_counter() - t0
+    if group is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
+        dt = float(t.item())
+    tr.model.check_asserts()
+
+    if rank == 0:
+        trc = cfg["training"]
+        S_tot = trc["n_samples_d"] + trc["n_range_d"]
+        ms = dt / args.steps * 1e3
+        out = {
+            "metric": "rendered rays/sec (train step), Replica office_0",
+            "value": round(n_total * args.steps / dt, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: office_0 bbox, {n_rays} rays x {S_tot} samples per GPU, hash L16 F2 T2^16, "
+                                   "MLP 2x32, uncert grid; one global_BA mapping iteration incl. smoothness + Adam",
+                       "rays_per_gpu": n_rays, "samples_per_ray": S_tot, "parallelism": f"ray-sharded dp{world}"},
+        }
+        if not args.no_kernels:
+            rows = kernel_table(tr, rays, cfg, max(10, args.steps))
+            dom = max(rows, key=lambda r: r["ms"])
+            if dom["bound"] == "mfma":
+                roof = {"bound": "mfma", "achieved": dom["TFLOPs"], "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": round(dom["TFLOPs"] / FP32_MFMA_PEAK_TF, 4), "traffic": None}
+            else:
+                roof = {"bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": None}
+            roof["kernel"] = dom["kernel"]
+            roof["kernel_ms"] = dom["ms"]
+            out["roofline"] = roof
+            out["kernels"] = rows
+            out["kernels_ms_sum"] = round(sum(r["ms"] for r in rows), 4)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, n_rays, args.cpu_iters)
+        print(json.dumps(out), flush=True)
+    if group is not None:
+        torch.distributed.barrier(group)
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

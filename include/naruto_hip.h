@@ -107,9 +107,11 @@ int naruto_sample_z(uint32_t n_rays, const float* target_d, float near_, float f
 /* A3 alone -- embed_fn(x): query_sdf(embed=True), scene_rep.py:109-111.  feat [M,32] level-major. */
 int naruto_hash_encode_fwd(const NarutoField* f, uint32_t M, const float* x, const float* table,
                            float* feat, void* stream);
-/* its backward (tcnn HashGrid backward): d_table += scatter(d_feat). */
+/* its backward (tcnn HashGrid backward): d_table += scatter(d_feat).
+ * workspace: naruto_scatter_workspace(f) bytes (per-split partial tables of the LDS-tiled scatter). */
+size_t naruto_scatter_workspace(const NarutoField* f);
 int naruto_hash_encode_bwd(const NarutoField* f, uint32_t M, const float* x, const float* d_feat,
-                           float* d_table, void* stream);
+                           float* d_table, void* workspace, void* stream);
 
 /* A2-A5 fused -- calc_embedding + embedpos_fn + decoder (scene_rep.py:58-64,132-148, decoder.py:29-41,
  * 99-116).  Outputs (any may be NULL):

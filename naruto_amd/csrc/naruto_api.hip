@@ -2,6 +2,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -18,6 +19,7 @@ struct NarutoField {
     uint32_t offset[NARUTO_MAX_LEVELS + 1];
     uint64_t n_entries;
     int n_cu;
+    ScatterPlan plan;
 };
 
 namespace {
@@ -39,7 +41,7 @@ int check_launch(const char* what) {
 }
 
 PointSrc make_points(const NarutoPoints* pts) {
-    PointSrc ps;
+    PointSrc ps{};
     ps.x = pts->x;
     ps.rays_o = pts->rays_o;
     ps.rays_d = pts->rays_d;
@@ -58,6 +60,34 @@ int check_points(const NarutoPoints* pts) {
 uint32_t cu_count(const NarutoField* f) { return f->n_cu > 0 ? (uint32_t)f->n_cu : 256u; }
 
 constexpr uint32_t kBwdMaxBlocks = 256;     // one 145 KB-LDS block per CU
+
+// table scatter: LDS-tiled units + k_scatter_reduce, and/or the global-atomic kernel for oversized levels
+int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const float* d_feat, size_t stride_m, size_t stride_l, float* d_table,
+                   float* partial, hipStream_t st) {
+    const size_t n_params = (size_t)f->n_entries * 2u;
+    if (f->plan.n_dense + f->plan.n_hashed > 0) {
+        static bool attr_set = false;
+        const size_t lds = (size_t)kChunk * 2u * sizeof(unsigned long long);
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_hash_scatter_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return fail(NARUTO_ERR_LAUNCH, "hash_scatter: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(hipGetLastError()));
+            attr_set = true;
+        }
+        const uint32_t blocks = f->plan.n_dense * f->plan.s_dense + f->plan.n_hashed * f->plan.s_hashed;
+        hipLaunchKernelGGL(k_hash_scatter_lds, dim3(blocks), dim3(kScatterThreads), lds, st, f->lt, f->bt, ps, M, d_feat, stride_m, stride_l, f->plan,
+                           partial, n_params);
+        if (int rc = check_launch("hash_scatter_lds")) return rc;
+        hipLaunchKernelGGL(k_scatter_reduce, dim3((uint32_t)((n_params / 4u + 255u) / 256u)), dim3(256), 0, st, f->lt, f->plan.atomic_levels, partial,
+                           f->plan.s_dense, f->plan.s_hashed, n_params, d_table);
+        if (int rc = check_launch("scatter_reduce")) return rc;
+    }
+    if (f->plan.atomic_levels != 0) {
+        hipLaunchKernelGGL(k_hash_scatter_atomic, dim3((M + 255u) / 256u, kLevels), dim3(256), 0, st, f->lt, f->bt, ps, M, d_feat, stride_m, stride_l,
+                           f->plan.atomic_levels, d_table);
+        if (int rc = check_launch("hash_scatter_atomic")) return rc;
+    }
+    return NARUTO_OK;
+}
 
 }  // namespace
 
@@ -114,6 +144,38 @@ int naruto_field_create(const NarutoFieldDesc* d, NarutoField** out) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) f->n_cu = cus;
     else { f->n_cu = 0; (void)hipGetLastError(); }
+    // scatter plan: levels of up to kMaxChunksPerLevel 8 192-entry chunks are LDS-tiled (dense levels first),
+    // larger ones use global atomics
+    memset(&f->plan, 0, sizeof(f->plan));
+    // profiling knobs (not part of the contract): restrict the scatter to some levels / force the split counts
+    const char* env_mask = getenv("NARUTO_DEBUG_SCATTER_LEVELS");
+    const uint32_t dbg_mask = env_mask ? (uint32_t)strtoul(env_mask, nullptr, 0) : 0xFFFFu;
+    uint32_t n_units = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (uint32_t l = 0; l < d->n_levels; ++l) {
+            if (!((dbg_mask >> l) & 1u)) continue;
+            const bool hashed = (f->lt.hashed >> l) & 1u;
+            if ((pass == 1) != hashed) continue;
+            const uint32_t chunks = (f->lt.size[l] + kChunk - 1u) / kChunk;
+            if (chunks > (uint32_t)kMaxChunksPerLevel) { f->plan.atomic_levels |= 1u << l; continue; }
+            for (uint32_t c = 0; c < chunks; ++c) {
+                f->plan.level[n_units] = (uint8_t)l;
+                f->plan.chunk[n_units] = (uint8_t)c;
+                ++n_units;
+            }
+            if (hashed) f->plan.n_hashed += chunks; else f->plan.n_dense += chunks;
+        }
+    }
+    // one 128 KB-LDS workgroup per CU: aim at ~1 workgroup per CU, dense units weighted x3
+    {
+        const uint32_t denom = f->plan.n_hashed + 3u * f->plan.n_dense;
+        uint32_t sh = denom ? cu_count(f) / denom : 1u;
+        sh = sh < 1u ? 1u : (sh > 4u ? 4u : sh);
+        f->plan.s_hashed = sh;
+        f->plan.s_dense = 3u * sh;
+        if (const char* e1 = getenv("NARUTO_DEBUG_SCATTER_SPLITS_HASHED")) f->plan.s_hashed = (uint32_t)atoi(e1);
+        if (const char* e2 = getenv("NARUTO_DEBUG_SCATTER_SPLITS_DENSE")) f->plan.s_dense = (uint32_t)atoi(e2);
+    }
     *out = f;
     return NARUTO_OK;
 }
@@ -157,15 +219,20 @@ int naruto_hash_encode_fwd(const NarutoField* f, uint32_t M, const float* x, con
     return check_launch("hash_encode_fwd");
 }
 
-int naruto_hash_encode_bwd(const NarutoField* f, uint32_t M, const float* x, const float* d_feat, float* d_table, void* stream) {
-    if (f == nullptr || x == nullptr || d_feat == nullptr || d_table == nullptr) return fail(NARUTO_ERR_INVALID, "hash_encode_bwd: NULL argument");
+size_t naruto_scatter_workspace(const NarutoField* f) {
+    if (f == nullptr || f->plan.n_dense + f->plan.n_hashed == 0) return 16;
+    const uint32_t smax = f->plan.s_dense > f->plan.s_hashed ? f->plan.s_dense : f->plan.s_hashed;
+    return (size_t)smax * (size_t)f->n_entries * 2u * sizeof(float);
+}
+
+int naruto_hash_encode_bwd(const NarutoField* f, uint32_t M, const float* x, const float* d_feat, float* d_table, void* workspace, void* stream) {
+    if (f == nullptr || x == nullptr || d_feat == nullptr || d_table == nullptr || workspace == nullptr)
+        return fail(NARUTO_ERR_INVALID, "hash_encode_bwd: NULL argument");
     if (M == 0) return NARUTO_OK;
     PointSrc ps{};
     ps.x = x;
     ps.S = 1;
-    hipLaunchKernelGGL(k_hash_scatter, dim3((M + 255u) / 256u, kLevels), dim3(256), 0, (hipStream_t)stream, f->lt, f->bt, ps, M, d_feat,
-                       (size_t)kFeat, (size_t)2, d_table);
-    return check_launch("hash_encode_bwd");
+    return launch_scatter(f, ps, M, d_feat, (size_t)kFeat, (size_t)2, d_table, reinterpret_cast<float*>(workspace), (hipStream_t)stream);
 }
 
 int naruto_query_fwd(const NarutoField* f, const NarutoParams* p, uint32_t M, const NarutoPoints* pts, float* raw, float* sdf_uncert,
@@ -193,8 +260,8 @@ int naruto_query_fwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
 }
 
 size_t naruto_query_bwd_workspace(const NarutoField* f, uint32_t M) {
-    (void)f;
-    return (size_t)kLevels * 2u * sizeof(float) * (size_t)M + (size_t)kBwdMaxBlocks * kAccFloats * sizeof(float);
+    // d_feat [16][M][2] | x [3][M] | wgrad partials | scatter partials
+    return ((size_t)kLevels * 2u + 3u) * sizeof(float) * (size_t)M + (size_t)kBwdMaxBlocks * kAccFloats * sizeof(float) + naruto_scatter_workspace(f);
 }
 
 int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, const NarutoPoints* pts, const float* feat_save,
@@ -206,7 +273,9 @@ int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
     if (int rc = check_points(pts)) return rc;
     if (M == 0) return NARUTO_OK;
     float* d_feat = reinterpret_cast<float*>(workspace);
-    float* partials = d_feat + (size_t)kLevels * 2u * (size_t)M;
+    float* x_soa = d_feat + (size_t)kLevels * 2u * (size_t)M;
+    float* partials = x_soa + 3u * (size_t)M;
+    float* scatter_ws = partials + (size_t)kBwdMaxBlocks * kAccFloats;
     const uint32_t n_tiles = (M + 31u) / 32u;
     uint32_t blocks = (n_tiles + 3u) / 4u;
     uint32_t cap = cu_count(f);
@@ -220,16 +289,18 @@ int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
         attr_set = true;
     }
     hipLaunchKernelGGL(k_query_bwd, dim3(blocks), dim3(256), sizeof(BwdLds), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, ps, M, feat_save, d_raw,
-                       d_geo, d_feat, g->uncert_grid, partials);
+                       d_geo, d_feat, g->table != nullptr ? x_soa : nullptr, g->uncert_grid, partials);
     if (int rc = check_launch("query_bwd")) return rc;
     if (g->sdf_w0 || g->sdf_w1 || g->col_w0 || g->col_w1) {
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3((kAccFloats + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, blocks, *g);
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3(kAccFloats / 32), dim3(256), 0, (hipStream_t)stream, partials, blocks, *g);
         if (int rc = check_launch("wgrad_reduce")) return rc;
     }
     if (g->table != nullptr) {
-        hipLaunchKernelGGL(k_hash_scatter, dim3((M + 255u) / 256u, kLevels), dim3(256), 0, (hipStream_t)stream, f->lt, f->bt, ps, M, d_feat, (size_t)2,
-                           (size_t)2 * (size_t)M, g->table);
-        if (int rc = check_launch("hash_scatter")) return rc;
+        PointSrc pss{};
+        pss.xsoa = x_soa;
+        pss.M = M;
+        pss.S = 1;
+        if (int rc = launch_scatter(f, pss, M, d_feat, (size_t)2, (size_t)2 * (size_t)M, g->table, scatter_ws, (hipStream_t)stream)) return rc;
     }
     return NARUTO_OK;
 }

@@ -43,11 +43,13 @@ struct BoxTab {
 };
 
 struct PointSrc {
-    const float* x;
-    const float* rays_o;
+    const float* x;          // [M,3] normalised points, or
+    const float* xsoa;       // [3][M] normalised points (written by k_query_bwd for the scatter), or
+    const float* rays_o;     // rays + depths
     const float* rays_d;
     const float* z_vals;
     uint32_t S;
+    uint32_t M;              // leading dimension of xsoa
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -55,7 +57,11 @@ struct PointSrc {
 // reference's eager torch ops), then (p - bmin) / (bmax - bmin)   [Co-SLAM run_network].
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void load_point(const PointSrc& ps, const BoxTab& bt, uint32_t m, float& x, float& y, float& z) {
-    if (ps.x) {
+    if (ps.xsoa) {
+        x = ps.xsoa[m];
+        y = ps.xsoa[(size_t)ps.M + m];
+        z = ps.xsoa[2 * (size_t)ps.M + m];
+    } else if (ps.x) {
         x = ps.x[3 * (size_t)m + 0];
         y = ps.x[3 * (size_t)m + 1];
         z = ps.x[3 * (size_t)m + 2];

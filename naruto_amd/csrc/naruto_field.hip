@@ -190,8 +190,44 @@ __global__ __launch_bounds__(256) void k_hash_encode_fwd(LevelTab lt, const floa
     });
 }
 
+// ------------------------------------------------------------------------------------------------
+// Table scatter (backward of the hash gather): d_table[idx] += w * d_feat, 256 updates per point.
+//
+// Measured on MI355X (tools/lds_atomic_bench.hip, profiles/):
+//   * a device-scope global_atomic_add_f32 executes at the memory side of the fabric (the 8 XCD L2s are
+//     not coherent with each other): ~50 G updates/s chip-wide, ~12 ns per same-address update --
+//     67 M updates (2048 rays x 128 samples) took 1.2 ms that way;
+//   * ds_add_f32 retires ~0.33 lanes/clk/CU (194 cycles per wave instruction) while ds_add_u64 retires a
+//     conflict-free wave instruction in ~8 cycles (25x faster).
+// So the scatter is LDS-tiled with FIXED-POINT accumulation: a workgroup owns one 8 192-entry chunk of
+// one level's table slice as a 128 KB image of int64 accumulators (value * 2^40: 9e-13 resolution,
+// +-8e6 range, order-independent => bitwise reproducible), streams a share of the points, recomputes
+// their corner indices (cheap VALU) and applies the updates that land in its chunk with ds_add_u64.  The
+// image is converted to fp32 and written with plain coalesced stores to a per-split partial table;
+// k_scatter_reduce adds the few partials into d_table.  No global atomics.  Levels whose slice is too
+// large for that (log2_hashmap_size > 16: the synthetic HBM-stress tables) keep the global-atomic path --
+// their updates are spread thinly anyway.
+// ------------------------------------------------------------------------------------------------
+constexpr int kChunkLog2 = 13;
+constexpr uint32_t kChunk = 1u << kChunkLog2;       // entries per LDS image (x2 int64 = 128 KB)
+constexpr int kMaxChunksPerLevel = 8;
+constexpr int kMaxUnits = kLevels * kMaxChunksPerLevel;
+constexpr int kScatterThreads = 512;
+constexpr float kFixScale = 1099511627776.0f;        // 2^40
+constexpr double kFixInv = 1.0 / 1099511627776.0;
+
+// Units are ordered dense-levels-first; dense (coarse) units take every update of their points and suffer
+// same-address conflicts, hashed units only 1/chunks of them, so dense units get more point splits.
+struct ScatterPlan {
+    uint8_t level[kMaxUnits];
+    uint8_t chunk[kMaxUnits];
+    uint32_t n_dense, n_hashed;   // LDS-tiled (level, chunk) units of non-hashed / hashed levels
+    uint32_t s_dense, s_hashed;   // point splits per unit
+    uint32_t atomic_levels;       // bit l: level l goes through the global-atomic kernel instead
+};
+
 template <int T>
-__device__ __forceinline__ void scatter_level(const LevelTab& lt, float x, float y, float z, float2 g, float* __restrict__ d_table) {
+__device__ __forceinline__ void scatter_level_atomic(const LevelTab& lt, float x, float y, float z, float2 g, float* __restrict__ d_table) {
     uint32_t idx[8];
     float w[8];
     hash_corners<T>(lt, x, y, z, idx, w);
@@ -203,25 +239,125 @@ __device__ __forceinline__ void scatter_level(const LevelTab& lt, float x, float
     }
 }
 
-// One thread per (point, level); blockIdx.y = level, so the atomics of concurrently running blocks
-// stay within one or two levels' slices of the table (<= 512 KB each: L2-resident).  d_feat is
-// addressed through (stride_m, stride_l) so that both [M,32] row-major (autograd of hash_encode) and
-// the [16][M][2] layout written by k_query_bwd can be consumed.
-__global__ __launch_bounds__(256) void k_hash_scatter(LevelTab lt, BoxTab bt, PointSrc ps, uint32_t M, const float* __restrict__ d_feat,
-                                                      size_t stride_m, size_t stride_l, float* __restrict__ d_table) {
+// d_feat is addressed through (stride_m, stride_l) so that both [M,32] row-major (autograd of
+// hash_encode) and the [16][M][2] layout written by k_query_bwd can be consumed.
+__global__ __launch_bounds__(256) void k_hash_scatter_atomic(LevelTab lt, BoxTab bt, PointSrc ps, uint32_t M, const float* __restrict__ d_feat,
+                                                             size_t stride_m, size_t stride_l, uint32_t level_mask, float* __restrict__ d_table) {
+    const int level = blockIdx.y;
+    if (!((level_mask >> level) & 1u)) return;
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
     float x, y, z;
     load_point(ps, bt, m, x, y, z);
-    const int level = blockIdx.y;
     const float2 g = *reinterpret_cast<const float2*>(d_feat + (size_t)m * stride_m + (size_t)level * stride_l);
     if (g.x == 0.0f && g.y == 0.0f) return;
     switch (level) {
-#define NARUTO_CASE(T) case T: scatter_level<T>(lt, x, y, z, g, d_table); break;
+#define NARUTO_CASE(T) case T: scatter_level_atomic<T>(lt, x, y, z, g, d_table); break;
         NARUTO_CASE(0) NARUTO_CASE(1) NARUTO_CASE(2) NARUTO_CASE(3) NARUTO_CASE(4) NARUTO_CASE(5) NARUTO_CASE(6) NARUTO_CASE(7)
         NARUTO_CASE(8) NARUTO_CASE(9) NARUTO_CASE(10) NARUTO_CASE(11) NARUTO_CASE(12) NARUTO_CASE(13) NARUTO_CASE(14) NARUTO_CASE(15)
 #undef NARUTO_CASE
     }
+}
+
+constexpr int kScatterBatch = 8;   // independent point loads in flight per thread (the loop is latency-bound otherwise)
+
+template <int T>
+__device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const BoxTab& bt, const PointSrc& ps, const float* __restrict__ d_feat,
+                                                    size_t stride_m, size_t stride_l, uint32_t m_lo, uint32_t m_hi, uint32_t chunk,
+                                                    unsigned long long* __restrict__ acc) {
+    for (uint32_t base = m_lo + threadIdx.x; base < m_hi; base += kScatterThreads * kScatterBatch) {
+        float2 g[kScatterBatch];
+        float px[kScatterBatch], py[kScatterBatch], pz[kScatterBatch];
+#pragma unroll
+        for (int b = 0; b < kScatterBatch; ++b) {
+            const uint32_t m = base + b * kScatterThreads;
+            const uint32_t mm = m < m_hi ? m : m_hi - 1u;
+            g[b] = *reinterpret_cast<const float2*>(d_feat + (size_t)mm * stride_m + (size_t)T * stride_l);
+            load_point(ps, bt, mm, px[b], py[b], pz[b]);
+            if (m >= m_hi) g[b] = make_float2(0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int b = 0; b < kScatterBatch; ++b) {
+            if (g[b].x == 0.0f && g[b].y == 0.0f) continue;
+            uint32_t idx[8];
+            float w[8];
+            hash_corners<T>(lt, px[b], py[b], pz[b], idx, w);
+            const float gx = g[b].x * kFixScale, gy = g[b].y * kFixScale;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if ((idx[c] >> kChunkLog2) == chunk) {
+                    const uint32_t e = (idx[c] & (kChunk - 1u)) * 2u;
+                    atomicAdd(acc + e, (unsigned long long)__float2ll_rn(w[c] * gx));          // ds_add_u64
+                    atomicAdd(acc + e + 1u, (unsigned long long)__float2ll_rn(w[c] * gy));
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab lt, BoxTab bt, PointSrc ps, uint32_t M, const float* __restrict__ d_feat,
+                                                                       size_t stride_m, size_t stride_l, ScatterPlan plan,
+                                                                       float* __restrict__ partial, size_t n_params) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];
+    uint32_t unit, split, n_splits;
+    const uint32_t dense_blocks = plan.n_dense * plan.s_dense;
+    if (blockIdx.x < dense_blocks) {
+        n_splits = plan.s_dense;
+        unit = blockIdx.x / n_splits;
+        split = blockIdx.x % n_splits;
+    } else {
+        n_splits = plan.s_hashed;
+        const uint32_t b = blockIdx.x - dense_blocks;
+        unit = plan.n_dense + b / n_splits;
+        split = b % n_splits;
+    }
+    const int level = plan.level[unit];
+    const uint32_t chunk = plan.chunk[unit];
+    for (uint32_t i = threadIdx.x; i < kChunk * 2u; i += kScatterThreads) acc[i] = 0ull;
+    __syncthreads();
+    const uint32_t per = (M + n_splits - 1u) / n_splits;
+    const uint32_t m_lo = split * per;
+    const uint32_t m_hi = m_lo + per < M ? m_lo + per : M;
+    switch (level) {
+#define NARUTO_CASE(T) case T: scatter_tile_points<T>(lt, bt, ps, d_feat, stride_m, stride_l, m_lo, m_hi, chunk, acc); break;
+        NARUTO_CASE(0) NARUTO_CASE(1) NARUTO_CASE(2) NARUTO_CASE(3) NARUTO_CASE(4) NARUTO_CASE(5) NARUTO_CASE(6) NARUTO_CASE(7)
+        NARUTO_CASE(8) NARUTO_CASE(9) NARUTO_CASE(10) NARUTO_CASE(11) NARUTO_CASE(12) NARUTO_CASE(13) NARUTO_CASE(14) NARUTO_CASE(15)
+#undef NARUTO_CASE
+    }
+    __syncthreads();
+    // level sizes are multiples of 8 entries and chunks start at multiples of 8 192: float4-aligned slices
+    const uint32_t n_e = lt.size[level] - chunk * kChunk < kChunk ? lt.size[level] - chunk * kChunk : kChunk;
+    float4* out = reinterpret_cast<float4*>(partial + (size_t)split * n_params + 2 * ((size_t)lt.off[level] + (size_t)chunk * kChunk));
+    for (uint32_t i = threadIdx.x; i < n_e / 2u; i += kScatterThreads) {
+        float4 v;
+        v.x = (float)((double)(long long)acc[4 * i + 0] * kFixInv);
+        v.y = (float)((double)(long long)acc[4 * i + 1] * kFixInv);
+        v.z = (float)((double)(long long)acc[4 * i + 2] * kFixInv);
+        v.w = (float)((double)(long long)acc[4 * i + 3] * kFixInv);
+        out[i] = v;
+    }
+}
+
+// d_table += sum over the level's splits of partial[split], for the entry ranges of the LDS-tiled levels
+__global__ __launch_bounds__(256) void k_scatter_reduce(LevelTab lt, uint32_t atomic_levels, const float* __restrict__ partial, uint32_t s_dense,
+                                                        uint32_t s_hashed, size_t n_params, float* __restrict__ d_table) {
+    const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // float4 index
+    if (i4 * 4 >= n_params) return;
+    const uint32_t entry = (uint32_t)(i4 * 2);
+    int level = 0;
+#pragma unroll
+    for (int l = 1; l < kLevels; ++l) level += entry >= lt.off[l] ? 1 : 0;
+    if ((atomic_levels >> level) & 1u) return;
+    const uint32_t n_splits = ((lt.hashed >> level) & 1u) ? s_hashed : s_dense;
+    float4 s = reinterpret_cast<const float4*>(partial)[i4];
+    for (uint32_t k = 1; k < n_splits; ++k) {
+        const float4 v = reinterpret_cast<const float4*>(partial + (size_t)k * n_params)[i4];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float4* d = reinterpret_cast<float4*>(d_table) + i4;
+    float4 o = *d;
+    o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+    *d = o;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -262,7 +398,6 @@ __device__ __forceinline__ void stage_bwd_weights(BwdLds& L, const NarutoParams&
         const int t = e >> 6, l = e & 63, i = l & 31, kk = l >> 5;
         L.c0gT[e] = (i >= 1 && i < kOut) ? p.col_w0[crow(t, kk) * kInCol + kPos + i - 1] : 0.0f;
     }
-    for (int e = tid; e < kAccFloats; e += nthreads) L.acc[e] = 0.0f;
 }
 
 // C-layout tile (units on regs/halves, points on lanes) -> [point][unit] stage
@@ -271,23 +406,21 @@ __device__ __forceinline__ void stage_ctile(float* __restrict__ buf, int ld, int
     for (int r = 0; r < 16; ++r) buf[j * ld + col0 + crow(r, hh)] = t[r];
 }
 
-// one 32x32 dW tile over this wave's 32 points: D[i][c] = sum_pt G[pt][i] * X[pt][c0 + c]
+// one 32x32 dW tile over this wave's 32 points: D[i][c] += sum_pt G[pt][i] * X[pt][c0 + c].  The tile lives in
+// this wave's registers for the whole kernel (ds_add_f32 is ~25x too slow on gfx950 to accumulate in LDS).
 __device__ __forceinline__ void wgrad_tile(const float* __restrict__ gbuf, int gld, const float* __restrict__ xbuf, int xld, int c0,
-                                           float* __restrict__ acc_tile, int lane) {
+                                           f32x16& d, int lane) {
     const int i = lane & 31, kk = lane >> 5;
-    f32x16 d = zero16();
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         const int pt = 2 * t + kk;
         d = mfma32(gbuf[pt * gld + i], xbuf[pt * xld + c0 + i], d);
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) unsafeAtomicAdd(&acc_tile[crow(r, kk) * 32 + i], d[r]);     // ds_add_f32
 }
 
 __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps, uint32_t M,
                                                    const float* __restrict__ feat_save, const float* __restrict__ d_raw,
-                                                   const float* __restrict__ d_geo, float* __restrict__ d_feat,
+                                                   const float* __restrict__ d_geo, float* __restrict__ d_feat, float* __restrict__ x_out,
                                                    float* __restrict__ d_uncert_grid, float* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     BwdLds& L = *reinterpret_cast<BwdLds*>(smem_raw);
@@ -299,6 +432,7 @@ __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, Bo
     float* __restrict__ xs = L.xs[wave];
     float* __restrict__ ga = L.ga[wave];
     float* __restrict__ gb = L.gb[wave];
+    f32x16 dW0a = zero16(), dW0b = zero16(), dW0c = zero16(), dW1 = zero16(), dWc0a = zero16(), dWc0b = zero16(), dWc1 = zero16();
     for (uint32_t tile = blockIdx.x * 4u + wave; tile < n_tiles; tile += gridDim.x * 4u) {
         // lanes j and j+32 both work on point tile*32 + j; hh selects the K-pair component
         const uint32_t m_raw = tile * 32u + j;
@@ -306,6 +440,11 @@ __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, Bo
         const uint32_t m = valid ? m_raw : M - 1u;
         float x, y, z;
         load_point(ps, bt, m, x, y, z);
+        if (x_out != nullptr && valid && hh == 0) {      // normalised points [3][M] for the table scatter
+            x_out[m] = x;
+            x_out[(size_t)M + m] = y;
+            x_out[2 * (size_t)M + m] = z;
+        }
         float g_rgb[3], g_sdf, g_unc;
         {
             const float* g = d_raw + (size_t)m * 5;     // padding lanes: zero cotangent => zero contribution
@@ -371,21 +510,18 @@ __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, Bo
         wave_lds_sync();
         {
             const int i = lane & 31;
-            f32x16 d = zero16();
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const uint32_t pt = tile * 32u + 2 * t + hh;
                 const float gv = (i < 3 && pt < M) ? d_raw[(size_t)pt * 5 + i] : 0.0f;
-                d = mfma32(gv, gb[(2 * t + hh) * kGradLd + i], d);
+                dWc1 = mfma32(gv, gb[(2 * t + hh) * kGradLd + i], dWc1);
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) unsafeAtomicAdd(&L.acc[6 * 1024 + crow(r, hh) * 32 + i], d[r]);
         }
         // ---- dW(col_w0) = d_c^T . [OneBlob48 | out16]   (tiles 4, 5)
         stage_ctile(ga, kGradLd, 0, dcv, j, hh);
         wave_lds_sync();
-        wgrad_tile(ga, kGradLd, xs, kStageLd, 32, &L.acc[4 * 1024], lane);
-        wgrad_tile(ga, kGradLd, xs, kStageLd, 64, &L.acc[5 * 1024], lane);
+        wgrad_tile(ga, kGradLd, xs, kStageLd, 32, dWc0a, lane);
+        wgrad_tile(ga, kGradLd, xs, kStageLd, 64, dWc0b, lane);
         // ---- dgrad colour layer 0 -> sdf-net outputs (rows 1..15 = geo features)
         f32x16 dov = zero16();
         static_for<0, 16>([&](auto tc) {
@@ -409,7 +545,7 @@ __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, Bo
             stage_ctile(gb, kGradLd, 0, hact, j, hh);
             stage_ctile(ga, kGradLd, 0, dov, j, hh);
             wave_lds_sync();
-            wgrad_tile(ga, kGradLd, gb, kGradLd, 0, &L.acc[3 * 1024], lane);
+            wgrad_tile(ga, kGradLd, gb, kGradLd, 0, dW1, lane);
         }
         // ---- dgrad sdf layer 1 -> hidden, masked by ReLU
         f32x16 dh = zero16();
@@ -423,9 +559,9 @@ __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, Bo
         wave_lds_sync();
         stage_ctile(ga, kGradLd, 0, dh, j, hh);
         wave_lds_sync();
-        wgrad_tile(ga, kGradLd, xs, kStageLd, 0, &L.acc[0 * 1024], lane);
-        wgrad_tile(ga, kGradLd, xs, kStageLd, 32, &L.acc[1 * 1024], lane);
-        wgrad_tile(ga, kGradLd, xs, kStageLd, 64, &L.acc[2 * 1024], lane);
+        wgrad_tile(ga, kGradLd, xs, kStageLd, 0, dW0a, lane);
+        wgrad_tile(ga, kGradLd, xs, kStageLd, 32, dW0b, lane);
+        wgrad_tile(ga, kGradLd, xs, kStageLd, 64, dW0c, lane);
         wave_lds_sync();
         // ---- dgrad sdf layer 0 -> hash features
         f32x16 df = zero16();
@@ -446,17 +582,39 @@ __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, Bo
             }
         }
     }
-    __syncthreads();
+    // block-level sum of the four waves' register tiles through the LDS image (plain stores / adds: every
+    // (tile,row,col) belongs to exactly one lane of a wave), then one coalesced write of the partial
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+            const f32x16* tiles[kAccTiles] = {&dW0a, &dW0b, &dW0c, &dW1, &dWc0a, &dWc0b, &dWc1};
+#pragma unroll
+            for (int t = 0; t < kAccTiles; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float* a = &L.acc[t * 1024 + crow(r, hh) * 32 + j];
+                    *a = (w == 0 ? 0.0f : *a) + (*tiles[t])[r];
+                }
+            }
+        }
+        __syncthreads();
+    }
     float* __restrict__ out = partials + (size_t)blockIdx.x * kAccFloats;
     for (int e = threadIdx.x; e < kAccFloats; e += blockDim.x) out[e] = L.acc[e];
 }
 
-// partials [n_blocks][7][32][32] -> += into the four weight gradients, fixed summation order
+// partials [n_blocks][7][32][32] -> += into the four weight gradients.  Block = 32 outputs x 8 slices of the
+// block range; fixed summation order (deterministic for a given grid).
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partials, uint32_t n_blocks, NarutoGrads g) {
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= kAccFloats) return;
+    __shared__ float red[8][32];
+    const int o = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const uint32_t e = blockIdx.x * 32u + o;
     float s = 0.0f;
-    for (uint32_t b = 0; b < n_blocks; ++b) s += partials[(size_t)b * kAccFloats + e];
+    for (uint32_t b = slice; b < n_blocks; b += 8) s += partials[(size_t)b * kAccFloats + e];
+    red[slice][o] = s;
+    __syncthreads();
+    if (slice != 0) return;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += red[k][o];
     const int tile = e >> 10, row = (e >> 5) & 31, col = e & 31;
     if (tile <= 2) {
         const int c = tile * 32 + col;

@@ -146,7 +146,8 @@ class _HashEncode(torch.autograd.Function):
             d_feat = _f32c(d_feat, "d_feat")
             d_table = torch.zeros_like(table)
             with torch.cuda.device(x.device):
-                check(lib.naruto_hash_encode_bwd(ctx.handle.ptr, x.shape[0], _p(x), _p(d_feat), _p(d_table), _stream()),
+                ws = torch.empty((lib.naruto_scatter_workspace(ctx.handle.ptr) + 3) // 4, dtype=torch.float32, device=x.device)
+                check(lib.naruto_hash_encode_bwd(ctx.handle.ptr, x.shape[0], _p(x), _p(d_feat), _p(d_table), _p(ws), _stream()),
                       "naruto_hash_encode_bwd")
         return None, None, d_table
 

@@ -40,13 +40,17 @@ def smoothness(model: NarutoFieldHIP, config: Dict, sample_points: int = 256, vo
     grid_size = (sample_points - 1) * voxel_size
     offset_max = bb[:, 1] - bb[:, 0] - grid_size - 2 * margin
     if offset_rand is None:
-        offset_rand = torch.rand(3)
+        offset_rand = torch.rand(3, device=bb.device)          # drawn on the device: no host sync per iteration
     if jitter_rand is None:
-        jitter_rand = torch.rand((1, 1, 1, 3))
+        jitter_rand = torch.rand((1, 1, 1, 3), device=bb.device)
     offset = offset_rand.to(offset_max) * offset_max + margin
     n = sample_points - 1
-    ax = torch.arange(0, n, dtype=torch.long, device=bb.device)
-    coords = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), dim=-1).float()
+    cache = model.__dict__.setdefault("_smooth_coords", {})
+    coords = cache.get((n, bb.device))
+    if coords is None:
+        ax = torch.arange(0, n, dtype=torch.long, device=bb.device)
+        coords = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), dim=-1).float()
+        cache[(n, bb.device)] = coords
     pts = (coords + jitter_rand.to(bb).reshape(1, 1, 1, 3)) * voxel_size + bb[:, 0] + offset
     pts_tcnn = (pts - bb[:, 0]) / (bb[:, 1] - bb[:, 0])
     sdf = model.query_sdf(pts_tcnn, embed=True)

@@ -181,6 +181,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=4)
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the fused HIP Adam")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph")
     args = ap.parse_args()
 
     group = parallel.init_from_env("nccl") if args.gpus > 1 else None
@@ -193,7 +195,11 @@ def main():
     cfg, n_rays = workload(args.workload)
     from naruto_amd.trainer import MappingTrainer
     torch.manual_seed(0)                                     # identical replicas on every rank
-    tr = MappingTrainer(cfg, torch.tensor(cfg["mapping"]["bound"], dtype=torch.float32), dev, 0.1, group=group)
+    tr = MappingTrainer(cfg, torch.tensor(cfg["mapping"]["bound"], dtype=torch.float32), dev, 0.1, group=group,
+                        fused_adam=not args.torch_adam)
+    use_graph = (not args.no_graph) and group is None
+    if use_graph:
+        tr.capture(n_rays, smooth=True, n_rays_total=n_rays * world)
     n_total = n_rays * world
     all_rays = syn.random_rays(n_total, cfg["mapping"]["bound"], seed=0)
     lo, hi = parallel.shard_bounds(n_total, rank, world)
@@ -232,7 +238,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: office_0 bbox, {n_rays} rays x {S_tot} samples per GPU, hash L16 F2 T2^16, "
                                    "MLP 2x32, uncert grid; one global_BA mapping iteration incl. smoothness + Adam",
-                       "rays_per_gpu": n_rays, "samples_per_ray": S_tot, "parallelism": f"ray-sharded dp{world}"},
+                       "rays_per_gpu": n_rays, "samples_per_ray": S_tot, "parallelism": f"ray-sharded dp{world}",
+                       "optimizer": "torch.optim.Adam" if args.torch_adam else "fused HIP Adam", "hip_graph": bool(use_graph)},
         }
         if not args.no_kernels:
             rows = kernel_table(tr, rays, cfg, max(10, args.steps))

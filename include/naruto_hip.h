@@ -168,10 +168,11 @@ int naruto_loss_bwd(const NarutoField* f, uint32_t n_rays, uint32_t S, const flo
                     void* stream);
 
 /* A10 helper -- one fused Adam step over a flat fp32 buffer (torch.optim.Adam semantics incl. L2
- * weight_decay, reference coslam.py:409-419); step is the 1-based step count. */
+ * weight_decay, reference coslam.py:409-419).  The 1-based step count comes from `step`, or -- when
+ * step_dev != NULL -- from device memory (int32), which keeps the launch valid under hipGraph replay. */
 int naruto_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n,
                      float lr, float beta1, float beta2, float eps, float weight_decay, uint32_t step,
-                     void* stream);
+                     const int32_t* step_dev, void* stream);
 
 /* Hardware self-checks used by the GPU tests: the MFMA / permlane layouts the kernels rely on.
  * out: device buffer of 64*16 floats; returns 0 and fills out (see tests/test_gpu_intrinsics.py). */

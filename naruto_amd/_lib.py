@@ -93,7 +93,7 @@ SIGNATURES = {
     "naruto_loss_sums": (_I, [_V, _U32, _U32, _V, _V, _V, _V, _V, _V, _V, _F, _F, _V, _V, _V]),
     "naruto_loss_finalize": (_I, [_V, _U64, _U32, _V, _V]),
     "naruto_loss_bwd": (_I, [_V, _U32, _U32, _V, _V, _V, _V, _F, _F, _V, _U64, _V, _V, _V]),
-    "naruto_adam_step": (_I, [_V, _V, _V, _V, _U64, _F, _F, _F, _F, _F, _U32, _V]),
+    "naruto_adam_step": (_I, [_V, _V, _V, _V, _U64, _F, _F, _F, _F, _F, _U32, _V, _V]),
     "naruto_debug_mfma_layout": (_I, [_V, _V, _V, _V]),
     "naruto_debug_permlane_swap": (_I, [_V, _V, _V, _V]),
 }

@@ -367,16 +367,16 @@ int naruto_loss_bwd(const NarutoField* f, uint32_t n_rays, uint32_t S, const flo
 }
 
 int naruto_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr, float beta1, float beta2, float eps,
-                     float weight_decay, uint32_t step, void* stream) {
+                     float weight_decay, uint32_t step, const int32_t* step_dev, void* stream) {
     if (param == nullptr || grad == nullptr || exp_avg == nullptr || exp_avg_sq == nullptr) return fail(NARUTO_ERR_INVALID, "adam_step: NULL argument");
     if (n == 0) return NARUTO_OK;
-    if (step == 0) return fail(NARUTO_ERR_INVALID, "adam_step: step is 1-based");
-    const float bc1 = 1.0f - powf(beta1, (float)step);
-    const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+    if (step == 0 && step_dev == nullptr) return fail(NARUTO_ERR_INVALID, "adam_step: step is 1-based (or pass step_dev)");
+    const float bc1 = step ? 1.0f - powf(beta1, (float)step) : 1.0f;
+    const float bc2_sqrt = step ? sqrtf(1.0f - powf(beta2, (float)step)) : 1.0f;
     uint64_t blocks = (n + 255u) / 256u;
     if (blocks > 2048u) blocks = 2048u;
     hipLaunchKernelGGL(k_adam, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
-                       weight_decay, bc1, bc2_sqrt);
+                       weight_decay, bc1, bc2_sqrt, step_dev);
     return check_launch("adam_step");
 }
 

@@ -422,7 +422,13 @@ template __global__ void k_composite_bwd<false>(uint32_t, uint32_t, float, float
 // Fused Adam (torch.optim.Adam, amsgrad off): one pass over p, g, m, v.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                              uint64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+                                              uint64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                              const int32_t* __restrict__ step_dev) {
+    if (step_dev != nullptr) {            // graph-replay safe: the 1-based step count lives in device memory
+        const float t = (float)step_dev[0];
+        bc1 = 1.0f - powf(b1, t);
+        bc2_sqrt = sqrtf(1.0f - powf(b2, t));
+    }
     const float step_size = lr / bc1;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         float gi = g[i];

@@ -236,11 +236,12 @@ class NarutoFieldHIP(nn.Module):
             self._pending_min_uncert = None
             assert v > 0, "uncert_map.min() > 0 violated (scene_rep.py:280)"
 
-    def forward(self, rays_o, rays_d, target_rgb, target_d, global_step=0, rand=None):
+    def forward(self, rays_o, rays_d, target_rgb, target_d, global_step=0, rand=None, _check=True):
         """scene_rep.py:227-287."""
         if not self.training:
             return self.render_rays(rays_o, rays_d, target_d=target_d, rand=rand)
-        self.check_asserts()
+        if _check:
+            self.check_asserts()
         cfg = self.config
         z_vals = self._sample_z(rays_o, target_d, rand)
         raw = ops.field_query(self._handle(), self._params(), rays_o=rays_o, rays_d=rays_d, z_vals=z_vals, color=True)
@@ -252,7 +253,7 @@ class NarutoFieldHIP(nn.Module):
         if self.strict_assert:
             self.check_asserts()
         return {"rgb": rgb, "depth": depth, "rgb_loss": losses[0], "depth_loss": losses[1], "sdf_loss": losses[2],
-                "fs_loss": losses[3], "psnr": losses[4].detach(), "uncert_loss": losses[5]}
+                "fs_loss": losses[3], "psnr": losses[4].detach(), "uncert_loss": losses[5], "_losses": losses}
 
 
 def get_map_volumes(query_fn, bounding_box: torch.Tensor, voxel_size: float):

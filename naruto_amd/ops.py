@@ -348,10 +348,14 @@ def render_loss(handle: FieldHandle, raw, z_vals, target_rgb, target_d, depth_tr
 # A10 helper
 # ---------------------------------------------------------------------------------------------------
 def adam_step_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, *, lr: float,
-               betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, step: int) -> None:
+               betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, step: int = 0,
+               step_dev: Optional[torch.Tensor] = None) -> None:
+    """In-place fused Adam.  ``step`` (host int, 1-based) or ``step_dev`` (int32 device tensor, graph-safe)."""
     lib = _lib.load()
     for t in (param, grad, exp_avg, exp_avg_sq):
         assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+    if step_dev is not None:
+        assert step_dev.dtype == torch.int32 and step_dev.is_cuda
     with torch.cuda.device(param.device):
         check(lib.naruto_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, betas[0], betas[1], eps,
-                                   weight_decay, step, _stream()), "naruto_adam_step")
+                                   weight_decay, step, _p(step_dev), _stream()), "naruto_adam_step")

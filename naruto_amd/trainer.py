@@ -80,40 +80,166 @@ def get_loss_from_ret(model: NarutoFieldHIP, config: Dict, ret: Dict, rgb=True, 
     return loss
 
 
-class MappingTrainer:
-    """Owns the model + the two Adam instances and runs mapping iterations on ray batches."""
+class FusedAdam:
+    """torch.optim.Adam semantics (amsgrad off, L2 weight decay) as one HIP kernel per tensor; the step count
+    lives on the device so that the launch stays valid under hipGraph replay.  ``param_groups`` uses the
+    same dict keys as torch.optim.Adam (params / lr / eps / weight_decay / betas)."""
 
-    def __init__(self, config: Dict, bounding_box: torch.Tensor, device, uncert_voxel: float = 0.1, group=None):
+    def __init__(self, param_groups, betas=(0.9, 0.999), lr=1e-3, eps=1e-8, weight_decay=0.0):
+        if isinstance(param_groups, (list, tuple)) and param_groups and not isinstance(param_groups[0], dict):
+            param_groups = [{'params': list(param_groups)}]
+        self.param_groups = []
+        for g in param_groups:
+            g = dict(g)
+            g['params'] = list(g['params'])
+            g.setdefault('lr', lr)
+            g.setdefault('eps', eps)
+            g.setdefault('weight_decay', weight_decay)
+            g.setdefault('betas', betas)
+            self.param_groups.append(g)
+        self.state = {}
+        dev = self.param_groups[0]['params'][0].device
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        for g in self.param_groups:
+            for p in g['params']:
+                self.state[p] = (torch.zeros_like(p), torch.zeros_like(p))
+
+    def zero_grad(self, set_to_none: bool = True):
+        for g in self.param_groups:
+            for p in g['params']:
+                if set_to_none:
+                    p.grad = None
+                elif p.grad is not None:
+                    p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self):
+        from . import ops
+        self.step_dev.add_(1)
+        for g in self.param_groups:
+            for p in g['params']:
+                if p.grad is None:
+                    continue
+                m, v = self.state[p]
+                ops.adam_step_(p.data, p.grad.contiguous(), m, v, lr=g['lr'], betas=g['betas'], eps=g['eps'],
+                               weight_decay=g['weight_decay'], step_dev=self.step_dev)
+
+
+class MappingTrainer:
+    """Owns the model + the two Adam instances and runs mapping iterations on ray batches.
+
+    ``fused_adam``: torch.optim.Adam (what the reference's driver builds) or the one-kernel-per-tensor HIP Adam.
+    ``capture(n_rays)`` records the whole iteration (forward, losses, backward, optimisers) into two hipGraphs
+    (with / without the every-5th-iteration uncertainty-grid step); ``step`` then replays them."""
+
+    def __init__(self, config: Dict, bounding_box: torch.Tensor, device, uncert_voxel: float = 0.1, group=None,
+                 fused_adam: bool = False):
         self.config = config
         self.device = torch.device(device)
         self.model = NarutoFieldHIP(config, bounding_box.to(self.device)).to(self.device)
-        self.map_optimizer = create_optimizer(self.model, config)
-        self.uncert_optim = init_uncert_grid_optim(self.model, uncert_voxel)
+        if fused_adam:
+            self.map_optimizer = FusedAdam(
+                [{'params': self.model.decoder.parameters(), 'weight_decay': 1e-6, 'lr': config['mapping']['lr_decoder']},
+                 {'params': self.model.embed_fn.parameters(), 'eps': 1e-15, 'lr': config['mapping']['lr_embed']}], betas=(0.9, 0.99))
+            self.uncert_optim = FusedAdam([self.model.get_uncert_grid(uncert_voxel)], lr=1)
+        else:
+            self.map_optimizer = create_optimizer(self.model, config)
+            self.uncert_optim = init_uncert_grid_optim(self.model, uncert_voxel)
+        # the uncertainty grid's gradient accumulates over 5 iterations (coslam.py:397-399): keep it as a
+        # persistent tensor that autograd adds into, zeroed after each uncert step
+        self.model.uncert_grid.grad = torch.zeros_like(self.model.uncert_grid)
         self.group = group
         self.iter = 0
-        self._flat = None
+        self._graphs = None
+        self._static = None
+        tr = config['training']
+        self._loss_w = torch.tensor([tr['rgb_weight'], tr['depth_weight'], tr['sdf_weight'], tr['fs_weight'], 0.0,
+                                     tr['uncert_weight'], 0.0, 0.0], dtype=torch.float32, device=self.device)
         if group is not None:
             self.model.enable_data_parallel(group)
 
     def parameters(self):
         return list(self.model.decoder.parameters()) + list(self.model.embed_fn.parameters()) + [self.model.uncert_grid]
 
-    def step(self, rays_o, rays_d, target_rgb, target_d, smooth: bool = False, n_rays_total: int = 0):
-        """One mapping iteration (global_BA body, coslam.py:361-399).  With a process group the rays passed
-        in are THIS RANK's shard; gradients are summed over ranks before the (identical) Adam steps."""
+    def _iteration(self, rays_o, rays_d, target_rgb, target_d, smooth: bool, uncert_step: bool, check: bool = True):
         model = self.model
         model.train()
-        model.n_rays_total = n_rays_total
-        if self.iter % 5 == 0:
-            self.uncert_optim.zero_grad()
-        self.map_optimizer.zero_grad()
-        ret = model.forward(rays_o, rays_d, target_rgb, target_d)
-        loss = get_loss_from_ret(model, self.config, ret, smooth=smooth)
+        self.map_optimizer.zero_grad(set_to_none=True)
+        ret = model.forward(rays_o, rays_d, target_rgb, target_d, _check=check)
+        # get_loss_from_ret (coslam.py:154-174) as one dot product over the loss vector
+        loss = torch.dot(ret['_losses'], self._loss_w)
+        if smooth and self.config['training']['smooth_weight'] > 0:
+            tr = self.config['training']
+            loss = loss + tr['smooth_weight'] * smoothness(model, self.config, tr['smooth_pts'], tr['smooth_vox'], margin=tr['smooth_margin'])
         loss.backward()
         if self.group is not None:
             parallel.allreduce_grads(self.parameters(), self.group)
         self.map_optimizer.step()
-        self.iter += 1
-        if self.iter % 5 == 0:
+        if uncert_step:
             self.uncert_optim.step()
+            self.model.uncert_grid.grad.zero_()
         return ret, loss
+
+    def step(self, rays_o, rays_d, target_rgb, target_d, smooth: bool = False, n_rays_total: int = 0):
+        """One mapping iteration (global_BA body, coslam.py:361-399).  With a process group the rays passed
+        in are THIS RANK's shard; gradients are summed over ranks before the (identical) Adam steps."""
+        self.model.n_rays_total = n_rays_total
+        self.iter += 1
+        uncert_step = self.iter % 5 == 0
+        if self._graphs is not None:
+            st = self._static
+            assert smooth == st['smooth'] and rays_o.shape[0] == st['rays_o'].shape[0], "captured for another configuration"
+            st['rays_o'].copy_(rays_o, non_blocking=True)
+            st['rays_d'].copy_(rays_d, non_blocking=True)
+            st['target_rgb'].copy_(target_rgb, non_blocking=True)
+            st['target_d'].copy_(target_d.reshape(st['target_d'].shape), non_blocking=True)
+            self._graphs[1 if uncert_step else 0].replay()
+            return st['ret'][1 if uncert_step else 0], st['loss'][1 if uncert_step else 0]
+        return self._iteration(rays_o, rays_d, target_rgb, target_d, smooth, uncert_step)
+
+    def capture(self, n_rays: int, smooth: bool = False, n_rays_total: int = 0, warmup: int = 3):
+        """Record the iteration into hipGraphs (static shapes: n_rays rays per call)."""
+        assert self.group is None, "graph capture of the RCCL exchange is not wired up yet: use eager steps with a process group"
+        dev = self.device
+        self.model.n_rays_total = n_rays_total
+        st = {'rays_o': torch.zeros(n_rays, 3, device=dev), 'rays_d': torch.zeros(n_rays, 3, device=dev),
+              'target_rgb': torch.zeros(n_rays, 3, device=dev), 'target_d': torch.ones(n_rays, 1, device=dev),
+              'smooth': smooth, 'ret': [None, None], 'loss': [None, None]}
+        st['rays_d'][:, 2] = 1.0
+        # snapshot: the warm-up / capture iterations below must not change the training state
+        params = self.parameters()
+        snap = [p.detach().clone() for p in params]
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            for i in range(warmup):
+                self._iteration(st['rays_o'], st['rays_d'], st['target_rgb'], st['target_d'], smooth, i == warmup - 1, check=False)
+        torch.cuda.current_stream(dev).wait_stream(s)
+        torch.cuda.synchronize(dev)
+        graphs = []
+        pool = None
+        for variant in (False, True):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                ret, loss = self._iteration(st['rays_o'], st['rays_d'], st['target_rgb'], st['target_d'], smooth, variant, check=False)
+            pool = g.pool()
+            st['ret'][1 if variant else 0] = ret
+            st['loss'][1 if variant else 0] = loss
+            graphs.append(g)
+        # restore parameters and optimiser state to "before capture"
+        with torch.no_grad():
+            for p, q in zip(params, snap):
+                p.copy_(q)
+            self.model.uncert_grid.grad.zero_()
+            for opt in (self.map_optimizer, self.uncert_optim):
+                if isinstance(opt, FusedAdam):
+                    opt.step_dev.zero_()
+                    for m, v in opt.state.values():
+                        m.zero_()
+                        v.zero_()
+                else:
+                    for stt in opt.state.values():
+                        for k, val in stt.items():
+                            if torch.is_tensor(val):
+                                val.zero_()
+        self._graphs, self._static = graphs, st

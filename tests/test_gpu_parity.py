@@ -348,3 +348,43 @@ def test_full_size_properties(gpu):
         got = tg[off[l] * 2: off[l + 1] * 2].reshape(-1, 2).sum(0)
         want = cot[:, 2 * l: 2 * l + 2].double().sum(0)
         assert torch.allclose(got, want, rtol=1e-3, atol=1e-2), (l, got, want)
+
+
+# --------------------------------------------------------------------------------------------- A10: optimiser + graph
+def test_fused_adam_matches_torch(gpu):
+    from naruto_amd.trainer import FusedAdam
+    torch.manual_seed(3)
+    p1 = [torch.nn.Parameter(torch.randn(1000, device=gpu)), torch.nn.Parameter(torch.randn(33, 7, device=gpu))]
+    p2 = [torch.nn.Parameter(p.detach().clone()) for p in p1]
+    groups = lambda ps: [{'params': [ps[0]], 'weight_decay': 1e-6, 'lr': 0.01}, {'params': [ps[1]], 'eps': 1e-15, 'lr': 0.02}]
+    o1 = torch.optim.Adam(groups(p1), betas=(0.9, 0.99))
+    o2 = FusedAdam(groups(p2), betas=(0.9, 0.99))
+    for it in range(7):
+        gs = [torch.randn_like(p) * (10.0 ** (-it)) for p in p1]
+        for p, q, g in zip(p1, p2, gs):
+            p.grad, q.grad = g.clone(), g.clone()
+        o1.step()
+        o2.step()
+    for p, q in zip(p1, p2):
+        H.assert_close(q, p, 2e-6, "fused adam", rel=1e-5)
+
+
+def test_graph_replay_equals_eager(gpu):
+    """The captured hipGraph iteration reproduces the eager iteration (same inputs, same jitter stream is not
+    possible -- the graph owns its RNG offsets -- so perturb is off here)."""
+    from naruto_amd import trainer
+    cfg = H.office_cfg(12, perturb=0.0)
+    bound = torch.tensor(cfg["mapping"]["bound"])
+    torch.manual_seed(5)
+    a = trainer.MappingTrainer(cfg, bound, gpu, fused_adam=True)
+    b = trainer.MappingTrainer(cfg, bound, gpu, fused_adam=True)
+    b.model.load_state_dict(a.model.state_dict())
+    b.capture(192, smooth=False)
+    for it in range(6):
+        rays = syn.random_rays(192, cfg["mapping"]["bound"], seed=200 + it)
+        t = [torch.from_numpy(rays[k]).to(gpu) for k in ("rays_o", "rays_d", "target_rgb", "target_d")]
+        ra, la = a.step(*t)
+        rb, lb = b.step(*t)
+        H.assert_close(lb.reshape(-1), la.reshape(-1), 1e-6, f"iter{it}.loss", rel=1e-5)
+    for (n, p), (_, q) in zip(a.model.named_parameters(), b.model.named_parameters()):
+        H.assert_close(q, p, 1e-6, f"param {n}", rel=1e-5)

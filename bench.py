@@ -114,8 +114,12 @@ def kernel_table(tr, rays, cfg, iters: int):
     gl = torch.tensor([trc["rgb_weight"], trc["depth_weight"], trc["sdf_weight"], trc["fs_weight"], 0.0, trc["uncert_weight"]],
                       dtype=torch.float32, device=dev)
     d_raw = torch.empty(M, 5, device=dev)
+    cnt, off = torch.empty(N, dtype=torch.int32, device=dev), torch.empty(N, dtype=torch.int32, device=dev)
+    act, nact = torch.empty(M, dtype=torch.int32, device=dev), torch.empty(1, dtype=torch.int32, device=dev)
     add("k_composite_bwd<loss>", lambda: _lib.check(lib.naruto_loss_bwd(h.ptr, N, S, p(raw), p(z), p(tgt), p(td), float(cam["depth_trunc"]),
-        float(trc["rgb_missing"]), p(sums), N, p(gl), p(d_raw), st())), M * 44 + N * 20, 0, "hbm")
+        float(trc["rgb_missing"]), p(sums), N, p(gl), p(d_raw), p(cnt), st())), M * 44 + N * 20, 0, "hbm")
+    add("k_compact_active", lambda: _lib.check(lib.naruto_compact_active(N, S, p(cnt), p(off), p(act), p(nact), st())), M * 4 + N * 8, 0, "hbm")
+    frac = float(nact.item()) / M
     grads = {k: torch.zeros_like(v) for k, v in params.items()}
     gs = _lib.NarutoGrads()
     for k, v in grads.items():
@@ -125,16 +129,19 @@ def kernel_table(tr, rays, cfg, iters: int):
     gs_mlp = _lib.NarutoGrads()
     for k in ("uncert_grid", "sdf_w0", "sdf_w1", "col_w0", "col_w1"):
         setattr(gs_mlp, k, p(grads[k]))
-    mlp_bwd_flops = M * 2 * (5184 + (15 * 32 + 16 * 32 + 32 * 32 + 3 * 32) + 5184)    # recompute + dgrad + wgrad
+    Ma = int(round(frac * M))                                                           # active (non-zero cotangent) samples
+    mlp_bwd_flops = Ma * 2 * (5184 + (15 * 32 + 16 * 32 + 32 * 32 + 3 * 32) + 5184)   # recompute + dgrad + wgrad
     add("k_query_bwd+k_wgrad_reduce", lambda: _lib.check(lib.naruto_query_bwd(h.ptr, CT.byref(ps), M, CT.byref(pts), p(feat), p(d_raw), None,
-        CT.byref(gs_mlp), p(wsb), st())), M * (128 + 20 + 128 + 4) + N * 24, mlp_bwd_flops, "mfma")
+        p(act), p(nact), CT.byref(gs_mlp), p(wsb), st())), Ma * (128 + 20 + 128 + 4 + 4) + N * 24, mlp_bwd_flops, "mfma")
     t_mlp = rows[-1]["ms"]
-    ms_all = events_ms(lambda: _lib.check(lib.naruto_query_bwd(h.ptr, CT.byref(ps), M, CT.byref(pts), p(feat), p(d_raw), None, CT.byref(gs),
-                                                               p(wsb), st())), iters)
-    sc_bytes = M * (16 * 8 * 2 * 8 + 128 + 4)          # 256 fp32 atomic read-modify-writes + d_feat + point
+    ms_all = events_ms(lambda: _lib.check(lib.naruto_query_bwd(h.ptr, CT.byref(ps), M, CT.byref(pts), p(feat), p(d_raw), None, p(act), p(nact),
+                                                               CT.byref(gs), p(wsb), st())), iters)
+    sc_bytes = Ma * (16 * 8 * 2 * 8 + 128 + 12)         # 256 fp32 read-modify-writes + d_feat + point
     ms_sc = max(ms_all - t_mlp, 1e-6)
     rows.append({"kernel": "k_hash_scatter", "ms": round(ms_sc, 5), "alg_bytes": int(sc_bytes), "alg_flops": 0,
                  "GBps": round(sc_bytes / ms_sc / 1e6, 1), "TFLOPs": 0.0, "bound": "hbm"})
+    rows.append({"kernel": "(active sample fraction)", "ms": 0.0, "alg_bytes": 0, "alg_flops": 0, "GBps": 0.0, "TFLOPs": 0.0,
+                 "bound": "hbm", "fraction": round(frac, 4)})
     return rows
 
 

@@ -124,10 +124,13 @@ int naruto_query_fwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
 
 /* Backward of naruto_query_fwd (autograd of the above through nn.Linear / tcnn / grid_sample).
  * d_raw [M,5] required; d_geo [M,15] optional (NULL = 0).  feat_save from the forward call.
+ * active_idx / n_active (both NULL, or both given): a list of the point indices to process and its length in
+ * DEVICE memory -- every point NOT in the list must have an all-zero cotangent (see naruto_compact_active).
  * workspace: naruto_query_bwd_workspace(M) bytes, contents undefined on entry and exit. */
 size_t naruto_query_bwd_workspace(const NarutoField* f, uint32_t M);
 int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, const NarutoPoints* pts,
                      const float* feat_save, const float* d_raw, const float* d_geo,
+                     const uint32_t* active_idx, const uint32_t* n_active,
                      const NarutoGrads* g, void* workspace, void* stream);
 
 /* A6+A7 -- sdf2weights [Co-SLAM] + raw2outputs (scene_rep.py:66-96).  Outputs (any may be NULL):
@@ -165,7 +168,13 @@ int naruto_loss_finalize(const double* sums, uint64_t n_rays_total, uint32_t S, 
 int naruto_loss_bwd(const NarutoField* f, uint32_t n_rays, uint32_t S, const float* raw, const float* z_vals,
                     const float* target_rgb, const float* target_d, float depth_trunc, float rgb_missing,
                     const double* sums, uint64_t n_rays_total, const float* loss_grad, float* d_raw,
-                    void* stream);
+                    uint32_t* ray_count, void* stream);
+/* The mapping losses leave the cotangent of every sample behind the surface band identically zero, and
+ * samples are depth-sorted, so the non-zero part of each ray is a PREFIX: naruto_loss_bwd can report its
+ * length per ray (ray_count [n_rays], optional), and naruto_compact_active turns the lengths into the
+ * flat list naruto_query_bwd consumes: active_idx [<= n_rays*S], n_active [1]; ray_offset [n_rays] scratch. */
+int naruto_compact_active(uint32_t n_rays, uint32_t S, const uint32_t* ray_count, uint32_t* ray_offset,
+                          uint32_t* active_idx, uint32_t* n_active, void* stream);
 
 /* A10 helper -- one fused Adam step over a flat fp32 buffer (torch.optim.Adam semantics incl. L2
  * weight_decay, reference coslam.py:409-419).  The 1-based step count comes from `step`, or -- when

@@ -85,14 +85,15 @@ SIGNATURES = {
     "naruto_hash_encode_bwd": (_I, [_V, _U32, _V, _V, _V, _V, _V]),
     "naruto_query_fwd": (_I, [_V, C.POINTER(NarutoParams), _U32, C.POINTER(NarutoPoints), _V, _V, _V, _V, _V]),
     "naruto_query_bwd_workspace": (C.c_size_t, [_V, _U32]),
-    "naruto_query_bwd": (_I, [_V, C.POINTER(NarutoParams), _U32, C.POINTER(NarutoPoints), _V, _V, _V,
+    "naruto_query_bwd": (_I, [_V, C.POINTER(NarutoParams), _U32, C.POINTER(NarutoPoints), _V, _V, _V, _V, _V,
                               C.POINTER(NarutoGrads), _V, _V]),
+    "naruto_compact_active": (_I, [_U32, _U32, _V, _V, _V, _V, _V]),
     "naruto_composite_fwd": (_I, [_V, _U32, _U32, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V]),
     "naruto_composite_bwd": (_I, [_V, _U32, _U32, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _I, _V]),
     "naruto_loss_workspace": (C.c_size_t, [_U32]),
     "naruto_loss_sums": (_I, [_V, _U32, _U32, _V, _V, _V, _V, _V, _V, _V, _F, _F, _V, _V, _V]),
     "naruto_loss_finalize": (_I, [_V, _U64, _U32, _V, _V]),
-    "naruto_loss_bwd": (_I, [_V, _U32, _U32, _V, _V, _V, _V, _F, _F, _V, _U64, _V, _V, _V]),
+    "naruto_loss_bwd": (_I, [_V, _U32, _U32, _V, _V, _V, _V, _F, _F, _V, _U64, _V, _V, _V, _V]),
     "naruto_adam_step": (_I, [_V, _V, _V, _V, _U64, _F, _F, _F, _F, _F, _U32, _V, _V]),
     "naruto_debug_mfma_layout": (_I, [_V, _V, _V, _V]),
     "naruto_debug_permlane_swap": (_I, [_V, _V, _V, _V]),

@@ -63,7 +63,7 @@ constexpr uint32_t kBwdMaxBlocks = 256;     // one 145 KB-LDS block per CU
 
 // table scatter: LDS-tiled units + k_scatter_reduce, and/or the global-atomic kernel for oversized levels
 int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const float* d_feat, size_t stride_m, size_t stride_l, float* d_table,
-                   float* partial, hipStream_t st) {
+                   float* partial, hipStream_t st, const uint32_t* m_dev = nullptr) {
     const size_t n_params = (size_t)f->n_entries * 2u;
     if (f->plan.n_dense + f->plan.n_hashed > 0) {
         static bool attr_set = false;
@@ -75,7 +75,7 @@ int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const f
         }
         const uint32_t blocks = f->plan.n_dense * f->plan.s_dense + f->plan.n_hashed * f->plan.s_hashed;
         hipLaunchKernelGGL(k_hash_scatter_lds, dim3(blocks), dim3(kScatterThreads), lds, st, f->lt, f->bt, ps, M, d_feat, stride_m, stride_l, f->plan,
-                           partial, n_params);
+                           partial, n_params, m_dev);
         if (int rc = check_launch("hash_scatter_lds")) return rc;
         hipLaunchKernelGGL(k_scatter_reduce, dim3((uint32_t)((n_params / 4u + 255u) / 256u)), dim3(256), 0, st, f->lt, f->plan.atomic_levels, partial,
                            f->plan.s_dense, f->plan.s_hashed, n_params, d_table);
@@ -83,7 +83,7 @@ int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const f
     }
     if (f->plan.atomic_levels != 0) {
         hipLaunchKernelGGL(k_hash_scatter_atomic, dim3((M + 255u) / 256u, kLevels), dim3(256), 0, st, f->lt, f->bt, ps, M, d_feat, stride_m, stride_l,
-                           f->plan.atomic_levels, d_table);
+                           f->plan.atomic_levels, d_table, m_dev);
         if (int rc = check_launch("hash_scatter_atomic")) return rc;
     }
     return NARUTO_OK;
@@ -265,7 +265,9 @@ size_t naruto_query_bwd_workspace(const NarutoField* f, uint32_t M) {
 }
 
 int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, const NarutoPoints* pts, const float* feat_save,
-                     const float* d_raw, const float* d_geo, const NarutoGrads* g, void* workspace, void* stream) {
+                     const float* d_raw, const float* d_geo, const uint32_t* active_idx, const uint32_t* n_active, const NarutoGrads* g,
+                     void* workspace, void* stream) {
+    if ((active_idx == nullptr) != (n_active == nullptr)) return fail(NARUTO_ERR_INVALID, "query_bwd: active_idx and n_active go together");
     if (f == nullptr || p == nullptr || g == nullptr || feat_save == nullptr || d_raw == nullptr || workspace == nullptr)
         return fail(NARUTO_ERR_INVALID, "query_bwd: NULL argument");
     if (p->table == nullptr || p->uncert_grid == nullptr || p->sdf_w0 == nullptr || p->sdf_w1 == nullptr || p->col_w0 == nullptr || p->col_w1 == nullptr)
@@ -289,7 +291,7 @@ int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
         attr_set = true;
     }
     hipLaunchKernelGGL(k_query_bwd, dim3(blocks), dim3(256), sizeof(BwdLds), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, ps, M, feat_save, d_raw,
-                       d_geo, d_feat, g->table != nullptr ? x_soa : nullptr, g->uncert_grid, partials);
+                       d_geo, d_feat, g->table != nullptr ? x_soa : nullptr, g->uncert_grid, partials, active_idx, n_active);
     if (int rc = check_launch("query_bwd")) return rc;
     if (g->sdf_w0 || g->sdf_w1 || g->col_w0 || g->col_w1) {
         hipLaunchKernelGGL(k_wgrad_reduce, dim3(kAccFloats / 32), dim3(256), 0, (hipStream_t)stream, partials, blocks, *g);
@@ -300,7 +302,7 @@ int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
         pss.xsoa = x_soa;
         pss.M = M;
         pss.S = 1;
-        if (int rc = launch_scatter(f, pss, M, d_feat, (size_t)2, (size_t)2 * (size_t)M, g->table, scatter_ws, (hipStream_t)stream)) return rc;
+        if (int rc = launch_scatter(f, pss, M, d_feat, (size_t)2, (size_t)2 * (size_t)M, g->table, scatter_ws, (hipStream_t)stream, n_active)) return rc;
     }
     return NARUTO_OK;
 }
@@ -324,7 +326,7 @@ int naruto_composite_bwd(const NarutoField* f, uint32_t n_rays, uint32_t S, cons
     CompositeCot cot{d_rgb, d_disp, d_acc, d_weights, d_depth, d_depth_var, d_uncert_map};
     LossArgs la{};
     hipLaunchKernelGGL(k_composite_bwd<false>, dim3((n_rays + kRaysPerBlock - 1) / kRaysPerBlock), dim3(64 * kRaysPerBlock), 0, (hipStream_t)stream,
-                       n_rays, S, f->desc.trunc, f->desc.sc_factor, f->desc.white_bkgd, raw, z_vals, cot, la, d_raw, accumulate);
+                       n_rays, S, f->desc.trunc, f->desc.sc_factor, f->desc.white_bkgd, raw, z_vals, cot, la, d_raw, accumulate, (uint32_t*)nullptr);
     return check_launch("composite_bwd");
 }
 
@@ -353,7 +355,7 @@ int naruto_loss_finalize(const double* sums, uint64_t n_rays_total, uint32_t S, 
 
 int naruto_loss_bwd(const NarutoField* f, uint32_t n_rays, uint32_t S, const float* raw, const float* z_vals, const float* target_rgb,
                     const float* target_d, float depth_trunc, float rgb_missing, const double* sums, uint64_t n_rays_total, const float* loss_grad,
-                    float* d_raw, void* stream) {
+                    float* d_raw, uint32_t* ray_count, void* stream) {
     if (f == nullptr || raw == nullptr || z_vals == nullptr || target_rgb == nullptr || target_d == nullptr || sums == nullptr || loss_grad == nullptr ||
         d_raw == nullptr)
         return fail(NARUTO_ERR_INVALID, "loss_bwd: NULL argument");
@@ -362,8 +364,19 @@ int naruto_loss_bwd(const NarutoField* f, uint32_t n_rays, uint32_t S, const flo
     CompositeCot cot{};
     LossArgs la{target_rgb, target_d, sums, loss_grad, n_rays_total, depth_trunc, rgb_missing, f->desc.trunc * f->desc.sc_factor};
     hipLaunchKernelGGL(k_composite_bwd<true>, dim3((n_rays + kRaysPerBlock - 1) / kRaysPerBlock), dim3(64 * kRaysPerBlock), 0, (hipStream_t)stream,
-                       n_rays, S, f->desc.trunc, f->desc.sc_factor, f->desc.white_bkgd, raw, z_vals, cot, la, d_raw, 0);
+                       n_rays, S, f->desc.trunc, f->desc.sc_factor, f->desc.white_bkgd, raw, z_vals, cot, la, d_raw, 0, ray_count);
     return check_launch("loss_bwd");
+}
+
+int naruto_compact_active(uint32_t n_rays, uint32_t S, const uint32_t* ray_count, uint32_t* ray_offset, uint32_t* active_idx, uint32_t* n_active,
+                          void* stream) {
+    if (ray_count == nullptr || ray_offset == nullptr || active_idx == nullptr || n_active == nullptr)
+        return fail(NARUTO_ERR_INVALID, "compact_active: NULL argument");
+    if (n_rays == 0) return fail(NARUTO_ERR_INVALID, "compact_active: no rays");
+    hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_rays, ray_count, ray_offset, n_active);
+    if (int rc = check_launch("compact_scan")) return rc;
+    hipLaunchKernelGGL(k_compact_write, dim3((n_rays + 3u) / 4u), dim3(256), 0, (hipStream_t)stream, n_rays, S, ray_count, ray_offset, active_idx);
+    return check_launch("compact_write");
 }
 
 int naruto_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr, float beta1, float beta2, float eps,

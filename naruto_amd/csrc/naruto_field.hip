@@ -212,7 +212,7 @@ constexpr int kChunkLog2 = 13;
 constexpr uint32_t kChunk = 1u << kChunkLog2;       // entries per LDS image (x2 int64 = 128 KB)
 constexpr int kMaxChunksPerLevel = 8;
 constexpr int kMaxUnits = kLevels * kMaxChunksPerLevel;
-constexpr int kScatterThreads = 512;
+constexpr int kScatterThreads = 1024;
 constexpr float kFixScale = 1099511627776.0f;        // 2^40
 constexpr double kFixInv = 1.0 / 1099511627776.0;
 
@@ -242,7 +242,9 @@ __device__ __forceinline__ void scatter_level_atomic(const LevelTab& lt, float x
 // d_feat is addressed through (stride_m, stride_l) so that both [M,32] row-major (autograd of
 // hash_encode) and the [16][M][2] layout written by k_query_bwd can be consumed.
 __global__ __launch_bounds__(256) void k_hash_scatter_atomic(LevelTab lt, BoxTab bt, PointSrc ps, uint32_t M, const float* __restrict__ d_feat,
-                                                             size_t stride_m, size_t stride_l, uint32_t level_mask, float* __restrict__ d_table) {
+                                                             size_t stride_m, size_t stride_l, uint32_t level_mask, float* __restrict__ d_table,
+                                                             const uint32_t* __restrict__ m_dev) {
+    if (m_dev != nullptr) M = m_dev[0];
     const int level = blockIdx.y;
     if (!((level_mask >> level) & 1u)) return;
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -259,46 +261,103 @@ __global__ __launch_bounds__(256) void k_hash_scatter_atomic(LevelTab lt, BoxTab
     }
 }
 
-constexpr int kScatterBatch = 8;   // independent point loads in flight per thread (the loop is latency-bound otherwise)
+constexpr int kScatterBatch = 4;   // independent point loads in flight per thread (the loop is latency-bound otherwise)
+
+constexpr int kScatterRun = 8;     // consecutive points per thread on the dense (coarse) levels
+
+__device__ __forceinline__ void fix_add(unsigned long long* __restrict__ acc, uint32_t idx, uint32_t chunk, float v0, float v1) {
+    if ((idx >> kChunkLog2) == chunk) {
+        const uint32_t e = (idx & (kChunk - 1u)) * 2u;
+        atomicAdd(acc + e, (unsigned long long)__float2ll_rn(v0 * kFixScale));          // ds_add_u64
+        atomicAdd(acc + e + 1u, (unsigned long long)__float2ll_rn(v1 * kFixScale));
+    }
+}
 
 template <int T>
 __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const BoxTab& bt, const PointSrc& ps, const float* __restrict__ d_feat,
                                                     size_t stride_m, size_t stride_l, uint32_t m_lo, uint32_t m_hi, uint32_t chunk,
                                                     unsigned long long* __restrict__ acc) {
-    for (uint32_t base = m_lo + threadIdx.x; base < m_hi; base += kScatterThreads * kScatterBatch) {
-        float2 g[kScatterBatch];
-        float px[kScatterBatch], py[kScatterBatch], pz[kScatterBatch];
+    if ((lt.hashed >> T) & 1u) {
+        // hashed (fine) levels: neighbouring points land in unrelated entries; one point per thread per step,
+        // kScatterBatch independent loads in flight
+        for (uint32_t base = m_lo + threadIdx.x; base < m_hi; base += kScatterThreads * kScatterBatch) {
+            float2 g[kScatterBatch];
+            float px[kScatterBatch], py[kScatterBatch], pz[kScatterBatch];
 #pragma unroll
-        for (int b = 0; b < kScatterBatch; ++b) {
-            const uint32_t m = base + b * kScatterThreads;
-            const uint32_t mm = m < m_hi ? m : m_hi - 1u;
-            g[b] = *reinterpret_cast<const float2*>(d_feat + (size_t)mm * stride_m + (size_t)T * stride_l);
-            load_point(ps, bt, mm, px[b], py[b], pz[b]);
-            if (m >= m_hi) g[b] = make_float2(0.0f, 0.0f);
+            for (int b = 0; b < kScatterBatch; ++b) {
+                const uint32_t m = base + b * kScatterThreads;
+                const uint32_t mm = m < m_hi ? m : m_hi - 1u;
+                g[b] = *reinterpret_cast<const float2*>(d_feat + (size_t)mm * stride_m + (size_t)T * stride_l);
+                load_point(ps, bt, mm, px[b], py[b], pz[b]);
+                if (m >= m_hi) g[b] = make_float2(0.0f, 0.0f);
+            }
+#pragma unroll
+            for (int b = 0; b < kScatterBatch; ++b) {
+                if (g[b].x == 0.0f && g[b].y == 0.0f) continue;
+                uint32_t idx[8];
+                float w[8];
+                hash_corners<T>(lt, px[b], py[b], pz[b], idx, w);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) fix_add(acc, idx[c], chunk, w[c] * g[b].x, w[c] * g[b].y);
+            }
         }
+    } else {
+        // dense (coarse) levels: consecutive points of a ray stay in one cell for several samples, so a thread
+        // walks a run of consecutive points and sums their contributions per corner in registers, touching
+        // LDS only when the cell changes (5-8x fewer, and far less conflicting, LDS atomics)
+        const float scale = lt.scale[T];
+        const uint32_t res = lt.res[T], size = lt.size[T], r2 = res * res;
+        for (uint32_t r0 = m_lo + threadIdx.x * kScatterRun; r0 < m_hi; r0 += kScatterThreads * kScatterRun) {
+            float a0[8], a1[8];
+            uint32_t cur = 0xFFFFFFFFu;
+            bool have = false;
 #pragma unroll
-        for (int b = 0; b < kScatterBatch; ++b) {
-            if (g[b].x == 0.0f && g[b].y == 0.0f) continue;
-            uint32_t idx[8];
-            float w[8];
-            hash_corners<T>(lt, px[b], py[b], pz[b], idx, w);
-            const float gx = g[b].x * kFixScale, gy = g[b].y * kFixScale;
+            for (int c = 0; c < 8; ++c) { a0[c] = 0.0f; a1[c] = 0.0f; }
+            auto flush = [&]() {
+                if (!have) return;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                if ((idx[c] >> kChunkLog2) == chunk) {
-                    const uint32_t e = (idx[c] & (kChunk - 1u)) * 2u;
-                    atomicAdd(acc + e, (unsigned long long)__float2ll_rn(w[c] * gx));          // ds_add_u64
-                    atomicAdd(acc + e + 1u, (unsigned long long)__float2ll_rn(w[c] * gy));
+                for (int c = 0; c < 8; ++c) {
+                    uint32_t i = cur + (uint32_t)(c & 1) + ((c & 2) ? res : 0u) + ((c & 4) ? r2 : 0u);
+                    if (i >= size) i %= size;
+                    fix_add(acc, i, chunk, a0[c], a1[c]);
+                    a0[c] = 0.0f; a1[c] = 0.0f;
+                }
+            };
+            for (int k = 0; k < kScatterRun; ++k) {
+                const uint32_t m = r0 + k;
+                if (m >= m_hi) break;
+                const float2 g = *reinterpret_cast<const float2*>(d_feat + (size_t)m * stride_m + (size_t)T * stride_l);
+                if (g.x == 0.0f && g.y == 0.0f) continue;
+                float x, y, z;
+                load_point(ps, bt, m, x, y, z);
+                const float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
+                const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+                const uint32_t cell = (uint32_t)(int)fx + (uint32_t)(int)fy * res + (uint32_t)(int)fz * r2;
+                if (!have || cell != cur) {
+                    flush();
+                    cur = cell;
+                    have = true;
+                }
+                const float wx = px - fx, wy = py - fy, wz = pz - fz;
+                const float ux = 1.0f - wx, uy = 1.0f - wy, uz = 1.0f - wz;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float w = ((c & 1) ? wx : ux) * ((c & 2) ? wy : uy) * ((c & 4) ? wz : uz);
+                    a0[c] = fmaf(w, g.x, a0[c]);
+                    a1[c] = fmaf(w, g.y, a1[c]);
                 }
             }
+            flush();
         }
     }
 }
 
 __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab lt, BoxTab bt, PointSrc ps, uint32_t M, const float* __restrict__ d_feat,
                                                                        size_t stride_m, size_t stride_l, ScatterPlan plan,
-                                                                       float* __restrict__ partial, size_t n_params) {
+                                                                       float* __restrict__ partial, size_t n_params,
+                                                                       const uint32_t* __restrict__ m_dev) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];
+    if (m_dev != nullptr) M = m_dev[0];          // compacted point list: the count lives on the device
     uint32_t unit, split, n_splits;
     const uint32_t dense_blocks = plan.n_dense * plan.s_dense;
     if (blockIdx.x < dense_blocks) {
@@ -421,29 +480,33 @@ __device__ __forceinline__ void wgrad_tile(const float* __restrict__ gbuf, int g
 __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps, uint32_t M,
                                                    const float* __restrict__ feat_save, const float* __restrict__ d_raw,
                                                    const float* __restrict__ d_geo, float* __restrict__ d_feat, float* __restrict__ x_out,
-                                                   float* __restrict__ d_uncert_grid, float* __restrict__ partials) {
+                                                   float* __restrict__ d_uncert_grid, float* __restrict__ partials,
+                                                   const uint32_t* __restrict__ active_idx, const uint32_t* __restrict__ n_active) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     BwdLds& L = *reinterpret_cast<BwdLds*>(smem_raw);
     stage_bwd_weights(L, p, threadIdx.x, blockDim.x);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hh = lane >> 5, j = lane & 31;
-    const uint32_t n_tiles = (M + 31u) / 32u;
+    // M_eff points are processed: all M, or the compacted list of points whose cotangent is not identically 0
+    const uint32_t M_eff = n_active != nullptr ? n_active[0] : M;
+    const uint32_t n_tiles = (M_eff + 31u) / 32u;
     float* __restrict__ xs = L.xs[wave];
     float* __restrict__ ga = L.ga[wave];
     float* __restrict__ gb = L.gb[wave];
     f32x16 dW0a = zero16(), dW0b = zero16(), dW0c = zero16(), dW1 = zero16(), dWc0a = zero16(), dWc0b = zero16(), dWc1 = zero16();
     for (uint32_t tile = blockIdx.x * 4u + wave; tile < n_tiles; tile += gridDim.x * 4u) {
-        // lanes j and j+32 both work on point tile*32 + j; hh selects the K-pair component
-        const uint32_t m_raw = tile * 32u + j;
-        const bool valid = m_raw < M;
-        const uint32_t m = valid ? m_raw : M - 1u;
+        // lanes j and j+32 both work on list entry i = tile*32 + j (point m); hh selects the K-pair component
+        const uint32_t i_raw = tile * 32u + j;
+        const bool valid = i_raw < M_eff;
+        const uint32_t i_pt = valid ? i_raw : M_eff - 1u;
+        const uint32_t m = active_idx != nullptr ? active_idx[i_pt] : i_pt;
         float x, y, z;
         load_point(ps, bt, m, x, y, z);
-        if (x_out != nullptr && valid && hh == 0) {      // normalised points [3][M] for the table scatter
-            x_out[m] = x;
-            x_out[(size_t)M + m] = y;
-            x_out[2 * (size_t)M + m] = z;
+        if (x_out != nullptr && valid && hh == 0) {      // normalised points [3][M] (list order) for the table scatter
+            x_out[i_pt] = x;
+            x_out[(size_t)M + i_pt] = y;
+            x_out[2 * (size_t)M + i_pt] = z;
         }
         float g_rgb[3], g_sdf, g_unc;
         {
@@ -513,7 +576,8 @@ __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, Bo
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const uint32_t pt = tile * 32u + 2 * t + hh;
-                const float gv = (i < 3 && pt < M) ? d_raw[(size_t)pt * 5 + i] : 0.0f;
+                float gv = 0.0f;
+                if (i < 3 && pt < M_eff) gv = d_raw[(size_t)(active_idx != nullptr ? active_idx[pt] : pt) * 5 + i];
                 dWc1 = mfma32(gv, gb[(2 * t + hh) * kGradLd + i], dWc1);
             }
         }
@@ -577,7 +641,7 @@ __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, Bo
 #pragma unroll
                 for (int e2 = 0; e2 < 2; ++e2) {
                     const int level = e2 + 4 * q + 2 * hh;
-                    dfo[(size_t)level * M + m] = make_float2(df[4 * q + 2 * e2], df[4 * q + 2 * e2 + 1]);
+                    dfo[(size_t)level * M + i_pt] = make_float2(df[4 * q + 2 * e2], df[4 * q + 2 * e2 + 1]);
                 }
             }
         }

@@ -321,7 +321,8 @@ struct LossArgs {
 template <bool LOSS>
 __global__ __launch_bounds__(64 * kRaysPerBlock) void k_composite_bwd(uint32_t n_rays, uint32_t S, float trunc, float sc_factor, int white_bkgd,
                                                                       const float* __restrict__ raw, const float* __restrict__ z_vals,
-                                                                      CompositeCot cot, LossArgs la, float* __restrict__ d_raw, int accumulate) {
+                                                                      CompositeCot cot, LossArgs la, float* __restrict__ d_raw, int accumulate,
+                                                                      uint32_t* __restrict__ ray_count) {
     __shared__ RayScratch scratch[kRaysPerBlock];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t n = blockIdx.x * kRaysPerBlock + wave;
@@ -383,6 +384,7 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_composite_bwd(uint32_t n
     }
     dot = wave_sum(dot);
     // pass 2: write d_raw
+    uint32_t last_nz = 0;      // 1 + index of the last sample with a non-zero cotangent (prefix length for compaction)
     for (uint32_t s = lane; s < S; s += 64) {
         const float z = rs.z[s];
         const float sdf = rs.sdf[s];
@@ -412,11 +414,58 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_composite_bwd(uint32_t n
         const float o4 = g_unc * w * w * softplus_grad_(p[4]);
         if (accumulate) { q[0] += o0; q[1] += o1; q[2] += o2; q[3] += g_s; q[4] += o4; }
         else { q[0] = o0; q[1] = o1; q[2] = o2; q[3] = g_s; q[4] = o4; }
+        if (o0 != 0.0f || o1 != 0.0f || o2 != 0.0f || g_s != 0.0f || o4 != 0.0f) last_nz = s + 1u;
+    }
+    if (ray_count != nullptr) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) last_nz = max(last_nz, (uint32_t)__shfl_xor((int)last_nz, o, 64));
+        if (lane == 0) ray_count[n] = last_nz;
     }
 }
 
-template __global__ void k_composite_bwd<true>(uint32_t, uint32_t, float, float, int, const float*, const float*, CompositeCot, LossArgs, float*, int);
-template __global__ void k_composite_bwd<false>(uint32_t, uint32_t, float, float, int, const float*, const float*, CompositeCot, LossArgs, float*, int);
+// ray prefix lengths -> flat list of active sample indices (ray order, then sample order) + their number.
+// k_compact_scan: one workgroup scans the ray counts; k_compact_write: one wave per ray writes its indices.
+__global__ __launch_bounds__(1024) void k_compact_scan(uint32_t n_rays, const uint32_t* __restrict__ ray_count, uint32_t* __restrict__ ray_off,
+                                                       uint32_t* __restrict__ n_active) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_rays; base += 1024u) {
+        const uint32_t n = base + threadIdx.x;
+        const uint32_t c = n < n_rays ? ray_count[n] : 0u;
+        uint32_t incl = c;                                   // inclusive scan within the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t before = carry;
+        for (int w = 0; w < wave; ++w) before += wave_tot[w];
+        if (n < n_rays) ray_off[n] = before + incl - c;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) n_active[0] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_compact_write(uint32_t n_rays, uint32_t S, const uint32_t* __restrict__ ray_count,
+                                                       const uint32_t* __restrict__ ray_off, uint32_t* __restrict__ active_idx) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t n = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (n >= n_rays) return;
+    const uint32_t off = ray_off[n], c = ray_count[n];
+    for (uint32_t s = lane; s < c; s += 64) active_idx[off + s] = n * S + s;
+}
+
+template __global__ void k_composite_bwd<true>(uint32_t, uint32_t, float, float, int, const float*, const float*, CompositeCot, LossArgs, float*, int,
+                                               uint32_t*);
+template __global__ void k_composite_bwd<false>(uint32_t, uint32_t, float, float, int, const float*, const float*, CompositeCot, LossArgs, float*, int,
+                                                uint32_t*);
 
 // ------------------------------------------------------------------------------------------------
 // Fused Adam (torch.optim.Adam, amsgrad off): one pass over p, g, m, v.

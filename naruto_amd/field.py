@@ -244,11 +244,9 @@ class NarutoFieldHIP(nn.Module):
             self.check_asserts()
         cfg = self.config
         z_vals = self._sample_z(rays_o, target_d, rand)
-        raw = ops.field_query(self._handle(), self._params(), rays_o=rays_o, rays_d=rays_d, z_vals=z_vals, color=True)
-        raw = raw.reshape(z_vals.shape[0], z_vals.shape[1], 5)
-        rgb, depth, _disp, _acc, _var, _um, losses = ops.render_loss(
-            self._handle(), raw, z_vals, target_rgb, target_d, cfg['cam']['depth_trunc'], cfg['training']['rgb_missing'],
-            group=self.process_group, n_rays_total=self.n_rays_total)
+        rgb, depth, _disp, _acc, _var, _um, _raw, losses = ops.render_train(
+            self._handle(), self._params(), rays_o, rays_d, z_vals, target_rgb, target_d, cfg['cam']['depth_trunc'],
+            cfg['training']['rgb_missing'], group=self.process_group, n_rays_total=self.n_rays_total)
         self._pending_min_uncert = losses[6].detach()
         if self.strict_assert:
             self.check_asserts()

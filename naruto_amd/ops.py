@@ -228,7 +228,7 @@ class _FieldQuery(torch.autograd.Function):
         with torch.cuda.device(dev):
             ws_bytes = lib.naruto_query_bwd_workspace(ctx.handle.ptr, M)
             ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
-            check(lib.naruto_query_bwd(ctx.handle.ptr, C.byref(ps), M, C.byref(pts), _p(feat), _p(d_raw), _p(d_geo),
+            check(lib.naruto_query_bwd(ctx.handle.ptr, C.byref(ps), M, C.byref(pts), _p(feat), _p(d_raw), _p(d_geo), None, None,
                                        C.byref(gs), _p(ws), _stream()), "naruto_query_bwd")
         return (None, None, None, None, None, None, None) + tuple(grads[n] for n in PARAM_NAMES)
 
@@ -329,7 +329,7 @@ class _RenderLoss(torch.autograd.Function):
         with torch.cuda.device(dev):
             st = _stream()
             check(lib.naruto_loss_bwd(ctx.handle.ptr, N, S, _p(raw), _p(z_vals), _p(target_rgb), _p(target_d), ctx.depth_trunc,
-                                      ctx.rgb_missing, _p(sums), ctx.n_total, _p(d_losses), _p(d_raw), st), "naruto_loss_bwd")
+                                      ctx.rgb_missing, _p(sums), ctx.n_total, _p(d_losses), _p(d_raw), None, st), "naruto_loss_bwd")
             if d_rgb is not None or d_depth is not None:       # someone differentiated the rendered rgb / depth too
                 d_rgb = None if d_rgb is None else _f32c(d_rgb, "d_rgb")
                 d_depth = None if d_depth is None else _f32c(d_depth, "d_depth")
@@ -342,6 +342,105 @@ def render_loss(handle: FieldHandle, raw, z_vals, target_rgb, target_d, depth_tr
                 n_rays_total: int = 0):
     return _RenderLoss.apply(handle, raw, z_vals, target_rgb, target_d, float(depth_trunc), float(rgb_missing), group,
                              int(n_rays_total))
+
+
+# ---------------------------------------------------------------------------------------------------
+# A1..A8 as ONE autograd node: what JointEncodingNaruto.forward does in training mode
+# ---------------------------------------------------------------------------------------------------
+class _RenderTrain(torch.autograd.Function):
+    """(rays, z_vals, targets, parameters) -> rgb, depth, losses[8] (+ non-differentiable render outputs).
+
+    Same kernels as field_query + render_loss, but because the whole chain lives in one node the backward can
+    use the structure of the mapping losses: every sample behind the surface band of its ray has an all-zero
+    cotangent, so only the active prefix of each ray (typically 35-55 % of the samples) goes through the MLP
+    backward and the table scatter (naruto_compact_active)."""
+
+    @staticmethod
+    def forward(ctx, handle, rays_o, rays_d, z_vals, target_rgb, target_d, depth_trunc, rgb_missing, group, n_rays_total,
+                table, uncert_grid, sdf_w0, sdf_w1, col_w0, col_w1):
+        lib = _lib.load()
+        params = {"table": table, "uncert_grid": uncert_grid, "sdf_w0": sdf_w0, "sdf_w1": sdf_w1, "col_w0": col_w0, "col_w1": col_w1}
+        params = {k: _f32c(v, k) for k, v in params.items()}
+        rays_o, rays_d, z_vals = _f32c(rays_o, "rays_o"), _f32c(rays_d, "rays_d"), _f32c(z_vals, "z_vals")
+        target_rgb, target_d = _f32c(target_rgb, "target_rgb"), _f32c(target_d, "target_d").reshape(-1)
+        N, S = z_vals.shape
+        M = N * S
+        dev = z_vals.device
+        need_grad = any(ctx.needs_input_grad[10:])
+        raw = torch.empty(N, S, 5, dtype=torch.float32, device=dev)
+        feat = torch.empty(16, M, 2, dtype=torch.float32, device=dev) if need_grad else None
+        rgb = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        disp, acc, depth, depth_var, um = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(5))
+        sums = torch.empty(_lib.LOSS_NSUMS, dtype=torch.float64, device=dev)
+        losses = torch.empty(8, dtype=torch.float32, device=dev)
+        ps = _params_struct(params)
+        pts, _ = _points_struct(None, rays_o, rays_d, z_vals)
+        n_total = N
+        with torch.cuda.device(dev):
+            st = _stream()
+            check(lib.naruto_query_fwd(handle.ptr, C.byref(ps), M, C.byref(pts), _p(raw), None, None, _p(feat), st), "naruto_query_fwd")
+            check(lib.naruto_composite_fwd(handle.ptr, N, S, _p(raw), _p(z_vals), _p(rgb), _p(disp), _p(acc), None, _p(depth),
+                                           _p(depth_var), _p(um), st), "naruto_composite_fwd")
+            ws = torch.empty(lib.naruto_loss_workspace(N) // 4, dtype=torch.float32, device=dev)
+            check(lib.naruto_loss_sums(handle.ptr, N, S, _p(raw), _p(z_vals), _p(rgb), _p(depth), _p(um), _p(target_rgb),
+                                       _p(target_d), depth_trunc, rgb_missing, _p(sums), _p(ws), st), "naruto_loss_sums")
+            if group is not None:
+                from . import parallel
+                parallel.allreduce_loss_sums(sums, group)
+                n_total = int(n_rays_total) if n_rays_total else N * parallel.world_size(group)
+            check(lib.naruto_loss_finalize(_p(sums), n_total, S, _p(losses), st), "naruto_loss_finalize")
+        ctx.handle, ctx.depth_trunc, ctx.rgb_missing, ctx.n_total = handle, depth_trunc, rgb_missing, n_total
+        if need_grad:
+            ctx.save_for_backward(raw, feat, rays_o, rays_d, z_vals, target_rgb, target_d, sums, *(params[k] for k in PARAM_NAMES))
+        ctx.mark_non_differentiable(disp, acc, depth_var, um, raw)
+        return rgb, depth, disp, acc, depth_var, um, raw, losses
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_depth, _d_disp, _d_acc, _d_var, _d_um, _d_raw, d_losses):
+        lib = _lib.load()
+        raw, feat, rays_o, rays_d, z_vals, target_rgb, target_d, sums = ctx.saved_tensors[:8]
+        params = dict(zip(PARAM_NAMES, ctx.saved_tensors[8:]))
+        N, S = z_vals.shape
+        M = N * S
+        dev = raw.device
+        if d_losses is None:
+            d_losses = torch.zeros(8, dtype=torch.float32, device=dev)
+        d_losses = _f32c(d_losses, "d_losses")
+        d_raw = torch.empty_like(raw)
+        extra = d_rgb is not None or d_depth is not None          # someone differentiated the rendered rgb / depth as well
+        grads = {n: (torch.zeros_like(params[n]) if ctx.needs_input_grad[10 + i] else None) for i, n in enumerate(PARAM_NAMES)}
+        gs = NarutoGrads()
+        for n in PARAM_NAMES:
+            setattr(gs, n, _p(grads[n]))
+        ps = _params_struct(params)
+        pts, _ = _points_struct(None, rays_o, rays_d, z_vals)
+        with torch.cuda.device(dev):
+            st = _stream()
+            count = None if extra else torch.empty(N, dtype=torch.int32, device=dev)
+            check(lib.naruto_loss_bwd(ctx.handle.ptr, N, S, _p(raw), _p(z_vals), _p(target_rgb), _p(target_d), ctx.depth_trunc,
+                                      ctx.rgb_missing, _p(sums), ctx.n_total, _p(d_losses), _p(d_raw), _p(count), st), "naruto_loss_bwd")
+            active = n_active = None
+            if extra:
+                d_rgb = None if d_rgb is None else _f32c(d_rgb, "d_rgb")
+                d_depth = None if d_depth is None else _f32c(d_depth, "d_depth")
+                check(lib.naruto_composite_bwd(ctx.handle.ptr, N, S, _p(raw), _p(z_vals), _p(d_rgb), None, None, None, _p(d_depth),
+                                               None, None, _p(d_raw), 1, st), "naruto_composite_bwd")
+            else:
+                off = torch.empty(N, dtype=torch.int32, device=dev)
+                active = torch.empty(M, dtype=torch.int32, device=dev)
+                n_active = torch.empty(1, dtype=torch.int32, device=dev)
+                check(lib.naruto_compact_active(N, S, _p(count), _p(off), _p(active), _p(n_active), st), "naruto_compact_active")
+            ws = torch.empty((lib.naruto_query_bwd_workspace(ctx.handle.ptr, M) + 3) // 4, dtype=torch.float32, device=dev)
+            check(lib.naruto_query_bwd(ctx.handle.ptr, C.byref(ps), M, C.byref(pts), _p(feat), _p(d_raw), None, _p(active), _p(n_active),
+                                       C.byref(gs), _p(ws), st), "naruto_query_bwd")
+        return (None,) * 10 + tuple(grads[n] for n in PARAM_NAMES)
+
+
+def render_train(handle: FieldHandle, params: Dict[str, torch.Tensor], rays_o, rays_d, z_vals, target_rgb, target_d,
+                 depth_trunc: float, rgb_missing: float, group=None, n_rays_total: int = 0):
+    """-> rgb, depth, disp, acc, depth_var, uncert_map, raw, losses[8]."""
+    return _RenderTrain.apply(handle, rays_o, rays_d, z_vals, target_rgb, target_d, float(depth_trunc), float(rgb_missing), group,
+                              int(n_rays_total), *(params[n] for n in PARAM_NAMES))
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -134,6 +134,7 @@ class _HashEncode(torch.autograd.Function):
         with torch.cuda.device(x.device):
             check(lib.naruto_hash_encode_fwd(handle.ptr, M, _p(x), _p(table), _p(feat), _stream()), "naruto_hash_encode_fwd")
         ctx.handle = handle
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(x, table)
         return feat
 
@@ -142,7 +143,7 @@ class _HashEncode(torch.autograd.Function):
         lib = _lib.load()
         x, table = ctx.saved_tensors
         d_table = None
-        if ctx.needs_input_grad[2]:
+        if ctx.needs_input_grad[2] and d_feat is not None:
             d_feat = _f32c(d_feat, "d_feat")
             d_table = torch.zeros_like(table)
             with torch.cuda.device(x.device):
@@ -185,6 +186,7 @@ class _FieldQuery(torch.autograd.Function):
             check(lib.naruto_query_fwd(handle.ptr, C.byref(ps), M, C.byref(pts), _p(out) if color else None,
                                        None if color else _p(out), _p(geo), _p(feat), _stream()), "naruto_query_fwd")
         ctx.handle, ctx.color, ctx.want_geo, ctx.M = handle, color, want_geo, M
+        ctx.set_materialize_grads(False)
         ctx.has_x = x is not None
         if need_grad:
             ctx.save_for_backward(feat, *(t for t in (x, rays_o, rays_d, z_vals) if t is not None),
@@ -255,6 +257,7 @@ class _Composite(torch.autograd.Function):
             check(lib.naruto_composite_fwd(handle.ptr, N, S, _p(raw), _p(z_vals), _p(rgb), _p(disp), _p(acc), _p(weights),
                                            _p(depth), _p(depth_var), _p(um), _stream()), "naruto_composite_fwd")
         ctx.handle = handle
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(raw, z_vals)
         return rgb, disp, acc, weights, depth, depth_var, um
 
@@ -312,6 +315,7 @@ class _RenderLoss(torch.autograd.Function):
                 n_total = int(n_rays_total) if n_rays_total else N * parallel.world_size(group)
             check(lib.naruto_loss_finalize(_p(sums), n_total, S, _p(losses), st), "naruto_loss_finalize")
         ctx.handle, ctx.depth_trunc, ctx.rgb_missing, ctx.n_total = handle, depth_trunc, rgb_missing, n_total
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(raw, z_vals, target_rgb, target_d, sums)
         ctx.mark_non_differentiable(disp, acc, depth_var, um)
         return rgb, depth, disp, acc, depth_var, um, losses
@@ -390,6 +394,7 @@ class _RenderTrain(torch.autograd.Function):
                 n_total = int(n_rays_total) if n_rays_total else N * parallel.world_size(group)
             check(lib.naruto_loss_finalize(_p(sums), n_total, S, _p(losses), st), "naruto_loss_finalize")
         ctx.handle, ctx.depth_trunc, ctx.rgb_missing, ctx.n_total = handle, depth_trunc, rgb_missing, n_total
+        ctx.set_materialize_grads(False)
         if need_grad:
             ctx.save_for_backward(raw, feat, rays_o, rays_d, z_vals, target_rgb, target_d, sums, *(params[k] for k in PARAM_NAMES))
         ctx.mark_non_differentiable(disp, acc, depth_var, um, raw)

@@ -1,0 +1,129 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every declared symbol, the level tables it
+derives equal the oracle's, argument validation, config loading, synthetic workloads."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from naruto_amd import config as cfgmod
+from naruto_amd import synthetic as syn
+from oracle import spec_torch as S
+
+import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    from naruto_amd import _lib
+    header = open(os.path.join(ROOT, "include", "naruto_hip.h")).read()
+    declared = set(re.findall(r"\b(naruto_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    for name in declared:
+        assert hasattr(built_lib, name), f"libnaruto_hip.so does not export {name}"
+    assert built_lib.naruto_version() >= 1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from naruto_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no fallback"):
+        _lib.load()
+
+
+@pytest.mark.parametrize("res,T", [(275, 16), (275, 12), (1015, 16), (1024, 22), (340, 16)])
+def test_field_levels_match_oracle(built_lib, res, T):
+    from naruto_amd import ops
+    meta = S.HashGridMeta.from_desired_resolution(res, log2_hashmap_size=T)
+    h = ops.FieldHandle(log2_hashmap_size=T, per_level_scale=float(np.exp2(np.log2(res / 16) / 15)), uncert_dims=(4, 5, 6),
+                        bbox_min=(0, 0, 0), bbox_max=(1, 1, 1), trunc=0.1, sc_factor=1.0)
+    scale, r, size, off = h.levels()
+    assert np.array_equal(np.asarray(scale, np.float32), meta.scale)
+    assert np.array_equal(np.asarray(r), meta.resolution) and np.array_equal(np.asarray(size), meta.size)
+    assert np.array_equal(np.asarray(off), meta.offset) and h.n_entries == meta.n_entries
+
+
+def test_create_rejects_unsupported_configurations(built_lib):
+    from naruto_amd import ops, _lib
+    kw = dict(per_level_scale=1.2, uncert_dims=(4, 5, 6), bbox_min=(0, 0, 0), bbox_max=(1, 1, 1), trunc=0.1, sc_factor=1.0)
+    for bad in (dict(n_levels=8), dict(n_features=4), dict(hidden_dim=64), dict(n_bins=8), dict(geo_feat_dim=7), dict(log2_hashmap_size=40),
+                dict(trunc=0.0), dict(uncert_dims=(0, 1, 1))):
+        with pytest.raises(_lib.NarutoError):
+            ops.FieldHandle(**{**kw, **bad})
+    # NULL arguments come back as error codes + message, never a crash
+    rc = built_lib.naruto_sample_z(4, None, 0.0, 5.0, 0, 0, 0.0, 64, None, None, None)
+    assert rc != 0 and b"NULL" in built_lib.naruto_last_error()
+
+
+def test_hot_path_refuses_cpu_tensors(built_lib):
+    from naruto_amd.field import NarutoFieldHIP
+    cfg = H.office_cfg(12)
+    m = NarutoFieldHIP(cfg, torch.tensor(cfg["mapping"]["bound"], dtype=torch.float32))
+    m.get_uncert_grid(0.1)
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        m.query_sdf(torch.rand(10, 3))
+    # state_dict keeps the reference's key set, incl. the aliased top-level nets
+    keys = set(m.state_dict().keys())
+    want = {"uncert_grid", "embed_fn.params", "embedpos_fn.params",
+            "decoder.sdf_net.model.0.weight", "decoder.sdf_net.model.2.weight",
+            "decoder.color_net.model.0.weight", "decoder.color_net.model.2.weight",
+            "sdf_net.model.0.weight", "sdf_net.model.2.weight", "color_net.model.0.weight", "color_net.model.2.weight"}
+    assert keys == want, keys ^ want
+    assert m.embed_fn.params.numel() == 2 * 4096 * 16 and tuple(m.uncert_grid.shape) == (49, 56, 35)
+    assert m.decoder.sdf_net.model[0].weight.shape == (32, 80) and m.decoder.color_net.model[0].weight.shape == (32, 63)
+
+
+def test_unsupported_model_configs_raise():
+    from naruto_amd.field import NarutoFieldHIP
+    bb = torch.tensor([[0.0, 1.0]] * 3)
+    for path, val in ((("grid", "oneGrid"), False), (("decoder", "tcnn_network"), True), (("decoder", "uncert_grid"), False),
+                      (("training", "n_importance"), 8)):
+        cfg = H.office_cfg(12)
+        cfg[path[0]][path[1]] = val
+        with pytest.raises(NotImplementedError):
+            NarutoFieldHIP(cfg, bb)
+
+
+def test_config_inherit_from(tmp_path):
+    base = tmp_path / "base.yaml"
+    base.write_text("mapping:\n  sample: 2048\n  iters: 10\ngrid:\n  hash_size: 16\ntraining:\n  trunc: 0.1\n")
+    scene = tmp_path / "scene.yaml"
+    scene.write_text(f"inherit_from: {base}\nmapping:\n  bound: [[-1,1],[-2,2],[0,3]]\n  iters: 20\n")
+    cfg = cfgmod.load_config(str(scene))
+    assert cfg["mapping"]["sample"] == 2048 and cfg["mapping"]["iters"] == 20 and cfg["grid"]["hash_size"] == 16
+    assert cfg["mapping"]["bound"][1] == [-2, 2]
+    o = cfgmod.office0_config()
+    assert o["mapping"]["bound"] == [[-2.2, 2.6], [-3.4, 2.1], [-1.4, 2.0]]
+    assert o["training"]["n_samples_d"] == 32 and o["training"]["n_range_d"] == 11 and o["grid"]["hash_size"] == 16
+    bb = torch.tensor(o["mapping"]["bound"])
+    assert S.get_resolution(bb, o["grid"]["voxel_sdf"]) == 275
+    assert S.get_resolution(torch.tensor(cfgmod.mp3d_large_config()["mapping"]["bound"]), 0.02) == 1015
+
+
+def test_synthetic_workloads_are_reproducible():
+    a = syn.random_rays(100, cfgmod.office0_config()["mapping"]["bound"], seed=5)
+    b = syn.random_rays(100, cfgmod.office0_config()["mapping"]["bound"], seed=5)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert np.allclose(np.linalg.norm(a["rays_d"], axis=1), 1.0, atol=1e-6)
+    assert (a["target_d"] == 0).sum() > 0
+    p = syn.pinhole_rays(64, 64, 32.0, 32.0, cfgmod.office0_config()["mapping"]["bound"])
+    assert p["rays_o"].shape == (4096, 3) and p["rays_d"].shape == (4096, 3)
+    assert syn.closed_form_table(10, 0.5).dtype == np.float32
+
+
+def test_reference_workload_config0_on_oracle():
+    """BASELINE.json configs[0]: office_0, 64x64 rays, 32 samples/ray, CPU path -- runs on the oracle."""
+    cfg = H.office_cfg(16, n_samples_d=21)          # 21 + 11 near-surface = 32 samples per ray
+    rays = syn.pinhole_rays(64, 64, 32.0, 32.0, cfg["mapping"]["bound"])
+    ora = H.make_oracle(cfg, 1e-4, 0).train()
+    t = {k: torch.from_numpy(v) for k, v in rays.items()}
+    ret = ora.forward(t["rays_o"], t["rays_d"], t["target_rgb"], t["target_d"])
+    loss = S.total_loss(ret, cfg["training"])
+    loss.backward()
+    assert torch.isfinite(loss) and ret["rgb"].shape == (4096, 3)
+    assert float(ora.table.grad.abs().sum()) > 0

@@ -1,18 +1,32 @@
 #!/usr/bin/env python3
-"""Summarise a rocprofv3 rocpd (.db) kernel trace: per-kernel count / total / average duration."""
-import sqlite3, sys
+"""Summarise a rocprofv3 rocpd (.db) run: per-kernel count / total / average duration, and -- when the run
+collected PMC counters -- the per-dispatch average of each counter.
+
+    python tools/prof_summary.py run_results.db [> profiles/xyz.txt]
+"""
+import sqlite3
+import sys
+
 db = sys.argv[1]
-skip = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 c = sqlite3.connect(db)
-cols = [r[1] for r in c.execute("pragma table_info(rocpd_kernel_dispatch)")]
 scols = [r[1] for r in c.execute("pragma table_info(rocpd_info_kernel_symbol)")]
 name_col = "kernel_name" if "kernel_name" in scols else ("display_name" if "display_name" in scols else scols[-1])
-q = f"""select s.{name_col}, count(*), sum(d.end-d.start), avg(d.end-d.start), min(d.end-d.start), max(d.end-d.start)
+rows = list(c.execute(f"""select s.{name_col}, count(*), sum(d.end-d.start), avg(d.end-d.start), min(d.end-d.start), max(d.end-d.start)
         from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id
-        group by s.{name_col} order by 3 desc"""
-rows = list(c.execute(q))
+        group by s.{name_col} order by 3 desc"""))
 tot = sum(r[2] for r in rows)
-print(f"{'kernel':90s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>9s} {'max_us':>9s} {'%':>6s}")
-for n, cnt, s, a, mn, mx in rows[:45]:
-    print(f"{n[:90]:90s} {cnt:7d} {s/1e6:10.3f} {a/1e3:10.2f} {mn/1e3:9.2f} {mx/1e3:9.2f} {100*s/tot:6.2f}")
+print(f"{'kernel':96s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>9s} {'max_us':>9s} {'%':>6s}")
+for n, cnt, s, a, mn, mx in rows[:48]:
+    print(f"{n[:96]:96s} {cnt:7d} {s/1e6:10.3f} {a/1e3:10.2f} {mn/1e3:9.2f} {mx/1e3:9.2f} {100*s/tot:6.2f}")
 print(f"total kernel time {tot/1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches")
+n_pmc = c.execute("select count(*) from rocpd_pmc_event").fetchone()[0]
+if n_pmc:
+    q = f"""select s.{name_col}, p.name, count(*), avg(e.value), sum(e.value)
+            from rocpd_pmc_event e join rocpd_info_pmc p on e.pmc_id = p.id
+            join rocpd_kernel_dispatch d on d.event_id = e.event_id
+            join rocpd_info_kernel_symbol s on d.kernel_id = s.id
+            group by s.{name_col}, p.name order by 5 desc"""
+    print("\nPMC counters (per-dispatch average):")
+    print(f"{'kernel':96s} {'counter':>16s} {'calls':>7s} {'avg':>16s}")
+    for n, pn, cnt, av, sm in list(c.execute(q))[:40]:
+        print(f"{n[:96]:96s} {pn:>16s} {cnt:7d} {av:16.1f}")

@@ -111,7 +111,18 @@ int naruto_hash_encode_fwd(const NarutoField* f, uint32_t M, const float* x, con
  * workspace: naruto_scatter_workspace(f) bytes (per-split partial tables of the LDS-tiled scatter). */
 size_t naruto_scatter_workspace(const NarutoField* f);
 int naruto_hash_encode_bwd(const NarutoField* f, uint32_t M, const float* x, const float* d_feat,
+                           const float* d_feat_scale /* device scalar multiplying d_feat, or NULL */,
                            float* d_table, void* workspace, void* stream);
+
+/* Feature-grid smoothness term of the mapping loss -- Co-SLAM CoSLAM.smoothness [not in tree], called by
+ * get_loss_from_ret (coslam.py:166-169): TV of the hash features on a (sample_points-1)^3 lattice placed
+ * at a random offset.  rand6 (device) = offset_rand[3] ++ jitter_rand[3] in [0,1).  Outputs: loss [1],
+ * x_out [n^3,3] (the normalised lattice points) and d_feat [n^3,32] = d(loss)/d(features), which
+ * naruto_hash_encode_bwd(x_out, d_feat, d_feat_scale = cotangent of the loss) turns into the table gradient. */
+size_t naruto_smoothness_workspace(uint32_t sample_points);
+int naruto_smoothness_fwd(const NarutoField* f, const float* table, uint32_t sample_points, float voxel_size,
+                          float margin, const float* rand6, float* x_out, float* d_feat, float* loss,
+                          void* workspace, void* stream);
 
 /* A2-A5 fused -- calc_embedding + embedpos_fn + decoder (scene_rep.py:58-64,132-148, decoder.py:29-41,
  * 99-116).  Outputs (any may be NULL):

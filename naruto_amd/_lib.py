@@ -82,7 +82,9 @@ SIGNATURES = {
     "naruto_sample_z": (_I, [_U32, _V, _F, _F, _U32, _U32, _F, _U32, _V, _V, _V]),
     "naruto_hash_encode_fwd": (_I, [_V, _U32, _V, _V, _V, _V]),
     "naruto_scatter_workspace": (C.c_size_t, [_V]),
-    "naruto_hash_encode_bwd": (_I, [_V, _U32, _V, _V, _V, _V, _V]),
+    "naruto_hash_encode_bwd": (_I, [_V, _U32, _V, _V, _V, _V, _V, _V]),
+    "naruto_smoothness_workspace": (C.c_size_t, [_U32]),
+    "naruto_smoothness_fwd": (_I, [_V, _V, _U32, _F, _F, _V, _V, _V, _V, _V, _V]),
     "naruto_query_fwd": (_I, [_V, C.POINTER(NarutoParams), _U32, C.POINTER(NarutoPoints), _V, _V, _V, _V, _V]),
     "naruto_query_bwd_workspace": (C.c_size_t, [_V, _U32]),
     "naruto_query_bwd": (_I, [_V, C.POINTER(NarutoParams), _U32, C.POINTER(NarutoPoints), _V, _V, _V, _V, _V,

@@ -63,7 +63,7 @@ constexpr uint32_t kBwdMaxBlocks = 256;     // one 145 KB-LDS block per CU
 
 // table scatter: LDS-tiled units + k_scatter_reduce, and/or the global-atomic kernel for oversized levels
 int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const float* d_feat, size_t stride_m, size_t stride_l, float* d_table,
-                   float* partial, hipStream_t st, const uint32_t* m_dev = nullptr) {
+                   float* partial, hipStream_t st, const uint32_t* m_dev = nullptr, const float* scale_dev = nullptr) {
     const size_t n_params = (size_t)f->n_entries * 2u;
     if (f->plan.n_dense + f->plan.n_hashed > 0) {
         static bool attr_set = false;
@@ -75,7 +75,7 @@ int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const f
         }
         const uint32_t blocks = f->plan.n_dense * f->plan.s_dense + f->plan.n_hashed * f->plan.s_hashed;
         hipLaunchKernelGGL(k_hash_scatter_lds, dim3(blocks), dim3(kScatterThreads), lds, st, f->lt, f->bt, ps, M, d_feat, stride_m, stride_l, f->plan,
-                           partial, n_params, m_dev);
+                           partial, n_params, m_dev, scale_dev);
         if (int rc = check_launch("hash_scatter_lds")) return rc;
         hipLaunchKernelGGL(k_scatter_reduce, dim3((uint32_t)((n_params / 4u + 255u) / 256u)), dim3(256), 0, st, f->lt, f->plan.atomic_levels, partial,
                            f->plan.s_dense, f->plan.s_hashed, n_params, d_table);
@@ -83,7 +83,7 @@ int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const f
     }
     if (f->plan.atomic_levels != 0) {
         hipLaunchKernelGGL(k_hash_scatter_atomic, dim3((M + 255u) / 256u, kLevels), dim3(256), 0, st, f->lt, f->bt, ps, M, d_feat, stride_m, stride_l,
-                           f->plan.atomic_levels, d_table, m_dev);
+                           f->plan.atomic_levels, d_table, m_dev, scale_dev);
         if (int rc = check_launch("hash_scatter_atomic")) return rc;
     }
     return NARUTO_OK;
@@ -225,14 +225,46 @@ size_t naruto_scatter_workspace(const NarutoField* f) {
     return (size_t)smax * (size_t)f->n_entries * 2u * sizeof(float);
 }
 
-int naruto_hash_encode_bwd(const NarutoField* f, uint32_t M, const float* x, const float* d_feat, float* d_table, void* workspace, void* stream) {
+int naruto_hash_encode_bwd(const NarutoField* f, uint32_t M, const float* x, const float* d_feat, const float* d_feat_scale, float* d_table,
+                           void* workspace, void* stream) {
     if (f == nullptr || x == nullptr || d_feat == nullptr || d_table == nullptr || workspace == nullptr)
         return fail(NARUTO_ERR_INVALID, "hash_encode_bwd: NULL argument");
     if (M == 0) return NARUTO_OK;
     PointSrc ps{};
     ps.x = x;
     ps.S = 1;
-    return launch_scatter(f, ps, M, d_feat, (size_t)kFeat, (size_t)2, d_table, reinterpret_cast<float*>(workspace), (hipStream_t)stream);
+    return launch_scatter(f, ps, M, d_feat, (size_t)kFeat, (size_t)2, d_table, reinterpret_cast<float*>(workspace), (hipStream_t)stream, nullptr,
+                          d_feat_scale);
+}
+
+size_t naruto_smoothness_workspace(uint32_t sample_points) {
+    const size_t n = sample_points > 1 ? sample_points - 1 : 1;
+    const size_t n3 = n * n * n;
+    return n3 * kFeat * sizeof(float) + ((n3 * kFeat + 255) / 256) * sizeof(double) + 64;
+}
+
+int naruto_smoothness_fwd(const NarutoField* f, const float* table, uint32_t sample_points, float voxel_size, float margin, const float* rand6,
+                          float* x_out, float* d_feat, float* loss, void* workspace, void* stream) {
+    if (f == nullptr || table == nullptr || rand6 == nullptr || x_out == nullptr || d_feat == nullptr || loss == nullptr || workspace == nullptr)
+        return fail(NARUTO_ERR_INVALID, "smoothness_fwd: NULL argument");
+    if (sample_points < 3 || sample_points > 257) return fail(NARUTO_ERR_INVALID, "smoothness_fwd: sample_points must be in [3, 257]");
+    TvArgs a;
+    a.n = sample_points - 1;
+    a.voxel = voxel_size;
+    a.margin = margin;
+    a.grid_size = (float)(sample_points - 1) * voxel_size;
+    a.inv_p3 = 1.0f / ((float)sample_points * (float)sample_points * (float)sample_points);
+    const uint32_t n3 = a.n * a.n * a.n;
+    float* feat = reinterpret_cast<float*>(workspace);
+    double* partial = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + (((size_t)n3 * kFeat * sizeof(float) + 63) / 64) * 64);
+    const uint32_t nb = (n3 * kFeat + 255u) / 256u;
+    hipLaunchKernelGGL(k_tv_encode, dim3((n3 + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, f->lt, f->bt, a, rand6, reinterpret_cast<const float2*>(table),
+                       x_out, feat);
+    if (int rc = check_launch("tv_encode")) return rc;
+    hipLaunchKernelGGL(k_tv_loss, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, feat, d_feat, partial);
+    if (int rc = check_launch("tv_loss")) return rc;
+    hipLaunchKernelGGL(k_tv_finalize, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nb, a.inv_p3, loss);
+    return check_launch("tv_finalize");
 }
 
 int naruto_query_fwd(const NarutoField* f, const NarutoParams* p, uint32_t M, const NarutoPoints* pts, float* raw, float* sdf_uncert,

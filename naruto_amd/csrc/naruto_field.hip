@@ -243,16 +243,19 @@ __device__ __forceinline__ void scatter_level_atomic(const LevelTab& lt, float x
 // hash_encode) and the [16][M][2] layout written by k_query_bwd can be consumed.
 __global__ __launch_bounds__(256) void k_hash_scatter_atomic(LevelTab lt, BoxTab bt, PointSrc ps, uint32_t M, const float* __restrict__ d_feat,
                                                              size_t stride_m, size_t stride_l, uint32_t level_mask, float* __restrict__ d_table,
-                                                             const uint32_t* __restrict__ m_dev) {
+                                                             const uint32_t* __restrict__ m_dev, const float* __restrict__ scale_dev) {
     if (m_dev != nullptr) M = m_dev[0];
+    const float gscale = scale_dev != nullptr ? scale_dev[0] : 1.0f;
     const int level = blockIdx.y;
     if (!((level_mask >> level) & 1u)) return;
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
     float x, y, z;
     load_point(ps, bt, m, x, y, z);
-    const float2 g = *reinterpret_cast<const float2*>(d_feat + (size_t)m * stride_m + (size_t)level * stride_l);
+    float2 g = *reinterpret_cast<const float2*>(d_feat + (size_t)m * stride_m + (size_t)level * stride_l);
     if (g.x == 0.0f && g.y == 0.0f) return;
+    g.x *= gscale;
+    g.y *= gscale;
     switch (level) {
 #define NARUTO_CASE(T) case T: scatter_level_atomic<T>(lt, x, y, z, g, d_table); break;
         NARUTO_CASE(0) NARUTO_CASE(1) NARUTO_CASE(2) NARUTO_CASE(3) NARUTO_CASE(4) NARUTO_CASE(5) NARUTO_CASE(6) NARUTO_CASE(7)
@@ -355,9 +358,10 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
 __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab lt, BoxTab bt, PointSrc ps, uint32_t M, const float* __restrict__ d_feat,
                                                                        size_t stride_m, size_t stride_l, ScatterPlan plan,
                                                                        float* __restrict__ partial, size_t n_params,
-                                                                       const uint32_t* __restrict__ m_dev) {
+                                                                       const uint32_t* __restrict__ m_dev, const float* __restrict__ scale_dev) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];
     if (m_dev != nullptr) M = m_dev[0];          // compacted point list: the count lives on the device
+    const float gscale = scale_dev != nullptr ? scale_dev[0] : 1.0f;     // cotangent of a scalar loss (smoothness term)
     uint32_t unit, split, n_splits;
     const uint32_t dense_blocks = plan.n_dense * plan.s_dense;
     if (blockIdx.x < dense_blocks) {
@@ -387,12 +391,13 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
     // level sizes are multiples of 8 entries and chunks start at multiples of 8 192: float4-aligned slices
     const uint32_t n_e = lt.size[level] - chunk * kChunk < kChunk ? lt.size[level] - chunk * kChunk : kChunk;
     float4* out = reinterpret_cast<float4*>(partial + (size_t)split * n_params + 2 * ((size_t)lt.off[level] + (size_t)chunk * kChunk));
+    const double inv = kFixInv * (double)gscale;
     for (uint32_t i = threadIdx.x; i < n_e / 2u; i += kScatterThreads) {
         float4 v;
-        v.x = (float)((double)(long long)acc[4 * i + 0] * kFixInv);
-        v.y = (float)((double)(long long)acc[4 * i + 1] * kFixInv);
-        v.z = (float)((double)(long long)acc[4 * i + 2] * kFixInv);
-        v.w = (float)((double)(long long)acc[4 * i + 3] * kFixInv);
+        v.x = (float)((double)(long long)acc[4 * i + 0] * inv);
+        v.y = (float)((double)(long long)acc[4 * i + 1] * inv);
+        v.z = (float)((double)(long long)acc[4 * i + 2] * inv);
+        v.w = (float)((double)(long long)acc[4 * i + 3] * inv);
         out[i] = v;
     }
 }
@@ -417,6 +422,82 @@ __global__ __launch_bounds__(256) void k_scatter_reduce(LevelTab lt, uint32_t at
     float4 o = *d;
     o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
     *d = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Feature-grid smoothness term (Co-SLAM CoSLAM.smoothness, called from get_loss_from_ret, reference
+// src/slam/coslam/coslam.py:166-169): total variation of the hash features on an n^3 lattice of points
+//   p = (ijk + jitter) * voxel + bbox_min + offset,  offset = offset_rand * (extent - (P-1) voxel - 2 margin) + margin
+//   loss = sum_axes sum (f[i+1] - f[i])^2 / P^3                         (P = sample_points, n = P - 1)
+// k_tv_encode computes the points and their features, k_tv_loss the loss partials and d(loss)/d(feat).
+// ------------------------------------------------------------------------------------------------
+struct TvArgs {
+    uint32_t n;
+    float voxel, margin, grid_size, inv_p3;
+};
+
+__global__ __launch_bounds__(256) void k_tv_encode(LevelTab lt, BoxTab bt, TvArgs a, const float* __restrict__ rand6, const float2* __restrict__ table,
+                                                   float* __restrict__ x_out, float* __restrict__ feat) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n3 = a.n * a.n * a.n;
+    if (m >= n3) return;
+    const uint32_t ijk[3] = {m / (a.n * a.n), (m / a.n) % a.n, m % a.n};
+    float xn[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float offset_max = bt.bext[d] - a.grid_size - 2.0f * a.margin;
+        const float offset = rand6[d] * offset_max + a.margin;
+        const float p = ((float)ijk[d] + rand6[3 + d]) * a.voxel + bt.bmin[d] + offset;
+        xn[d] = __fdiv_rn(p - bt.bmin[d], bt.bext[d]);
+        x_out[3 * (size_t)m + d] = xn[d];
+    }
+    float2* out = reinterpret_cast<float2*>(feat + (size_t)m * kFeat);
+    static_for<0, kLevels>([&](auto tc) {
+        constexpr int T = decltype(tc)::value;
+        out[T] = hash_level<T>(lt, table, xn[0], xn[1], xn[2]);
+    });
+}
+
+__global__ __launch_bounds__(256) void k_tv_loss(TvArgs a, const float* __restrict__ feat, float* __restrict__ d_feat, double* __restrict__ partial) {
+    __shared__ double red[4];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;          // (point, channel)
+    const uint32_t n = a.n, total = n * n * n * kFeat;
+    double acc = 0.0;
+    if (t < total) {
+        const uint32_t c = t % kFeat, m = t / kFeat;
+        const uint32_t i = m / (n * n), j = (m / n) % n, k = m % n;
+        const float f = feat[t];
+        const uint32_t stride[3] = {n * n * kFeat, n * kFeat, (uint32_t)kFeat};
+        const uint32_t pos[3] = {i, j, k};
+        float g = 0.0f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            if (pos[d] + 1 < n) {
+                const float df = feat[t + stride[d]] - f;
+                acc += (double)(df * df);
+                g -= df;
+            }
+            if (pos[d] > 0) g += f - feat[t - stride[d]];
+        }
+        d_feat[t] = 2.0f * g * a.inv_p3;
+        (void)c;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void k_tv_finalize(const double* __restrict__ partial, uint32_t n_partial, float inv_p3, float* __restrict__ loss) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (uint32_t i = threadIdx.x; i < n_partial; i += 256) acc += partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (float)((red[0] + red[1] + red[2] + red[3]) * (double)inv_p3);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -148,13 +148,55 @@ class _HashEncode(torch.autograd.Function):
             d_table = torch.zeros_like(table)
             with torch.cuda.device(x.device):
                 ws = torch.empty((lib.naruto_scatter_workspace(ctx.handle.ptr) + 3) // 4, dtype=torch.float32, device=x.device)
-                check(lib.naruto_hash_encode_bwd(ctx.handle.ptr, x.shape[0], _p(x), _p(d_feat), _p(d_table), _p(ws), _stream()),
+                check(lib.naruto_hash_encode_bwd(ctx.handle.ptr, x.shape[0], _p(x), _p(d_feat), None, _p(d_table), _p(ws), _stream()),
                       "naruto_hash_encode_bwd")
         return None, None, d_table
 
 
 def hash_encode(handle: FieldHandle, x: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
     return _HashEncode.apply(handle, x, table)
+
+
+class _Smoothness(torch.autograd.Function):
+    """Co-SLAM's feature-grid smoothness term as three small kernels forward + the table scatter backward."""
+
+    @staticmethod
+    def forward(ctx, handle, table, sample_points, voxel_size, margin, rand6):
+        lib = _lib.load()
+        table = _f32c(table, "table")
+        rand6 = _f32c(rand6, "rand6").reshape(-1)
+        assert rand6.numel() == 6
+        n = sample_points - 1
+        dev = table.device
+        x = torch.empty(n ** 3, 3, dtype=torch.float32, device=dev)
+        d_feat = torch.empty(n ** 3, 32, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            ws = torch.empty((lib.naruto_smoothness_workspace(sample_points) + 3) // 4, dtype=torch.float32, device=dev)
+            check(lib.naruto_smoothness_fwd(handle.ptr, _p(table), sample_points, voxel_size, margin, _p(rand6), _p(x), _p(d_feat), _p(loss),
+                                            _p(ws), _stream()), "naruto_smoothness_fwd")
+        ctx.handle = handle
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x, d_feat, table)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, d_feat, table = ctx.saved_tensors
+        if g is None or not ctx.needs_input_grad[1]:
+            return None, None, None, None, None, None
+        g = _f32c(g, "grad").reshape(1)
+        d_table = torch.zeros_like(table)
+        with torch.cuda.device(x.device):
+            ws = torch.empty((lib.naruto_scatter_workspace(ctx.handle.ptr) + 3) // 4, dtype=torch.float32, device=x.device)
+            check(lib.naruto_hash_encode_bwd(ctx.handle.ptr, x.shape[0], _p(x), _p(d_feat), _p(g), _p(d_table), _p(ws), _stream()),
+                  "naruto_hash_encode_bwd")
+        return None, d_table, None, None, None, None
+
+
+def smoothness(handle: FieldHandle, table: torch.Tensor, sample_points: int, voxel_size: float, margin: float, rand6: torch.Tensor):
+    return _Smoothness.apply(handle, table, int(sample_points), float(voxel_size), float(margin), rand6)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -35,29 +35,16 @@ def init_uncert_grid_optim(model: NarutoFieldHIP, voxel_size: float = 0.1) -> op
 
 def smoothness(model: NarutoFieldHIP, config: Dict, sample_points: int = 256, voxel_size: float = 0.1, margin: float = 0.05,
                offset_rand: Optional[torch.Tensor] = None, jitter_rand: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Co-SLAM CoSLAM.smoothness: total variation of the hash features on a (sample_points-1)^3 lattice."""
-    bb = model.bounding_box
-    grid_size = (sample_points - 1) * voxel_size
-    offset_max = bb[:, 1] - bb[:, 0] - grid_size - 2 * margin
-    if offset_rand is None:
-        offset_rand = torch.rand(3, device=bb.device)          # drawn on the device: no host sync per iteration
-    if jitter_rand is None:
-        jitter_rand = torch.rand((1, 1, 1, 3), device=bb.device)
-    offset = offset_rand.to(offset_max) * offset_max + margin
-    n = sample_points - 1
-    cache = model.__dict__.setdefault("_smooth_coords", {})
-    coords = cache.get((n, bb.device))
-    if coords is None:
-        ax = torch.arange(0, n, dtype=torch.long, device=bb.device)
-        coords = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), dim=-1).float()
-        cache[(n, bb.device)] = coords
-    pts = (coords + jitter_rand.to(bb).reshape(1, 1, 1, 3)) * voxel_size + bb[:, 0] + offset
-    pts_tcnn = (pts - bb[:, 0]) / (bb[:, 1] - bb[:, 0])
-    sdf = model.query_sdf(pts_tcnn, embed=True)
-    tv_x = torch.pow(sdf[1:, ...] - sdf[:-1, ...], 2).sum()
-    tv_y = torch.pow(sdf[:, 1:, ...] - sdf[:, :-1, ...], 2).sum()
-    tv_z = torch.pow(sdf[:, :, 1:, ...] - sdf[:, :, :-1, ...], 2).sum()
-    return (tv_x + tv_y + tv_z) / (sample_points ** 3)
+    """Co-SLAM CoSLAM.smoothness: total variation of the hash features on a (sample_points-1)^3 lattice placed at a
+    random offset (fused: lattice points + gather, TV loss + its feature gradient, table scatter in the backward)."""
+    from . import ops
+    dev = model.embed_fn.params.device
+    r = torch.rand(6, device=dev)                     # drawn on the device: no host sync per iteration
+    if offset_rand is not None:
+        r[:3] = offset_rand.to(dev).reshape(3)
+    if jitter_rand is not None:
+        r[3:] = jitter_rand.to(dev).reshape(3)
+    return ops.smoothness(model._handle(), model.embed_fn.params, sample_points, voxel_size, margin, r)
 
 
 def get_loss_from_ret(model: NarutoFieldHIP, config: Dict, ret: Dict, rgb=True, sdf=True, depth=True, fs=True, uncert=True,

@@ -74,8 +74,10 @@ __device__ __forceinline__ void stage_fwd_weights(FwdLds& L, const NarutoParams&
     }
 }
 
+constexpr int kGatherGroup = 4;
+
 template <bool COLOR>
-__global__ __launch_bounds__(256) void k_query_fwd(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps,
+__global__ __launch_bounds__(256, 2) void k_query_fwd(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps,
                                                    uint32_t M, float* __restrict__ raw, float* __restrict__ sdf_uncert,
                                                    float* __restrict__ geo, float* __restrict__ feat_save) {
     __shared__ FwdLds L;
@@ -104,6 +106,9 @@ __global__ __launch_bounds__(256) void k_query_fwd(LevelTab lt, UncertTab ut, Bo
             swap32(b0, b1);                      // b0: tile A operand, b1: tile B operand
             hA = mfma32(a, b0, hA);
             hB = mfma32(a, b1, hB);
+            // keep at most kGatherGroup levels' gathers in flight: bounds the registers the scheduler may spend on
+            // hoisted loads, which is what decides between 1 and 2 waves per SIMD for this kernel
+            if constexpr ((T + 1) % kGatherGroup == 0) __builtin_amdgcn_sched_barrier(0);
         });
         static_for<0, 3>([&](auto dc) {
             constexpr int D = decltype(dc)::value;

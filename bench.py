@@ -107,10 +107,11 @@ def kernel_table(tr, rays, cfg, iters: int):
     add("k_composite_fwd", lambda: _lib.check(lib.naruto_composite_fwd(h.ptr, N, S, p(raw), p(z), p(rgb), p(outs[0]), p(outs[1]), None,
         p(outs[2]), p(outs[3]), p(outs[4]), st())), M * 24 + N * 32, 0, "hbm")
     sums = torch.empty(16, dtype=torch.float64, device=dev)
+    losses = torch.empty(8, device=dev)
     ws = torch.empty(N * 16, device=dev)
     tgt, td = rays["target_rgb"], rays["target_d"].reshape(-1)
     add("k_loss_terms+reduce", lambda: _lib.check(lib.naruto_loss_sums(h.ptr, N, S, p(raw), p(z), p(rgb), p(outs[2]), p(outs[4]), p(tgt), p(td),
-        float(cam["depth_trunc"]), float(trc["rgb_missing"]), p(sums), p(ws), st())), M * 8 + N * 100, 0, "hbm")
+        float(cam["depth_trunc"]), float(trc["rgb_missing"]), p(sums), p(losses), p(ws), st())), M * 8 + N * 100, 0, "hbm")
     gl = torch.tensor([trc["rgb_weight"], trc["depth_weight"], trc["sdf_weight"], trc["fs_weight"], 0.0, trc["uncert_weight"]],
                       dtype=torch.float32, device=dev)
     d_raw = torch.empty(M, 5, device=dev)
@@ -132,10 +133,10 @@ def kernel_table(tr, rays, cfg, iters: int):
     Ma = int(round(frac * M))                                                           # active (non-zero cotangent) samples
     mlp_bwd_flops = Ma * 2 * (5184 + (15 * 32 + 16 * 32 + 32 * 32 + 3 * 32) + 5184)   # recompute + dgrad + wgrad
     add("k_query_bwd+k_wgrad_reduce", lambda: _lib.check(lib.naruto_query_bwd(h.ptr, CT.byref(ps), M, CT.byref(pts), p(feat), p(d_raw), None,
-        p(act), p(nact), CT.byref(gs_mlp), p(wsb), st())), Ma * (128 + 20 + 128 + 4 + 4) + N * 24, mlp_bwd_flops, "mfma")
+        p(act), p(nact), None, 0, CT.byref(gs_mlp), p(wsb), st())), Ma * (128 + 20 + 128 + 4 + 4) + N * 24, mlp_bwd_flops, "mfma")
     t_mlp = rows[-1]["ms"]
     ms_all = events_ms(lambda: _lib.check(lib.naruto_query_bwd(h.ptr, CT.byref(ps), M, CT.byref(pts), p(feat), p(d_raw), None, p(act), p(nact),
-                                                               CT.byref(gs), p(wsb), st())), iters)
+                                                               None, 0, CT.byref(gs), p(wsb), st())), iters)
     sc_bytes = Ma * (16 * 8 * 2 * 8 + 128 + 12)         # 256 fp32 read-modify-writes + d_feat + point
     ms_sc = max(ms_all - t_mlp, 1e-6)
     rows.append({"kernel": "k_hash_scatter", "ms": round(ms_sc, 5), "alg_bytes": int(sc_bytes), "alg_flops": 0,

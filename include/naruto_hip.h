@@ -137,11 +137,25 @@ int naruto_query_fwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
  * d_raw [M,5] required; d_geo [M,15] optional (NULL = 0).  feat_save from the forward call.
  * active_idx / n_active (both NULL, or both given): a list of the point indices to process and its length in
  * DEVICE memory -- every point NOT in the list must have an all-zero cotangent (see naruto_compact_active).
- * workspace: naruto_query_bwd_workspace(M) bytes, contents undefined on entry and exit. */
+ * workspace: naruto_query_bwd_workspace(M) bytes, contents undefined on entry and exit.
+ * extra (optional): E more points whose feature cotangents are already known (the smoothness lattice of
+ * naruto_smoothness_fwd); they are appended to the scatter's point list so that ONE scatter pass produces the
+ * whole table gradient.  flags: NARUTO_BWD_OVERWRITE_* make the reductions WRITE the weight / table gradients
+ * instead of accumulating (saves the caller the zero fill; table: needs log2_hashmap_size <= 16).
+ * Workspace: naruto_query_bwd_workspace(f, M + E). */
+typedef struct NarutoExtraPoints {
+    const float* x;        /* [E,3] normalised points                         */
+    const float* d_feat;   /* [E,32] cotangent of their hash features         */
+    const float* scale;    /* device scalar multiplying d_feat, or NULL (= 1)  */
+    uint32_t     n;        /* E                                               */
+} NarutoExtraPoints;
+#define NARUTO_BWD_OVERWRITE_WEIGHT_GRADS 1u
+#define NARUTO_BWD_OVERWRITE_TABLE_GRAD 2u
 size_t naruto_query_bwd_workspace(const NarutoField* f, uint32_t M);
 int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, const NarutoPoints* pts,
                      const float* feat_save, const float* d_raw, const float* d_geo,
                      const uint32_t* active_idx, const uint32_t* n_active,
+                     const NarutoExtraPoints* extra, uint32_t flags,
                      const NarutoGrads* g, void* workspace, void* stream);
 
 /* A6+A7 -- sdf2weights [Co-SLAM] + raw2outputs (scene_rep.py:66-96).  Outputs (any may be NULL):
@@ -171,6 +185,7 @@ size_t naruto_loss_workspace(uint32_t n_rays);
 int naruto_loss_sums(const NarutoField* f, uint32_t n_rays, uint32_t S, const float* raw, const float* z_vals,
                      const float* rgb, const float* depth, const float* uncert_map, const float* target_rgb,
                      const float* target_d, float depth_trunc, float rgb_missing, double* sums,
+                     float* losses /* optional: single-process shortcut, = finalize(sums, n_rays) */,
                      void* workspace, void* stream);
 int naruto_loss_finalize(const double* sums, uint64_t n_rays_total, uint32_t S, float* losses, void* stream);
 /* Backward of the whole loss block down to d_raw [N,S,5] (composite backward fused in):
@@ -193,6 +208,15 @@ int naruto_compact_active(uint32_t n_rays, uint32_t S, const uint32_t* ray_count
 int naruto_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n,
                      float lr, float beta1, float beta2, float eps, float weight_decay, uint32_t step,
                      const int32_t* step_dev, void* stream);
+
+/* All parameter tensors of one optimiser in a single launch (<= 8 segments, per-segment lr / eps / weight_decay,
+ * shared betas and step). */
+typedef struct NarutoAdamSeg {
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+    uint64_t n; float lr, eps, weight_decay;
+} NarutoAdamSeg;
+int naruto_adam_multi(const NarutoAdamSeg* segs /* host array */, uint32_t n_segs, float beta1, float beta2,
+                      uint32_t step, const int32_t* step_dev, void* stream);
 
 /* Hardware self-checks used by the GPU tests: the MFMA / permlane layouts the kernels rely on.
  * out: device buffer of 64*16 floats; returns 0 and fills out (see tests/test_gpu_intrinsics.py). */

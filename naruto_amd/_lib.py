@@ -40,6 +40,19 @@ class NarutoGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("table", "uncert_grid", "sdf_w0", "sdf_w1", "col_w0", "col_w1")]
 
 
+class NarutoExtraPoints(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("d_feat", C.c_void_p), ("scale", C.c_void_p), ("n", C.c_uint32)]
+
+
+class NarutoAdamSeg(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("n", C.c_uint64), ("lr", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float)]
+
+
+BWD_OVERWRITE_WEIGHT_GRADS = 1
+BWD_OVERWRITE_TABLE_GRAD = 2
+
+
 class NarutoPoints(C.Structure):
     _fields_ = [("x", C.c_void_p), ("rays_o", C.c_void_p), ("rays_d", C.c_void_p), ("z_vals", C.c_void_p),
                 ("n_samples", C.c_uint32)]
@@ -88,12 +101,13 @@ SIGNATURES = {
     "naruto_query_fwd": (_I, [_V, C.POINTER(NarutoParams), _U32, C.POINTER(NarutoPoints), _V, _V, _V, _V, _V]),
     "naruto_query_bwd_workspace": (C.c_size_t, [_V, _U32]),
     "naruto_query_bwd": (_I, [_V, C.POINTER(NarutoParams), _U32, C.POINTER(NarutoPoints), _V, _V, _V, _V, _V,
-                              C.POINTER(NarutoGrads), _V, _V]),
+                              C.POINTER(NarutoExtraPoints), _U32, C.POINTER(NarutoGrads), _V, _V]),
+    "naruto_adam_multi": (_I, [C.POINTER(NarutoAdamSeg), _U32, _F, _F, _U32, _V, _V]),
     "naruto_compact_active": (_I, [_U32, _U32, _V, _V, _V, _V, _V]),
     "naruto_composite_fwd": (_I, [_V, _U32, _U32, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V]),
     "naruto_composite_bwd": (_I, [_V, _U32, _U32, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _I, _V]),
     "naruto_loss_workspace": (C.c_size_t, [_U32]),
-    "naruto_loss_sums": (_I, [_V, _U32, _U32, _V, _V, _V, _V, _V, _V, _V, _F, _F, _V, _V, _V]),
+    "naruto_loss_sums": (_I, [_V, _U32, _U32, _V, _V, _V, _V, _V, _V, _V, _F, _F, _V, _V, _V, _V]),
     "naruto_loss_finalize": (_I, [_V, _U64, _U32, _V, _V]),
     "naruto_loss_bwd": (_I, [_V, _U32, _U32, _V, _V, _V, _V, _F, _F, _V, _U64, _V, _V, _V, _V]),
     "naruto_adam_step": (_I, [_V, _V, _V, _V, _U64, _F, _F, _F, _F, _F, _U32, _V, _V]),

@@ -63,7 +63,8 @@ constexpr uint32_t kBwdMaxBlocks = 256;     // one 145 KB-LDS block per CU
 
 // table scatter: LDS-tiled units + k_scatter_reduce, and/or the global-atomic kernel for oversized levels
 int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const float* d_feat, size_t stride_m, size_t stride_l, float* d_table,
-                   float* partial, hipStream_t st, const uint32_t* m_dev = nullptr, const float* scale_dev = nullptr) {
+                   float* partial, hipStream_t st, const uint32_t* m_dev = nullptr, const float* scale_dev = nullptr, int overwrite = 0) {
+    if (overwrite && f->plan.atomic_levels != 0) return fail(NARUTO_ERR_INVALID, "scatter: overwrite mode needs every level LDS-tiled (log2_hashmap_size <= 16)");
     const size_t n_params = (size_t)f->n_entries * 2u;
     if (f->plan.n_dense + f->plan.n_hashed > 0) {
         static bool attr_set = false;
@@ -78,7 +79,7 @@ int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const f
                            partial, n_params, m_dev, scale_dev);
         if (int rc = check_launch("hash_scatter_lds")) return rc;
         hipLaunchKernelGGL(k_scatter_reduce, dim3((uint32_t)((n_params / 4u + 255u) / 256u)), dim3(256), 0, st, f->lt, f->plan.atomic_levels, partial,
-                           f->plan.s_dense, f->plan.s_hashed, n_params, d_table);
+                           f->plan.s_dense, f->plan.s_hashed, n_params, d_table, overwrite);
         if (int rc = check_launch("scatter_reduce")) return rc;
     }
     if (f->plan.atomic_levels != 0) {
@@ -258,7 +259,7 @@ int naruto_smoothness_fwd(const NarutoField* f, const float* table, uint32_t sam
     float* feat = reinterpret_cast<float*>(workspace);
     double* partial = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + (((size_t)n3 * kFeat * sizeof(float) + 63) / 64) * 64);
     const uint32_t nb = (n3 * kFeat + 255u) / 256u;
-    hipLaunchKernelGGL(k_tv_encode, dim3((n3 + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, f->lt, f->bt, a, rand6, reinterpret_cast<const float2*>(table),
+    hipLaunchKernelGGL(k_tv_encode, dim3((n3 + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, f->lt, f->bt, a, rand6, reinterpret_cast<const float2*>(table),
                        x_out, feat);
     if (int rc = check_launch("tv_encode")) return rc;
     hipLaunchKernelGGL(k_tv_loss, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, feat, d_feat, partial);
@@ -292,14 +293,17 @@ int naruto_query_fwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
 }
 
 size_t naruto_query_bwd_workspace(const NarutoField* f, uint32_t M) {
-    // d_feat [16][M][2] | x [3][M] | wgrad partials | scatter partials
-    return ((size_t)kLevels * 2u + 3u) * sizeof(float) * (size_t)M + (size_t)kBwdMaxBlocks * kAccFloats * sizeof(float) + naruto_scatter_workspace(f);
+    // M here = points + extra points.  d_feat [16][M][2] | x [3][M] | wgrad partials | scatter partials | count word
+    return ((size_t)kLevels * 2u + 3u) * sizeof(float) * (size_t)M + (size_t)kBwdMaxBlocks * kAccFloats * sizeof(float) + naruto_scatter_workspace(f) + 64;
 }
 
 int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, const NarutoPoints* pts, const float* feat_save,
-                     const float* d_raw, const float* d_geo, const uint32_t* active_idx, const uint32_t* n_active, const NarutoGrads* g,
-                     void* workspace, void* stream) {
+                     const float* d_raw, const float* d_geo, const uint32_t* active_idx, const uint32_t* n_active, const NarutoExtraPoints* extra,
+                     uint32_t flags, const NarutoGrads* g, void* workspace, void* stream) {
     if ((active_idx == nullptr) != (n_active == nullptr)) return fail(NARUTO_ERR_INVALID, "query_bwd: active_idx and n_active go together");
+    const uint32_t E = (extra != nullptr && g != nullptr && g->table != nullptr) ? extra->n : 0u;
+    if (E > 0 && (extra->x == nullptr || extra->d_feat == nullptr)) return fail(NARUTO_ERR_INVALID, "query_bwd: extra points need x and d_feat");
+    const uint32_t cap = M + E;                      // leading dimension of the scatter's point list
     if (f == nullptr || p == nullptr || g == nullptr || feat_save == nullptr || d_raw == nullptr || workspace == nullptr)
         return fail(NARUTO_ERR_INVALID, "query_bwd: NULL argument");
     if (p->table == nullptr || p->uncert_grid == nullptr || p->sdf_w0 == nullptr || p->sdf_w1 == nullptr || p->col_w0 == nullptr || p->col_w1 == nullptr)
@@ -307,14 +311,15 @@ int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
     if (int rc = check_points(pts)) return rc;
     if (M == 0) return NARUTO_OK;
     float* d_feat = reinterpret_cast<float*>(workspace);
-    float* x_soa = d_feat + (size_t)kLevels * 2u * (size_t)M;
-    float* partials = x_soa + 3u * (size_t)M;
+    float* x_soa = d_feat + (size_t)kLevels * 2u * (size_t)cap;
+    float* partials = x_soa + 3u * (size_t)cap;
     float* scatter_ws = partials + (size_t)kBwdMaxBlocks * kAccFloats;
+    uint32_t* n_total = reinterpret_cast<uint32_t*>(scatter_ws + naruto_scatter_workspace(f) / sizeof(float));
     const uint32_t n_tiles = (M + 31u) / 32u;
     uint32_t blocks = (n_tiles + 3u) / 4u;
-    uint32_t cap = cu_count(f);
-    if (cap > kBwdMaxBlocks) cap = kBwdMaxBlocks;
-    if (blocks > cap) blocks = cap;
+    uint32_t max_blocks = cu_count(f);
+    if (max_blocks > kBwdMaxBlocks) max_blocks = kBwdMaxBlocks;
+    if (blocks > max_blocks) blocks = max_blocks;
     const PointSrc ps = make_points(pts);
     static bool attr_set = false;
     if (!attr_set) {
@@ -322,19 +327,29 @@ int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
             return fail(NARUTO_ERR_LAUNCH, "query_bwd: cannot reserve %zu bytes of LDS: %s", sizeof(BwdLds), hipGetErrorString(hipGetLastError()));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_query_bwd, dim3(blocks), dim3(256), sizeof(BwdLds), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, ps, M, feat_save, d_raw,
+    hipLaunchKernelGGL(k_query_bwd, dim3(blocks), dim3(256), sizeof(BwdLds), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, ps, M, cap, feat_save, d_raw,
                        d_geo, d_feat, g->table != nullptr ? x_soa : nullptr, g->uncert_grid, partials, active_idx, n_active);
     if (int rc = check_launch("query_bwd")) return rc;
     if (g->sdf_w0 || g->sdf_w1 || g->col_w0 || g->col_w1) {
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3(kAccFloats / 32), dim3(256), 0, (hipStream_t)stream, partials, blocks, *g);
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3(kAccFloats / 32), dim3(256), 0, (hipStream_t)stream, partials, blocks, *g,
+                           (int)(flags & NARUTO_BWD_OVERWRITE_WEIGHT_GRADS));
         if (int rc = check_launch("wgrad_reduce")) return rc;
     }
     if (g->table != nullptr) {
         PointSrc pss{};
         pss.xsoa = x_soa;
-        pss.M = M;
+        pss.M = cap;
         pss.S = 1;
-        if (int rc = launch_scatter(f, pss, M, d_feat, (size_t)2, (size_t)2 * (size_t)M, g->table, scatter_ws, (hipStream_t)stream, n_active)) return rc;
+        const uint32_t* count_dev = n_active;
+        if (E > 0) {          // the smoothness lattice rides along in the same scatter launch
+            hipLaunchKernelGGL(k_append_points, dim3((E * kLevels + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, E, extra->x, extra->d_feat, extra->scale,
+                               n_active, M, cap, x_soa, d_feat, n_total);
+            if (int rc = check_launch("append_points")) return rc;
+            count_dev = n_total;
+        }
+        if (int rc = launch_scatter(f, pss, cap, d_feat, (size_t)2, (size_t)2 * (size_t)cap, g->table, scatter_ws, (hipStream_t)stream, count_dev, nullptr,
+                                    (int)(flags & NARUTO_BWD_OVERWRITE_TABLE_GRAD)))
+            return rc;
     }
     return NARUTO_OK;
 }
@@ -366,7 +381,7 @@ size_t naruto_loss_workspace(uint32_t n_rays) { return (size_t)n_rays * 16u * si
 
 int naruto_loss_sums(const NarutoField* f, uint32_t n_rays, uint32_t S, const float* raw, const float* z_vals, const float* rgb, const float* depth,
                      const float* uncert_map, const float* target_rgb, const float* target_d, float depth_trunc, float rgb_missing, double* sums,
-                     void* workspace, void* stream) {
+                     float* losses, void* workspace, void* stream) {
     if (f == nullptr || raw == nullptr || z_vals == nullptr || rgb == nullptr || depth == nullptr || uncert_map == nullptr || target_rgb == nullptr ||
         target_d == nullptr || sums == nullptr || workspace == nullptr)
         return fail(NARUTO_ERR_INVALID, "loss_sums: NULL argument");
@@ -375,7 +390,7 @@ int naruto_loss_sums(const NarutoField* f, uint32_t n_rays, uint32_t S, const fl
     hipLaunchKernelGGL(k_loss_terms, dim3((n_rays + kRaysPerBlock - 1) / kRaysPerBlock), dim3(64 * kRaysPerBlock), 0, (hipStream_t)stream, n_rays, S,
                        f->desc.trunc * f->desc.sc_factor, raw, z_vals, rgb, depth, uncert_map, target_rgb, target_d, depth_trunc, rgb_missing, terms);
     if (int rc = check_launch("loss_terms")) return rc;
-    hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(256), 0, (hipStream_t)stream, terms, n_rays, sums);
+    hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(256), 0, (hipStream_t)stream, terms, n_rays, sums, S, losses);
     return check_launch("loss_reduce");
 }
 
@@ -423,6 +438,28 @@ int naruto_adam_step(float* param, const float* grad, float* exp_avg, float* exp
     hipLaunchKernelGGL(k_adam, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
                        weight_decay, bc1, bc2_sqrt, step_dev);
     return check_launch("adam_step");
+}
+
+int naruto_adam_multi(const NarutoAdamSeg* segs, uint32_t n_segs, float beta1, float beta2, uint32_t step, const int32_t* step_dev, void* stream) {
+    if (segs == nullptr || n_segs == 0 || n_segs > (uint32_t)kAdamMaxSegs) return fail(NARUTO_ERR_INVALID, "adam_multi: 1..%d segments", kAdamMaxSegs);
+    if (step == 0 && step_dev == nullptr) return fail(NARUTO_ERR_INVALID, "adam_multi: step is 1-based (or pass step_dev)");
+    AdamSegs a{};
+    a.n_segs = n_segs;
+    uint32_t blocks = 0;
+    for (uint32_t k = 0; k < n_segs; ++k) {
+        if (segs[k].param == nullptr || segs[k].grad == nullptr || segs[k].exp_avg == nullptr || segs[k].exp_avg_sq == nullptr)
+            return fail(NARUTO_ERR_INVALID, "adam_multi: NULL pointer in segment %u", k);
+        a.p[k] = segs[k].param; a.g[k] = segs[k].grad; a.m[k] = segs[k].exp_avg; a.v[k] = segs[k].exp_avg_sq;
+        a.n[k] = segs[k].n; a.lr[k] = segs[k].lr; a.eps[k] = segs[k].eps; a.wd[k] = segs[k].weight_decay;
+        a.block_begin[k] = blocks;
+        uint64_t nb = (segs[k].n + 1023u) / 1024u;          // 4 elements per thread
+        if (nb < 1) nb = 1;
+        if (nb > 1024u) nb = 1024u;
+        blocks += (uint32_t)nb;
+    }
+    for (uint32_t k = n_segs; k <= (uint32_t)kAdamMaxSegs; ++k) a.block_begin[k] = blocks;
+    hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, beta1, beta2, step_dev, step);
+    return check_launch("adam_multi");
 }
 
 // ---- hardware layout probes (tests/test_gpu_intrinsics.py) ---------------------------------------

@@ -409,7 +409,7 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
 
 // d_table += sum over the level's splits of partial[split], for the entry ranges of the LDS-tiled levels
 __global__ __launch_bounds__(256) void k_scatter_reduce(LevelTab lt, uint32_t atomic_levels, const float* __restrict__ partial, uint32_t s_dense,
-                                                        uint32_t s_hashed, size_t n_params, float* __restrict__ d_table) {
+                                                        uint32_t s_hashed, size_t n_params, float* __restrict__ d_table, int overwrite) {
     const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // float4 index
     if (i4 * 4 >= n_params) return;
     const uint32_t entry = (uint32_t)(i4 * 2);
@@ -424,6 +424,7 @@ __global__ __launch_bounds__(256) void k_scatter_reduce(LevelTab lt, uint32_t at
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     float4* d = reinterpret_cast<float4*>(d_table) + i4;
+    if (overwrite) { *d = s; return; }
     float4 o = *d;
     o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
     *d = o;
@@ -441,7 +442,7 @@ struct TvArgs {
     float voxel, margin, grid_size, inv_p3;
 };
 
-__global__ __launch_bounds__(256) void k_tv_encode(LevelTab lt, BoxTab bt, TvArgs a, const float* __restrict__ rand6, const float2* __restrict__ table,
+__global__ __launch_bounds__(64) void k_tv_encode(LevelTab lt, BoxTab bt, TvArgs a, const float* __restrict__ rand6, const float2* __restrict__ table,
                                                    float* __restrict__ x_out, float* __restrict__ feat) {
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n3 = a.n * a.n * a.n;
@@ -505,6 +506,23 @@ __global__ __launch_bounds__(256) void k_tv_finalize(const double* __restrict__ 
     if (threadIdx.x == 0) loss[0] = (float)((red[0] + red[1] + red[2] + red[3]) * (double)inv_p3);
 }
 
+// Append E extra points ([E,3] points, [E,32] feature cotangents, scaled by a device scalar) to the point list
+// the scatter consumes (x [3][cap], d_feat [16][cap][2]), so that one scatter launch serves both the rendered
+// samples and the smoothness lattice.  n_total = n_base (device word or host value) + E.
+__global__ __launch_bounds__(256) void k_append_points(uint32_t E, const float* __restrict__ ex, const float* __restrict__ ed, const float* __restrict__ scale_dev,
+                                                       const uint32_t* __restrict__ n_base_dev, uint32_t n_base_host, uint32_t cap, float* __restrict__ x_soa,
+                                                       float* __restrict__ d_feat, uint32_t* __restrict__ n_total) {
+    const uint32_t base = n_base_dev != nullptr ? n_base_dev[0] : n_base_host;
+    const float sc = scale_dev != nullptr ? scale_dev[0] : 1.0f;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;          // (point, level)
+    if (t == 0) n_total[0] = base + E;
+    if (t >= E * kLevels) return;
+    const uint32_t i = t / kLevels, level = t % kLevels;
+    const float2 g = *reinterpret_cast<const float2*>(ed + (size_t)i * kFeat + 2 * level);
+    reinterpret_cast<float2*>(d_feat)[(size_t)level * cap + base + i] = make_float2(g.x * sc, g.y * sc);
+    if (level < 3) x_soa[(size_t)level * cap + base + i] = ex[3 * (size_t)i + level];
+}
+
 // ------------------------------------------------------------------------------------------------
 // Backward of k_query_fwd<true>.
 // ------------------------------------------------------------------------------------------------
@@ -563,7 +581,7 @@ __device__ __forceinline__ void wgrad_tile(const float* __restrict__ gbuf, int g
     }
 }
 
-__global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps, uint32_t M,
+__global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps, uint32_t M, uint32_t cap,
                                                    const float* __restrict__ feat_save, const float* __restrict__ d_raw,
                                                    const float* __restrict__ d_geo, float* __restrict__ d_feat, float* __restrict__ x_out,
                                                    float* __restrict__ d_uncert_grid, float* __restrict__ partials,
@@ -591,8 +609,8 @@ __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, Bo
         load_point(ps, bt, m, x, y, z);
         if (x_out != nullptr && valid && hh == 0) {      // normalised points [3][M] (list order) for the table scatter
             x_out[i_pt] = x;
-            x_out[(size_t)M + i_pt] = y;
-            x_out[2 * (size_t)M + i_pt] = z;
+            x_out[(size_t)cap + i_pt] = y;
+            x_out[2 * (size_t)cap + i_pt] = z;
         }
         float g_rgb[3], g_sdf, g_unc;
         {
@@ -727,7 +745,7 @@ __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, Bo
 #pragma unroll
                 for (int e2 = 0; e2 < 2; ++e2) {
                     const int level = e2 + 4 * q + 2 * hh;
-                    dfo[(size_t)level * M + i_pt] = make_float2(df[4 * q + 2 * e2], df[4 * q + 2 * e2 + 1]);
+                    dfo[(size_t)level * cap + i_pt] = make_float2(df[4 * q + 2 * e2], df[4 * q + 2 * e2 + 1]);
                 }
             }
         }
@@ -754,7 +772,7 @@ __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, Bo
 
 // partials [n_blocks][7][32][32] -> += into the four weight gradients.  Block = 32 outputs x 8 slices of the
 // block range; fixed summation order (deterministic for a given grid).
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partials, uint32_t n_blocks, NarutoGrads g) {
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partials, uint32_t n_blocks, NarutoGrads g, int overwrite) {
     __shared__ float red[8][32];
     const int o = threadIdx.x & 31, slice = threadIdx.x >> 5;
     const uint32_t e = blockIdx.x * 32u + o;
@@ -766,21 +784,23 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 #pragma unroll
     for (int k = 1; k < 8; ++k) s += red[k][o];
     const int tile = e >> 10, row = (e >> 5) & 31, col = e & 31;
+    float* dst = nullptr;
     if (tile <= 2) {
         const int c = tile * 32 + col;
-        if (c < kInSdf && g.sdf_w0) g.sdf_w0[row * kInSdf + c] += s;
+        if (c < kInSdf && g.sdf_w0) dst = g.sdf_w0 + row * kInSdf + c;
     } else if (tile == 3) {
-        if (row < kOut && g.sdf_w1) g.sdf_w1[row * kHidden + col] += s;
+        if (row < kOut && g.sdf_w1) dst = g.sdf_w1 + row * kHidden + col;
     } else if (tile == 4) {
-        if (g.col_w0) g.col_w0[row * kInCol + col] += s;                       // OneBlob 0..31
+        if (g.col_w0) dst = g.col_w0 + row * kInCol + col;                             // OneBlob 0..31
     } else if (tile == 5) {
         if (g.col_w0) {
-            if (col < 16) g.col_w0[row * kInCol + 32 + col] += s;               // OneBlob 32..47
-            else if (col >= 17) g.col_w0[row * kInCol + kPos + (col - 17)] += s;  // out row col-16 >= 1 -> geo col-17
+            if (col < 16) dst = g.col_w0 + row * kInCol + 32 + col;                     // OneBlob 32..47
+            else if (col >= 17) dst = g.col_w0 + row * kInCol + kPos + (col - 17);      // out row col-16 >= 1 -> geo col-17
         }
     } else {
-        if (row < 3 && g.col_w1) g.col_w1[row * kHidden + col] += s;
+        if (row < 3 && g.col_w1) dst = g.col_w1 + row * kHidden + col;
     }
+    if (dst != nullptr) *dst = overwrite ? s : *dst + s;
 }
 
 }  // namespace naruto

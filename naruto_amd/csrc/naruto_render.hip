@@ -238,7 +238,12 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_terms(uint32_t n_ra
     }
 }
 
-__global__ __launch_bounds__(256) void k_loss_reduce(const float* __restrict__ terms, uint32_t n_rays, double* __restrict__ sums) {
+struct LossScalars;
+__device__ __forceinline__ void loss_finalize_body(const double* __restrict__ sums, uint64_t n_total, uint32_t S, float* __restrict__ losses);
+
+// terms -> sums[16]; when losses != nullptr (single process: nothing to all-reduce) also the final losses
+__global__ __launch_bounds__(256) void k_loss_reduce(const float* __restrict__ terms, uint32_t n_rays, double* __restrict__ sums, uint32_t S,
+                                                     float* __restrict__ losses) {
     __shared__ double part[4][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double acc[10];
@@ -271,6 +276,13 @@ __global__ __launch_bounds__(256) void k_loss_reduce(const float* __restrict__ t
         }
         sums[k] = v;
     }
+    if (losses != nullptr) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence_block();
+            loss_finalize_body(sums, n_rays, S, losses);
+        }
+    }
 }
 
 struct LossScalars {
@@ -292,8 +304,7 @@ __device__ __forceinline__ LossScalars loss_scalars(const double* __restrict__ s
     return k;
 }
 
-__global__ void k_loss_finalize(const double* __restrict__ sums, uint64_t n_total, uint32_t S, float* __restrict__ losses) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void loss_finalize_body(const double* __restrict__ sums, uint64_t n_total, uint32_t S, float* __restrict__ losses) {
     const LossScalars k = loss_scalars(sums, n_total, S);
     const float rgb_loss = (float)sums[0] * k.inv_3n;
     const float depth_loss = (float)(sums[1] / sums[2]);            // mean over an empty selection is NaN, as in torch
@@ -303,6 +314,11 @@ __global__ void k_loss_finalize(const double* __restrict__ sums, uint64_t n_tota
     const float uncert_loss = k.mean_a * k.mean_e + 0.5f * (float)(sums[8] / sums[2]);
     losses[0] = rgb_loss; losses[1] = depth_loss; losses[2] = sdf_loss; losses[3] = fs_loss;
     losses[4] = psnr; losses[5] = uncert_loss; losses[6] = (float)sums[9]; losses[7] = (float)sums[2];
+}
+
+__global__ void k_loss_finalize(const double* __restrict__ sums, uint64_t n_total, uint32_t S, float* __restrict__ losses) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    loss_finalize_body(sums, n_total, S, losses);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -489,6 +505,44 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
         v[i] = vi;
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
         p[i] = pi - step_size * (mi / denom);
+    }
+}
+
+constexpr int kAdamMaxSegs = 8;
+struct AdamSegs {
+    float* p[kAdamMaxSegs];
+    const float* g[kAdamMaxSegs];
+    float* m[kAdamMaxSegs];
+    float* v[kAdamMaxSegs];
+    uint64_t n[kAdamMaxSegs];
+    uint32_t block_begin[kAdamMaxSegs + 1];   // first block of each segment
+    float lr[kAdamMaxSegs], eps[kAdamMaxSegs], wd[kAdamMaxSegs];
+    uint32_t n_segs;
+};
+
+// all parameter tensors of one optimiser in ONE launch: blocks are partitioned over the segments
+__global__ __launch_bounds__(256) void k_adam_multi(AdamSegs a, float b1, float b2, const int32_t* __restrict__ step_dev, uint32_t step_host) {
+    int sgi = 0;
+#pragma unroll
+    for (int k = 1; k < kAdamMaxSegs; ++k) sgi += (k < (int)a.n_segs && blockIdx.x >= a.block_begin[k]) ? 1 : 0;
+    const float t = step_dev != nullptr ? (float)step_dev[0] : (float)step_host;
+    const float bc1 = 1.0f - powf(b1, t), bc2_sqrt = sqrtf(1.0f - powf(b2, t));
+    const float step_size = a.lr[sgi] / bc1, eps = a.eps[sgi], wd = a.wd[sgi];
+    float* __restrict__ p = a.p[sgi];
+    const float* __restrict__ g = a.g[sgi];
+    float* __restrict__ m = a.m[sgi];
+    float* __restrict__ v = a.v[sgi];
+    const uint64_t n = a.n[sgi];
+    const uint32_t nb = a.block_begin[sgi + 1] - a.block_begin[sgi];
+    for (uint64_t i = (uint64_t)(blockIdx.x - a.block_begin[sgi]) * 256u + threadIdx.x; i < n; i += (uint64_t)nb * 256u) {
+        float gi = g[i];
+        const float pi = p[i];
+        if (wd != 0.0f) gi = fmaf(wd, pi, gi);
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = pi - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
     }
 }
 

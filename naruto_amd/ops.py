@@ -273,7 +273,7 @@ class _FieldQuery(torch.autograd.Function):
             ws_bytes = lib.naruto_query_bwd_workspace(ctx.handle.ptr, M)
             ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
             check(lib.naruto_query_bwd(ctx.handle.ptr, C.byref(ps), M, C.byref(pts), _p(feat), _p(d_raw), _p(d_geo), None, None,
-                                       C.byref(gs), _p(ws), _stream()), "naruto_query_bwd")
+                                       None, 0, C.byref(gs), _p(ws), _stream()), "naruto_query_bwd")
         return (None, None, None, None, None, None, None) + tuple(grads[n] for n in PARAM_NAMES)
 
 
@@ -350,12 +350,13 @@ class _RenderLoss(torch.autograd.Function):
                                            _p(depth_var), _p(um), st), "naruto_composite_fwd")
             ws = torch.empty(lib.naruto_loss_workspace(N) // 4, dtype=torch.float32, device=dev)
             check(lib.naruto_loss_sums(handle.ptr, N, S, _p(raw), _p(z_vals), _p(rgb), _p(depth), _p(um), _p(target_rgb),
-                                       _p(target_d), depth_trunc, rgb_missing, _p(sums), _p(ws), st), "naruto_loss_sums")
+                                       _p(target_d), depth_trunc, rgb_missing, _p(sums), None if group is not None else _p(losses),
+                                       _p(ws), st), "naruto_loss_sums")
             if group is not None:
                 from . import parallel
                 parallel.allreduce_loss_sums(sums, group)
                 n_total = int(n_rays_total) if n_rays_total else N * parallel.world_size(group)
-            check(lib.naruto_loss_finalize(_p(sums), n_total, S, _p(losses), st), "naruto_loss_finalize")
+                check(lib.naruto_loss_finalize(_p(sums), n_total, S, _p(losses), st), "naruto_loss_finalize")
         ctx.handle, ctx.depth_trunc, ctx.rgb_missing, ctx.n_total = handle, depth_trunc, rgb_missing, n_total
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(raw, z_vals, target_rgb, target_d, sums)
@@ -402,7 +403,7 @@ class _RenderTrain(torch.autograd.Function):
     backward and the table scatter (naruto_compact_active)."""
 
     @staticmethod
-    def forward(ctx, handle, rays_o, rays_d, z_vals, target_rgb, target_d, depth_trunc, rgb_missing, group, n_rays_total,
+    def forward(ctx, handle, rays_o, rays_d, z_vals, target_rgb, target_d, depth_trunc, rgb_missing, group, n_rays_total, smooth,
                 table, uncert_grid, sdf_w0, sdf_w1, col_w0, col_w1):
         lib = _lib.load()
         params = {"table": table, "uncert_grid": uncert_grid, "sdf_w0": sdf_w0, "sdf_w1": sdf_w1, "col_w0": col_w0, "col_w1": col_w1}
@@ -412,8 +413,15 @@ class _RenderTrain(torch.autograd.Function):
         N, S = z_vals.shape
         M = N * S
         dev = z_vals.device
-        need_grad = any(ctx.needs_input_grad[10:])
+        need_grad = any(ctx.needs_input_grad[11:])
         raw = torch.empty(N, S, 5, dtype=torch.float32, device=dev)
+        sm_loss = sm_x = sm_d = None
+        if smooth is not None:                      # (sample_points, voxel_size, margin, rand6): Co-SLAM smoothness term
+            sp, vox, mar, rand6 = smooth
+            n3 = (sp - 1) ** 3
+            sm_x = torch.empty(n3, 3, dtype=torch.float32, device=dev)
+            sm_d = torch.empty(n3, 32, dtype=torch.float32, device=dev)
+            sm_loss = torch.empty(1, dtype=torch.float32, device=dev)
         feat = torch.empty(16, M, 2, dtype=torch.float32, device=dev) if need_grad else None
         rgb = torch.empty(N, 3, dtype=torch.float32, device=dev)
         disp, acc, depth, depth_var, um = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(5))
@@ -429,24 +437,33 @@ class _RenderTrain(torch.autograd.Function):
                                            _p(depth_var), _p(um), st), "naruto_composite_fwd")
             ws = torch.empty(lib.naruto_loss_workspace(N) // 4, dtype=torch.float32, device=dev)
             check(lib.naruto_loss_sums(handle.ptr, N, S, _p(raw), _p(z_vals), _p(rgb), _p(depth), _p(um), _p(target_rgb),
-                                       _p(target_d), depth_trunc, rgb_missing, _p(sums), _p(ws), st), "naruto_loss_sums")
+                                       _p(target_d), depth_trunc, rgb_missing, _p(sums), None if group is not None else _p(losses),
+                                       _p(ws), st), "naruto_loss_sums")
             if group is not None:
                 from . import parallel
                 parallel.allreduce_loss_sums(sums, group)
                 n_total = int(n_rays_total) if n_rays_total else N * parallel.world_size(group)
-            check(lib.naruto_loss_finalize(_p(sums), n_total, S, _p(losses), st), "naruto_loss_finalize")
+                check(lib.naruto_loss_finalize(_p(sums), n_total, S, _p(losses), st), "naruto_loss_finalize")
+            if smooth is not None:
+                ws2 = torch.empty((lib.naruto_smoothness_workspace(sp) + 3) // 4, dtype=torch.float32, device=dev)
+                check(lib.naruto_smoothness_fwd(handle.ptr, _p(params["table"]), sp, vox, mar, _p(_f32c(rand6, "rand6")), _p(sm_x), _p(sm_d),
+                                                _p(sm_loss), _p(ws2), st), "naruto_smoothness_fwd")
         ctx.handle, ctx.depth_trunc, ctx.rgb_missing, ctx.n_total = handle, depth_trunc, rgb_missing, n_total
+        ctx.has_smooth = smooth is not None
         ctx.set_materialize_grads(False)
         if need_grad:
-            ctx.save_for_backward(raw, feat, rays_o, rays_d, z_vals, target_rgb, target_d, sums, *(params[k] for k in PARAM_NAMES))
+            extra = (sm_x, sm_d) if smooth is not None else ()
+            ctx.save_for_backward(raw, feat, rays_o, rays_d, z_vals, target_rgb, target_d, sums, *(params[k] for k in PARAM_NAMES), *extra)
         ctx.mark_non_differentiable(disp, acc, depth_var, um, raw)
-        return rgb, depth, disp, acc, depth_var, um, raw, losses
+        sm_out = sm_loss.reshape(()) if smooth is not None else torch.zeros((), dtype=torch.float32, device=dev)
+        return rgb, depth, disp, acc, depth_var, um, raw, losses, sm_out
 
     @staticmethod
-    def backward(ctx, d_rgb, d_depth, _d_disp, _d_acc, _d_var, _d_um, _d_raw, d_losses):
+    def backward(ctx, d_rgb, d_depth, _d_disp, _d_acc, _d_var, _d_um, _d_raw, d_losses, d_smooth):
         lib = _lib.load()
         raw, feat, rays_o, rays_d, z_vals, target_rgb, target_d, sums = ctx.saved_tensors[:8]
-        params = dict(zip(PARAM_NAMES, ctx.saved_tensors[8:]))
+        params = dict(zip(PARAM_NAMES, ctx.saved_tensors[8:14]))
+        sm_x, sm_d = (ctx.saved_tensors[14], ctx.saved_tensors[15]) if ctx.has_smooth else (None, None)
         N, S = z_vals.shape
         M = N * S
         dev = raw.device
@@ -455,7 +472,17 @@ class _RenderTrain(torch.autograd.Function):
         d_losses = _f32c(d_losses, "d_losses")
         d_raw = torch.empty_like(raw)
         extra = d_rgb is not None or d_depth is not None          # someone differentiated the rendered rgb / depth as well
-        grads = {n: (torch.zeros_like(params[n]) if ctx.needs_input_grad[10 + i] else None) for i, n in enumerate(PARAM_NAMES)}
+        # weight / table gradients are WRITTEN by the reductions (no zero fill); the uncertainty grid is scattered into
+        overwrite_table = handle_supports_overwrite(ctx.handle)
+        grads = {}
+        for i, n in enumerate(PARAM_NAMES):
+            if not ctx.needs_input_grad[11 + i]:
+                grads[n] = None
+            elif n == "uncert_grid" or (n == "table" and not overwrite_table):
+                grads[n] = torch.zeros_like(params[n])
+            else:
+                grads[n] = torch.empty_like(params[n])
+        flags = _lib.BWD_OVERWRITE_WEIGHT_GRADS | (_lib.BWD_OVERWRITE_TABLE_GRAD if overwrite_table else 0)
         gs = NarutoGrads()
         for n in PARAM_NAMES:
             setattr(gs, n, _p(grads[n]))
@@ -477,17 +504,46 @@ class _RenderTrain(torch.autograd.Function):
                 active = torch.empty(M, dtype=torch.int32, device=dev)
                 n_active = torch.empty(1, dtype=torch.int32, device=dev)
                 check(lib.naruto_compact_active(N, S, _p(count), _p(off), _p(active), _p(n_active), st), "naruto_compact_active")
-            ws = torch.empty((lib.naruto_query_bwd_workspace(ctx.handle.ptr, M) + 3) // 4, dtype=torch.float32, device=dev)
+            ex = None
+            n_extra = 0
+            if ctx.has_smooth and d_smooth is not None and grads["table"] is not None:
+                ex = _lib.NarutoExtraPoints()
+                ex.x, ex.d_feat, ex.scale, ex.n = _p(sm_x), _p(sm_d), _p(_f32c(d_smooth, "d_smooth").reshape(1)), sm_x.shape[0]
+                n_extra = sm_x.shape[0]
+            ws = torch.empty((lib.naruto_query_bwd_workspace(ctx.handle.ptr, M + n_extra) + 3) // 4, dtype=torch.float32, device=dev)
             check(lib.naruto_query_bwd(ctx.handle.ptr, C.byref(ps), M, C.byref(pts), _p(feat), _p(d_raw), None, _p(active), _p(n_active),
-                                       C.byref(gs), _p(ws), st), "naruto_query_bwd")
-        return (None,) * 10 + tuple(grads[n] for n in PARAM_NAMES)
+                                       None if ex is None else C.byref(ex), flags, C.byref(gs), _p(ws), st), "naruto_query_bwd")
+        return (None,) * 11 + tuple(grads[n] for n in PARAM_NAMES)
+
+
+def handle_supports_overwrite(handle: FieldHandle) -> bool:
+    """Table gradients can be written (not accumulated) when every level is LDS-tiled, i.e. log2_hashmap_size <= 16."""
+    return handle.desc.log2_hashmap_size <= 16
 
 
 def render_train(handle: FieldHandle, params: Dict[str, torch.Tensor], rays_o, rays_d, z_vals, target_rgb, target_d,
-                 depth_trunc: float, rgb_missing: float, group=None, n_rays_total: int = 0):
-    """-> rgb, depth, disp, acc, depth_var, uncert_map, raw, losses[8]."""
+                 depth_trunc: float, rgb_missing: float, group=None, n_rays_total: int = 0, smooth=None):
+    """-> rgb, depth, disp, acc, depth_var, uncert_map, raw, losses[8], smooth_loss.
+
+    ``smooth`` = (sample_points, voxel_size, margin, rand6) adds Co-SLAM's feature-grid smoothness term as a 9th
+    output; its table gradient is produced by the same scatter pass as the rendering losses'."""
+    if smooth is not None:
+        smooth = (int(smooth[0]), float(smooth[1]), float(smooth[2]), smooth[3])
     return _RenderTrain.apply(handle, rays_o, rays_d, z_vals, target_rgb, target_d, float(depth_trunc), float(rgb_missing), group,
-                              int(n_rays_total), *(params[n] for n in PARAM_NAMES))
+                              int(n_rays_total), smooth, *(params[n] for n in PARAM_NAMES))
+
+
+def adam_multi_(entries, *, betas, step: int = 0, step_dev: Optional[torch.Tensor] = None) -> None:
+    """entries: list of (param, grad, exp_avg, exp_avg_sq, lr, eps, weight_decay); one launch for all of them."""
+    lib = _lib.load()
+    segs = (_lib.NarutoAdamSeg * len(entries))()
+    for k, (p, g, m, v, lr, eps, wd) in enumerate(entries):
+        for t in (p, g, m, v):
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        segs[k].param, segs[k].grad, segs[k].exp_avg, segs[k].exp_avg_sq = _p(p), _p(g), _p(m), _p(v)
+        segs[k].n, segs[k].lr, segs[k].eps, segs[k].weight_decay = p.numel(), lr, eps, wd
+    with torch.cuda.device(entries[0][0].device):
+        check(lib.naruto_adam_multi(segs, len(entries), betas[0], betas[1], step, _p(step_dev), _stream()), "naruto_adam_multi")
 
 
 # ---------------------------------------------------------------------------------------------------

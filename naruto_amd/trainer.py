@@ -103,13 +103,16 @@ class FusedAdam:
     def step(self):
         from . import ops
         self.step_dev.add_(1)
+        by_betas = {}
         for g in self.param_groups:
             for p in g['params']:
                 if p.grad is None:
                     continue
                 m, v = self.state[p]
-                ops.adam_step_(p.data, p.grad.contiguous(), m, v, lr=g['lr'], betas=g['betas'], eps=g['eps'],
-                               weight_decay=g['weight_decay'], step_dev=self.step_dev)
+                by_betas.setdefault(tuple(g['betas']), []).append((p.data, p.grad.contiguous(), m, v, g['lr'], g['eps'], g['weight_decay']))
+        for betas, entries in by_betas.items():
+            for i in range(0, len(entries), 8):
+                ops.adam_multi_(entries[i:i + 8], betas=betas, step_dev=self.step_dev)
 
 
 class MappingTrainer:
@@ -152,12 +155,15 @@ class MappingTrainer:
         model = self.model
         model.train()
         self.map_optimizer.zero_grad(set_to_none=True)
-        ret = model.forward(rays_o, rays_d, target_rgb, target_d, _check=check)
-        # get_loss_from_ret (coslam.py:154-174) as one dot product over the loss vector
+        tr = self.config['training']
+        use_smooth = smooth and tr['smooth_weight'] > 0
+        sm = (tr['smooth_pts'], tr['smooth_vox'], tr['smooth_margin'], torch.rand(6, device=self.device)) if use_smooth else None
+        ret = model.forward(rays_o, rays_d, target_rgb, target_d, _check=check, _smooth=sm)
+        # get_loss_from_ret (coslam.py:154-174) as one dot product over the loss vector (+ the smoothness term, which
+        # the fused node computed alongside so that its table gradient shares the scatter pass)
         loss = torch.dot(ret['_losses'], self._loss_w)
-        if smooth and self.config['training']['smooth_weight'] > 0:
-            tr = self.config['training']
-            loss = loss + tr['smooth_weight'] * smoothness(model, self.config, tr['smooth_pts'], tr['smooth_vox'], margin=tr['smooth_margin'])
+        if use_smooth:
+            loss = torch.add(loss, ret['_smooth_loss'], alpha=tr['smooth_weight'])
         loss.backward()
         if self.group is not None:
             parallel.allreduce_grads(self.parameters(), self.group)

@@ -388,3 +388,31 @@ def test_graph_replay_equals_eager(gpu):
         H.assert_close(lb.reshape(-1), la.reshape(-1), 1e-6, f"iter{it}.loss", rel=1e-5)
     for (n, p), (_, q) in zip(a.model.named_parameters(), b.model.named_parameters()):
         H.assert_close(q, p, 1e-6, f"param {n}", rel=1e-5)
+
+
+def test_train_node_with_fused_smoothness(gpu):
+    """The training node with the smoothness term riding along (one scatter pass, written-not-accumulated
+    gradients) against the oracle: rendering losses + smooth_weight * TV(hash features)."""
+    cfg = H.office_cfg(12)
+    ora = H.make_oracle(cfg, 0.25, 41)
+    m = H.make_hip_from_oracle(cfg, ora, gpu)
+    rays = syn.random_rays(160, cfg["mapping"]["bound"], seed=41, zero_depth_frac=0.15)
+    t = {k: torch.from_numpy(v) for k, v in rays.items()}
+    r6 = torch.tensor([0.3, 0.6, 0.2, 0.1, 0.7, 0.4])
+    w_s = 0.37                                   # a large weight so that the term matters in the comparison
+    ora.train()
+    ret_o = ora.forward(t["rays_o"], t["rays_d"], t["target_rgb"], t["target_d"])
+    sm_o = S.smoothness(ora, 12, 0.1, 0.05, r6[:3], r6[3:])
+    (S.total_loss(ret_o, cfg["training"]) + w_s * sm_o).backward()
+    m.train()
+    ret_h = m.forward(*(t[k].to(gpu) for k in ("rays_o", "rays_d", "target_rgb", "target_d")), _smooth=(12, 0.1, 0.05, r6.to(gpu)))
+    H.assert_close(ret_h["_smooth_loss"], sm_o, 1e-7, "smooth_loss", rel=1e-4)
+    (S.total_loss(ret_h, cfg["training"]) + w_s * ret_h["_smooth_loss"]).backward()
+    gh, go = H.hip_grads(m), H.ora_grads(ora)
+    for k in gh:
+        grad_close(gh[k], go[k], f"fused.grad.{k}")
+    # a second backward pass into the same .grad accumulates (the node writes fresh tensors, autograd adds them)
+    ret_h = m.forward(*(t[k].to(gpu) for k in ("rays_o", "rays_d", "target_rgb", "target_d")), _smooth=(12, 0.1, 0.05, r6.to(gpu)))
+    (S.total_loss(ret_h, cfg["training"]) + w_s * ret_h["_smooth_loss"]).backward()
+    for k in gh:
+        grad_close(H.hip_grads(m)[k], 2 * go[k], f"fused.grad2.{k}")

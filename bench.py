@@ -193,7 +193,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph")
     args = ap.parse_args()
 
-    group = parallel.init_from_env("nccl") if args.gpus > 1 else None
+    group = parallel.init_from_env("nccl") if (args.gpus > 1 or os.environ.get("NARUTO_FORCE_DIST") == "1") else None
     world, rank = parallel.world_size(group), parallel.rank(group)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE is {world}"
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -205,7 +205,7 @@ def main():
     torch.manual_seed(0)                                     # identical replicas on every rank
     tr = MappingTrainer(cfg, torch.tensor(cfg["mapping"]["bound"], dtype=torch.float32), dev, 0.1, group=group,
                         fused_adam=not args.torch_adam)
-    use_graph = (not args.no_graph) and group is None
+    use_graph = (not args.no_graph) and (group is None or os.environ.get("NARUTO_GRAPH_DIST", "1") == "1")
     if use_graph:
         tr.capture(n_rays, smooth=True, n_rays_total=n_rays * world)
     n_total = n_rays * world

@@ -174,8 +174,8 @@ int naruto_composite_bwd(const NarutoField* f, uint32_t n_rays, uint32_t S, cons
  * get_sdf_loss/get_masks).  Three steps so that data-parallel ranks can all-reduce the sums in
  * between (the loss weights depend on GLOBAL sample counts):
  *   1. naruto_loss_sums     : this rank's rays -> sums[NARUTO_LOSS_NSUMS] (fp64, device)
- *   2. (optional) all-reduce of sums over ranks: SUM for every slot except slot
- *      NARUTO_LOSS_SLOT_MINUNCERT which is a MIN
+ *   2. (optional) all-reduce (SUM) of slots [0, NARUTO_LOSS_SLOT_MINUNCERT) over ranks; slot
+ *      NARUTO_LOSS_SLOT_MINUNCERT is a minimum (MIN-reduce it, or keep it per rank: it only feeds an assertion)
  *   3. naruto_loss_finalize : sums (+ total ray count over all ranks) -> losses[8] =
  *      {rgb_loss, depth_loss, sdf_loss, fs_loss, psnr, uncert_loss, min(uncert_map), n_valid_depth}
  * workspace: naruto_loss_workspace(n_rays) bytes. */

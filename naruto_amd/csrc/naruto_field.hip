@@ -574,10 +574,61 @@ __device__ __forceinline__ void stage_ctile(float* __restrict__ buf, int ld, int
 __device__ __forceinline__ void wgrad_tile(const float* __restrict__ gbuf, int gld, const float* __restrict__ xbuf, int xld, int c0,
                                            f32x16& d, int lane) {
     const int i = lane & 31, kk = lane >> 5;
+    // all 32 operand reads first (one lgkmcnt wait), then the 16 dependent MFMAs back to back: with one wave per
+    // SIMD nothing else hides an LDS round trip in front of every MFMA
+    float gv[16], xv[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         const int pt = 2 * t + kk;
-        d = mfma32(gbuf[pt * gld + i], xbuf[pt * xld + c0 + i], d);
+        gv[t] = gbuf[pt * gld + i];
+        xv[t] = xbuf[pt * xld + c0 + i];
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) d = mfma32(gv[t], xv[t], d);
+}
+
+// three tiles sharing the G operand (dW of one layer, 96 input columns): G is read once, the three accumulators
+// are independent so consecutive MFMAs never wait on each other
+__device__ __forceinline__ void wgrad_tile3(const float* __restrict__ gbuf, int gld, const float* __restrict__ xbuf, int xld, f32x16& d0,
+                                            f32x16& d1, f32x16& d2, int lane) {
+    const int i = lane & 31, kk = lane >> 5;
+    float gv[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) gv[t] = gbuf[(2 * t + kk) * gld + i];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float x0[8], x1[8], x2[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int pt = 2 * (8 * h + t) + kk;
+            x0[t] = xbuf[pt * xld + i];
+            x1[t] = xbuf[pt * xld + 32 + i];
+            x2[t] = xbuf[pt * xld + 64 + i];
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            d0 = mfma32(gv[8 * h + t], x0[t], d0);
+            d1 = mfma32(gv[8 * h + t], x1[t], d1);
+            d2 = mfma32(gv[8 * h + t], x2[t], d2);
+        }
+    }
+}
+
+__device__ __forceinline__ void wgrad_tile2(const float* __restrict__ gbuf, int gld, const float* __restrict__ xbuf, int xld, int c0, f32x16& d0,
+                                            f32x16& d1, int lane) {
+    const int i = lane & 31, kk = lane >> 5;
+    float gv[16], x0[16], x1[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int pt = 2 * t + kk;
+        gv[t] = gbuf[pt * gld + i];
+        x0[t] = xbuf[pt * xld + c0 + i];
+        x1[t] = xbuf[pt * xld + c0 + 32 + i];
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        d0 = mfma32(gv[t], x0[t], d0);
+        d1 = mfma32(gv[t], x1[t], d1);
     }
 }
 
@@ -677,19 +728,21 @@ __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, Bo
         wave_lds_sync();
         {
             const int i = lane & 31;
+            float gv[16], xv[16];
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const uint32_t pt = tile * 32u + 2 * t + hh;
-                float gv = 0.0f;
-                if (i < 3 && pt < M_eff) gv = d_raw[(size_t)(active_idx != nullptr ? active_idx[pt] : pt) * 5 + i];
-                dWc1 = mfma32(gv, gb[(2 * t + hh) * kGradLd + i], dWc1);
+                gv[t] = 0.0f;
+                if (i < 3 && pt < M_eff) gv[t] = d_raw[(size_t)(active_idx != nullptr ? active_idx[pt] : pt) * 5 + i];
+                xv[t] = gb[(2 * t + hh) * kGradLd + i];
             }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) dWc1 = mfma32(gv[t], xv[t], dWc1);
         }
         // ---- dW(col_w0) = d_c^T . [OneBlob48 | out16]   (tiles 4, 5)
         stage_ctile(ga, kGradLd, 0, dcv, j, hh);
         wave_lds_sync();
-        wgrad_tile(ga, kGradLd, xs, kStageLd, 32, dWc0a, lane);
-        wgrad_tile(ga, kGradLd, xs, kStageLd, 64, dWc0b, lane);
+        wgrad_tile2(ga, kGradLd, xs, kStageLd, 32, dWc0a, dWc0b, lane);
         // ---- dgrad colour layer 0 -> sdf-net outputs (rows 1..15 = geo features)
         f32x16 dov = zero16();
         static_for<0, 16>([&](auto tc) {
@@ -727,9 +780,7 @@ __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, Bo
         wave_lds_sync();
         stage_ctile(ga, kGradLd, 0, dh, j, hh);
         wave_lds_sync();
-        wgrad_tile(ga, kGradLd, xs, kStageLd, 0, dW0a, lane);
-        wgrad_tile(ga, kGradLd, xs, kStageLd, 32, dW0b, lane);
-        wgrad_tile(ga, kGradLd, xs, kStageLd, 64, dW0c, lane);
+        wgrad_tile3(ga, kGradLd, xs, kStageLd, dW0a, dW0b, dW0c, lane);
         wave_lds_sync();
         // ---- dgrad sdf layer 0 -> hash features
         f32x16 df = zero16();

@@ -475,13 +475,22 @@ class _RenderTrain(torch.autograd.Function):
         # weight / table gradients are WRITTEN by the reductions (no zero fill); the uncertainty grid is scattered into
         overwrite_table = handle_supports_overwrite(ctx.handle)
         grads = {}
+        # table + MLP weight gradients are carved out of ONE flat buffer, so that data-parallel ranks can all-reduce
+        # them with a single collective and no staging copies (naruto_amd.parallel.allreduce_grads)
+        flat_names = [n for i, n in enumerate(PARAM_NAMES) if ctx.needs_input_grad[11 + i] and n != "uncert_grid"]
+        flat = torch.empty(sum(params[n].numel() for n in flat_names), dtype=torch.float32, device=dev) if flat_names else None
+        off = 0
+        for n in flat_names:
+            k = params[n].numel()
+            grads[n] = flat[off:off + k].view_as(params[n])
+            off += k
+        if "table" in flat_names and not overwrite_table:
+            grads["table"].zero_()
         for i, n in enumerate(PARAM_NAMES):
             if not ctx.needs_input_grad[11 + i]:
                 grads[n] = None
-            elif n == "uncert_grid" or (n == "table" and not overwrite_table):
+            elif n == "uncert_grid":
                 grads[n] = torch.zeros_like(params[n])
-            else:
-                grads[n] = torch.empty_like(params[n])
         flags = _lib.BWD_OVERWRITE_WEIGHT_GRADS | (_lib.BWD_OVERWRITE_TABLE_GRAD if overwrite_table else 0)
         gs = NarutoGrads()
         for n in PARAM_NAMES:

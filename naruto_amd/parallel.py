@@ -31,6 +31,11 @@ def world_size(group=None) -> int:
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+def is_distributed(group=None) -> bool:
+    """True when a process group exists (even with a single rank: the collective code path is then exercised)."""
+    return group is not None and dist.is_available() and dist.is_initialized()
+
+
 def rank(group=None) -> int:
     return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
 
@@ -48,23 +53,29 @@ def shard_rays(tensors: Sequence[torch.Tensor], rank_: int, world: int) -> List[
 
 
 def allreduce_loss_sums(sums: torch.Tensor, group=None) -> torch.Tensor:
-    """In-place all-reduce of the loss sums: SUM everywhere except the min(uncert_map) slot (MIN)."""
-    if world_size(group) == 1:
+    """In-place all-reduce (SUM) of the nine additive loss-sum slots.  Slot 9, min(uncert_map), stays this rank's own
+    minimum: it only feeds the reference's ``assert uncert_map.min() > 0``, which every rank can check for its own
+    rays -- not worth a second collective per iteration."""
+    if not (dist.is_available() and dist.is_initialized()):
         return sums
-    mn = sums[LOSS_SLOT_MINUNCERT].clone()
-    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
-    dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=group)
-    sums[LOSS_SLOT_MINUNCERT] = mn
+    dist.all_reduce(sums[:LOSS_SLOT_MINUNCERT], op=dist.ReduceOp.SUM, group=group)
     return sums
 
 
 def allreduce_grads(params: Iterable[torch.nn.Parameter], group=None, flat: Optional[torch.Tensor] = None) -> None:
     """Sum the .grad of all parameters over ranks through one flat bucket (one collective per step)."""
-    if world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return
     ps = [p for p in params if p.grad is not None]
     if not ps:
         return
+    # fast path: the gradients are views that tile one flat buffer (what the fused training node returns)
+    bases = {id(p.grad._base) for p in ps if p.grad._base is not None}
+    if len(bases) == 1 and all(p.grad._base is not None for p in ps):
+        base = ps[0].grad._base
+        if base.is_contiguous() and base.numel() == sum(p.grad.numel() for p in ps):
+            dist.all_reduce(base, op=dist.ReduceOp.SUM, group=group)
+            return
     n = sum(p.grad.numel() for p in ps)
     if flat is None or flat.numel() != n or flat.device != ps[0].grad.device:
         flat = torch.empty(n, dtype=ps[0].grad.dtype, device=ps[0].grad.device)
@@ -84,8 +95,13 @@ def allreduce_grads(params: Iterable[torch.nn.Parameter], group=None, flat: Opti
 def init_from_env(backend: Optional[str] = None):
     """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
     import os
-    if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+    # NARUTO_FORCE_DIST=1 builds the process group even for a single rank (exercises the collective path on one GPU)
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1 and os.environ.get("NARUTO_FORCE_DIST", "0") != "1":
         return None
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    os.environ.setdefault("LOCAL_RANK", "0")
+    os.environ.setdefault("MASTER_PORT", "29511")
     if not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"

@@ -166,9 +166,13 @@ class MappingTrainer:
             loss = torch.add(loss, ret['_smooth_loss'], alpha=tr['smooth_weight'])
         loss.backward()
         if self.group is not None:
-            parallel.allreduce_grads(self.parameters(), self.group)
+            # one collective over the flat (table + MLP weights) gradient; the uncertainty grid's gradient keeps
+            # accumulating locally and is reduced only when its optimiser steps (every 5th iteration)
+            parallel.allreduce_grads(list(self.model.decoder.parameters()) + list(self.model.embed_fn.parameters()), self.group)
         self.map_optimizer.step()
         if uncert_step:
+            if self.group is not None:
+                parallel.allreduce_grads([self.model.uncert_grid], self.group)
             self.uncert_optim.step()
             self.model.uncert_grid.grad.zero_()
         return ret, loss
@@ -192,7 +196,6 @@ class MappingTrainer:
 
     def capture(self, n_rays: int, smooth: bool = False, n_rays_total: int = 0, warmup: int = 3):
         """Record the iteration into hipGraphs (static shapes: n_rays rays per call)."""
-        assert self.group is None, "graph capture of the RCCL exchange is not wired up yet: use eager steps with a process group"
         dev = self.device
         self.model.n_rays_total = n_rays_total
         st = {'rays_o': torch.zeros(n_rays, 3, device=dev), 'rays_d': torch.zeros(n_rays, 3, device=dev),

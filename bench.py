@@ -212,6 +212,9 @@ def main():
     all_rays = syn.random_rays(n_total, cfg["mapping"]["bound"], seed=0)
     lo, hi = parallel.shard_bounds(n_total, rank, world)
     rays = {k: torch.from_numpy(v[lo:hi]).to(dev) for k, v in all_rays.items()}
+    from naruto_amd.trainer import pack_rays
+    rays["rays_o"], rays["rays_d"], rays["target_rgb"], rays["target_d"] = pack_rays(rays["rays_o"], rays["rays_d"], rays["target_rgb"],
+                                                                                      rays["target_d"])
 
     def step():
         tr.step(rays["rays_o"], rays["rays_d"], rays["target_rgb"], rays["target_d"], smooth=True, n_rays_total=n_total)

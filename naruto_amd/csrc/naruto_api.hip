@@ -259,7 +259,7 @@ int naruto_smoothness_fwd(const NarutoField* f, const float* table, uint32_t sam
     float* feat = reinterpret_cast<float*>(workspace);
     double* partial = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + (((size_t)n3 * kFeat * sizeof(float) + 63) / 64) * 64);
     const uint32_t nb = (n3 * kFeat + 255u) / 256u;
-    hipLaunchKernelGGL(k_tv_encode, dim3((n3 + 63u) / 64u), dim3(64), 0, (hipStream_t)stream, f->lt, f->bt, a, rand6, reinterpret_cast<const float2*>(table),
+    hipLaunchKernelGGL(k_tv_encode, dim3((4u * n3 + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, f->lt, f->bt, a, rand6, reinterpret_cast<const float2*>(table),
                        x_out, feat);
     if (int rc = check_launch("tv_encode")) return rc;
     hipLaunchKernelGGL(k_tv_loss, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, feat, d_feat, partial);

@@ -273,11 +273,22 @@ constexpr int kScatterBatch = 4;   // independent point loads in flight per thre
 
 constexpr int kScatterRun = 8;     // consecutive points per thread on the dense (coarse) levels
 
+// float -> two's-complement fixed point with 40 fractional bits, in six VALU ops instead of the generic f32 -> i64
+// conversion: v * 2^40 = H * 2^32 + L,  H = floor(v * 2^8) (int32),  L = (v * 2^8 - H) * 2^32 (uint32, exact in fp32
+// apart from the final truncation: error < 2^-40).  Valid for |v| < 2^23.
+__device__ __forceinline__ unsigned long long to_fix40(float v) {
+    const float t = v * 256.0f;
+    const float fh = floorf(t);
+    const uint32_t lo = (uint32_t)((t - fh) * 4294967296.0f);
+    const uint32_t hi = (uint32_t)(int)fh;
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 __device__ __forceinline__ void fix_add(unsigned long long* __restrict__ acc, uint32_t idx, uint32_t chunk, float v0, float v1) {
     if ((idx >> kChunkLog2) == chunk) {
         const uint32_t e = (idx & (kChunk - 1u)) * 2u;
-        atomicAdd(acc + e, (unsigned long long)__float2ll_rn(v0 * kFixScale));          // ds_add_u64
-        atomicAdd(acc + e + 1u, (unsigned long long)__float2ll_rn(v1 * kFixScale));
+        atomicAdd(acc + e, to_fix40(v0));          // ds_add_u64
+        atomicAdd(acc + e + 1u, to_fix40(v1));
     }
 }
 
@@ -442,10 +453,12 @@ struct TvArgs {
     float voxel, margin, grid_size, inv_p3;
 };
 
-__global__ __launch_bounds__(64) void k_tv_encode(LevelTab lt, BoxTab bt, TvArgs a, const float* __restrict__ rand6, const float2* __restrict__ table,
-                                                   float* __restrict__ x_out, float* __restrict__ feat) {
-    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_tv_encode(LevelTab lt, BoxTab bt, TvArgs a, const float* __restrict__ rand6, const float2* __restrict__ table,
+                                                    float* __restrict__ x_out, float* __restrict__ feat) {
+    // thread = (point, group of 4 levels): 4x the parallelism of a thread per point for this small (n^3 = 29 791) problem
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n3 = a.n * a.n * a.n;
+    const uint32_t m = t >> 2, grp = t & 3u;
     if (m >= n3) return;
     const uint32_t ijk[3] = {m / (a.n * a.n), (m / a.n) % a.n, m % a.n};
     float xn[3];
@@ -455,13 +468,15 @@ __global__ __launch_bounds__(64) void k_tv_encode(LevelTab lt, BoxTab bt, TvArgs
         const float offset = rand6[d] * offset_max + a.margin;
         const float p = ((float)ijk[d] + rand6[3 + d]) * a.voxel + bt.bmin[d] + offset;
         xn[d] = __fdiv_rn(p - bt.bmin[d], bt.bext[d]);
-        x_out[3 * (size_t)m + d] = xn[d];
+        if (grp == 0) x_out[3 * (size_t)m + d] = xn[d];
     }
     float2* out = reinterpret_cast<float2*>(feat + (size_t)m * kFeat);
-    static_for<0, kLevels>([&](auto tc) {
-        constexpr int T = decltype(tc)::value;
-        out[T] = hash_level<T>(lt, table, xn[0], xn[1], xn[2]);
-    });
+    switch (grp) {
+        case 0: static_for<0, 4>([&](auto tc) { constexpr int T = decltype(tc)::value; out[T] = hash_level<T>(lt, table, xn[0], xn[1], xn[2]); }); break;
+        case 1: static_for<4, 8>([&](auto tc) { constexpr int T = decltype(tc)::value; out[T] = hash_level<T>(lt, table, xn[0], xn[1], xn[2]); }); break;
+        case 2: static_for<8, 12>([&](auto tc) { constexpr int T = decltype(tc)::value; out[T] = hash_level<T>(lt, table, xn[0], xn[1], xn[2]); }); break;
+        default: static_for<12, 16>([&](auto tc) { constexpr int T = decltype(tc)::value; out[T] = hash_level<T>(lt, table, xn[0], xn[1], xn[2]); }); break;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_tv_loss(TvArgs a, const float* __restrict__ feat, float* __restrict__ d_feat, double* __restrict__ partial) {

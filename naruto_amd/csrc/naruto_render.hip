@@ -28,7 +28,8 @@ __device__ __forceinline__ float linspace_at(float start, float end, uint32_t st
 __global__ __launch_bounds__(64) void k_sample_z(uint32_t n_rays, const float* __restrict__ target_d, float near_, float far_,
                                                  uint32_t nu, uint32_t nr, float range_d, const float* __restrict__ rand,
                                                  float* __restrict__ z_vals) {
-    __shared__ float zs[kMaxSamples];
+    __shared__ float zs[kMaxSamples];      // merged list
+    __shared__ float us[kMaxSamples];      // the two sorted input lists: uniform [0, nu) then near-surface [nu, nu+nr)
     const uint32_t n = blockIdx.x;
     const uint32_t S = nu + nr;
     const int lane = threadIdx.x;
@@ -37,22 +38,26 @@ __global__ __launch_bounds__(64) void k_sample_z(uint32_t n_rays, const float* _
     } else {
         const float d = target_d[n];
         const bool use_near_far = !(d > 0.0f);           // rows with target_d <= 0 (NaN also lands here)
-        auto range_val = [&](uint32_t k) {
-            return use_near_far ? linspace_at(near_, far_, nr, k) : __fadd_rn(linspace_at(-range_d, range_d, nr, k), d);
-        };
         for (uint32_t s = lane; s < S; s += 64) {
+            if (s < nu) us[s] = linspace_at(near_, far_, nu, s);
+            else us[s] = use_near_far ? linspace_at(near_, far_, nr, s - nu) : __fadd_rn(linspace_at(-range_d, range_d, nr, s - nu), d);
+        }
+        __syncthreads();
+        for (uint32_t s = lane; s < S; s += 64) {
+            const float v = us[s];
+            uint32_t rank;
             if (s < nu) {                                 // uniform element: rank = i + #{R < U[i]}
-                const float v = linspace_at(near_, far_, nu, s);
-                uint32_t rank = s;
-                for (uint32_t k = 0; k < nr; ++k) rank += range_val(k) < v ? 1u : 0u;
-                zs[rank] = v;
-            } else {                                      // near-surface element: rank = k + #{U <= R[k]}
-                const uint32_t k = s - nu;
-                const float v = range_val(k);
-                uint32_t rank = k;
-                for (uint32_t i = 0; i < nu; ++i) rank += linspace_at(near_, far_, nu, i) <= v ? 1u : 0u;
-                zs[rank] = v;
+                rank = s;
+                for (uint32_t k = 0; k < nr; ++k) rank += us[nu + k] < v ? 1u : 0u;
+            } else {                                      // near-surface element: rank = k + #{U <= R[k]} (binary search)
+                uint32_t lo = 0, hi = nu;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (us[mid] <= v) lo = mid + 1; else hi = mid;
+                }
+                rank = (s - nu) + lo;
             }
+            zs[rank] = v;
         }
     }
     __syncthreads();

@@ -244,14 +244,14 @@ class NarutoFieldHIP(nn.Module):
             self.check_asserts()
         cfg = self.config
         z_vals = self._sample_z(rays_o, target_d, rand)
-        rgb, depth, _disp, _acc, _var, _um, _raw, losses, smooth_loss = ops.render_train(
+        rgb, depth, _disp, _acc, _var, _um, _raw, losses = ops.render_train(
             self._handle(), self._params(), rays_o, rays_d, z_vals, target_rgb, target_d, cfg['cam']['depth_trunc'],
             cfg['training']['rgb_missing'], group=self.process_group, n_rays_total=self.n_rays_total, smooth=_smooth)
         self._pending_min_uncert = losses[6].detach()
         if self.strict_assert:
             self.check_asserts()
         return {"rgb": rgb, "depth": depth, "rgb_loss": losses[0], "depth_loss": losses[1], "sdf_loss": losses[2],
-                "fs_loss": losses[3], "psnr": losses[4].detach(), "uncert_loss": losses[5], "_losses": losses, "_smooth_loss": smooth_loss}
+                "fs_loss": losses[3], "psnr": losses[4].detach(), "uncert_loss": losses[5], "_losses": losses, "_smooth_loss": losses[8]}
 
 
 def get_map_volumes(query_fn, bounding_box: torch.Tensor, voxel_size: float):

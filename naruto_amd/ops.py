@@ -395,7 +395,8 @@ def render_loss(handle: FieldHandle, raw, z_vals, target_rgb, target_d, depth_tr
 # A1..A8 as ONE autograd node: what JointEncodingNaruto.forward does in training mode
 # ---------------------------------------------------------------------------------------------------
 class _RenderTrain(torch.autograd.Function):
-    """(rays, z_vals, targets, parameters) -> rgb, depth, losses[8] (+ non-differentiable render outputs).
+    """(rays, z_vals, targets, parameters) -> rgb, depth, losses[10] (+ non-differentiable render outputs).
+    losses = [rgb, depth, sdf, fs, psnr, uncert, min(uncert_map), n_valid_depth, smoothness term (0 if off), 0].
 
     Same kernels as field_query + render_loss, but because the whole chain lives in one node the backward can
     use the structure of the mapping losses: every sample behind the surface band of its ray has an all-zero
@@ -415,18 +416,18 @@ class _RenderTrain(torch.autograd.Function):
         dev = z_vals.device
         need_grad = any(ctx.needs_input_grad[11:])
         raw = torch.empty(N, S, 5, dtype=torch.float32, device=dev)
+        losses = torch.zeros(10, dtype=torch.float32, device=dev)
         sm_loss = sm_x = sm_d = None
         if smooth is not None:                      # (sample_points, voxel_size, margin, rand6): Co-SLAM smoothness term
             sp, vox, mar, rand6 = smooth
             n3 = (sp - 1) ** 3
             sm_x = torch.empty(n3, 3, dtype=torch.float32, device=dev)
             sm_d = torch.empty(n3, 32, dtype=torch.float32, device=dev)
-            sm_loss = torch.empty(1, dtype=torch.float32, device=dev)
+            sm_loss = losses[8:10]                      # the term lands in slot 8 of the loss vector (slot 9: spare)
         feat = torch.empty(16, M, 2, dtype=torch.float32, device=dev) if need_grad else None
         rgb = torch.empty(N, 3, dtype=torch.float32, device=dev)
         disp, acc, depth, depth_var, um = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(5))
         sums = torch.empty(_lib.LOSS_NSUMS, dtype=torch.float64, device=dev)
-        losses = torch.empty(8, dtype=torch.float32, device=dev)
         ps = _params_struct(params)
         pts, _ = _points_struct(None, rays_o, rays_d, z_vals)
         n_total = N
@@ -447,7 +448,7 @@ class _RenderTrain(torch.autograd.Function):
             if smooth is not None:
                 ws2 = torch.empty((lib.naruto_smoothness_workspace(sp) + 3) // 4, dtype=torch.float32, device=dev)
                 check(lib.naruto_smoothness_fwd(handle.ptr, _p(params["table"]), sp, vox, mar, _p(_f32c(rand6, "rand6")), _p(sm_x), _p(sm_d),
-                                                _p(sm_loss), _p(ws2), st), "naruto_smoothness_fwd")
+                                                sm_loss.data_ptr(), _p(ws2), st), "naruto_smoothness_fwd")
         ctx.handle, ctx.depth_trunc, ctx.rgb_missing, ctx.n_total = handle, depth_trunc, rgb_missing, n_total
         ctx.has_smooth = smooth is not None
         ctx.set_materialize_grads(False)
@@ -455,11 +456,10 @@ class _RenderTrain(torch.autograd.Function):
             extra = (sm_x, sm_d) if smooth is not None else ()
             ctx.save_for_backward(raw, feat, rays_o, rays_d, z_vals, target_rgb, target_d, sums, *(params[k] for k in PARAM_NAMES), *extra)
         ctx.mark_non_differentiable(disp, acc, depth_var, um, raw)
-        sm_out = sm_loss.reshape(()) if smooth is not None else torch.zeros((), dtype=torch.float32, device=dev)
-        return rgb, depth, disp, acc, depth_var, um, raw, losses, sm_out
+        return rgb, depth, disp, acc, depth_var, um, raw, losses
 
     @staticmethod
-    def backward(ctx, d_rgb, d_depth, _d_disp, _d_acc, _d_var, _d_um, _d_raw, d_losses, d_smooth):
+    def backward(ctx, d_rgb, d_depth, _d_disp, _d_acc, _d_var, _d_um, _d_raw, d_losses):
         lib = _lib.load()
         raw, feat, rays_o, rays_d, z_vals, target_rgb, target_d, sums = ctx.saved_tensors[:8]
         params = dict(zip(PARAM_NAMES, ctx.saved_tensors[8:14]))
@@ -468,8 +468,9 @@ class _RenderTrain(torch.autograd.Function):
         M = N * S
         dev = raw.device
         if d_losses is None:
-            d_losses = torch.zeros(8, dtype=torch.float32, device=dev)
+            d_losses = torch.zeros(10, dtype=torch.float32, device=dev)
         d_losses = _f32c(d_losses, "d_losses")
+        d_smooth = d_losses[8:9]
         d_raw = torch.empty_like(raw)
         extra = d_rgb is not None or d_depth is not None          # someone differentiated the rendered rgb / depth as well
         # weight / table gradients are WRITTEN by the reductions (no zero fill); the uncertainty grid is scattered into
@@ -515,9 +516,9 @@ class _RenderTrain(torch.autograd.Function):
                 check(lib.naruto_compact_active(N, S, _p(count), _p(off), _p(active), _p(n_active), st), "naruto_compact_active")
             ex = None
             n_extra = 0
-            if ctx.has_smooth and d_smooth is not None and grads["table"] is not None:
+            if ctx.has_smooth and grads["table"] is not None:
                 ex = _lib.NarutoExtraPoints()
-                ex.x, ex.d_feat, ex.scale, ex.n = _p(sm_x), _p(sm_d), _p(_f32c(d_smooth, "d_smooth").reshape(1)), sm_x.shape[0]
+                ex.x, ex.d_feat, ex.scale, ex.n = _p(sm_x), _p(sm_d), d_smooth.data_ptr(), sm_x.shape[0]
                 n_extra = sm_x.shape[0]
             ws = torch.empty((lib.naruto_query_bwd_workspace(ctx.handle.ptr, M + n_extra) + 3) // 4, dtype=torch.float32, device=dev)
             check(lib.naruto_query_bwd(ctx.handle.ptr, C.byref(ps), M, C.byref(pts), _p(feat), _p(d_raw), None, _p(active), _p(n_active),
@@ -532,10 +533,10 @@ def handle_supports_overwrite(handle: FieldHandle) -> bool:
 
 def render_train(handle: FieldHandle, params: Dict[str, torch.Tensor], rays_o, rays_d, z_vals, target_rgb, target_d,
                  depth_trunc: float, rgb_missing: float, group=None, n_rays_total: int = 0, smooth=None):
-    """-> rgb, depth, disp, acc, depth_var, uncert_map, raw, losses[8], smooth_loss.
+    """-> rgb, depth, disp, acc, depth_var, uncert_map, raw, losses[10].
 
-    ``smooth`` = (sample_points, voxel_size, margin, rand6) adds Co-SLAM's feature-grid smoothness term as a 9th
-    output; its table gradient is produced by the same scatter pass as the rendering losses'."""
+    ``smooth`` = (sample_points, voxel_size, margin, rand6) adds Co-SLAM's feature-grid smoothness term as
+    losses[8]; its table gradient is produced by the same scatter pass as the rendering losses'."""
     if smooth is not None:
         smooth = (int(smooth[0]), float(smooth[1]), float(smooth[2]), smooth[3])
     return _RenderTrain.apply(handle, rays_o, rays_d, z_vals, target_rgb, target_d, float(depth_trunc), float(rgb_missing), group,

@@ -67,6 +67,20 @@ def get_loss_from_ret(model: NarutoFieldHIP, config: Dict, ret: Dict, rgb=True, 
     return loss
 
 
+def unpack_rays(flat: torch.Tensor, n_rays: int):
+    """Views (rays_o [N,3], rays_d [N,3], target_rgb [N,3], target_d [N,1]) into one flat [10 N] buffer."""
+    n = n_rays
+    return (flat[0:3 * n].view(n, 3), flat[3 * n:6 * n].view(n, 3), flat[6 * n:9 * n].view(n, 3), flat[9 * n:10 * n].view(n, 1))
+
+
+def pack_rays(rays_o, rays_d, target_rgb, target_d):
+    """One contiguous buffer holding a ray batch; returns the four views.  A batch built this way reaches a
+    graph-captured trainer with a single device copy."""
+    n = rays_o.shape[0]
+    flat = torch.cat([rays_o.reshape(-1), rays_d.reshape(-1), target_rgb.reshape(-1), target_d.reshape(-1)]).contiguous()
+    return unpack_rays(flat, n)
+
+
 class FusedAdam:
     """torch.optim.Adam semantics (amsgrad off, L2 weight decay) as one HIP kernel per tensor; the step count
     lives on the device so that the launch stays valid under hipGraph replay.  ``param_groups`` uses the
@@ -143,8 +157,9 @@ class MappingTrainer:
         self._graphs = None
         self._static = None
         tr = config['training']
+        # get_loss_from_ret's weights laid out like the node's loss vector (slot 8 = smoothness term)
         self._loss_w = torch.tensor([tr['rgb_weight'], tr['depth_weight'], tr['sdf_weight'], tr['fs_weight'], 0.0,
-                                     tr['uncert_weight'], 0.0, 0.0], dtype=torch.float32, device=self.device)
+                                     tr['uncert_weight'], 0.0, 0.0, tr['smooth_weight'], 0.0], dtype=torch.float32, device=self.device)
         if group is not None:
             self.model.enable_data_parallel(group)
 
@@ -157,13 +172,16 @@ class MappingTrainer:
         self.map_optimizer.zero_grad(set_to_none=True)
         tr = self.config['training']
         use_smooth = smooth and tr['smooth_weight'] > 0
-        sm = (tr['smooth_pts'], tr['smooth_vox'], tr['smooth_margin'], torch.rand(6, device=self.device)) if use_smooth else None
-        ret = model.forward(rays_o, rays_d, target_rgb, target_d, _check=check, _smooth=sm)
-        # get_loss_from_ret (coslam.py:154-174) as one dot product over the loss vector (+ the smoothness term, which
-        # the fused node computed alongside so that its table gradient shares the scatter pass)
+        # one RNG launch per iteration: the depth jitter [N,S] and the six numbers placing the smoothness lattice
+        n_rays = rays_o.shape[0]
+        n_z = n_rays * (tr['n_samples_d'] + tr['n_range_d']) if tr['perturb'] > 0. else 0
+        r = torch.rand(n_z + 6, device=self.device)
+        rand = r[:n_z].view(n_rays, -1) if n_z else None
+        sm = (tr['smooth_pts'], tr['smooth_vox'], tr['smooth_margin'], r[n_z:]) if use_smooth else None
+        ret = model.forward(rays_o, rays_d, target_rgb, target_d, rand=rand, _check=check, _smooth=sm)
+        # get_loss_from_ret (coslam.py:154-174) as ONE dot product over the node's loss vector (the smoothness term sits
+        # in slot 8; the fused node computed it alongside so that its table gradient shares the scatter pass)
         loss = torch.dot(ret['_losses'], self._loss_w)
-        if use_smooth:
-            loss = torch.add(loss, ret['_smooth_loss'], alpha=tr['smooth_weight'])
         loss.backward()
         if self.group is not None:
             # one collective over the flat (table + MLP weights) gradient; the uncertainty grid's gradient keeps
@@ -186,10 +204,15 @@ class MappingTrainer:
         if self._graphs is not None:
             st = self._static
             assert smooth == st['smooth'] and rays_o.shape[0] == st['rays_o'].shape[0], "captured for another configuration"
-            st['rays_o'].copy_(rays_o, non_blocking=True)
-            st['rays_d'].copy_(rays_d, non_blocking=True)
-            st['target_rgb'].copy_(target_rgb, non_blocking=True)
-            st['target_d'].copy_(target_d.reshape(st['target_d'].shape), non_blocking=True)
+            src = getattr(rays_o, "_base", None)
+            if src is not None and src.numel() == st['flat'].numel() and src.is_contiguous() and all(
+                    t._base is src for t in (rays_d, target_rgb, target_d)) and rays_o.data_ptr() == src.data_ptr():
+                st['flat'].copy_(src.reshape(-1), non_blocking=True)      # rays packed by pack_rays(): one copy
+            else:
+                st['rays_o'].copy_(rays_o, non_blocking=True)
+                st['rays_d'].copy_(rays_d, non_blocking=True)
+                st['target_rgb'].copy_(target_rgb, non_blocking=True)
+                st['target_d'].copy_(target_d.reshape(st['target_d'].shape), non_blocking=True)
             self._graphs[1 if uncert_step else 0].replay()
             return st['ret'][1 if uncert_step else 0], st['loss'][1 if uncert_step else 0]
         return self._iteration(rays_o, rays_d, target_rgb, target_d, smooth, uncert_step)
@@ -198,10 +221,11 @@ class MappingTrainer:
         """Record the iteration into hipGraphs (static shapes: n_rays rays per call)."""
         dev = self.device
         self.model.n_rays_total = n_rays_total
-        st = {'rays_o': torch.zeros(n_rays, 3, device=dev), 'rays_d': torch.zeros(n_rays, 3, device=dev),
-              'target_rgb': torch.zeros(n_rays, 3, device=dev), 'target_d': torch.ones(n_rays, 1, device=dev),
-              'smooth': smooth, 'ret': [None, None], 'loss': [None, None]}
+        flat = torch.zeros(n_rays * 10, device=dev)
+        st = {'flat': flat, 'smooth': smooth, 'ret': [None, None], 'loss': [None, None]}
+        st['rays_o'], st['rays_d'], st['target_rgb'], st['target_d'] = unpack_rays(flat, n_rays)
         st['rays_d'][:, 2] = 1.0
+        st['target_d'].fill_(1.0)
         # snapshot: the warm-up / capture iterations below must not change the training state
         params = self.parameters()
         snap = [p.detach().clone() for p in params]

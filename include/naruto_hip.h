@@ -209,6 +209,10 @@ int naruto_adam_step(float* param, const float* grad, float* exp_avg, float* exp
                      float lr, float beta1, float beta2, float eps, float weight_decay, uint32_t step,
                      const int32_t* step_dev, void* stream);
 
+/* A9 caller -- get_map_volumes' post-processing (coslam_utils.py:89-95): sdf_uncert [M,2] from
+ * naruto_query_fwd -> out [2,M] = (uncertainty volume: softplus(raw)+0.01 where 0 <= sdf < 0.5 else 0 | sdf volume). */
+int naruto_map_volumes(uint32_t M, const float* sdf_uncert, float* out, void* stream);
+
 /* All parameter tensors of one optimiser in a single launch (<= 8 segments, per-segment lr / eps / weight_decay,
  * shared betas and step). */
 typedef struct NarutoAdamSeg {

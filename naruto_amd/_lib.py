@@ -102,6 +102,7 @@ SIGNATURES = {
     "naruto_query_bwd_workspace": (C.c_size_t, [_V, _U32]),
     "naruto_query_bwd": (_I, [_V, C.POINTER(NarutoParams), _U32, C.POINTER(NarutoPoints), _V, _V, _V, _V, _V,
                               C.POINTER(NarutoExtraPoints), _U32, C.POINTER(NarutoGrads), _V, _V]),
+    "naruto_map_volumes": (_I, [_U32, _V, _V, _V]),
     "naruto_adam_multi": (_I, [C.POINTER(NarutoAdamSeg), _U32, _F, _F, _U32, _V, _V]),
     "naruto_compact_active": (_I, [_U32, _U32, _V, _V, _V, _V, _V]),
     "naruto_composite_fwd": (_I, [_V, _U32, _U32, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V]),

@@ -440,6 +440,13 @@ int naruto_adam_step(float* param, const float* grad, float* exp_avg, float* exp
     return check_launch("adam_step");
 }
 
+int naruto_map_volumes(uint32_t M, const float* sdf_uncert, float* out, void* stream) {
+    if (sdf_uncert == nullptr || out == nullptr) return fail(NARUTO_ERR_INVALID, "map_volumes: NULL argument");
+    if (M == 0) return NARUTO_OK;
+    hipLaunchKernelGGL(k_map_post, dim3((M + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, M, reinterpret_cast<const float2*>(sdf_uncert), out);
+    return check_launch("map_volumes");
+}
+
 int naruto_adam_multi(const NarutoAdamSeg* segs, uint32_t n_segs, float beta1, float beta2, uint32_t step, const int32_t* step_dev, void* stream) {
     if (segs == nullptr || n_segs == 0 || n_segs > (uint32_t)kAdamMaxSegs) return fail(NARUTO_ERR_INVALID, "adam_multi: 1..%d segments", kAdamMaxSegs);
     if (step == 0 && step_dev == nullptr) return fail(NARUTO_ERR_INVALID, "adam_multi: step is 1-based (or pass step_dev)");

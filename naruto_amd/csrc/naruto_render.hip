@@ -513,6 +513,17 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
     }
 }
 
+// planner volumes from (sdf, uncert_raw) pairs: uncert = softplus(raw) + 0.01 where 0 <= sdf < 0.5, else 0
+// (reference src/slam/coslam/coslam_utils.py:89-95); out = [uncert[M] | sdf[M]] so one D2H copy moves both
+__global__ __launch_bounds__(256) void k_map_post(uint32_t M, const float2* __restrict__ sdf_uncert, float* __restrict__ out) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const float2 v = sdf_uncert[m];
+    const bool on_surface = v.x >= 0.0f && v.x < 0.5f;
+    out[m] = on_surface ? softplus_(v.y) + 0.01f : 0.0f;
+    out[(size_t)M + m] = v.x;
+}
+
 constexpr int kAdamMaxSegs = 8;
 struct AdamSegs {
     float* p[kAdamMaxSegs];

@@ -254,20 +254,40 @@ class NarutoFieldHIP(nn.Module):
                 "fs_loss": losses[3], "psnr": losses[4].detach(), "uncert_loss": losses[5], "_losses": losses, "_smooth_loss": losses[8]}
 
 
+_LATTICE_CACHE: Dict = {}
+
+
+def _map_lattice(bounding_box: torch.Tensor, voxel_size: float) -> torch.Tensor:
+    """Normalised query lattice of get_map_volumes (Co-SLAM getVoxels + meshgrid), cached on the device."""
+    key = (tuple(float(v) for v in bounding_box.detach().cpu().reshape(-1)), float(voxel_size), str(bounding_box.device))
+    q = _LATTICE_CACHE.get(key)
+    if q is None:
+        ts = []
+        for i in range(3):
+            lo, hi = float(bounding_box[i, 0]), float(bounding_box[i, 1])
+            n = round((hi - lo) / voxel_size + 0.0005)                        # Co-SLAM getVoxels
+            ts.append(torch.linspace(lo, hi, n + 1))
+        q = torch.stack(torch.meshgrid(*ts, indexing='ij'), -1).to(torch.float32).to(bounding_box.device)
+        q = ((q - bounding_box[:, 0]) / (bounding_box[:, 1] - bounding_box[:, 0])).contiguous()
+        _LATTICE_CACHE[key] = q
+    return q
+
+
 def get_map_volumes(query_fn, bounding_box: torch.Tensor, voxel_size: float):
     """Planner query path (reference src/slam/coslam/coslam_utils.py:58-97): dense lattice -> [uncert_vol,
-    sdf_vol] as numpy.  The reference's discarded ``embed=True`` pass (coslam_utils.py:86-87) is skipped."""
-    ts = []
-    for i in range(3):
-        lo, hi = float(bounding_box[i, 0]), float(bounding_box[i, 1])
-        n = round((hi - lo) / voxel_size + 0.0005)                        # Co-SLAM getVoxels
-        ts.append(torch.linspace(lo, hi, n + 1))
-    q = torch.stack(torch.meshgrid(*ts, indexing='ij'), -1).to(torch.float32).to(bounding_box.device)
-    q = (q - bounding_box[:, 0]) / (bounding_box[:, 1] - bounding_box[:, 0])
+    sdf_vol] as numpy.  The lattice is cached on the device, the reference's discarded ``embed=True`` pass
+    (coslam_utils.py:86-87) is skipped, the post-processing is one kernel and both volumes come back in one
+    device-to-host copy."""
+    import ctypes as C
+    from . import _lib
+    q = _map_lattice(bounding_box, voxel_size)
     with torch.no_grad():
-        su = query_fn(q, embed=False, return_uncert=True)
-        sdf, uncert = su[..., 0], su[..., 1]
-        uncert_map = torch.nn.functional.softplus(uncert) + 0.01
-        mask = (sdf >= 0) * (sdf < 0.5)
-        uncert_map[torch.logical_not(mask)] = 0
-    return [uncert_map.cpu().numpy().copy(), sdf.cpu().numpy().copy()]
+        su = query_fn(q, embed=False, return_uncert=True).contiguous()
+        M = su.numel() // 2
+        out = torch.empty(2, M, dtype=torch.float32, device=su.device)
+        with torch.cuda.device(su.device):
+            _lib.check(_lib.load().naruto_map_volumes(M, su.data_ptr(), out.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                       "naruto_map_volumes")
+        host = out.cpu().numpy()
+    shape = tuple(q.shape[:-1])
+    return [host[0].reshape(shape).copy(), host[1].reshape(shape).copy()]

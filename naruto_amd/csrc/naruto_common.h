@@ -197,6 +197,39 @@ __device__ __forceinline__ void oneblob16(float x, float (&e)[kBins]) {
     e[kBins - 1] = (c[0] + 1.0f) - c[kBins - 1];
 }
 
+// Closed form of the same encoding for x in (-0.9375, 1.9375): only three (cyclically adjacent) bins are
+// non-zero.  With y = 16 x wrapped to [0,16), b0 = floor(y), f = y - b0:
+//   e[b0-1] = C'(-f),  e[b0] = C'(1-f) - C'(-f),  e[b0+1] = 1 - C'(1-f),   C'(u) = clamp(15/16 u (1 - 2/3 u^2 + 1/5 u^4) + 1/2)
+// (verified against the dense form to 1.2e-6 over that range; outside it the +-1 periodic images of the dense
+// form run out and the two differ, so callers fall back to oneblob16).  ~125 VALU ops per coordinate instead of ~270.
+__device__ __forceinline__ float oneblob_cq(float u) {
+    const float u2 = u * u;
+    const float u4 = u2 * u2;
+    const float p = (15.0f / 16.0f) * u * (1.0f - (2.0f / 3.0f) * u2 + (1.0f / 5.0f) * u4) + 0.5f;
+    return fminf(fmaxf(p, 0.0f), 1.0f);
+}
+
+__device__ __forceinline__ bool oneblob_sparse_ok(float x) { return x > -0.93f && x < 1.93f; }
+
+__device__ __forceinline__ void oneblob16_sparse(float x, float (&e)[kBins]) {
+    const float y = x * 16.0f;
+    const float yw = y - 16.0f * floorf(y * 0.0625f);
+    const float fb = floorf(yw);
+    const float f = yw - fb;
+    const int b0 = ((int)fb) & 15;
+    const int bm = (b0 + 15) & 15, bp = (b0 + 1) & 15;
+    const float p = oneblob_cq(-f), q = oneblob_cq(1.0f - f);
+    const float mid = q - p, hi = 1.0f - q;
+#pragma unroll
+    for (int b = 0; b < kBins; ++b) e[b] = b == bm ? p : (b == b0 ? mid : (b == bp ? hi : 0.0f));
+}
+
+// wave-uniform choice: the closed form when every lane's coordinate allows it, the dense form otherwise
+__device__ __forceinline__ void oneblob16_auto(float x, bool all_sparse_ok, float (&e)[kBins]) {
+    if (all_sparse_ok) oneblob16_sparse(x, e);
+    else oneblob16(x, e);
+}
+
 // ---------------------------------------------------------------------------------------------
 // MFMA / cross-lane primitives (layouts verified on hardware by naruto_debug_* + tests).
 //   mfma32: D[i][j] += sum_k A[i][k] B[k][j], 32x32x2 fp32 (exact fp32 fma chain).

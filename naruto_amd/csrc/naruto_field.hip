@@ -110,10 +110,11 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd(LevelTab lt, UncertTab ut,
             // hoisted loads, which is what decides between 1 and 2 waves per SIMD for this kernel
             if constexpr ((T + 1) % kGatherGroup == 0) __builtin_amdgcn_sched_barrier(0);
         });
+        const bool blob_fast = __all(oneblob_sparse_ok(x) && oneblob_sparse_ok(y) && oneblob_sparse_ok(z));
         static_for<0, 3>([&](auto dc) {
             constexpr int D = decltype(dc)::value;
             float e[kBins];
-            oneblob16(D == 0 ? x : (D == 1 ? y : z), e);
+            oneblob16_auto(D == 0 ? x : (D == 1 ? y : z), blob_fast, e);
             static_for<0, 8>([&](auto qc) {
                 constexpr int Q = decltype(qc)::value;
                 constexpr int P = D * 8 + Q;
@@ -702,10 +703,11 @@ __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, Bo
             xs[j * kStageLd + 2 * T + hh] = valid ? b : 0.0f;
             h = mfma32(L.f.s0[T * 64 + lane], b, h);
         });
+        const bool blob_fast = __all(oneblob_sparse_ok(x) && oneblob_sparse_ok(y) && oneblob_sparse_ok(z));
         static_for<0, 3>([&](auto dc) {
             constexpr int D = decltype(dc)::value;
             float e[kBins];
-            oneblob16(D == 0 ? x : (D == 1 ? y : z), e);
+            oneblob16_auto(D == 0 ? x : (D == 1 ? y : z), blob_fast, e);
             static_for<0, 8>([&](auto qc) {
                 constexpr int Q = decltype(qc)::value;
                 constexpr int P = D * 8 + Q;

@@ -107,7 +107,10 @@ __device__ __forceinline__ void hash_corners(const LevelTab& lt, float x, float 
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             uint32_t i = base + (uint32_t)(c & 1) + ((c & 2) ? res : 0u) + ((c & 4) ? r2 : 0u);
-            if (i >= size) i %= size;     // only out-of-box / wrap-around corners take this path
+            if (i >= size) {              // only out-of-box / wrap-around corners: i % size by multiply-high (<= 1 correction)
+                i -= __umulhi(i, 0xFFFFFFFFu / size) * size;
+                if (i >= size) i -= size;
+            }
             idx[c] = i;
         }
     }
@@ -115,6 +118,56 @@ __device__ __forceinline__ void hash_corners(const LevelTab& lt, float x, float 
     for (int c = 0; c < 8; ++c) {
         w[c] = ((c & 1) ? wx : ux) * ((c & 2) ? wy : uy) * ((c & 4) ? wz : uz);
     }
+}
+
+// Same arithmetic with the level as a RUNTIME (wave-uniform) index: lets the per-level work sit in a real loop
+// (the fully unrolled 16-level body is ~60 KB of code, the size of the instruction cache two CUs share).
+__device__ __forceinline__ float2 hash_level_rt(const LevelTab& lt, int T, const float2* __restrict__ table, float x, float y, float z) {
+    const float scale = lt.scale[T];
+    const uint32_t res = lt.res[T];
+    const uint32_t size = lt.size[T];
+    const float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
+    const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+    const uint32_t gx = (uint32_t)(int)fx, gy = (uint32_t)(int)fy, gz = (uint32_t)(int)fz;
+    const float wx = px - fx, wy = py - fy, wz = pz - fz;
+    const float ux = 1.0f - wx, uy = 1.0f - wy, uz = 1.0f - wz;
+    uint32_t idx[8];
+    if ((lt.hashed >> T) & 1u) {
+        const uint32_t mask = size - 1u;
+        const uint32_t hy0 = gy * kPrime1, hy1 = hy0 + kPrime1;
+        const uint32_t hz0 = gz * kPrime2, hz1 = hz0 + kPrime2;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) idx[c] = ((gx + (uint32_t)(c & 1)) ^ ((c & 2) ? hy1 : hy0) ^ ((c & 4) ? hz1 : hz0)) & mask;
+    } else {
+        const uint32_t r2 = res * res;
+        const uint32_t base = gx + gy * res + gz * r2;
+        const uint32_t magic = 0xFFFFFFFFu / size;           // i % size = i - floor(i * magic / 2^32) * size, at most one correction
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            uint32_t i = base + (uint32_t)(c & 1) + ((c & 2) ? res : 0u) + ((c & 4) ? r2 : 0u);
+            i -= __umulhi(i, magic) * size;
+            if (i >= size) i -= size;
+            idx[c] = i;
+        }
+    }
+    const float2* __restrict__ tl = table + lt.off[T];
+    float2 v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+#ifdef NARUTO_ABLATE_GATHER        // profiling only: index math kept, the table read replaced by a register value
+        v[c] = make_float2(__uint_as_float(idx[c] | 0x3f000000u), 0.25f);
+#else
+        v[c] = tl[idx[c]];
+#endif
+    }
+    float2 acc = make_float2(0.0f, 0.0f);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float w = ((c & 1) ? wx : ux) * ((c & 2) ? wy : uy) * ((c & 4) ? wz : uz);
+        acc.x = fmaf(w, v[c].x, acc.x);
+        acc.y = fmaf(w, v[c].y, acc.y);
+    }
+    return acc;
 }
 
 template <int T>
@@ -238,7 +291,13 @@ __device__ __forceinline__ void oneblob16_auto(float x, bool all_sparse_ok, floa
 //   swap32(a, b): lanes 32..63 of a <-> lanes 0..31 of b.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+#ifdef NARUTO_ABLATE_MFMA          // profiling only: keep the operands live, drop the matrix op
+    asm volatile("" ::"v"(a), "v"(b));
+    c[0] += a * b;
+    return c;
+#else
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+#endif
 }
 
 __device__ __forceinline__ void swap32(float& a, float& b) {

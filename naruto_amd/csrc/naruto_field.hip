@@ -74,10 +74,16 @@ __device__ __forceinline__ void stage_fwd_weights(FwdLds& L, const NarutoParams&
     }
 }
 
-constexpr int kGatherGroup = 4;
+#ifndef NARUTO_GATHER_GROUP
+#define NARUTO_GATHER_GROUP 4
+#endif
+#ifndef NARUTO_FWD_MINWAVES
+#define NARUTO_FWD_MINWAVES 2
+#endif
+constexpr int kGatherGroup = NARUTO_GATHER_GROUP;
 
 template <bool COLOR>
-__global__ __launch_bounds__(256, 2) void k_query_fwd(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps,
+__global__ __launch_bounds__(256, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps,
                                                    uint32_t M, float* __restrict__ raw, float* __restrict__ sdf_uncert,
                                                    float* __restrict__ geo, float* __restrict__ feat_save) {
     __shared__ FwdLds L;
@@ -97,6 +103,7 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd(LevelTab lt, UncertTab ut,
         const float u = uncert_sample(ut, p.uncert_grid, x, y, z);
 
         f32x16 hA = zero16(), hB = zero16(), cA = zero16(), cB = zero16();
+#ifdef NARUTO_FWD_UNROLLED_LEVELS
         static_for<0, kLevels>([&](auto tc) {
             constexpr int T = decltype(tc)::value;
             const float2 f = hash_level<T>(lt, table, x, y, z);
@@ -106,10 +113,22 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd(LevelTab lt, UncertTab ut,
             swap32(b0, b1);                      // b0: tile A operand, b1: tile B operand
             hA = mfma32(a, b0, hA);
             hB = mfma32(a, b1, hB);
-            // keep at most kGatherGroup levels' gathers in flight: bounds the registers the scheduler may spend on
-            // hoisted loads, which is what decides between 1 and 2 waves per SIMD for this kernel
             if constexpr ((T + 1) % kGatherGroup == 0) __builtin_amdgcn_sched_barrier(0);
         });
+#else
+        // levels in a real loop (unrolled by kGatherGroup): the gathers of a group are in flight together, the code
+        // stays an order of magnitude smaller than the fully unrolled form
+#pragma unroll NARUTO_GATHER_GROUP
+        for (int T = 0; T < kLevels; ++T) {
+            const float2 f = hash_level_rt(lt, T, table, x, y, z);
+            if (feat_out != nullptr && valid) feat_out[(size_t)T * M + m] = f;
+            const float a = L.s0[T * 64 + lane];
+            float b0 = f.x, b1 = f.y;
+            swap32(b0, b1);                      // b0: tile A operand, b1: tile B operand
+            hA = mfma32(a, b0, hA);
+            hB = mfma32(a, b1, hB);
+        }
+#endif
         const bool blob_fast = __all(oneblob_sparse_ok(x) && oneblob_sparse_ok(y) && oneblob_sparse_ok(z));
         static_for<0, 3>([&](auto dc) {
             constexpr int D = decltype(dc)::value;

@@ -213,6 +213,26 @@ int naruto_adam_step(float* param, const float* grad, float* exp_avg, float* exp
  * naruto_query_fwd -> out [2,M] = (uncertainty volume: softplus(raw)+0.01 where 0 <= sdf < 0.5 else 0 | sdf volume). */
 int naruto_map_volumes(uint32_t M, const float* sdf_uncert, float* out, void* stream);
 
+/* N1 ("next" row) -- ActiveRaySampler.sample_rays (reference src/slam/coslam/active_ray_sampler.py:77-149) on the
+ * device.  Input batch of n_total rays = [oversampled keyframe rays ..., n_cur current-frame rays]; base =
+ * mapping.sample (2048), K = num_uncert_sample (500), n_tail = ceil(n_cur / oversample_mul).  Candidates are rays
+ * [base, n_total - n_tail); the K with the SMALLEST cached-uncertainty value at their measured end point
+ * (round((o + d*depth - bbox_min) * voxel_scale), clipped; numpy argpartition semantics, ties by lower index) are
+ * moved to the front: out = [K selected | rays [0, base-K) | last n_tail rays], base + n_tail rows.
+ * uncert_vol [X,Y,Z] fp32 on the device; vol_dims / bbox_min are HOST arrays of 3.
+ * workspace: naruto_active_ray_workspace(n_total, K) bytes. */
+size_t naruto_active_ray_workspace(uint32_t n_total, uint32_t K);
+int naruto_active_ray_select(uint32_t n_total, uint32_t base, uint32_t K, uint32_t n_tail, const float* rays_o,
+                             const float* rays_d, const float* target_s, const float* target_d,
+                             const float* uncert_vol, const uint32_t* vol_dims, const float* bbox_min,
+                             float voxel_scale, float* out_o, float* out_d, float* out_s, float* out_t,
+                             void* workspace, void* stream);
+
+/* N2 ("next" row) -- camera-frame directions to world rays (coslam.py:342-344): rays_d[r] = R[pose_id[r]] . d_cam[r],
+ * rays_o[r] = t[pose_id[r]]; poses [P,4,4] row-major camera-to-world, pose_id int64 [n]. */
+int naruto_rays_to_world(uint32_t n, const float* d_cam, const int64_t* pose_id, const float* poses, float* rays_o,
+                         float* rays_d, void* stream);
+
 /* All parameter tensors of one optimiser in a single launch (<= 8 segments, per-segment lr / eps / weight_decay,
  * shared betas and step). */
 typedef struct NarutoAdamSeg {

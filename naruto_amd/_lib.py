@@ -14,7 +14,7 @@ from typing import List, Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnaruto_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["naruto_api.hip", "naruto_field.hip", "naruto_render.hip", "naruto_common.h"]
+SOURCES = ["naruto_api.hip", "naruto_field.hip", "naruto_render.hip", "naruto_rays.hip", "naruto_common.h"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "naruto_hip.h")
 
 MAX_LEVELS = 16
@@ -102,6 +102,9 @@ SIGNATURES = {
     "naruto_query_bwd_workspace": (C.c_size_t, [_V, _U32]),
     "naruto_query_bwd": (_I, [_V, C.POINTER(NarutoParams), _U32, C.POINTER(NarutoPoints), _V, _V, _V, _V, _V,
                               C.POINTER(NarutoExtraPoints), _U32, C.POINTER(NarutoGrads), _V, _V]),
+    "naruto_active_ray_workspace": (C.c_size_t, [_U32, _U32]),
+    "naruto_active_ray_select": (_I, [_U32, _U32, _U32, _U32, _V, _V, _V, _V, _V, C.POINTER(_U32), C.POINTER(_F), _F, _V, _V, _V, _V, _V, _V]),
+    "naruto_rays_to_world": (_I, [_U32, _V, _V, _V, _V, _V, _V]),
     "naruto_map_volumes": (_I, [_U32, _V, _V, _V]),
     "naruto_adam_multi": (_I, [C.POINTER(NarutoAdamSeg), _U32, _F, _F, _U32, _V, _V]),
     "naruto_compact_active": (_I, [_U32, _U32, _V, _V, _V, _V, _V]),

@@ -1,0 +1,74 @@
+"""ActiveRaySamplerHIP: drop-in for the reference's ``ActiveRaySampler`` (reference
+src/slam/coslam/active_ray_sampler.py:31-149) with the uncertainty lookup, the K-smallest selection and the batch
+re-assembly on the device.  The reference does them in numpy on the host inside every
+mapping iteration (GPU -> CPU -> GPU); here nothing leaves the device and nothing synchronises.
+
+Quirks kept: the K rays with the SMALLEST cached value are chosen (``np.argpartition(...)[:K]``, :127); the voxel scale
+is the hard-coded ``* 10`` (:112); ``-len(idx_cur) // oversample_mul`` floor-divides a negative number (:111,:131), i.e.
+ceil(len/mul) rays are kept from the current frame.  Not reproducible by construction: the ORDER of the K selected rays
+(numpy's introselect order is unspecified); here they come out by ascending candidate index, ties at the threshold
+value go to the lower index.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .ops import _f32c, _p, _stream
+
+
+def rays_to_world(rays_d_cam: torch.Tensor, pose_ids: torch.Tensor, poses: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """coslam.py:342-344: (rays_o, rays_d) in world coordinates from camera-frame directions and per-ray pose ids."""
+    lib = _lib.load()
+    d = _f32c(rays_d_cam, "rays_d_cam").reshape(-1, 3)
+    ids = pose_ids.to(device=d.device, dtype=torch.int64).contiguous()
+    P = _f32c(poses, "poses").reshape(-1, 4, 4)
+    n = d.shape[0]
+    o_out, d_out = torch.empty(n, 3, device=d.device), torch.empty(n, 3, device=d.device)
+    with torch.cuda.device(d.device):
+        _lib.check(lib.naruto_rays_to_world(n, _p(d), _p(ids), _p(P), _p(o_out), _p(d_out), _stream()), "naruto_rays_to_world")
+    return o_out, d_out
+
+
+class ActiveRaySamplerHIP:
+    def __init__(self, config: Dict = None, num_uncert_sample: int = 500, oversample_mul: int = 4) -> None:
+        self.num_uncert_sample = num_uncert_sample
+        self.oversample_mul = oversample_mul
+        self.base_sample_num = config['mapping']['sample']
+        self.oversample_num = self.base_sample_num * self.oversample_mul
+        self.min_pixels_cur = config['mapping']['min_pixels_cur'] * self.oversample_mul
+        self._vol_key = None
+        self._vol_dev = None
+
+    def _volume(self, uncert_vol, device) -> torch.Tensor:
+        if torch.is_tensor(uncert_vol):
+            return _f32c(uncert_vol.to(device), "uncert_vol")
+        key = (id(uncert_vol), uncert_vol.shape, str(device))
+        if key != self._vol_key:                       # the planner volume changes every 5 frames: one upload per change
+            self._vol_dev = torch.from_numpy(np.ascontiguousarray(uncert_vol, dtype=np.float32)).to(device)
+            self._vol_key = key
+        return self._vol_dev
+
+    def sample_rays(self, rays_o, rays_d, target_s, target_d, idx_cur: List, uncert_vol, bbox: List):
+        lib = _lib.load()
+        rays_o, rays_d, target_s = _f32c(rays_o, "rays_o"), _f32c(rays_d, "rays_d"), _f32c(target_s, "target_s")
+        td = _f32c(target_d, "target_d").reshape(-1)
+        dev = rays_o.device
+        vol = self._volume(uncert_vol, dev)
+        n_total, base, K = rays_o.shape[0], self.base_sample_num, self.num_uncert_sample
+        n_tail = -((-len(idx_cur)) // self.oversample_mul)          # ceil(len / mul), as the reference's -len//mul slice
+        n_out = base + n_tail
+        o_out, d_out, s_out = (torch.empty(n_out, 3, device=dev) for _ in range(3))
+        t_out = torch.empty(n_out, 1, device=dev)
+        dims = (C.c_uint32 * 3)(*vol.shape)
+        bmin = (C.c_float * 3)(*(float(b[0]) for b in bbox))
+        with torch.cuda.device(dev):
+            ws = torch.empty(lib.naruto_active_ray_workspace(n_total, K) // 4 + 4, dtype=torch.int32, device=dev)
+            _lib.check(lib.naruto_active_ray_select(n_total, base, K, n_tail, _p(rays_o), _p(rays_d), _p(target_s), _p(td), _p(vol), dims, bmin, 10.0,
+                                                    _p(o_out), _p(d_out), _p(s_out), _p(t_out), _p(ws), _stream()), "naruto_active_ray_select")
+        return o_out, d_out, s_out, t_out

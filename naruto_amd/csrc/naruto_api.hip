@@ -8,6 +8,7 @@
 
 #include "naruto_field.hip"
 #include "naruto_render.hip"
+#include "naruto_rays.hip"
 
 using namespace naruto;
 
@@ -438,6 +439,39 @@ int naruto_adam_step(float* param, const float* grad, float* exp_avg, float* exp
     hipLaunchKernelGGL(k_adam, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
                        weight_decay, bc1, bc2_sqrt, step_dev);
     return check_launch("adam_step");
+}
+
+size_t naruto_active_ray_workspace(uint32_t n_total, uint32_t K) { return ((size_t)n_total + K + 16) * sizeof(uint32_t); }
+
+int naruto_active_ray_select(uint32_t n_total, uint32_t base, uint32_t K, uint32_t n_tail, const float* rays_o, const float* rays_d, const float* target_s,
+                             const float* target_d, const float* uncert_vol, const uint32_t* vol_dims, const float* bbox_min, float voxel_scale,
+                             float* out_o, float* out_d, float* out_s, float* out_t, void* workspace, void* stream) {
+    if (rays_o == nullptr || rays_d == nullptr || target_s == nullptr || target_d == nullptr || uncert_vol == nullptr || vol_dims == nullptr ||
+        bbox_min == nullptr || out_o == nullptr || out_d == nullptr || out_s == nullptr || out_t == nullptr || workspace == nullptr)
+        return fail(NARUTO_ERR_INVALID, "active_ray_select: NULL argument");
+    if (n_tail == 0 || K == 0 || K > base || (uint64_t)base + n_tail >= n_total)
+        return fail(NARUTO_ERR_INVALID, "active_ray_select: need 0 < K <= base, n_tail > 0, base + n_tail < n_total");
+    const uint32_t n_cand = n_total - n_tail - base;
+    if (n_cand <= K) return fail(NARUTO_ERR_INVALID, "active_ray_select: %u candidates for K = %u (numpy argpartition needs K < n)", n_cand, K);
+    uint32_t* keys = reinterpret_cast<uint32_t*>(workspace);
+    uint32_t* sel = keys + n_cand;
+    hipLaunchKernelGGL(k_ars_lookup, dim3((n_cand + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, n_cand, base, rays_o, rays_d, target_d, uncert_vol,
+                       (int)vol_dims[0], (int)vol_dims[1], (int)vol_dims[2], bbox_min[0], bbox_min[1], bbox_min[2], voxel_scale, keys);
+    if (int rc = check_launch("ars_lookup")) return rc;
+    hipLaunchKernelGGL(k_ars_select, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_cand, K, keys, sel);
+    if (int rc = check_launch("ars_select")) return rc;
+    const uint32_t n_out = base + n_tail;
+    hipLaunchKernelGGL(k_ars_gather, dim3((n_out + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, n_out, K, base, n_total, n_tail, sel, rays_o, rays_d,
+                       target_s, target_d, out_o, out_d, out_s, out_t);
+    return check_launch("ars_gather");
+}
+
+int naruto_rays_to_world(uint32_t n, const float* d_cam, const int64_t* pose_id, const float* poses, float* rays_o, float* rays_d, void* stream) {
+    if (d_cam == nullptr || pose_id == nullptr || poses == nullptr || rays_o == nullptr || rays_d == nullptr)
+        return fail(NARUTO_ERR_INVALID, "rays_to_world: NULL argument");
+    if (n == 0) return NARUTO_OK;
+    hipLaunchKernelGGL(k_rays_to_world, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, n, d_cam, pose_id, poses, rays_o, rays_d);
+    return check_launch("rays_to_world");
 }
 
 int naruto_map_volumes(uint32_t M, const float* sdf_uncert, float* out, void* stream) {

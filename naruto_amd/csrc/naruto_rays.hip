@@ -1,0 +1,142 @@
+// Ray assembly on the device: the "next" rows N1 / N2 of SURVEY.md section 8(f).
+//
+//   N1  ActiveRaySampler.sample_rays (reference src/slam/coslam/active_ray_sampler.py:77-149): among the oversampled
+//       keyframe rays, look up the cached uncertainty volume at every ray's measured end point and move the K rays
+//       with the SMALLEST value to the front of the batch.  The reference does this on the host (numpy round /
+//       clip / fancy index / argpartition) inside every mapping iteration: a GPU->CPU->GPU round trip.
+//   N2  camera-frame directions -> world rays through the keyframe poses (reference
+//       src/slam/coslam/coslam.py:337-344).
+
+#include "naruto_common.h"
+
+namespace naruto {
+
+// float -> uint32 whose unsigned order is the float order (NaN sorts last)
+__device__ __forceinline__ uint32_t sortable_key(float v) {
+    const uint32_t b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// keys[j] = sortable(uncert_vol[round((o + d * depth - bbox_min) * voxel_scale) clipped]) for candidate ray first + j
+__global__ __launch_bounds__(256) void k_ars_lookup(uint32_t n_cand, uint32_t first, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                    const float* __restrict__ target_d, const float* __restrict__ vol, int X, int Y, int Z, float bx, float by,
+                                                    float bz, float voxel_scale, uint32_t* __restrict__ keys) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_cand) return;
+    const size_t r = (size_t)first + j;
+    const float t = target_d[r];
+    const float px = __fadd_rn(rays_o[3 * r + 0], __fmul_rn(rays_d[3 * r + 0], t));
+    const float py = __fadd_rn(rays_o[3 * r + 1], __fmul_rn(rays_d[3 * r + 1], t));
+    const float pz = __fadd_rn(rays_o[3 * r + 2], __fmul_rn(rays_d[3 * r + 2], t));
+    // numpy: ((pts - bbox_min) * 10).round().astype(int), then np.clip -- rintf is round-half-to-even like np.round
+    const float fx = rintf(__fmul_rn(__fsub_rn(px, bx), voxel_scale));
+    const float fy = rintf(__fmul_rn(__fsub_rn(py, by), voxel_scale));
+    const float fz = rintf(__fmul_rn(__fsub_rn(pz, bz), voxel_scale));
+    const int ix = (int)fminf(fmaxf(fx, 0.0f), (float)(X - 1));
+    const int iy = (int)fminf(fmaxf(fy, 0.0f), (float)(Y - 1));
+    const int iz = (int)fminf(fmaxf(fz, 0.0f), (float)(Z - 1));
+    keys[j] = sortable_key(vol[((size_t)ix * Y + iy) * Z + iz]);
+}
+
+// One workgroup: exact K-smallest selection by 4-pass radix select on the sortable keys; ties at the threshold are
+// broken by candidate index (smallest first), so the result is deterministic.  sel[0..K) = selected candidates,
+// ascending.  n_cand >= K.
+__global__ __launch_bounds__(1024) void k_ars_select(uint32_t n_cand, uint32_t K, const uint32_t* __restrict__ keys, uint32_t* __restrict__ sel) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t s_prefix, s_remaining, s_bucket;
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { s_prefix = 0; s_remaining = K; }
+    __syncthreads();
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const uint32_t prefix = s_prefix;
+        const uint32_t hi_mask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (uint32_t j = tid; j < n_cand; j += 1024) {
+            const uint32_t k = keys[j];
+            if ((k & hi_mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);        // ds_add_u32
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t rem = s_remaining, b = 0;
+            while (b < 255u && hist[b] < rem) { rem -= hist[b]; ++b; }
+            s_remaining = rem;                // how many of bucket b (and, in the end, of the threshold key) are taken
+            s_bucket = b;
+            s_prefix = prefix | (b << shift);
+        }
+        __syncthreads();
+    }
+    const uint32_t thr = s_prefix, take_eq = s_remaining;
+    if (tid == 0) { carry[0] = 0; carry[1] = 0; }
+    __syncthreads();
+    // ordered compaction: every key < thr, plus the first take_eq keys == thr in index order
+    for (uint32_t base = 0; base < n_cand; base += 1024) {
+        const uint32_t j = base + tid;
+        const uint32_t k = j < n_cand ? keys[j] : 0xFFFFFFFFu;
+        const uint32_t is_eq = (j < n_cand && k == thr) ? 1u : 0u;
+        // rank among the equal keys (block-wide exclusive scan)
+        uint32_t incl = is_eq;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t before = carry[0];
+        for (int w = 0; w < wave; ++w) before += wave_tot[w];
+        const uint32_t eq_rank = before + incl - is_eq;
+        const uint32_t chosen = (j < n_cand && (k < thr || (is_eq && eq_rank < take_eq))) ? 1u : 0u;
+        __syncthreads();
+        if (tid == 1023) carry[0] = before + incl;
+        // output slot (second block-wide scan)
+        uint32_t incl2 = chosen;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl2, o, 64); if (lane >= o) incl2 += t; }
+        __syncthreads();
+        if (lane == 63) wave_tot[wave] = incl2;
+        __syncthreads();
+        uint32_t before2 = carry[1];
+        for (int w = 0; w < wave; ++w) before2 += wave_tot[w];
+        if (chosen) sel[before2 + incl2 - 1u] = j;
+        __syncthreads();
+        if (tid == 1023) carry[1] = before2 + incl2;
+        __syncthreads();
+    }
+}
+
+// assemble [K selected | first (base-K) rays | last n_tail rays] (active_ray_sampler.py:128-147)
+__global__ __launch_bounds__(256) void k_ars_gather(uint32_t n_out, uint32_t K, uint32_t base, uint32_t n_total, uint32_t n_tail,
+                                                    const uint32_t* __restrict__ sel, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                    const float* __restrict__ target_s, const float* __restrict__ target_d, float* __restrict__ o_out,
+                                                    float* __restrict__ d_out, float* __restrict__ s_out, float* __restrict__ t_out) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_out) return;
+    size_t src;
+    if (r < K) src = (size_t)sel[r] + base;
+    else if (r < base) src = r - K;
+    else src = (size_t)n_total - n_tail + (r - base);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        o_out[3 * (size_t)r + c] = rays_o[3 * src + c];
+        d_out[3 * (size_t)r + c] = rays_d[3 * src + c];
+        s_out[3 * (size_t)r + c] = target_s[3 * src + c];
+    }
+    t_out[r] = target_d[src];
+}
+
+// N2: rays_d = sum_j d_cam[j] * R[i][j], rays_o = t   with (R | t) = poses[pose_id]  (coslam.py:342-344)
+__global__ __launch_bounds__(256) void k_rays_to_world(uint32_t n, const float* __restrict__ d_cam, const int64_t* __restrict__ pose_id,
+                                                       const float* __restrict__ poses, float* __restrict__ rays_o, float* __restrict__ rays_d) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const float* P = poses + 16 * (size_t)pose_id[r];
+    const float dx = d_cam[3 * (size_t)r], dy = d_cam[3 * (size_t)r + 1], dz = d_cam[3 * (size_t)r + 2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        // torch.sum over the last axis of the elementwise product: ((a + b) + c), separately rounded
+        rays_d[3 * (size_t)r + i] = __fadd_rn(__fadd_rn(__fmul_rn(dx, P[4 * i + 0]), __fmul_rn(dy, P[4 * i + 1])), __fmul_rn(dz, P[4 * i + 2]));
+        rays_o[3 * (size_t)r + i] = P[4 * i + 3];
+    }
+}
+
+}  // namespace naruto

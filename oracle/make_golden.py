@@ -241,6 +241,46 @@ def case_composite_edges(name, seed):
     print(f"{name}: ok")
 
 
+def case_active_ray(name, seed):
+    """N1: the reference's own ActiveRaySampler (its .cuda() calls are no-ops here) on a small batch."""
+    from src.slam.coslam.active_ray_sampler import ActiveRaySampler          # the reference
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    cfg = C.office0_config()
+    cfg["mapping"]["sample"] = 256
+    cfg["mapping"]["min_pixels_cur"] = 25
+    smp = ActiveRaySampler(config=cfg, num_uncert_sample=60, oversample_mul=4)
+    rs = np.random.RandomState(seed)
+    n_cur = 101
+    n_total = smp.oversample_num + n_cur
+    rays = syn.random_rays(n_total, cfg["mapping"]["bound"], seed=seed, zero_depth_frac=0.0)
+    vol = rs.uniform(0.0, 2.0, size=(49, 56, 35)).astype(np.float32)
+    vol[rs.uniform(size=vol.shape) < 0.35] = 0.0                       # many exact ties, as in a real uncertainty volume
+    t = {k: torch.from_numpy(v) for k, v in rays.items()}
+    out = smp.sample_rays(t["rays_o"], t["rays_d"], t["target_rgb"], t["target_d"], list(range(n_cur)), vol, cfg["mapping"]["bound"])
+    (o2, vals, sel) = S.active_ray_sample(t["rays_o"], t["rays_d"], t["target_rgb"], t["target_d"], n_cur, vol, cfg["mapping"]["bound"],
+                                          256, 60, 4, deterministic=False)
+    for a, b in zip(out, o2):
+        assert torch.equal(a, b), "oracle != reference (active ray sampler)"
+    # camera -> world transform (coslam.py:342-344 is inline code, restated): fixture for N2
+    poses = torch.eye(4).repeat(5, 1, 1)
+    for i in range(5):
+        a = 0.3 * i + 0.1
+        poses[i, :3, :3] = torch.tensor([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], dtype=torch.float32)
+        poses[i, :3, 3] = torch.tensor(rs.uniform(-1, 1, 3), dtype=torch.float32)
+    ids = torch.from_numpy(rs.randint(0, 5, size=300)).to(torch.int64)
+    ids[-7:] = -1                                                      # the current frame's rays use index -1 (coslam.py:333)
+    dcam = torch.from_numpy(rs.normal(size=(300, 3)).astype(np.float32))
+    w_o, w_d = S.rays_to_world(dcam, ids, poses)
+    res = {"n_cur": np.int64(n_cur), "base": np.int64(256), "K": np.int64(60), "mul": np.int64(4), "vol": vol,
+           "bound": np.asarray(cfg["mapping"]["bound"], np.float32), "cand_vals": vals,
+           "poses": poses.numpy(), "ids": ids.numpy(), "dcam": dcam.numpy(), "world_o": w_o.numpy(), "world_d": w_d.numpy()}
+    res.update(rays)
+    for k, a in zip(("out_rays_o", "out_rays_d", "out_target_rgb", "out_target_d"), out):
+        res[k] = a.numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **res)
+    print(f"{name}: ok, {n_total} rays -> {out[0].shape[0]}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -252,6 +292,7 @@ def main():
     case_query_volume("g3_query_volume_t12", 12, 0.25, 5)
     case_query_volume("g3_query_volume_t16", 16, 0.25, 6)
     case_composite_edges("g5_composite_edges", 7)
+    case_active_ray("g8_active_ray", 8)
 
 
 if __name__ == "__main__":

@@ -479,3 +479,41 @@ def smoothness(field, sample_points, voxel_size, margin, offset_rand, jitter_ran
     tv_y = torch.pow(sdf[:, 1:, ...] - sdf[:, :-1, ...], 2).sum()
     tv_z = torch.pow(sdf[:, :, 1:, ...] - sdf[:, :, :-1, ...], 2).sum()
     return (tv_x + tv_y + tv_z) / (sample_points ** 3)
+
+
+# ----------------------------------------------------------------------------------
+# N1 / N2 ("next" rows): active ray sampler (src/slam/coslam/active_ray_sampler.py:77-149) and the
+# camera->world ray transform (src/slam/coslam/coslam.py:342-344), restated in numpy / torch.
+# ----------------------------------------------------------------------------------
+def active_ray_lookup(rays_o, rays_d, target_d, n_cur, uncert_vol, bbox, base, mul):
+    """Cached-uncertainty value of every candidate ray (reference :108-122)."""
+    pts = rays_o + rays_d * target_d
+    n_tail = -((-n_cur) // mul)
+    pts = pts[base:-n_tail]
+    loc = ((pts - torch.tensor(bbox, dtype=torch.float32)[:, 0]) * 10).detach().cpu().numpy()
+    idx = loc.round().astype(int)
+    for a in range(3):
+        idx[:, a] = np.clip(idx[:, a], 0, uncert_vol.shape[a] - 1)
+    return uncert_vol[idx[:, 0], idx[:, 1], idx[:, 2]], n_tail
+
+
+def active_ray_sample(rays_o, rays_d, target_s, target_d, n_cur, uncert_vol, bbox, base, K, mul, deterministic=False):
+    """Reference :124-147.  deterministic=True fixes what numpy leaves open: the K smallest by (value, index), listed
+    by ascending candidate index -- the order the HIP kernel produces."""
+    vals, n_tail = active_ray_lookup(rays_o, rays_d, target_d, n_cur, uncert_vol, bbox, base, mul)
+    if deterministic:
+        order = np.lexsort((np.arange(vals.size), vals))[:K]
+        sel = np.sort(order)
+    else:
+        sel = np.argpartition(vals, K, axis=None)[:K]
+    out = []
+    for t in (rays_o, rays_d, target_s, target_d):
+        out.append(torch.cat([t[sel + base], t[:base - K], t[-n_tail:]]))
+    return out, vals, sel
+
+
+def rays_to_world(rays_d_cam, ids_all, poses_all):
+    """coslam.py:342-344."""
+    rays_d = torch.sum(rays_d_cam[..., None, None, :] * poses_all[ids_all, None, :3, :3], -1)
+    rays_o = poses_all[ids_all, None, :3, -1].repeat(1, rays_d.shape[1], 1).reshape(-1, 3)
+    return rays_o, rays_d.reshape(-1, 3)

@@ -225,3 +225,33 @@ def test_loss_quirks():
     um, x, y = rend["uncert_map"][valid], rend["depth"][valid], t["target_d"].squeeze()[valid]
     outer = torch.mean(1 / (2 * (um + 1e-9))) * torch.mean((x - y) ** 2) + 0.5 * torch.mean(torch.log(um + 1e-9))
     assert abs(float(ret["uncert_loss"]) - float(outer)) < 1e-5 * max(1.0, abs(float(outer)))
+
+
+# ------------------------------------------------------------------------------ N1 / N2 ("next" rows)
+def _active_inputs(g):
+    t = {k: torch.from_numpy(g[k]) for k in ("rays_o", "rays_d", "target_rgb", "target_d")}
+    return t, int(g["n_cur"]), int(g["base"]), int(g["K"]), int(g["mul"]), [list(map(float, b)) for b in g["bound"]]
+
+
+def test_oracle_active_ray_sampler_golden():
+    """The numpy restatement reproduces the reference's ActiveRaySampler output exactly; its deterministic variant
+    (what the HIP kernel implements) selects the same multiset of uncertainty values -- only ties may differ."""
+    g = H.load_golden("g8_active_ray")
+    t, n_cur, base, K, mul, bound = _active_inputs(g)
+    out, vals, sel = S.active_ray_sample(t["rays_o"], t["rays_d"], t["target_rgb"], t["target_d"], n_cur, g["vol"], bound, base, K, mul)
+    for k, a in zip(("out_rays_o", "out_rays_d", "out_target_rgb", "out_target_d"), out):
+        assert np.array_equal(a.numpy(), g[k]), k
+    assert np.array_equal(vals, g["cand_vals"])
+    out_d, _, sel_d = S.active_ray_sample(t["rays_o"], t["rays_d"], t["target_rgb"], t["target_d"], n_cur, g["vol"], bound, base, K, mul,
+                                          deterministic=True)
+    assert np.array_equal(np.sort(vals[sel]), np.sort(vals[sel_d]))                  # same K smallest values
+    assert vals[sel_d].max() <= np.partition(vals, K)[K]                             # nothing above the (K+1)-th smallest
+    for a, b in zip(out, out_d):
+        assert torch.equal(a[K:], b[K:])                                             # the untouched parts are identical
+    assert (np.diff(sel_d) > 0).all()
+
+
+def test_oracle_rays_to_world_golden():
+    g = H.load_golden("g8_active_ray")
+    o, d = S.rays_to_world(torch.from_numpy(g["dcam"]), torch.from_numpy(g["ids"]), torch.from_numpy(g["poses"]))
+    assert np.array_equal(o.numpy(), g["world_o"]) and np.allclose(d.numpy(), g["world_d"], atol=1e-7)

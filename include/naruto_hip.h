@@ -239,8 +239,51 @@ typedef struct NarutoAdamSeg {
     float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
     uint64_t n; float lr, eps, weight_decay;
 } NarutoAdamSeg;
+#define NARUTO_ADAM_ADVANCE 1u   /* step_dev = int32[2] {completed steps, 0}: this launch is step step_dev[0]+1 and stores it back */
+#define NARUTO_ADAM_ZERO_GRAD 2u /* zero every gradient once consumed (the segments' grad buffers are written) */
 int naruto_adam_multi(const NarutoAdamSeg* segs /* host array */, uint32_t n_segs, float beta1, float beta2,
-                      uint32_t step, const int32_t* step_dev, void* stream);
+                      uint32_t step, int32_t* step_dev, uint32_t flags, void* stream);
+
+/* ---- The mapping iteration as two calls: naruto_amd.trainer.MappingTrainer's fast path ----------------------------
+ * What JointEncodingNaruto.forward (scene_rep.py:227-287) + get_loss_from_ret incl. Co-SLAM smoothness
+ * (coslam.py:154-174) + loss.backward() do in one global_BA iteration (coslam.py:361-399), as few launches as
+ * possible: side work rides in a bigger launch as extra workgroups, the small reductions share one tail launch
+ * (naruto_train.hip).  Same kernels' arithmetic as the modular entry points above.
+ *   naruto_train_forward : z_vals, raw, feat_save, rgb, depth, uncert_map, sums[16]; with finalize != 0 also
+ *                          losses[10] = {rgb, depth, sdf, fs, psnr, uncert, min(uncert_map), n_valid,
+ *                                        smoothness term, total = sum_i loss_weights[i] * losses[i]}
+ *   (data parallel: finalize = 0, all-reduce sums[0..9), naruto_train_finalize)
+ *   naruto_train_backward: gradient of the total w.r.t. the parameters in g (table / MLP weights written or
+ *                          accumulated per flags as in naruto_query_bwd; uncert_grid always accumulated) */
+typedef struct NarutoTrainStep {
+    uint32_t n_rays, n_samples_d, n_range_d;          /* S = n_samples_d + n_range_d samples per ray          */
+    uint32_t perturb;                                 /* != 0: stratified depth jitter (training.perturb > 0) */
+    float near_, far_, range_d, depth_trunc, rgb_missing;
+    uint32_t smooth_points;                           /* 0: no smoothness term (else Co-SLAM sample_points)   */
+    float smooth_voxel, smooth_margin;
+    float smooth_grad_scale;                          /* extra factor on the term's gradient (0 = 1; 1/world) */
+    uint64_t n_rays_total;                            /* rays over all ranks (0: n_rays)                      */
+    const float *rays_o, *rays_d, *target_rgb, *target_d;      /* [N,3] [N,3] [N,3] [N]                       */
+    const float *rand;                                /* [N,S] depth jitter in [0,1), with perturb (or rng)   */
+    const float *rand6;                               /* [6] lattice placement, with smooth_points (or rng)   */
+    uint64_t *rng;                                    /* {seed, counter}: where rand / rand6 is NULL the kernels
+                                                         draw their own numbers (splitmix64 keyed by seed, counter,
+                                                         index); the counter advances once per forward.        */
+    const float *loss_weights;                        /* [10] device: d(total)/d(losses[i]); slots 4,6,7,9 ignored */
+    float *z_vals, *raw, *feat_save;                  /* [N,S] [N,S,5] [16][N*S][2]                           */
+    float *rgb, *depth, *uncert_map;                  /* [N,3] [N] [N] (any may be NULL)                      */
+    double *sums;                                     /* [NARUTO_LOSS_NSUMS]                                  */
+    float *losses;                                    /* [10]                                                 */
+    float *d_raw;                                     /* [N,S,5]          (backward)                          */
+    uint32_t *ray_count, *ray_offset, *active_idx, *n_active;  /* [N] [N] [N*S] [1]  (backward)               */
+    float *smooth_x, *smooth_d;                       /* [(P-1)^3,3] [(P-1)^3,32], with smooth_points         */
+    void *workspace;                                  /* naruto_train_workspace() bytes                       */
+} NarutoTrainStep;
+size_t naruto_train_workspace(const NarutoField* f, const NarutoTrainStep* t);
+int naruto_train_forward(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, int finalize, void* stream);
+int naruto_train_finalize(const NarutoField* f, const NarutoTrainStep* t, void* stream);
+int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, const NarutoGrads* g,
+                          uint32_t flags, void* stream);
 
 /* Hardware self-checks used by the GPU tests: the MFMA / permlane layouts the kernels rely on.
  * out: device buffer of 64*16 floats; returns 0 and fills out (see tests/test_gpu_intrinsics.py). */

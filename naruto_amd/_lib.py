@@ -14,7 +14,7 @@ from typing import List, Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnaruto_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["naruto_api.hip", "naruto_field.hip", "naruto_render.hip", "naruto_rays.hip", "naruto_common.h"]
+SOURCES = ["naruto_api.hip", "naruto_field.hip", "naruto_render.hip", "naruto_rays.hip", "naruto_train.hip", "naruto_common.h"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "naruto_hip.h")
 
 MAX_LEVELS = 16
@@ -51,6 +51,24 @@ class NarutoAdamSeg(C.Structure):
 
 BWD_OVERWRITE_WEIGHT_GRADS = 1
 BWD_OVERWRITE_TABLE_GRAD = 2
+ADAM_ADVANCE = 1
+ADAM_ZERO_GRAD = 2
+
+
+class NarutoTrainStep(C.Structure):
+    _fields_ = [
+        ("n_rays", C.c_uint32), ("n_samples_d", C.c_uint32), ("n_range_d", C.c_uint32), ("perturb", C.c_uint32),
+        ("near_", C.c_float), ("far_", C.c_float), ("range_d", C.c_float), ("depth_trunc", C.c_float), ("rgb_missing", C.c_float),
+        ("smooth_points", C.c_uint32), ("smooth_voxel", C.c_float), ("smooth_margin", C.c_float), ("smooth_grad_scale", C.c_float),
+        ("n_rays_total", C.c_uint64),
+        ("rays_o", C.c_void_p), ("rays_d", C.c_void_p), ("target_rgb", C.c_void_p), ("target_d", C.c_void_p),
+        ("rand", C.c_void_p), ("rand6", C.c_void_p), ("rng", C.c_void_p), ("loss_weights", C.c_void_p),
+        ("z_vals", C.c_void_p), ("raw", C.c_void_p), ("feat_save", C.c_void_p),
+        ("rgb", C.c_void_p), ("depth", C.c_void_p), ("uncert_map", C.c_void_p),
+        ("sums", C.c_void_p), ("losses", C.c_void_p), ("d_raw", C.c_void_p),
+        ("ray_count", C.c_void_p), ("ray_offset", C.c_void_p), ("active_idx", C.c_void_p), ("n_active", C.c_void_p),
+        ("smooth_x", C.c_void_p), ("smooth_d", C.c_void_p), ("workspace", C.c_void_p),
+    ]
 
 
 class NarutoPoints(C.Structure):
@@ -106,7 +124,11 @@ SIGNATURES = {
     "naruto_active_ray_select": (_I, [_U32, _U32, _U32, _U32, _V, _V, _V, _V, _V, C.POINTER(_U32), C.POINTER(_F), _F, _V, _V, _V, _V, _V, _V]),
     "naruto_rays_to_world": (_I, [_U32, _V, _V, _V, _V, _V, _V]),
     "naruto_map_volumes": (_I, [_U32, _V, _V, _V]),
-    "naruto_adam_multi": (_I, [C.POINTER(NarutoAdamSeg), _U32, _F, _F, _U32, _V, _V]),
+    "naruto_adam_multi": (_I, [C.POINTER(NarutoAdamSeg), _U32, _F, _F, _U32, _V, _U32, _V]),
+    "naruto_train_workspace": (C.c_size_t, [_V, C.POINTER(NarutoTrainStep)]),
+    "naruto_train_forward": (_I, [_V, C.POINTER(NarutoParams), C.POINTER(NarutoTrainStep), _I, _V]),
+    "naruto_train_finalize": (_I, [_V, C.POINTER(NarutoTrainStep), _V]),
+    "naruto_train_backward": (_I, [_V, C.POINTER(NarutoParams), C.POINTER(NarutoTrainStep), C.POINTER(NarutoGrads), _U32, _V]),
     "naruto_compact_active": (_I, [_U32, _U32, _V, _V, _V, _V, _V]),
     "naruto_composite_fwd": (_I, [_V, _U32, _U32, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V]),
     "naruto_composite_bwd": (_I, [_V, _U32, _U32, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _I, _V]),

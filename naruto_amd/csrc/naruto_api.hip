@@ -9,6 +9,7 @@
 #include "naruto_field.hip"
 #include "naruto_render.hip"
 #include "naruto_rays.hip"
+#include "naruto_train.hip"
 
 using namespace naruto;
 
@@ -209,7 +210,8 @@ int naruto_sample_z(uint32_t n_rays, const float* target_d, float near_, float f
     if (S < 2 || S > (uint32_t)kMaxSamples) return fail(NARUTO_ERR_INVALID, "sample_z: need 2 <= samples per ray <= %d (got %u)", kMaxSamples, S);
     if (target_d != nullptr && nr < 2) return fail(NARUTO_ERR_INVALID, "sample_z: n_range_d must be >= 2");
     if (target_d != nullptr && nu == 1) return fail(NARUTO_ERR_INVALID, "sample_z: n_samples_d must be 0 or >= 2");
-    hipLaunchKernelGGL(k_sample_z, dim3(n_rays), dim3(64), 0, (hipStream_t)stream, n_rays, target_d, near_, far_, nu, nr, range_d, rand, z_vals);
+    hipLaunchKernelGGL(k_sample_z, dim3(n_rays), dim3(64), 0, (hipStream_t)stream, n_rays, target_d, near_, far_, nu, nr, range_d, rand,
+                       static_cast<const uint64_t*>(nullptr), z_vals);
     return check_launch("sample_z");
 }
 
@@ -260,8 +262,8 @@ int naruto_smoothness_fwd(const NarutoField* f, const float* table, uint32_t sam
     float* feat = reinterpret_cast<float*>(workspace);
     double* partial = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + (((size_t)n3 * kFeat * sizeof(float) + 63) / 64) * 64);
     const uint32_t nb = (n3 * kFeat + 255u) / 256u;
-    hipLaunchKernelGGL(k_tv_encode, dim3((4u * n3 + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, f->lt, f->bt, a, rand6, reinterpret_cast<const float2*>(table),
-                       x_out, feat);
+    hipLaunchKernelGGL(k_tv_encode, dim3(16u * ((n3 + 255u) / 256u)), dim3(256), 0, (hipStream_t)stream, f->lt, f->bt, a, rand6,
+                       static_cast<const uint64_t*>(nullptr), reinterpret_cast<const float2*>(table), x_out, feat);
     if (int rc = check_launch("tv_encode")) return rc;
     hipLaunchKernelGGL(k_tv_loss, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, feat, d_feat, partial);
     if (int rc = check_launch("tv_loss")) return rc;
@@ -298,9 +300,13 @@ size_t naruto_query_bwd_workspace(const NarutoField* f, uint32_t M) {
     return ((size_t)kLevels * 2u + 3u) * sizeof(float) * (size_t)M + (size_t)kBwdMaxBlocks * kAccFloats * sizeof(float) + naruto_scatter_workspace(f) + 64;
 }
 
-int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, const NarutoPoints* pts, const float* feat_save,
-                     const float* d_raw, const float* d_geo, const uint32_t* active_idx, const uint32_t* n_active, const NarutoExtraPoints* extra,
-                     uint32_t flags, const NarutoGrads* g, void* workspace, void* stream) {
+}  // extern "C"
+
+namespace {
+// fused_post: weight-gradient reduction and lattice append share one launch; extra_scale: host factor on extra->scale
+int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, const NarutoPoints* pts, const float* feat_save,
+                   const float* d_raw, const float* d_geo, const uint32_t* active_idx, const uint32_t* n_active, const NarutoExtraPoints* extra,
+                   uint32_t flags, const NarutoGrads* g, void* workspace, void* stream, bool fused_post, float extra_scale) {
     if ((active_idx == nullptr) != (n_active == nullptr)) return fail(NARUTO_ERR_INVALID, "query_bwd: active_idx and n_active go together");
     const uint32_t E = (extra != nullptr && g != nullptr && g->table != nullptr) ? extra->n : 0u;
     if (E > 0 && (extra->x == nullptr || extra->d_feat == nullptr)) return fail(NARUTO_ERR_INVALID, "query_bwd: extra points need x and d_feat");
@@ -331,7 +337,21 @@ int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
     hipLaunchKernelGGL(k_query_bwd, dim3(blocks), dim3(256), sizeof(BwdLds), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, ps, M, cap, feat_save, d_raw,
                        d_geo, d_feat, g->table != nullptr ? x_soa : nullptr, g->uncert_grid, partials, active_idx, n_active);
     if (int rc = check_launch("query_bwd")) return rc;
-    if (g->sdf_w0 || g->sdf_w1 || g->col_w0 || g->col_w1) {
+    const bool want_w = g->sdf_w0 || g->sdf_w1 || g->col_w0 || g->col_w1;
+    if (fused_post && want_w && E > 0 && g->table != nullptr) {
+        const uint32_t nw = kAccFloats / 32, na = (E * kLevels + 255u) / 256u;
+        hipLaunchKernelGGL(k_bwd_post, dim3(nw + na), dim3(256), 0, (hipStream_t)stream, partials, blocks, *g, (int)(flags & NARUTO_BWD_OVERWRITE_WEIGHT_GRADS), nw,
+                           E, extra->x, extra->d_feat, extra->scale, extra_scale, n_active, M, cap, x_soa, d_feat, n_total);
+        if (int rc = check_launch("bwd_post")) return rc;
+        PointSrc pss{};
+        pss.xsoa = x_soa;
+        pss.M = cap;
+        pss.S = 1;
+        return launch_scatter(f, pss, cap, d_feat, (size_t)2, (size_t)2 * (size_t)cap, g->table, scatter_ws, (hipStream_t)stream, n_total, nullptr,
+                              (int)(flags & NARUTO_BWD_OVERWRITE_TABLE_GRAD));
+    }
+    if (extra_scale != 1.0f) return fail(NARUTO_ERR_INVALID, "query_bwd: host scale only on the fused path");
+    if (want_w) {
         hipLaunchKernelGGL(k_wgrad_reduce, dim3(kAccFloats / 32), dim3(256), 0, (hipStream_t)stream, partials, blocks, *g,
                            (int)(flags & NARUTO_BWD_OVERWRITE_WEIGHT_GRADS));
         if (int rc = check_launch("wgrad_reduce")) return rc;
@@ -353,6 +373,165 @@ int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
             return rc;
     }
     return NARUTO_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, const NarutoPoints* pts, const float* feat_save,
+                     const float* d_raw, const float* d_geo, const uint32_t* active_idx, const uint32_t* n_active, const NarutoExtraPoints* extra,
+                     uint32_t flags, const NarutoGrads* g, void* workspace, void* stream) {
+    return query_bwd_impl(f, p, M, pts, feat_save, d_raw, d_geo, active_idx, n_active, extra, flags, g, workspace, stream, false, 1.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The mapping iteration as two calls (see naruto_train.hip)
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct TrainWs {
+    float* terms; float* tv_feat; double* tv_partial; void* bwd;
+    uint32_t n3, n_tv_blocks;
+    size_t total;
+};
+TrainWs train_ws(const NarutoField* f, const NarutoTrainStep* t) {
+    TrainWs w{};
+    const uint32_t S = t->n_samples_d + t->n_range_d;
+    const size_t M = (size_t)t->n_rays * S;
+    const uint32_t n = t->smooth_points > 1 ? t->smooth_points - 1 : 0;
+    w.n3 = n * n * n;
+    w.n_tv_blocks = (w.n3 * (uint32_t)kFeat + 255u) / 256u;        // smoothness role blocks of the loss stage (grid-stride beyond 512)
+    if (w.n_tv_blocks > 512u) w.n_tv_blocks = 512u;
+    auto al = [](size_t b) { return (b + 255u) / 256u * 256u; };
+    size_t off = 0;
+    char* base = reinterpret_cast<char*>(t->workspace);
+    w.terms = reinterpret_cast<float*>(base + off);       off += al((size_t)t->n_rays * 16u * sizeof(float));
+    w.tv_feat = reinterpret_cast<float*>(base + off);     off += al((size_t)w.n3 * kFeat * sizeof(float));
+    w.tv_partial = reinterpret_cast<double*>(base + off); off += al((size_t)w.n_tv_blocks * sizeof(double));
+    w.bwd = base + off;                                   off += al(naruto_query_bwd_workspace(f, (uint32_t)(M + w.n3)));
+    w.total = off;
+    return w;
+}
+int train_check(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, const char* who) {
+    if (f == nullptr || p == nullptr || t == nullptr) return fail(NARUTO_ERR_INVALID, "%s: NULL argument", who);
+    if (p->table == nullptr || p->uncert_grid == nullptr || p->sdf_w0 == nullptr || p->sdf_w1 == nullptr || p->col_w0 == nullptr || p->col_w1 == nullptr)
+        return fail(NARUTO_ERR_INVALID, "%s: NULL parameter", who);
+    if (t->rays_o == nullptr || t->rays_d == nullptr || t->target_rgb == nullptr || t->target_d == nullptr || t->z_vals == nullptr || t->raw == nullptr ||
+        t->sums == nullptr || t->losses == nullptr || t->workspace == nullptr)
+        return fail(NARUTO_ERR_INVALID, "%s: NULL buffer in NarutoTrainStep", who);
+    const uint32_t S = t->n_samples_d + t->n_range_d;
+    if (t->n_rays == 0 || S < 2 || S > (uint32_t)kMaxSamples) return fail(NARUTO_ERR_INVALID, "%s: need rays and 2..%d samples per ray", who, kMaxSamples);
+    if (t->n_range_d < 2 || t->n_samples_d == 1) return fail(NARUTO_ERR_INVALID, "%s: n_range_d must be >= 2 and n_samples_d 0 or >= 2", who);
+    if ((uint64_t)t->n_rays * S > 0x7FFFFFFFull) return fail(NARUTO_ERR_INVALID, "%s: too many samples for 32-bit indices", who);
+    if (t->smooth_points != 0 && (t->smooth_points < 3 || t->smooth_points > 257)) return fail(NARUTO_ERR_INVALID, "%s: smooth_points must be 0 or in [3, 257]", who);
+    if (t->perturb && t->rand == nullptr && t->rng == nullptr) return fail(NARUTO_ERR_INVALID, "%s: perturb needs rand or rng", who);
+    if (t->smooth_points != 0 && ((t->rand6 == nullptr && t->rng == nullptr) || t->smooth_x == nullptr || t->smooth_d == nullptr))
+        return fail(NARUTO_ERR_INVALID, "%s: the smoothness term needs rand6 (or rng), smooth_x and smooth_d", who);
+    return NARUTO_OK;
+}
+TvArgs tv_args(const NarutoTrainStep* t) {
+    TvArgs a{};
+    if (t->smooth_points == 0) return a;
+    a.n = t->smooth_points - 1;
+    a.voxel = t->smooth_voxel;
+    a.margin = t->smooth_margin;
+    a.grid_size = (float)(t->smooth_points - 1) * t->smooth_voxel;
+    a.inv_p3 = 1.0f / ((float)t->smooth_points * (float)t->smooth_points * (float)t->smooth_points);
+    return a;
+}
+}  // namespace
+
+size_t naruto_train_workspace(const NarutoField* f, const NarutoTrainStep* t) {
+    if (f == nullptr || t == nullptr) return 0;
+    NarutoTrainStep c = *t;
+    c.workspace = nullptr;
+    return train_ws(f, &c).total;
+}
+
+int naruto_train_forward(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, int finalize, void* stream) {
+    if (int rc = train_check(f, p, t, "train_forward")) return rc;
+    const hipStream_t st = (hipStream_t)stream;
+    const uint32_t N = t->n_rays, S = t->n_samples_d + t->n_range_d, M = N * S;
+    const TrainWs w = train_ws(f, t);
+    // A1
+    const float* jitter = t->perturb ? t->rand : nullptr;
+    const uint64_t* jitter_rng = (t->perturb && t->rand == nullptr) ? t->rng : nullptr;
+    hipLaunchKernelGGL(k_sample_z, dim3(N), dim3(64), 0, st, N, t->target_d, t->near_, t->far_, t->n_samples_d, t->n_range_d, t->range_d, jitter, jitter_rng,
+                       t->z_vals);
+    if (int rc = check_launch("sample_z")) return rc;
+    // the smoothness lattice: points + hash features
+    const TvArgs tva = tv_args(t);
+    if (t->smooth_points != 0) {
+        hipLaunchKernelGGL(k_tv_encode, dim3(16u * ((w.n3 + 255u) / 256u)), dim3(256), 0, st, f->lt, f->bt, tva, t->rand6, t->rng,
+                           reinterpret_cast<const float2*>(p->table), t->smooth_x, w.tv_feat);
+        if (int rc = check_launch("tv_encode")) return rc;
+    }
+    // A2..A5
+    PointSrc ps{};
+    ps.rays_o = t->rays_o; ps.rays_d = t->rays_d; ps.z_vals = t->z_vals; ps.S = S;
+    const uint32_t n_tiles = (M + 63u) / 64u;
+    uint32_t blocks = (n_tiles + 3u) / 4u;
+    if (blocks > cu_count(f) * 4u) blocks = cu_count(f) * 4u;
+    hipLaunchKernelGGL(k_query_fwd<true>, dim3(blocks), dim3(256), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save);
+    if (int rc = check_launch("query_fwd")) return rc;
+    // A6..A8 (+ the lattice's TV term), then the one-workgroup tail
+    LossStageArgs a{};
+    a.n_rays = N; a.S = S;
+    a.trunc = f->desc.trunc; a.sc_factor = f->desc.sc_factor; a.trunc_sc = f->desc.trunc * f->desc.sc_factor;
+    a.depth_trunc = t->depth_trunc; a.rgb_missing = t->rgb_missing; a.white_bkgd = f->desc.white_bkgd;
+    a.raw = t->raw; a.z_vals = t->z_vals; a.target_rgb = t->target_rgb; a.target_d = t->target_d;
+    a.rgb = t->rgb; a.depth = t->depth; a.uncert_map = t->uncert_map;
+    a.partials = reinterpret_cast<double*>(w.terms);       // n_rays/4 x 16 doubles fit the n_rays x 16 floats of the modular path
+    a.n_ray_blocks = (N + kRaysPerBlock - 1) / kRaysPerBlock;
+    a.tv = tva; a.tv_feat = w.tv_feat; a.tv_d_feat = t->smooth_d; a.tv_partial = w.tv_partial;
+    a.n_tv_blocks = t->smooth_points != 0 ? w.n_tv_blocks : 0u;
+    hipLaunchKernelGGL(k_loss_stage, dim3(a.n_ray_blocks + a.n_tv_blocks), dim3(64 * kRaysPerBlock), 0, st, a);
+    if (int rc = check_launch("loss_stage")) return rc;
+    LossTailArgs tl{};
+    tl.partials = a.partials; tl.n_ray_blocks = a.n_ray_blocks;
+    tl.tv_partial = w.tv_partial; tl.n_tv_blocks = a.n_tv_blocks; tl.tv_inv_p3 = tva.inv_p3;
+    tl.sums = t->sums; tl.losses = t->losses; tl.loss_weights = t->loss_weights;
+    tl.n_rays_total = t->n_rays_total ? t->n_rays_total : N; tl.S = S;
+    tl.finalize = finalize;
+    tl.rng = t->rng;                                        // the iteration counter advances once per forward, used or not
+    hipLaunchKernelGGL(k_loss_tail, dim3(1), dim3(256), 0, st, tl);
+    return check_launch("loss_tail");
+}
+
+int naruto_train_finalize(const NarutoField* f, const NarutoTrainStep* t, void* stream) {
+    if (f == nullptr || t == nullptr || t->sums == nullptr || t->losses == nullptr) return fail(NARUTO_ERR_INVALID, "train_finalize: NULL argument");
+    const uint32_t S = t->n_samples_d + t->n_range_d;
+    hipLaunchKernelGGL(k_loss_finalize_total, dim3(1), dim3(64), 0, (hipStream_t)stream, t->sums, t->n_rays_total ? t->n_rays_total : t->n_rays, S, t->losses,
+                       t->loss_weights);
+    return check_launch("loss_finalize_total");
+}
+
+int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, const NarutoGrads* g, uint32_t flags, void* stream) {
+    if (int rc = train_check(f, p, t, "train_backward")) return rc;
+    if (g == nullptr || t->loss_weights == nullptr || t->feat_save == nullptr || t->d_raw == nullptr || t->ray_count == nullptr || t->ray_offset == nullptr ||
+        t->active_idx == nullptr || t->n_active == nullptr)
+        return fail(NARUTO_ERR_INVALID, "train_backward: NULL buffer");
+    const hipStream_t st = (hipStream_t)stream;
+    const uint32_t N = t->n_rays, S = t->n_samples_d + t->n_range_d, M = N * S;
+    const TrainWs w = train_ws(f, t);
+    CompositeCot cot{};
+    LossArgs la{t->target_rgb, t->target_d, t->sums, t->loss_weights, t->n_rays_total ? t->n_rays_total : N, t->depth_trunc, t->rgb_missing,
+                f->desc.trunc * f->desc.sc_factor};
+    hipLaunchKernelGGL(k_composite_bwd<true>, dim3((N + kRaysPerBlock - 1) / kRaysPerBlock), dim3(64 * kRaysPerBlock), 0, st, N, S, f->desc.trunc,
+                       f->desc.sc_factor, f->desc.white_bkgd, t->raw, t->z_vals, cot, la, t->d_raw, 0, t->ray_count);
+    if (int rc = check_launch("loss_bwd")) return rc;
+    if (N <= 8192u) {
+        hipLaunchKernelGGL(k_compact, dim3((N + 3u) / 4u), dim3(256), 0, st, N, S, t->ray_count, t->ray_offset, t->active_idx, t->n_active);
+        if (int rc = check_launch("compact")) return rc;
+    } else if (int rc = naruto_compact_active(N, S, t->ray_count, t->ray_offset, t->active_idx, t->n_active, stream)) {
+        return rc;
+    }
+    NarutoPoints pts{};
+    pts.rays_o = t->rays_o; pts.rays_d = t->rays_d; pts.z_vals = t->z_vals; pts.n_samples = S;
+    NarutoExtraPoints ex{};
+    const bool smooth = t->smooth_points != 0 && g->table != nullptr;
+    if (smooth) { ex.x = t->smooth_x; ex.d_feat = t->smooth_d; ex.scale = t->loss_weights + 8; ex.n = w.n3; }
+    return query_bwd_impl(f, p, M, &pts, t->feat_save, t->d_raw, nullptr, t->active_idx, t->n_active, smooth ? &ex : nullptr, flags, g, w.bwd, stream, true,
+                          smooth ? (t->smooth_grad_scale != 0.0f ? t->smooth_grad_scale : 1.0f) : 1.0f);
 }
 
 int naruto_composite_fwd(const NarutoField* f, uint32_t n_rays, uint32_t S, const float* raw, const float* z_vals, float* rgb, float* disp,
@@ -481,8 +660,9 @@ int naruto_map_volumes(uint32_t M, const float* sdf_uncert, float* out, void* st
     return check_launch("map_volumes");
 }
 
-int naruto_adam_multi(const NarutoAdamSeg* segs, uint32_t n_segs, float beta1, float beta2, uint32_t step, const int32_t* step_dev, void* stream) {
+int naruto_adam_multi(const NarutoAdamSeg* segs, uint32_t n_segs, float beta1, float beta2, uint32_t step, int32_t* step_dev, uint32_t flags, void* stream) {
     if (segs == nullptr || n_segs == 0 || n_segs > (uint32_t)kAdamMaxSegs) return fail(NARUTO_ERR_INVALID, "adam_multi: 1..%d segments", kAdamMaxSegs);
+    if ((flags & NARUTO_ADAM_ADVANCE) && step_dev == nullptr) return fail(NARUTO_ERR_INVALID, "adam_multi: NARUTO_ADAM_ADVANCE needs step_dev");
     if (step == 0 && step_dev == nullptr) return fail(NARUTO_ERR_INVALID, "adam_multi: step is 1-based (or pass step_dev)");
     AdamSegs a{};
     a.n_segs = n_segs;
@@ -493,13 +673,13 @@ int naruto_adam_multi(const NarutoAdamSeg* segs, uint32_t n_segs, float beta1, f
         a.p[k] = segs[k].param; a.g[k] = segs[k].grad; a.m[k] = segs[k].exp_avg; a.v[k] = segs[k].exp_avg_sq;
         a.n[k] = segs[k].n; a.lr[k] = segs[k].lr; a.eps[k] = segs[k].eps; a.wd[k] = segs[k].weight_decay;
         a.block_begin[k] = blocks;
-        uint64_t nb = (segs[k].n + 1023u) / 1024u;          // 4 elements per thread
+        uint64_t nb = (segs[k].n + 1023u) / 1024u;          // >= 4 elements per thread, grid-stride beyond 1024 workgroups
         if (nb < 1) nb = 1;
         if (nb > 1024u) nb = 1024u;
         blocks += (uint32_t)nb;
     }
     for (uint32_t k = n_segs; k <= (uint32_t)kAdamMaxSegs; ++k) a.block_begin[k] = blocks;
-    hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, beta1, beta2, step_dev, step);
+    hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, beta1, beta2, step_dev, step, flags);
     return check_launch("adam_multi");
 }
 

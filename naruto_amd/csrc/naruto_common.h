@@ -338,4 +338,17 @@ __device__ __forceinline__ float wave_min(float v) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// Counter-based uniform numbers for the depth jitter / lattice placement when the caller does not supply its own:
+// rng = {seed, iteration counter} in device memory; value(idx) = top 24 bits of splitmix64 keyed by (seed, counter).
+// (The reference draws the jitter with torch.rand on the host, scene_rep.py:180: any uniform stream is equivalent.)
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ uint64_t rng_key(const uint64_t* __restrict__ rng) { return splitmix64(rng[0] ^ splitmix64(rng[1])); }
+__device__ __forceinline__ float rng_uniform(uint64_t key, uint64_t idx) { return (float)(splitmix64(key + idx) >> 40) * 0x1p-24f; }
+constexpr uint64_t kRngLatticeBase = 1ull << 40;     // idx of the six lattice-placement numbers
+
 }  // namespace naruto

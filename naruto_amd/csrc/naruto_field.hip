@@ -74,6 +74,39 @@ __device__ __forceinline__ void stage_fwd_weights(FwdLds& L, const NarutoParams&
     }
 }
 
+// ---- smoothness lattice (see the comment block at k_tv_encode below) ----
+struct TvArgs {
+    uint32_t n;
+    float voxel, margin, grid_size, inv_p3;
+};
+
+__device__ __forceinline__ void tv_encode_body(const LevelTab& lt, const BoxTab& bt, const TvArgs& a, const float* __restrict__ rand6,
+                                               const uint64_t* __restrict__ rng, const float2* __restrict__ table, float* __restrict__ x_out,
+                                               float* __restrict__ feat, uint32_t block) {
+    // thread = (level, point), the point index fastest: 16x the parallelism of a thread per point for this small
+    // (n^3 = 29 791) problem, and neighbouring lanes are neighbouring lattice points of ONE level, which share cells
+    // (cache lines) on the coarse levels
+    const uint32_t n3 = a.n * a.n * a.n;
+    const uint32_t per_level = (n3 + 255u) / 256u;
+    const uint32_t level = block / per_level;
+    const uint32_t m = (block % per_level) * 256u + threadIdx.x;
+    if (m >= n3) return;
+    const uint32_t ijk[3] = {m / (a.n * a.n), (m / a.n) % a.n, m % a.n};
+    const uint64_t key = rand6 == nullptr ? rng_key(rng) : 0ull;
+    float xn[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float r_off = rand6 != nullptr ? rand6[d] : rng_uniform(key, kRngLatticeBase + d);
+        const float r_jit = rand6 != nullptr ? rand6[3 + d] : rng_uniform(key, kRngLatticeBase + 3 + d);
+        const float offset_max = bt.bext[d] - a.grid_size - 2.0f * a.margin;
+        const float offset = r_off * offset_max + a.margin;
+        const float p = ((float)ijk[d] + r_jit) * a.voxel + bt.bmin[d] + offset;
+        xn[d] = __fdiv_rn(p - bt.bmin[d], bt.bext[d]);
+        if (level == 0) x_out[3 * (size_t)m + d] = xn[d];
+    }
+    reinterpret_cast<float2*>(feat + (size_t)m * kFeat)[level] = hash_level_rt(lt, (int)level, table, xn[0], xn[1], xn[2]);
+}
+
 #ifndef NARUTO_GATHER_GROUP
 #define NARUTO_GATHER_GROUP 4
 #endif
@@ -468,43 +501,17 @@ __global__ __launch_bounds__(256) void k_scatter_reduce(LevelTab lt, uint32_t at
 //   loss = sum_axes sum (f[i+1] - f[i])^2 / P^3                         (P = sample_points, n = P - 1)
 // k_tv_encode computes the points and their features, k_tv_loss the loss partials and d(loss)/d(feat).
 // ------------------------------------------------------------------------------------------------
-struct TvArgs {
-    uint32_t n;
-    float voxel, margin, grid_size, inv_p3;
-};
-
-__global__ __launch_bounds__(256) void k_tv_encode(LevelTab lt, BoxTab bt, TvArgs a, const float* __restrict__ rand6, const float2* __restrict__ table,
-                                                    float* __restrict__ x_out, float* __restrict__ feat) {
-    // thread = (point, group of 4 levels): 4x the parallelism of a thread per point for this small (n^3 = 29 791) problem
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t n3 = a.n * a.n * a.n;
-    const uint32_t m = t >> 2, grp = t & 3u;
-    if (m >= n3) return;
-    const uint32_t ijk[3] = {m / (a.n * a.n), (m / a.n) % a.n, m % a.n};
-    float xn[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const float offset_max = bt.bext[d] - a.grid_size - 2.0f * a.margin;
-        const float offset = rand6[d] * offset_max + a.margin;
-        const float p = ((float)ijk[d] + rand6[3 + d]) * a.voxel + bt.bmin[d] + offset;
-        xn[d] = __fdiv_rn(p - bt.bmin[d], bt.bext[d]);
-        if (grp == 0) x_out[3 * (size_t)m + d] = xn[d];
-    }
-    float2* out = reinterpret_cast<float2*>(feat + (size_t)m * kFeat);
-    switch (grp) {
-        case 0: static_for<0, 4>([&](auto tc) { constexpr int T = decltype(tc)::value; out[T] = hash_level<T>(lt, table, xn[0], xn[1], xn[2]); }); break;
-        case 1: static_for<4, 8>([&](auto tc) { constexpr int T = decltype(tc)::value; out[T] = hash_level<T>(lt, table, xn[0], xn[1], xn[2]); }); break;
-        case 2: static_for<8, 12>([&](auto tc) { constexpr int T = decltype(tc)::value; out[T] = hash_level<T>(lt, table, xn[0], xn[1], xn[2]); }); break;
-        default: static_for<12, 16>([&](auto tc) { constexpr int T = decltype(tc)::value; out[T] = hash_level<T>(lt, table, xn[0], xn[1], xn[2]); }); break;
-    }
+__global__ __launch_bounds__(256) void k_tv_encode(LevelTab lt, BoxTab bt, TvArgs a, const float* __restrict__ rand6, const uint64_t* __restrict__ rng,
+                                                    const float2* __restrict__ table, float* __restrict__ x_out, float* __restrict__ feat) {
+    tv_encode_body(lt, bt, a, rand6, rng, table, x_out, feat, blockIdx.x);
 }
 
-__global__ __launch_bounds__(256) void k_tv_loss(TvArgs a, const float* __restrict__ feat, float* __restrict__ d_feat, double* __restrict__ partial) {
-    __shared__ double red[4];
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;          // (point, channel)
+// block handles the 256-element chunks block, block + n_blocks, ... ; partial[block] = its share of the sum
+__device__ __forceinline__ void tv_loss_body(const TvArgs& a, const float* __restrict__ feat, float* __restrict__ d_feat, double* __restrict__ partial,
+                                             uint32_t block, uint32_t n_blocks, double* red) {
     const uint32_t n = a.n, total = n * n * n * kFeat;
     double acc = 0.0;
-    if (t < total) {
+    for (uint32_t t = block * 256u + threadIdx.x; t < total; t += n_blocks * 256u) {          // (point, channel)
         const uint32_t c = t % kFeat, m = t / kFeat;
         const uint32_t i = m / (n * n), j = (m / n) % n, k = m % n;
         const float f = feat[t];
@@ -527,7 +534,14 @@ __global__ __launch_bounds__(256) void k_tv_loss(TvArgs a, const float* __restri
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) {
+        partial[block] = red[0] + red[1] + red[2] + red[3];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tv_loss(TvArgs a, const float* __restrict__ feat, float* __restrict__ d_feat, double* __restrict__ partial) {
+    __shared__ double red[4];
+    tv_loss_body(a, feat, d_feat, partial, blockIdx.x, gridDim.x, red);
 }
 
 __global__ __launch_bounds__(256) void k_tv_finalize(const double* __restrict__ partial, uint32_t n_partial, float inv_p3, float* __restrict__ loss) {
@@ -544,18 +558,24 @@ __global__ __launch_bounds__(256) void k_tv_finalize(const double* __restrict__ 
 // Append E extra points ([E,3] points, [E,32] feature cotangents, scaled by a device scalar) to the point list
 // the scatter consumes (x [3][cap], d_feat [16][cap][2]), so that one scatter launch serves both the rendered
 // samples and the smoothness lattice.  n_total = n_base (device word or host value) + E.
-__global__ __launch_bounds__(256) void k_append_points(uint32_t E, const float* __restrict__ ex, const float* __restrict__ ed, const float* __restrict__ scale_dev,
-                                                       const uint32_t* __restrict__ n_base_dev, uint32_t n_base_host, uint32_t cap, float* __restrict__ x_soa,
-                                                       float* __restrict__ d_feat, uint32_t* __restrict__ n_total) {
+__device__ __forceinline__ void append_points_body(uint32_t E, const float* __restrict__ ex, const float* __restrict__ ed, const float* __restrict__ scale_dev,
+                                                   float scale_host, const uint32_t* __restrict__ n_base_dev, uint32_t n_base_host, uint32_t cap,
+                                                   float* __restrict__ x_soa, float* __restrict__ d_feat, uint32_t* __restrict__ n_total, uint32_t block) {
     const uint32_t base = n_base_dev != nullptr ? n_base_dev[0] : n_base_host;
-    const float sc = scale_dev != nullptr ? scale_dev[0] : 1.0f;
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;          // (point, level)
+    const float sc = (scale_dev != nullptr ? scale_dev[0] : 1.0f) * scale_host;
+    const uint32_t t = block * 256u + threadIdx.x;          // (point, level)
     if (t == 0) n_total[0] = base + E;
     if (t >= E * kLevels) return;
     const uint32_t i = t / kLevels, level = t % kLevels;
     const float2 g = *reinterpret_cast<const float2*>(ed + (size_t)i * kFeat + 2 * level);
     reinterpret_cast<float2*>(d_feat)[(size_t)level * cap + base + i] = make_float2(g.x * sc, g.y * sc);
     if (level < 3) x_soa[(size_t)level * cap + base + i] = ex[3 * (size_t)i + level];
+}
+
+__global__ __launch_bounds__(256) void k_append_points(uint32_t E, const float* __restrict__ ex, const float* __restrict__ ed, const float* __restrict__ scale_dev,
+                                                       const uint32_t* __restrict__ n_base_dev, uint32_t n_base_host, uint32_t cap, float* __restrict__ x_soa,
+                                                       float* __restrict__ d_feat, uint32_t* __restrict__ n_total) {
+    append_points_body(E, ex, ed, scale_dev, 1.0f, n_base_dev, n_base_host, cap, x_soa, d_feat, n_total, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -859,10 +879,10 @@ __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, Bo
 
 // partials [n_blocks][7][32][32] -> += into the four weight gradients.  Block = 32 outputs x 8 slices of the
 // block range; fixed summation order (deterministic for a given grid).
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partials, uint32_t n_blocks, NarutoGrads g, int overwrite) {
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ partials, uint32_t n_blocks, const NarutoGrads& g, int overwrite, uint32_t block) {
     __shared__ float red[8][32];
     const int o = threadIdx.x & 31, slice = threadIdx.x >> 5;
-    const uint32_t e = blockIdx.x * 32u + o;
+    const uint32_t e = block * 32u + o;
     float s = 0.0f;
     for (uint32_t b = slice; b < n_blocks; b += 8) s += partials[(size_t)b * kAccFloats + e];
     red[slice][o] = s;
@@ -888,6 +908,10 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
         if (row < 3 && g.col_w1) dst = g.col_w1 + row * kHidden + col;
     }
     if (dst != nullptr) *dst = overwrite ? s : *dst + s;
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partials, uint32_t n_blocks, NarutoGrads g, int overwrite) {
+    wgrad_reduce_body(partials, n_blocks, g, overwrite, blockIdx.x);
 }
 
 }  // namespace naruto

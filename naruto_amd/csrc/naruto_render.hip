@@ -27,7 +27,7 @@ __device__ __forceinline__ float linspace_at(float start, float end, uint32_t st
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_sample_z(uint32_t n_rays, const float* __restrict__ target_d, float near_, float far_,
                                                  uint32_t nu, uint32_t nr, float range_d, const float* __restrict__ rand,
-                                                 float* __restrict__ z_vals) {
+                                                 const uint64_t* __restrict__ rng, float* __restrict__ z_vals) {
     __shared__ float zs[kMaxSamples];      // merged list
     __shared__ float us[kMaxSamples];      // the two sorted input lists: uniform [0, nu) then near-surface [nu, nu+nr)
     const uint32_t n = blockIdx.x;
@@ -61,12 +61,14 @@ __global__ __launch_bounds__(64) void k_sample_z(uint32_t n_rays, const float* _
         }
     }
     __syncthreads();
+    const uint64_t key = rng != nullptr ? rng_key(rng) : 0ull;
     for (uint32_t s = lane; s < S; s += 64) {
         float v = zs[s];
-        if (rand != nullptr) {
+        if (rand != nullptr || rng != nullptr) {
             const float lo = s == 0 ? zs[0] : 0.5f * (zs[s] + zs[s - 1]);
             const float up = s == S - 1 ? zs[S - 1] : 0.5f * (zs[s + 1] + zs[s]);
-            v = __fadd_rn(lo, __fmul_rn(__fsub_rn(up, lo), rand[(size_t)n * S + s]));
+            const float r = rand != nullptr ? rand[(size_t)n * S + s] : rng_uniform(key, (uint64_t)n * S + s);
+            v = __fadd_rn(lo, __fmul_rn(__fsub_rn(up, lo), r));
         }
         z_vals[(size_t)n * S + s] = v;
     }
@@ -246,9 +248,8 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_terms(uint32_t n_ra
 struct LossScalars;
 __device__ __forceinline__ void loss_finalize_body(const double* __restrict__ sums, uint64_t n_total, uint32_t S, float* __restrict__ losses);
 
-// terms -> sums[16]; when losses != nullptr (single process: nothing to all-reduce) also the final losses
-__global__ __launch_bounds__(256) void k_loss_reduce(const float* __restrict__ terms, uint32_t n_rays, double* __restrict__ sums, uint32_t S,
-                                                     float* __restrict__ losses) {
+// terms [n_rays][16] -> sums[16], by one 256-thread workgroup in a fixed order
+__device__ __forceinline__ void loss_reduce_body(const float* __restrict__ terms, uint32_t n_rays, double* __restrict__ sums) {
     __shared__ double part[4][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double acc[10];
@@ -281,6 +282,12 @@ __global__ __launch_bounds__(256) void k_loss_reduce(const float* __restrict__ t
         }
         sums[k] = v;
     }
+}
+
+// terms -> sums[16]; when losses != nullptr (single process: nothing to all-reduce) also the final losses
+__global__ __launch_bounds__(256) void k_loss_reduce(const float* __restrict__ terms, uint32_t n_rays, double* __restrict__ sums, uint32_t S,
+                                                     float* __restrict__ losses) {
+    loss_reduce_body(terms, n_rays, sums);
     if (losses != nullptr) {
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -537,11 +544,15 @@ struct AdamSegs {
 };
 
 // all parameter tensors of one optimiser in ONE launch: blocks are partitioned over the segments
-__global__ __launch_bounds__(256) void k_adam_multi(AdamSegs a, float b1, float b2, const int32_t* __restrict__ step_dev, uint32_t step_host) {
+// flags & 1 (NARUTO_ADAM_ADVANCE): step_dev = {completed steps, ticket}; this launch is step step_dev[0] + 1 and the last
+// workgroup to retire stores it back (no separate "step += 1" launch).  flags & 2 (NARUTO_ADAM_ZERO_GRAD): gradients are
+// zeroed once consumed.
+__global__ __launch_bounds__(256) void k_adam_multi(AdamSegs a, float b1, float b2, int32_t* __restrict__ step_dev, uint32_t step_host, uint32_t flags) {
     int sgi = 0;
 #pragma unroll
     for (int k = 1; k < kAdamMaxSegs; ++k) sgi += (k < (int)a.n_segs && blockIdx.x >= a.block_begin[k]) ? 1 : 0;
-    const float t = step_dev != nullptr ? (float)step_dev[0] : (float)step_host;
+    const int32_t t_int = step_dev != nullptr ? __hip_atomic_load(step_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + ((flags & 1u) ? 1 : 0) : (int32_t)step_host;
+    const float t = (float)t_int;
     const float bc1 = 1.0f - powf(b1, t), bc2_sqrt = sqrtf(1.0f - powf(b2, t));
     const float step_size = a.lr[sgi] / bc1, eps = a.eps[sgi], wd = a.wd[sgi];
     float* __restrict__ p = a.p[sgi];
@@ -559,6 +570,20 @@ __global__ __launch_bounds__(256) void k_adam_multi(AdamSegs a, float b1, float 
         m[i] = mi;
         v[i] = vi;
         p[i] = pi - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+        if (flags & 2u) const_cast<float*>(g)[i] = 0.0f;
+    }
+    if (flags & 1u) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t* ticket = reinterpret_cast<uint32_t*>(step_dev + 1);
+            // relaxed: the ticket only counts retirements (every workgroup read the old count before it got here); the
+            // new count is consumed by the NEXT launch
+            const uint32_t k = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (k == gridDim.x - 1u) {
+                __hip_atomic_store(step_dev, t_int, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 

@@ -1,0 +1,245 @@
+// The mapping iteration as few launches as possible (naruto_train_forward / naruto_train_backward).
+//
+// At 2 048 rays an iteration is ~0.4 ms of GPU time; the modular path spreads it over ~30 launches, each costing 4-5 us
+// even under hipGraph replay.  Here side work RIDES in a bigger launch as extra workgroups ("roles" selected by
+// blockIdx) and the small reductions share one tail launch:
+//
+//   k_loss_stage = composite + per-ray loss terms (-> per-workgroup fp64 partials) | smoothness TV (-> partials)
+//   k_loss_tail  = one workgroup: partials -> sums, losses, total, iteration counter
+//   k_compact    = ray-count prefix + index write in one launch
+//   k_bwd_post   = weight-gradient reduction | append the lattice to the scatter's point list
+//
+// Two things that were tried and measured slower on MI355X, so they are NOT done:
+//   * finishing the reductions in the last workgroup to retire (device-scope ticket): an agent-scope release fence per
+//     workgroup writes back a whole L2 (4 236 workgroups: 383 us); with relaxed atomics + write-through stores the
+//     ~2 us round trip of the ticket still extends the life of every (short) workgroup: +14 us, vs 4.5 us for a tail launch;
+//   * letting the lattice's hash encode ride in k_query_fwd: role workgroups inherit that kernel's 248-VGPR allocation
+//     and cannot share a SIMD with the tile waves (+17 us, no overlap).
+//
+// Reference semantics are those of the modular kernels (scene_rep.py:66-96, 246-285; Co-SLAM smoothness); all summation
+// orders are fixed.
+
+#include "naruto_common.h"
+
+namespace naruto {
+
+struct LossStageArgs {
+    // ray role
+    uint32_t n_rays, S;
+    float trunc, sc_factor, trunc_sc, depth_trunc, rgb_missing;
+    int white_bkgd;
+    const float* raw; const float* z_vals; const float* target_rgb; const float* target_d;
+    float* rgb; float* depth; float* uncert_map;
+    double* partials;             // [n_ray_blocks][16]: per-workgroup shares of the loss sums
+    uint32_t n_ray_blocks;
+    // smoothness role (n_tv_blocks == 0: absent)
+    TvArgs tv;
+    const float* tv_feat; float* tv_d_feat; double* tv_partial;
+    uint32_t n_tv_blocks;
+};
+
+struct LossTailArgs {
+    const double* partials; uint32_t n_ray_blocks;
+    const double* tv_partial; uint32_t n_tv_blocks; float tv_inv_p3;
+    double* sums; float* losses;  // sums [16], losses [10]
+    const float* loss_weights;    // [10] or NULL
+    uint64_t n_rays_total; uint32_t S;
+    int finalize;                 // 0: stop at sums (+ losses[8]); the caller all-reduces and calls k_loss_finalize_total
+    uint64_t* rng;                // {seed, iteration counter} or NULL: the counter advances once per forward
+};
+
+__device__ __forceinline__ void loss_total(float* __restrict__ losses, const float* __restrict__ w) {
+    // total = sum_i w[i] * losses[i] over the differentiable slots; a zero weight drops the slot even if it holds NaN
+    // (depth_loss is NaN on batches without valid depth only if its weight is used, as in the reference)
+    float t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) t += w[i] != 0.0f ? w[i] * losses[i] : 0.0f;
+    losses[9] = t;
+}
+
+__global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_stage(LossStageArgs a) {
+    __shared__ RayScratch scratch[kRaysPerBlock];
+    __shared__ double red[4];
+    __shared__ float terms[kRaysPerBlock][10];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x < a.n_ray_blocks) {
+        const uint32_t n = blockIdx.x * kRaysPerBlock + wave;
+        if (n < a.n_rays) {
+            const uint32_t S = a.S;
+            RayScratch& rs = scratch[wave];
+            load_ray(rs, a.raw, a.z_vals, n, S, lane);
+            const RayWeights rw = ray_weights(rs, S, a.trunc, a.sc_factor, lane);
+            const RayOut o = ray_composite(rs, rw, a.raw, n, S, a.trunc, a.white_bkgd, nullptr, lane);
+            const float td = a.target_d[n];
+            const bool valid = depth_valid(td, a.depth_trunc);
+            const float dm = td > 0.0f ? 1.0f : 0.0f;
+            float fs = 0.0f, nfs = 0.0f, sl = 0.0f, nsdf = 0.0f;
+            for (uint32_t s = lane; s < S; s += 64) {
+                const float z = rs.z[s], sdf = rs.sdf[s];
+                const float front = z < (td - a.trunc_sc) ? 1.0f : 0.0f;
+                const float back = z > (td + a.trunc_sc) ? 1.0f : 0.0f;
+                const float sm = (1.0f - front) * (1.0f - back) * dm;
+                const float e = sdf * front - front;
+                fs = fmaf(e, e, fs);
+                nfs += front;
+                const float c = (z + sdf * a.trunc_sc) * sm - td * sm;
+                sl = fmaf(c, c, sl);
+                nsdf += sm != 0.0f ? 1.0f : 0.0f;
+            }
+            fs = wave_sum(fs); nfs = wave_sum(nfs); sl = wave_sum(sl); nsdf = wave_sum(nsdf);
+            if (lane == 0) {
+                if (a.rgb) { a.rgb[3 * (size_t)n] = o.rgb[0]; a.rgb[3 * (size_t)n + 1] = o.rgb[1]; a.rgb[3 * (size_t)n + 2] = o.rgb[2]; }
+                if (a.depth) a.depth[n] = o.depth;
+                if (a.uncert_map) a.uncert_map[n] = o.uncert;
+                const float w = rgb_weight(valid, a.rgb_missing);
+                float s0 = 0.0f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float e = o.rgb[c] * w - a.target_rgb[3 * (size_t)n + c] * w;
+                    s0 = fmaf(e, e, s0);
+                }
+                const float D = o.depth, u = o.uncert;
+                float* t = terms[wave];
+                t[0] = s0;
+                t[1] = valid ? (D - td) * (D - td) : 0.0f;
+                t[2] = valid ? 1.0f : 0.0f;
+                t[3] = fs; t[4] = nfs; t[5] = sl; t[6] = nsdf;
+                t[7] = valid ? 1.0f / (2.0f * (u + 1e-9f)) : 0.0f;
+                t[8] = valid ? logf(u + 1e-9f) : 0.0f;
+                t[9] = u;
+            }
+        } else if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 10; ++k) terms[wave][k] = k == 9 ? __builtin_huge_valf() : 0.0f;
+        }
+        __syncthreads();
+        if (threadIdx.x < 10) {          // this workgroup's share of the sums, fixed order; one coherent store per slot
+            const int k = threadIdx.x;
+            double v = (double)terms[0][k];
+#pragma unroll
+            for (int w = 1; w < kRaysPerBlock; ++w) {
+                const double u = (double)terms[w][k];
+                v = k == 9 ? ((u < v || u != u) ? u : v) : v + u;
+            }
+            a.partials[(size_t)blockIdx.x * 16 + k] = v;
+        }
+    } else {
+        tv_loss_body(a.tv, a.tv_feat, a.tv_d_feat, a.tv_partial, blockIdx.x - a.n_ray_blocks, a.n_tv_blocks, red);
+    }
+}
+
+// one workgroup: per-workgroup partials -> sums[16], smoothness term, losses[10], iteration counter
+__global__ __launch_bounds__(256) void k_loss_tail(LossTailArgs a) {
+    __shared__ double red[4];
+    __shared__ double part[4][10];
+    __shared__ double s_sums[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        // thread t owns workgroups t, t + 256, ...: all of a thread's loads are independent and issued together (the
+        // partials were written by other XCDs, so every load is a trip to memory), then a fixed-shape tree over the threads
+        double acc[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) acc[k] = k == 9 ? 1e300 : 0.0;
+        for (uint32_t b0 = 0; b0 < a.n_ray_blocks; b0 += 1024u) {
+            double v[4][10];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t b = b0 + threadIdx.x + 256u * j;
+#pragma unroll
+                for (int k = 0; k < 10; ++k) v[j][k] = b < a.n_ray_blocks ? a.partials[(size_t)b * 16 + k] : (k == 9 ? 1e300 : 0.0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc[k] += v[j][k];
+                acc[9] = (v[j][9] < acc[9] || v[j][9] != v[j][9]) ? v[j][9] : acc[9];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            double v = acc[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double other = __shfl_xor(v, o, 64);
+                v = k == 9 ? ((other < v || other != other) ? other : v) : v + other;
+            }
+            if (lane == 0) part[wave][k] = v;
+        }
+        // the smoothness partials ride in the same round of loads
+        double tv = 0.0;
+        for (uint32_t i = threadIdx.x; i < a.n_tv_blocks; i += 256) tv += a.tv_partial[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tv += __shfl_xor(tv, o, 64);
+        if (lane == 0) red[wave] = tv;
+        __syncthreads();
+        if (threadIdx.x < 10) {
+            const int k = threadIdx.x;
+            double v = part[0][k];
+            for (int i = 1; i < 4; ++i) v = k == 9 ? ((part[i][k] < v || part[i][k] != part[i][k]) ? part[i][k] : v) : v + part[i][k];
+            s_sums[k] = v;
+            a.sums[k] = v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // everything from LDS / registers: a store -> load round trip through global memory costs ~1 us each here
+        float l[10];
+        l[8] = a.n_tv_blocks > 0 ? (float)((red[0] + red[1] + red[2] + red[3]) * (double)a.tv_inv_p3) : 0.0f;
+        a.losses[8] = l[8];
+        if (a.finalize) {
+            loss_finalize_body(s_sums, a.n_rays_total, a.S, l);
+            l[9] = 0.0f;
+            if (a.loss_weights != nullptr) loss_total(l, a.loss_weights);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) a.losses[i] = l[i];
+        }
+        if (a.rng != nullptr) a.rng[1] += 1ull;
+    }
+}
+
+// data-parallel tail of the loss stage: all-reduced sums -> losses[0..7], total -> losses[9]
+__global__ void k_loss_finalize_total(const double* __restrict__ sums, uint64_t n_total, uint32_t S, float* __restrict__ losses,
+                                      const float* __restrict__ loss_weights) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    loss_finalize_body(sums, n_total, S, losses);
+    if (loss_weights != nullptr) loss_total(losses, loss_weights); else losses[9] = 0.0f;
+}
+
+// ray prefix lengths -> flat active list, one launch: every workgroup (4 rays, one wave each) sums the counts of the
+// rays before it (integer sums: any order gives the same result), then writes its rays' indices.
+__global__ __launch_bounds__(256) void k_compact(uint32_t n_rays, uint32_t S, const uint32_t* __restrict__ ray_count, uint32_t* __restrict__ ray_off,
+                                                 uint32_t* __restrict__ active_idx, uint32_t* __restrict__ n_active) {
+    __shared__ uint32_t red[4], cnt[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t r0 = blockIdx.x * 4u;
+    uint32_t s = 0;
+    for (uint32_t i = threadIdx.x; i < r0; i += 256u) s += ray_count[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += (uint32_t)__shfl_xor((int)s, o, 64);
+    const uint32_t n = r0 + wave;
+    const uint32_t c = n < n_rays ? ray_count[n] : 0u;
+    if (lane == 0) { red[wave] = s; cnt[wave] = c; }
+    __syncthreads();
+    uint32_t off = red[0] + red[1] + red[2] + red[3];
+    for (int w = 0; w < wave; ++w) off += cnt[w];
+    if (n >= n_rays) return;
+    if (lane == 0) {
+        ray_off[n] = off;
+        if (n == n_rays - 1u) n_active[0] = off + c;
+    }
+    for (uint32_t k = lane; k < c; k += 64) active_idx[off + k] = n * S + k;
+}
+
+// weight-gradient reduction | lattice append, one launch
+__global__ __launch_bounds__(256) void k_bwd_post(const float* __restrict__ partials, uint32_t n_blocks, NarutoGrads g, int overwrite, uint32_t n_wgrad_blocks,
+                                                  uint32_t E, const float* __restrict__ ex, const float* __restrict__ ed, const float* __restrict__ scale_dev,
+                                                  float scale_host, const uint32_t* __restrict__ n_base_dev, uint32_t n_base_host, uint32_t cap,
+                                                  float* __restrict__ x_soa, float* __restrict__ d_feat, uint32_t* __restrict__ n_total) {
+    if (blockIdx.x < n_wgrad_blocks) {
+        wgrad_reduce_body(partials, n_blocks, g, overwrite, blockIdx.x);
+        return;
+    }
+    append_points_body(E, ex, ed, scale_dev, scale_host, n_base_dev, n_base_host, cap, x_soa, d_feat, n_total, blockIdx.x - n_wgrad_blocks);
+}
+
+}  // namespace naruto

@@ -543,9 +543,15 @@ def render_train(handle: FieldHandle, params: Dict[str, torch.Tensor], rays_o, r
                               int(n_rays_total), smooth, *(params[n] for n in PARAM_NAMES))
 
 
-def adam_multi_(entries, *, betas, step: int = 0, step_dev: Optional[torch.Tensor] = None) -> None:
-    """entries: list of (param, grad, exp_avg, exp_avg_sq, lr, eps, weight_decay); one launch for all of them."""
+def adam_multi_(entries, *, betas, step: int = 0, step_dev: Optional[torch.Tensor] = None, advance: bool = False,
+                zero_grad: bool = False) -> None:
+    """entries: list of (param, grad, exp_avg, exp_avg_sq, lr, eps, weight_decay); one launch for all of them.
+    ``advance``: step_dev is int32[2] = {completed steps, 0}; the launch is step step_dev[0]+1 and stores it back.
+    ``zero_grad``: the gradients are zeroed once consumed."""
     lib = _lib.load()
+    flags = (_lib.ADAM_ADVANCE if advance else 0) | (_lib.ADAM_ZERO_GRAD if zero_grad else 0)
+    if advance:
+        assert step_dev is not None and step_dev.numel() >= 2 and step_dev.dtype == torch.int32
     segs = (_lib.NarutoAdamSeg * len(entries))()
     for k, (p, g, m, v, lr, eps, wd) in enumerate(entries):
         for t in (p, g, m, v):
@@ -553,7 +559,140 @@ def adam_multi_(entries, *, betas, step: int = 0, step_dev: Optional[torch.Tenso
         segs[k].param, segs[k].grad, segs[k].exp_avg, segs[k].exp_avg_sq = _p(p), _p(g), _p(m), _p(v)
         segs[k].n, segs[k].lr, segs[k].eps, segs[k].weight_decay = p.numel(), lr, eps, wd
     with torch.cuda.device(entries[0][0].device):
-        check(lib.naruto_adam_multi(segs, len(entries), betas[0], betas[1], step, _p(step_dev), _stream()), "naruto_adam_multi")
+        check(lib.naruto_adam_multi(segs, len(entries), betas[0], betas[1], step, _p(step_dev), flags, _stream()), "naruto_adam_multi")
+
+
+class TrainStep:
+    """The mapping iteration's forward + backward as two C calls on persistent buffers (naruto_train_forward /
+    naruto_train_backward): no autograd graph, no per-iteration allocations or fills, a dozen launches.
+
+    ``params``: the six parameter tensors (PARAM_NAMES).  Gradients: table + MLP weights are WRITTEN into views of
+    ``self.flat_grad`` (one buffer, so data-parallel ranks reduce it with one collective); the uncertainty grid's
+    gradient is ACCUMULATED into ``uncert_grad`` (it is stepped every 5th iteration, coslam.py:397-399)."""
+
+    FLAT_NAMES = ("table", "sdf_w0", "sdf_w1", "col_w0", "col_w1")
+
+    def __init__(self, handle: FieldHandle, params: Dict[str, torch.Tensor], uncert_grad: torch.Tensor, n_rays: int, *, n_samples_d: int,
+                 n_range_d: int, near: float, far: float, range_d: float, depth_trunc: float, rgb_missing: float, perturb: bool,
+                 loss_weights: torch.Tensor, smooth: Optional[Tuple[int, float, float]] = None, group=None, n_rays_total: int = 0,
+                 device_rng: bool = True, seed: Optional[int] = None, rng_state: Optional[torch.Tensor] = None):
+        lib = _lib.load()
+        self.handle, self.group = handle, group
+        self.params = {k: _f32c(params[k].detach(), k) for k in PARAM_NAMES}
+        for k in PARAM_NAMES:
+            assert self.params[k].data_ptr() == params[k].data_ptr(), f"{k}: parameters must be contiguous fp32 on the GPU"
+        dev = self.params["table"].device
+        self.device = dev
+        N, S = int(n_rays), int(n_samples_d) + int(n_range_d)
+        M = N * S
+        self.N, self.S, self.perturb = N, S, bool(perturb)
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.loss_weights = _f32c(loss_weights, "loss_weights")
+        assert self.loss_weights.numel() == 10
+        # device_rng: the kernels draw the depth jitter / lattice placement themselves from (seed, iteration counter) --
+        # no RNG launch, and no generator state for hipGraph replay to refresh.  Otherwise: one torch RNG launch per
+        # iteration into self.rand, or the caller's own numbers (run(rand=...)).
+        self.device_rng = bool(device_rng)
+        if rng_state is not None:          # int64 {seed, iteration counter} shared with the caller (the counter advances once per run)
+            assert rng_state.is_cuda and rng_state.dtype == torch.int64 and rng_state.numel() == 2
+            self.rng_state = rng_state
+        else:
+            if seed is None:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())            # follows torch.manual_seed
+            self.rng_state = torch.tensor([seed, 0], dtype=torch.int64, device=dev)
+        self.rand = torch.empty(M + 6, **f32)                  # [N*S] depth jitter | 6 numbers placing the smoothness lattice
+        self.z_vals = torch.empty(N, S, **f32)
+        self.raw = torch.empty(N, S, 5, **f32)
+        self.feat = torch.empty(16, M, 2, **f32)
+        self.rgb, self.depth, self.uncert_map = torch.empty(N, 3, **f32), torch.empty(N, **f32), torch.empty(N, **f32)
+        self.sums = torch.zeros(_lib.LOSS_NSUMS, dtype=torch.float64, device=dev)
+        self.losses = torch.zeros(10, **f32)
+        self.d_raw = torch.empty(N, S, 5, **f32)
+        self.ray_count, self.ray_offset = torch.empty(N, **i32), torch.empty(N, **i32)
+        self.active_idx, self.n_active = torch.empty(M, **i32), torch.zeros(1, **i32)
+        n3 = 0
+        if smooth is not None:
+            n3 = (int(smooth[0]) - 1) ** 3
+        self.smooth_x, self.smooth_d = (torch.empty(n3, 3, **f32), torch.empty(n3, 32, **f32)) if n3 else (None, None)
+        self.flat_grad = torch.zeros(sum(self.params[n].numel() for n in self.FLAT_NAMES), **f32)
+        self.grads, off = {}, 0
+        for n in self.FLAT_NAMES:
+            k = self.params[n].numel()
+            self.grads[n] = self.flat_grad[off:off + k].view_as(self.params[n])
+            off += k
+        assert uncert_grad.is_cuda and uncert_grad.dtype == torch.float32 and uncert_grad.is_contiguous()
+        self.grads["uncert_grid"] = uncert_grad
+        world = 1
+        if group is not None:
+            from . import parallel
+            world = parallel.world_size(group)
+        t = _lib.NarutoTrainStep()
+        self.t = t
+        t.n_rays, t.n_samples_d, t.n_range_d = N, int(n_samples_d), int(n_range_d)
+        t.near_, t.far_, t.range_d, t.depth_trunc, t.rgb_missing = float(near), float(far), float(range_d), float(depth_trunc), float(rgb_missing)
+        if smooth is not None:
+            t.smooth_points, t.smooth_voxel, t.smooth_margin = int(smooth[0]), float(smooth[1]), float(smooth[2])
+            t.smooth_grad_scale = 1.0 / world            # every rank adds the same lattice's gradient; the sum over ranks is one term
+            t.smooth_x, t.smooth_d = _p(self.smooth_x), _p(self.smooth_d)
+        t.n_rays_total = int(n_rays_total) if n_rays_total else N * world
+        self._set_rng_mode(self.device_rng)
+        t.loss_weights = _p(self.loss_weights)
+        t.z_vals, t.raw, t.feat_save = _p(self.z_vals), _p(self.raw), _p(self.feat)
+        t.rgb, t.depth, t.uncert_map = _p(self.rgb), _p(self.depth), _p(self.uncert_map)
+        t.sums, t.losses, t.d_raw = _p(self.sums), _p(self.losses), _p(self.d_raw)
+        t.ray_count, t.ray_offset, t.active_idx, t.n_active = _p(self.ray_count), _p(self.ray_offset), _p(self.active_idx), _p(self.n_active)
+        self.ws = torch.empty((lib.naruto_train_workspace(handle.ptr, C.byref(t)) + 3) // 4, **f32)
+        t.workspace = _p(self.ws)
+        self.t = t
+        self.ps = _params_struct(self.params)
+        self.gs = NarutoGrads()
+        for n in PARAM_NAMES:
+            setattr(self.gs, n, _p(self.grads[n]))
+        self.flags = _lib.BWD_OVERWRITE_WEIGHT_GRADS | (_lib.BWD_OVERWRITE_TABLE_GRAD if handle_supports_overwrite(handle) else 0)
+        if not handle_supports_overwrite(handle):
+            self._zero_table = True
+        else:
+            self._zero_table = False
+
+    def _set_rng_mode(self, device_rng: bool):
+        t, M = self.t, self.N * self.S
+        t.perturb = 1 if self.perturb else 0
+        if device_rng:
+            t.rand, t.rand6, t.rng = None, None, self.rng_state.data_ptr()
+        else:
+            t.rand = self.rand.data_ptr() if self.perturb else None
+            t.rand6 = self.rand[M:].data_ptr() if t.smooth_points else None
+            t.rng = None
+
+    def run(self, rays_o, rays_d, target_rgb, target_d, rand: Optional[torch.Tensor] = None):
+        """One forward + backward.  Afterwards: self.losses[10], self.rgb / depth / uncert_map, gradients in self.grads.
+        ``rand`` ([N,S], only with device_rng=False): the depth jitter to use instead of a fresh draw; the six lattice
+        numbers in self.rand[N*S:] are then left as they are."""
+        lib = _lib.load()
+        t = self.t
+        for a, n in ((rays_o, "rays_o"), (rays_d, "rays_d"), (target_rgb, "target_rgb"), (target_d, "target_d")):
+            if not (a.is_cuda and a.dtype == torch.float32 and a.is_contiguous()):
+                raise RuntimeError(f"{n}: expected a contiguous fp32 tensor on the GPU")
+        assert rays_o.shape[0] == self.N and target_d.numel() == self.N, "TrainStep was built for another ray count"
+        t.rays_o, t.rays_d, t.target_rgb, t.target_d = _p(rays_o), _p(rays_d), _p(target_rgb), _p(target_d)
+        if rand is not None:
+            assert not self.device_rng, "an explicit jitter draw needs TrainStep(device_rng=False)"
+            self.rand[:self.N * self.S].copy_(rand.reshape(-1))
+        elif not self.device_rng and (self.perturb or t.smooth_points):
+            self.rand.uniform_()                                # one RNG launch: jitter + lattice placement
+        with torch.cuda.device(self.device):
+            st = _stream()
+            if self._zero_table:
+                self.grads["table"].zero_()
+            check(lib.naruto_train_forward(self.handle.ptr, C.byref(self.ps), C.byref(t), 0 if self.group is not None else 1, st),
+                  "naruto_train_forward")
+            if self.group is not None:
+                from . import parallel
+                parallel.allreduce_loss_sums(self.sums, self.group)
+                check(lib.naruto_train_finalize(self.handle.ptr, C.byref(t), st), "naruto_train_finalize")
+            check(lib.naruto_train_backward(self.handle.ptr, C.byref(self.ps), C.byref(t), C.byref(self.gs), self.flags, st), "naruto_train_backward")
+        return self.losses
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -100,7 +100,10 @@ class FusedAdam:
             self.param_groups.append(g)
         self.state = {}
         dev = self.param_groups[0]['params'][0].device
-        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.step_dev = torch.zeros(2, dtype=torch.int32, device=dev)       # {completed steps, ticket word of k_adam_multi}
+        # int32[1] device word that already holds THIS step's 1-based number when step() runs (MappingTrainer's iteration
+        # counter, advanced by the forward): no counting in the optimiser at all
+        self.external_step = None
         for g in self.param_groups:
             for p in g['params']:
                 self.state[p] = (torch.zeros_like(p), torch.zeros_like(p))
@@ -114,9 +117,9 @@ class FusedAdam:
                     p.grad.zero_()
 
     @torch.no_grad()
-    def step(self):
+    def step(self, zero_grad: bool = False):
+        """``zero_grad``: zero the gradients inside the same launch, once consumed."""
         from . import ops
-        self.step_dev.add_(1)
         by_betas = {}
         for g in self.param_groups:
             for p in g['params']:
@@ -124,9 +127,21 @@ class FusedAdam:
                     continue
                 m, v = self.state[p]
                 by_betas.setdefault(tuple(g['betas']), []).append((p.data, p.grad.contiguous(), m, v, g['lr'], g['eps'], g['weight_decay']))
+        n_launches = sum((len(e) + 7) // 8 for e in by_betas.values())
+        if self.external_step is not None:
+            for betas, entries in by_betas.items():
+                for i in range(0, len(entries), 8):
+                    ops.adam_multi_(entries[i:i + 8], betas=betas, step_dev=self.external_step, zero_grad=zero_grad)
+            return
+        if n_launches == 1:
+            # the common case: the kernel itself advances the device-side step count (no "step += 1" launch)
+            (betas, entries), = by_betas.items()
+            ops.adam_multi_(entries, betas=betas, step_dev=self.step_dev, advance=True, zero_grad=zero_grad)
+            return
+        self.step_dev[:1].add_(1)
         for betas, entries in by_betas.items():
             for i in range(0, len(entries), 8):
-                ops.adam_multi_(entries[i:i + 8], betas=betas, step_dev=self.step_dev)
+                ops.adam_multi_(entries[i:i + 8], betas=betas, step_dev=self.step_dev, zero_grad=zero_grad)
 
 
 class MappingTrainer:
@@ -156,6 +171,15 @@ class MappingTrainer:
         self.iter = 0
         self._graphs = None
         self._static = None
+        # fast path: forward + backward as two C calls on persistent buffers (ops.TrainStep) instead of the autograd node
+        self.direct = bool(fused_adam)
+        self._train_steps = {}
+        if self.direct:
+            # {seed, iteration counter}: the kernels' own random numbers are keyed by it, the forward advances the counter,
+            # and the mapping Adam reads its step number from it (one iteration = one step)
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            self.iter_state = torch.tensor([seed, 0], dtype=torch.int64, device=self.device)
+            self.map_optimizer.external_step = self.iter_state.view(torch.int32)[2:3]
         tr = config['training']
         # get_loss_from_ret's weights laid out like the node's loss vector (slot 8 = smoothness term)
         self._loss_w = torch.tensor([tr['rgb_weight'], tr['depth_weight'], tr['sdf_weight'], tr['fs_weight'], 0.0,
@@ -166,7 +190,52 @@ class MappingTrainer:
     def parameters(self):
         return list(self.model.decoder.parameters()) + list(self.model.embed_fn.parameters()) + [self.model.uncert_grid]
 
+    def _train_step(self, n_rays: int, use_smooth: bool):
+        from . import ops
+        key = (n_rays, use_smooth, self.model.n_rays_total)
+        ts = self._train_steps.get(key)
+        if ts is None:
+            tr, cam = self.config['training'], self.config['cam']
+            m = self.model
+            ts = ops.TrainStep(m._handle(), m._params(), m.uncert_grid.grad, n_rays, n_samples_d=tr['n_samples_d'], n_range_d=tr['n_range_d'],
+                               near=cam['near'], far=cam['far'], range_d=tr['range_d'], depth_trunc=cam['depth_trunc'],
+                               rgb_missing=tr['rgb_missing'], perturb=tr['perturb'] > 0., loss_weights=self._loss_w,
+                               smooth=(tr['smooth_pts'], tr['smooth_vox'], tr['smooth_margin']) if use_smooth else None,
+                               group=self.group, n_rays_total=self.model.n_rays_total, rng_state=self.iter_state)
+            self._train_steps[key] = ts
+        return ts
+
+    def _iteration_direct(self, rays_o, rays_d, target_rgb, target_d, smooth: bool, uncert_step: bool, check: bool = True):
+        """Same iteration as _iteration, without autograd: ops.TrainStep + the fused Adams (11-13 launches in all)."""
+        model = self.model
+        model.train()
+        if check:
+            model.check_asserts()
+        tr = self.config['training']
+        use_smooth = bool(smooth and tr['smooth_weight'] > 0)
+        ts = self._train_step(rays_o.shape[0], use_smooth)
+        with torch.no_grad():
+            losses = ts.run(rays_o, rays_d, target_rgb, target_d.reshape(-1))
+            for name, p in model._params().items():
+                p.grad = ts.grads[name]
+            if self.group is not None:
+                torch.distributed.all_reduce(ts.flat_grad, op=torch.distributed.ReduceOp.SUM, group=self.group)
+            self.map_optimizer.step()
+            if uncert_step:
+                if self.group is not None:
+                    parallel.allreduce_grads([model.uncert_grid], self.group)
+                self.uncert_optim.step(zero_grad=True)
+        model._pending_min_uncert = losses[6]
+        if model.strict_assert:
+            model.check_asserts()
+        ret = {"rgb": ts.rgb, "depth": ts.depth, "rgb_loss": losses[0], "depth_loss": losses[1], "sdf_loss": losses[2], "fs_loss": losses[3],
+               "psnr": losses[4], "uncert_loss": losses[5], "_losses": losses, "_smooth_loss": losses[8]}
+        return ret, losses[9]
+
     def _iteration(self, rays_o, rays_d, target_rgb, target_d, smooth: bool, uncert_step: bool, check: bool = True):
+        if self.direct:
+            rays_o, rays_d, target_rgb, target_d = (t.to(self.device, torch.float32).contiguous() for t in (rays_o, rays_d, target_rgb, target_d))
+            return self._iteration_direct(rays_o, rays_d, target_rgb, target_d, smooth, uncert_step, check)
         model = self.model
         model.train()
         self.map_optimizer.zero_grad(set_to_none=True)
@@ -181,7 +250,14 @@ class MappingTrainer:
         ret = model.forward(rays_o, rays_d, target_rgb, target_d, rand=rand, _check=check, _smooth=sm)
         # get_loss_from_ret (coslam.py:154-174) as ONE dot product over the node's loss vector (the smoothness term sits
         # in slot 8; the fused node computed it alongside so that its table gradient shares the scatter pass)
-        loss = torch.dot(ret['_losses'], self._loss_w)
+        w = self._loss_w
+        if self.group is not None and use_smooth:
+            # every rank differentiates the same lattice: scale the term so that the sum over ranks is ONE smoothness term
+            if getattr(self, '_loss_w_dp', None) is None:
+                self._loss_w_dp = self._loss_w.clone()
+                self._loss_w_dp[8] /= parallel.world_size(self.group)
+            w = self._loss_w_dp
+        loss = torch.dot(ret['_losses'], w)
         loss.backward()
         if self.group is not None:
             # one collective over the flat (table + MLP weights) gradient; the uncertainty grid's gradient keeps
@@ -229,6 +305,7 @@ class MappingTrainer:
         # snapshot: the warm-up / capture iterations below must not change the training state
         params = self.parameters()
         snap = [p.detach().clone() for p in params]
+        iter_snap = self.iter_state.clone() if self.direct else None
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
@@ -250,6 +327,8 @@ class MappingTrainer:
         with torch.no_grad():
             for p, q in zip(params, snap):
                 p.copy_(q)
+            if iter_snap is not None:
+                self.iter_state.copy_(iter_snap)
             self.model.uncert_grid.grad.zero_()
             for opt in (self.map_optimizer, self.uncert_optim):
                 if isinstance(opt, FusedAdam):

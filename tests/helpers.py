@@ -76,3 +76,20 @@ def assert_close(a, b, tol, what, rel=0.0):
     assert not bad.any(), (f"{what}: max abs err {err.max().item():.3e} (tol {tol:g}, rel {rel:g}) at "
                            f"{int(bad.sum())}/{bad.numel()} elements; worst idx {int(err.argmax())}, "
                            f"got {a.reshape(-1)[int(err.argmax())].item():.6g} want {b.reshape(-1)[int(err.argmax())].item():.6g}")
+
+
+# ---- the kernels' own uniform numbers (naruto_common.h: splitmix64 keyed by seed, iteration counter, index) ----
+_M64 = (1 << 64) - 1
+
+
+def _splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _M64
+    return x ^ (x >> 31)
+
+
+def device_rng_uniform(seed: int, counter: int, idx):
+    """float32 array of the values rng_uniform(rng_key({seed, counter}), i) for i in idx (python ints: exact)."""
+    key = _splitmix64((seed & _M64) ^ _splitmix64(counter & _M64))
+    return np.array([(_splitmix64((key + int(i)) & _M64) >> 40) * 2.0 ** -24 for i in idx], dtype=np.float32)

@@ -418,6 +418,86 @@ def test_train_node_with_fused_smoothness(gpu):
         grad_close(H.hip_grads(m)[k], 2 * go[k], f"fused.grad2.{k}")
 
 
+def test_train_step_direct_against_oracle(gpu):
+    """naruto_train_forward / naruto_train_backward (the trainer's fast path: role blocks, last-workgroup reductions,
+    no autograd) against the oracle, with the smoothness term, zero-depth rays and a given jitter draw; run twice to
+    check that the self-resetting tickets and the written-not-accumulated gradients hold up, and that the
+    uncertainty-grid gradient accumulates."""
+    from naruto_amd import ops
+    cfg = H.office_cfg(12, perturb=1.0)
+    tr, cam = cfg["training"], cfg["cam"]
+    ora = H.make_oracle(cfg, 0.25, 43)
+    m = H.make_hip_from_oracle(cfg, ora, gpu)
+    N = 150                                                     # not a multiple of 4: a partly filled ray block
+    S_tot = tr["n_samples_d"] + tr["n_range_d"]
+    rays = syn.random_rays(N, cfg["mapping"]["bound"], seed=43, zero_depth_frac=0.15)
+    t = {k: torch.from_numpy(v) for k, v in rays.items()}
+    r6 = torch.tensor([0.3, 0.6, 0.2, 0.1, 0.7, 0.4])
+    rand = torch.rand(N, S_tot, generator=torch.Generator().manual_seed(7))
+    w_s = 0.37
+    w = torch.tensor([tr["rgb_weight"], tr["depth_weight"], tr["sdf_weight"], tr["fs_weight"], 0.0, tr["uncert_weight"], 0.0, 0.0, w_s, 0.0])
+    ora.train()
+    ret_o = ora.forward(t["rays_o"], t["rays_d"], t["target_rgb"], t["target_d"], rand=rand)
+    sm_o = S.smoothness(ora, 12, 0.1, 0.05, r6[:3], r6[3:])
+    total_o = S.total_loss(ret_o, tr) + w_s * sm_o
+    total_o.backward()
+    go = H.ora_grads(ora)
+    ug = torch.zeros_like(m.uncert_grid)
+    ts = ops.TrainStep(m._handle(), m._params(), ug, N, n_samples_d=tr["n_samples_d"], n_range_d=tr["n_range_d"], near=cam["near"], far=cam["far"],
+                       range_d=tr["range_d"], depth_trunc=cam["depth_trunc"], rgb_missing=tr["rgb_missing"], perturb=True,
+                       loss_weights=w.to(gpu), smooth=(12, 0.1, 0.05), device_rng=False)
+    args = [t[k].to(gpu).contiguous() for k in ("rays_o", "rays_d", "target_rgb")] + [t["target_d"].to(gpu).reshape(-1).contiguous()]
+    for rep in range(2):
+        ts.rand[N * S_tot:].copy_(r6)
+        torch.cuda.synchronize()
+        # run() with an explicit jitter leaves the six lattice numbers alone
+        losses = ts.run(*args, rand=rand.to(gpu))
+        torch.cuda.synchronize()
+        for i, k in enumerate(("rgb_loss", "depth_loss", "sdf_loss", "fs_loss")):
+            H.assert_close(losses[i].reshape(-1), ret_o[k].reshape(-1), 1e-6, f"direct.{k}", rel=1e-4)
+        H.assert_close(losses[5].reshape(-1), ret_o["uncert_loss"].reshape(-1), 1e-5, "direct.uncert_loss", rel=1e-4)
+        H.assert_close(losses[8].reshape(-1), sm_o.reshape(-1), 1e-7, "direct.smooth", rel=1e-4)
+        H.assert_close(losses[9].reshape(-1), total_o.detach().reshape(-1), 1e-5, "direct.total", rel=1e-4)
+        H.assert_close(ts.rgb, ret_o["rgb"], 1e-5, "direct.rgb")
+        H.assert_close(ts.depth, ret_o["depth"], 1e-5, "direct.depth", rel=1e-5)
+        for k in ("table", "sdf_w0", "sdf_w1", "col_w0", "col_w1"):
+            grad_close(ts.grads[k].reshape(-1), go[k].reshape(-1), f"direct.rep{rep}.grad.{k}")
+        grad_close(ug.reshape(-1), (rep + 1) * ora.uncert_grid.grad.reshape(-1), f"direct.rep{rep}.grad.uncert_grid")
+
+
+def test_train_step_device_rng(gpu):
+    """With device_rng the kernels draw the depth jitter and the lattice placement themselves (splitmix64 keyed by seed,
+    iteration counter, index): z_vals and the lattice points equal the oracle's for exactly those numbers, and the
+    counter advances once per forward."""
+    from naruto_amd import ops
+    cfg = H.office_cfg(12, perturb=1.0)
+    tr, cam = cfg["training"], cfg["cam"]
+    ora = H.make_oracle(cfg, 0.25, 47)
+    m = H.make_hip_from_oracle(cfg, ora, gpu)
+    N, S_tot, seed = 96, tr["n_samples_d"] + tr["n_range_d"], 0x1234567
+    rays = syn.random_rays(N, cfg["mapping"]["bound"], seed=47, zero_depth_frac=0.1)
+    t = {k: torch.from_numpy(v) for k, v in rays.items()}
+    w = torch.tensor([tr["rgb_weight"], tr["depth_weight"], tr["sdf_weight"], tr["fs_weight"], 0.0, tr["uncert_weight"], 0.0, 0.0, 0.1, 0.0])
+    ts = ops.TrainStep(m._handle(), m._params(), torch.zeros_like(m.uncert_grid), N, n_samples_d=tr["n_samples_d"], n_range_d=tr["n_range_d"],
+                       near=cam["near"], far=cam["far"], range_d=tr["range_d"], depth_trunc=cam["depth_trunc"], rgb_missing=tr["rgb_missing"],
+                       perturb=True, loss_weights=w.to(gpu), smooth=(12, 0.1, 0.05), device_rng=True, seed=seed)
+    args = [t[k].to(gpu).contiguous() for k in ("rays_o", "rays_d", "target_rgb")] + [t["target_d"].to(gpu).reshape(-1).contiguous()]
+    ora.train()
+    for it in range(2):
+        losses = ts.run(*args).clone()
+        torch.cuda.synchronize()
+        assert ts.rng_state.cpu().tolist() == [seed, it + 1]
+        rand = torch.from_numpy(H.device_rng_uniform(seed, it, range(N * S_tot))).view(N, S_tot)
+        assert rand.min() >= 0.0 and rand.max() < 1.0 and abs(rand.mean().item() - 0.5) < 0.02
+        r6 = torch.from_numpy(H.device_rng_uniform(seed, it, [(1 << 40) + i for i in range(6)]))
+        ret_o = ora.forward(t["rays_o"], t["rays_d"], t["target_rgb"], t["target_d"], rand=rand)
+        H.assert_close(ts.z_vals, ret_o["z_vals"] if "z_vals" in ret_o else ora.render_rays(t["rays_o"], t["rays_d"], target_d=t["target_d"],
+                       rand=rand)["z_vals"], 2e-6, f"iter{it}.z_vals", rel=2e-6)
+        sm_o = S.smoothness(ora, 12, 0.1, 0.05, r6[:3], r6[3:])
+        H.assert_close(losses[8].reshape(-1), sm_o.reshape(-1), 1e-7, f"iter{it}.smooth", rel=1e-4)
+        H.assert_close(losses[0].reshape(-1), ret_o["rgb_loss"].reshape(-1), 1e-6, f"iter{it}.rgb_loss", rel=1e-4)
+
+
 # --------------------------------------------------------------------------------------------- N1 / N2 ("next" rows)
 def test_active_ray_sampler_golden(gpu):
     """ActiveRaySamplerHIP against the reference's sampler (golden) and the oracle's deterministic variant."""

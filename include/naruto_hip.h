@@ -141,7 +141,7 @@ int naruto_query_fwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
  * extra (optional): E more points whose feature cotangents are already known (the smoothness lattice of
  * naruto_smoothness_fwd); they are appended to the scatter's point list so that ONE scatter pass produces the
  * whole table gradient.  flags: NARUTO_BWD_OVERWRITE_* make the reductions WRITE the weight / table gradients
- * instead of accumulating (saves the caller the zero fill; table: needs log2_hashmap_size <= 16).
+ * instead of accumulating (saves the caller the zero fill; table: needs log2_hashmap_size <= 17).
  * Workspace: naruto_query_bwd_workspace(f, M + E). */
 typedef struct NarutoExtraPoints {
     const float* x;        /* [E,3] normalised points                         */

@@ -66,11 +66,11 @@ constexpr uint32_t kBwdMaxBlocks = 256;     // one 145 KB-LDS block per CU
 // table scatter: LDS-tiled units + k_scatter_reduce, and/or the global-atomic kernel for oversized levels
 int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const float* d_feat, size_t stride_m, size_t stride_l, float* d_table,
                    float* partial, hipStream_t st, const uint32_t* m_dev = nullptr, const float* scale_dev = nullptr, int overwrite = 0) {
-    if (overwrite && f->plan.atomic_levels != 0) return fail(NARUTO_ERR_INVALID, "scatter: overwrite mode needs every level LDS-tiled (log2_hashmap_size <= 16)");
+    if (overwrite && f->plan.atomic_levels != 0) return fail(NARUTO_ERR_INVALID, "scatter: overwrite mode needs every level LDS-tiled (log2_hashmap_size <= 17)");
     const size_t n_params = (size_t)f->n_entries * 2u;
     if (f->plan.n_dense + f->plan.n_hashed > 0) {
         static bool attr_set = false;
-        const size_t lds = (size_t)kChunk * 2u * sizeof(unsigned long long);
+        const size_t lds = (size_t)kChunk * sizeof(unsigned long long);
         if (!attr_set) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_hash_scatter_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return fail(NARUTO_ERR_LAUNCH, "hash_scatter: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(hipGetLastError()));
@@ -147,8 +147,8 @@ int naruto_field_create(const NarutoFieldDesc* d, NarutoField** out) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) f->n_cu = cus;
     else { f->n_cu = 0; (void)hipGetLastError(); }
-    // scatter plan: levels of up to kMaxChunksPerLevel 8 192-entry chunks are LDS-tiled (dense levels first),
-    // larger ones use global atomics
+    // scatter plan: levels of up to kMaxChunksPerLevel 16 384-entry chunks are LDS-tiled, one unit per (chunk, feature),
+    // dense levels first; larger levels use global atomics
     memset(&f->plan, 0, sizeof(f->plan));
     // profiling knobs (not part of the contract): restrict the scatter to some levels / force the split counts
     const char* env_mask = getenv("NARUTO_DEBUG_SCATTER_LEVELS");
@@ -162,20 +162,27 @@ int naruto_field_create(const NarutoFieldDesc* d, NarutoField** out) {
             const uint32_t chunks = (f->lt.size[l] + kChunk - 1u) / kChunk;
             if (chunks > (uint32_t)kMaxChunksPerLevel) { f->plan.atomic_levels |= 1u << l; continue; }
             for (uint32_t c = 0; c < chunks; ++c) {
-                f->plan.level[n_units] = (uint8_t)l;
-                f->plan.chunk[n_units] = (uint8_t)c;
-                ++n_units;
+                for (uint32_t ft = 0; ft < 2u; ++ft) {
+                    f->plan.level[n_units] = (uint8_t)l;
+                    f->plan.chunk[n_units] = (uint8_t)(c | (ft << 7));
+                    ++n_units;
+                }
             }
-            if (hashed) f->plan.n_hashed += chunks; else f->plan.n_dense += chunks;
+            if (hashed) f->plan.n_hashed += 2u * chunks; else f->plan.n_dense += 2u * chunks;
         }
     }
-    // one 128 KB-LDS workgroup per CU: aim at ~1 workgroup per CU, dense units weighted x3
+    // one 128 KB-LDS workgroup per CU and every workgroup takes about the same time (it is bound by the points it
+    // streams, not by its unit): never launch more workgroups than CUs (a second round doubles the kernel time).  About
+    // 70 % of the CUs go to the hashed units, the rest to the dense ones (measured optimum on MI355X: 2 x 88 + 5 x 16).
     {
-        const uint32_t denom = f->plan.n_hashed + 3u * f->plan.n_dense;
-        uint32_t sh = denom ? cu_count(f) / denom : 1u;
-        sh = sh < 1u ? 1u : (sh > 4u ? 4u : sh);
+        const uint32_t cus = cu_count(f);
+        uint32_t sh = f->plan.n_hashed ? (cus * 7u / 10u) / f->plan.n_hashed : 1u;
+        sh = sh < 1u ? 1u : (sh > 8u ? 8u : sh);
+        const uint32_t left = cus > f->plan.n_hashed * sh ? cus - f->plan.n_hashed * sh : 0u;
+        uint32_t sd = f->plan.n_dense ? left / f->plan.n_dense : 1u;
+        sd = sd < 1u ? 1u : (sd > 8u ? 8u : sd);
         f->plan.s_hashed = sh;
-        f->plan.s_dense = 3u * sh;
+        f->plan.s_dense = sd;
         if (const char* e1 = getenv("NARUTO_DEBUG_SCATTER_SPLITS_HASHED")) f->plan.s_hashed = (uint32_t)atoi(e1);
         if (const char* e2 = getenv("NARUTO_DEBUG_SCATTER_SPLITS_DENSE")) f->plan.s_dense = (uint32_t)atoi(e2);
     }

@@ -266,10 +266,10 @@ __global__ __launch_bounds__(256) void k_hash_encode_fwd(LevelTab lt, const floa
 // large for that (log2_hashmap_size > 16: the synthetic HBM-stress tables) keep the global-atomic path --
 // their updates are spread thinly anyway.
 // ------------------------------------------------------------------------------------------------
-constexpr int kChunkLog2 = 13;
-constexpr uint32_t kChunk = 1u << kChunkLog2;       // entries per LDS image (x2 int64 = 128 KB)
+constexpr int kChunkLog2 = 14;
+constexpr uint32_t kChunk = 1u << kChunkLog2;       // entries per LDS image: ONE feature of 16 384 entries as int64 = 128 KB
 constexpr int kMaxChunksPerLevel = 8;
-constexpr int kMaxUnits = kLevels * kMaxChunksPerLevel;
+constexpr int kMaxUnits = kLevels * kMaxChunksPerLevel * 2;      // unit = (level, chunk, feature)
 constexpr int kScatterThreads = 1024;
 constexpr float kFixScale = 1099511627776.0f;        // 2^40
 constexpr double kFixInv = 1.0 / 1099511627776.0;
@@ -278,7 +278,7 @@ constexpr double kFixInv = 1.0 / 1099511627776.0;
 // same-address conflicts, hashed units only 1/chunks of them, so dense units get more point splits.
 struct ScatterPlan {
     uint8_t level[kMaxUnits];
-    uint8_t chunk[kMaxUnits];
+    uint8_t chunk[kMaxUnits];     // bit 7: feature, bits 0..6: chunk
     uint32_t n_dense, n_hashed;   // LDS-tiled (level, chunk) units of non-hashed / hashed levels
     uint32_t s_dense, s_hashed;   // point splits per unit
     uint32_t atomic_levels;       // bit l: level l goes through the global-atomic kernel instead
@@ -337,40 +337,37 @@ __device__ __forceinline__ unsigned long long to_fix40(float v) {
     return ((unsigned long long)hi << 32) | lo;
 }
 
-__device__ __forceinline__ void fix_add(unsigned long long* __restrict__ acc, uint32_t idx, uint32_t chunk, float v0, float v1) {
-    if ((idx >> kChunkLog2) == chunk) {
-        const uint32_t e = (idx & (kChunk - 1u)) * 2u;
-        atomicAdd(acc + e, to_fix40(v0));          // ds_add_u64
-        atomicAdd(acc + e + 1u, to_fix40(v1));
-    }
+__device__ __forceinline__ void fix_add(unsigned long long* __restrict__ acc, uint32_t idx, uint32_t chunk, float v) {
+    if ((idx >> kChunkLog2) == chunk) atomicAdd(acc + (idx & (kChunk - 1u)), to_fix40(v));          // ds_add_u64
 }
 
 template <int T>
 __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const BoxTab& bt, const PointSrc& ps, const float* __restrict__ d_feat,
                                                     size_t stride_m, size_t stride_l, uint32_t m_lo, uint32_t m_hi, uint32_t chunk,
                                                     unsigned long long* __restrict__ acc) {
+    // d_feat already points at this unit's feature (0 or 1)
     if ((lt.hashed >> T) & 1u) {
         // hashed (fine) levels: neighbouring points land in unrelated entries; one point per thread per step,
         // kScatterBatch independent loads in flight
         for (uint32_t base = m_lo + threadIdx.x; base < m_hi; base += kScatterThreads * kScatterBatch) {
-            float2 g[kScatterBatch];
+            float g[kScatterBatch];
             float px[kScatterBatch], py[kScatterBatch], pz[kScatterBatch];
 #pragma unroll
             for (int b = 0; b < kScatterBatch; ++b) {
                 const uint32_t m = base + b * kScatterThreads;
                 const uint32_t mm = m < m_hi ? m : m_hi - 1u;
-                g[b] = *reinterpret_cast<const float2*>(d_feat + (size_t)mm * stride_m + (size_t)T * stride_l);
+                g[b] = d_feat[(size_t)mm * stride_m + (size_t)T * stride_l];
                 load_point(ps, bt, mm, px[b], py[b], pz[b]);
-                if (m >= m_hi) g[b] = make_float2(0.0f, 0.0f);
+                if (m >= m_hi) g[b] = 0.0f;
             }
 #pragma unroll
             for (int b = 0; b < kScatterBatch; ++b) {
-                if (g[b].x == 0.0f && g[b].y == 0.0f) continue;
+                if (g[b] == 0.0f) continue;
                 uint32_t idx[8];
                 float w[8];
                 hash_corners<T>(lt, px[b], py[b], pz[b], idx, w);
 #pragma unroll
-                for (int c = 0; c < 8; ++c) fix_add(acc, idx[c], chunk, w[c] * g[b].x, w[c] * g[b].y);
+                for (int c = 0; c < 8; ++c) fix_add(acc, idx[c], chunk, w[c] * g[b]);
             }
         }
     } else {
@@ -380,26 +377,26 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
         const float scale = lt.scale[T];
         const uint32_t res = lt.res[T], size = lt.size[T], r2 = res * res;
         for (uint32_t r0 = m_lo + threadIdx.x * kScatterRun; r0 < m_hi; r0 += kScatterThreads * kScatterRun) {
-            float a0[8], a1[8];
+            float a0[8];
             uint32_t cur = 0xFFFFFFFFu;
             bool have = false;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) { a0[c] = 0.0f; a1[c] = 0.0f; }
+            for (int c = 0; c < 8; ++c) a0[c] = 0.0f;
             auto flush = [&]() {
                 if (!have) return;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     uint32_t i = cur + (uint32_t)(c & 1) + ((c & 2) ? res : 0u) + ((c & 4) ? r2 : 0u);
                     if (i >= size) i %= size;
-                    fix_add(acc, i, chunk, a0[c], a1[c]);
-                    a0[c] = 0.0f; a1[c] = 0.0f;
+                    fix_add(acc, i, chunk, a0[c]);
+                    a0[c] = 0.0f;
                 }
             };
             for (int k = 0; k < kScatterRun; ++k) {
                 const uint32_t m = r0 + k;
                 if (m >= m_hi) break;
-                const float2 g = *reinterpret_cast<const float2*>(d_feat + (size_t)m * stride_m + (size_t)T * stride_l);
-                if (g.x == 0.0f && g.y == 0.0f) continue;
+                const float g = d_feat[(size_t)m * stride_m + (size_t)T * stride_l];
+                if (g == 0.0f) continue;
                 float x, y, z;
                 load_point(ps, bt, m, x, y, z);
                 const float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
@@ -415,8 +412,7 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     const float w = ((c & 1) ? wx : ux) * ((c & 2) ? wy : uy) * ((c & 4) ? wz : uz);
-                    a0[c] = fmaf(w, g.x, a0[c]);
-                    a1[c] = fmaf(w, g.y, a1[c]);
+                    a0[c] = fmaf(w, g, a0[c]);
                 }
             }
             flush();
@@ -444,8 +440,9 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
         split = b % n_splits;
     }
     const int level = plan.level[unit];
-    const uint32_t chunk = plan.chunk[unit];
-    for (uint32_t i = threadIdx.x; i < kChunk * 2u; i += kScatterThreads) acc[i] = 0ull;
+    const uint32_t chunk = plan.chunk[unit] & 0x7Fu, feat = plan.chunk[unit] >> 7;
+    d_feat += feat;
+    for (uint32_t i = threadIdx.x; i < kChunk; i += kScatterThreads) acc[i] = 0ull;
     __syncthreads();
     const uint32_t per = (M + n_splits - 1u) / n_splits;
     const uint32_t m_lo = split * per;
@@ -457,11 +454,13 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
 #undef NARUTO_CASE
     }
     __syncthreads();
-    // level sizes are multiples of 8 entries and chunks start at multiples of 8 192: float4-aligned slices
+    // partial tables are feature-planar: [split][feature][n_entries]; level sizes are multiples of 8 entries and chunks
+    // start at multiples of 16 384: float4-aligned slices
     const uint32_t n_e = lt.size[level] - chunk * kChunk < kChunk ? lt.size[level] - chunk * kChunk : kChunk;
-    float4* out = reinterpret_cast<float4*>(partial + (size_t)split * n_params + 2 * ((size_t)lt.off[level] + (size_t)chunk * kChunk));
+    const size_t n_entries = n_params / 2u;
+    float4* out = reinterpret_cast<float4*>(partial + ((size_t)split * 2u + feat) * n_entries + (size_t)lt.off[level] + (size_t)chunk * kChunk);
     const double inv = kFixInv * (double)gscale;
-    for (uint32_t i = threadIdx.x; i < n_e / 2u; i += kScatterThreads) {
+    for (uint32_t i = threadIdx.x; i < n_e / 4u; i += kScatterThreads) {
         float4 v;
         v.x = (float)((double)(long long)acc[4 * i + 0] * inv);
         v.y = (float)((double)(long long)acc[4 * i + 1] * inv);
@@ -474,7 +473,7 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
 // d_table += sum over the level's splits of partial[split], for the entry ranges of the LDS-tiled levels
 __global__ __launch_bounds__(256) void k_scatter_reduce(LevelTab lt, uint32_t atomic_levels, const float* __restrict__ partial, uint32_t s_dense,
                                                         uint32_t s_hashed, size_t n_params, float* __restrict__ d_table, int overwrite) {
-    const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // float4 index
+    const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // float4 index of the output = entries 2 i4, 2 i4 + 1
     if (i4 * 4 >= n_params) return;
     const uint32_t entry = (uint32_t)(i4 * 2);
     int level = 0;
@@ -482,10 +481,12 @@ __global__ __launch_bounds__(256) void k_scatter_reduce(LevelTab lt, uint32_t at
     for (int l = 1; l < kLevels; ++l) level += entry >= lt.off[l] ? 1 : 0;
     if ((atomic_levels >> level) & 1u) return;
     const uint32_t n_splits = ((lt.hashed >> level) & 1u) ? s_hashed : s_dense;
-    float4 s = reinterpret_cast<const float4*>(partial)[i4];
-    for (uint32_t k = 1; k < n_splits; ++k) {
-        const float4 v = reinterpret_cast<const float4*>(partial + (size_t)k * n_params)[i4];
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    const size_t n_entries = n_params / 2u;
+    float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (uint32_t k = 0; k < n_splits; ++k) {
+        const float2 f0 = *reinterpret_cast<const float2*>(partial + ((size_t)k * 2u) * n_entries + entry);          // feature 0 of both entries
+        const float2 f1 = *reinterpret_cast<const float2*>(partial + ((size_t)k * 2u + 1u) * n_entries + entry);     // feature 1
+        s.x += f0.x; s.y += f1.x; s.z += f0.y; s.w += f1.y;
     }
     float4* d = reinterpret_cast<float4*>(d_table) + i4;
     if (overwrite) { *d = s; return; }

@@ -527,8 +527,8 @@ class _RenderTrain(torch.autograd.Function):
 
 
 def handle_supports_overwrite(handle: FieldHandle) -> bool:
-    """Table gradients can be written (not accumulated) when every level is LDS-tiled, i.e. log2_hashmap_size <= 16."""
-    return handle.desc.log2_hashmap_size <= 16
+    """Table gradients can be written (not accumulated) when every level is LDS-tiled, i.e. log2_hashmap_size <= 17."""
+    return handle.desc.log2_hashmap_size <= 17
 
 
 def render_train(handle: FieldHandle, params: Dict[str, torch.Tensor], rays_o, rays_d, z_vals, target_rgb, target_d,

@@ -127,23 +127,47 @@ def kernel_table(tr, rays, cfg, iters: int):
         setattr(gs, k, p(v))
     wsb = torch.empty(lib.naruto_query_bwd_workspace(h.ptr, M) // 4, device=dev)
     # the three kernels of naruto_query_bwd, split by giving each call only the outputs one kernel produces
-    gs_mlp = _lib.NarutoGrads()
-    for k in ("uncert_grid", "sdf_w0", "sdf_w1", "col_w0", "col_w1"):
-        setattr(gs_mlp, k, p(grads[k]))
+    gs_mlp = _lib.NarutoGrads()                 # k_query_bwd alone: no table (scatter), no weight outputs (k_wgrad_reduce)
+    gs_mlp.uncert_grid = p(grads["uncert_grid"])
     Ma = int(round(frac * M))                                                           # active (non-zero cotangent) samples
     mlp_bwd_flops = Ma * 2 * (5184 + (15 * 32 + 16 * 32 + 32 * 32 + 3 * 32) + 5184)   # recompute + dgrad + wgrad
-    add("k_query_bwd+k_wgrad_reduce", lambda: _lib.check(lib.naruto_query_bwd(h.ptr, CT.byref(ps), M, CT.byref(pts), p(feat), p(d_raw), None,
+    add("k_query_bwd", lambda: _lib.check(lib.naruto_query_bwd(h.ptr, CT.byref(ps), M, CT.byref(pts), p(feat), p(d_raw), None,
         p(act), p(nact), None, 0, CT.byref(gs_mlp), p(wsb), st())), Ma * (128 + 20 + 128 + 4 + 4) + N * 24, mlp_bwd_flops, "mfma")
     t_mlp = rows[-1]["ms"]
     ms_all = events_ms(lambda: _lib.check(lib.naruto_query_bwd(h.ptr, CT.byref(ps), M, CT.byref(pts), p(feat), p(d_raw), None, p(act), p(nact),
                                                                None, 0, CT.byref(gs), p(wsb), st())), iters)
     sc_bytes = Ma * (16 * 8 * 2 * 8 + 128 + 12)         # 256 fp32 read-modify-writes + d_feat + point
     ms_sc = max(ms_all - t_mlp, 1e-6)
-    rows.append({"kernel": "k_hash_scatter", "ms": round(ms_sc, 5), "alg_bytes": int(sc_bytes), "alg_flops": 0,
+    rows.append({"kernel": "k_hash_scatter+reduce+k_wgrad_reduce", "ms": round(ms_sc, 5), "alg_bytes": int(sc_bytes), "alg_flops": 0,
                  "GBps": round(sc_bytes / ms_sc / 1e6, 1), "TFLOPs": 0.0, "bound": "hbm"})
+    # the two calls the trainer actually makes per iteration (naruto_train.hip), for reference: not roofline rows
+    ts = tr._train_step(N, True)
+    args = (rays["rays_o"], rays["rays_d"], rays["target_rgb"], rays["target_d"].reshape(-1))
+    ts.run(*args)
+    t = ts.t
+    t.rays_o, t.rays_d, t.target_rgb, t.target_d = (p(a) for a in args)
+    fwd_ms = events_ms(lambda: _lib.check(lib.naruto_train_forward(h.ptr, CT.byref(ts.ps), CT.byref(t), 1, st())), iters)
+    bwd_ms = events_ms(lambda: _lib.check(lib.naruto_train_backward(h.ptr, CT.byref(ts.ps), CT.byref(t), CT.byref(ts.gs), ts.flags, st())), iters)
+    for name, ms in (("naruto_train_forward (5 launches, eager)", fwd_ms), ("naruto_train_backward (6 launches, eager)", bwd_ms)):
+        rows.append({"kernel": name, "ms": round(ms, 5), "alg_bytes": 0, "alg_flops": 0, "GBps": 0.0, "TFLOPs": 0.0, "bound": None})
     rows.append({"kernel": "(active sample fraction)", "ms": 0.0, "alg_bytes": 0, "alg_flops": 0, "GBps": 0.0, "TFLOPs": 0.0,
                  "bound": "hbm", "fraction": round(frac, 4)})
     return rows
+
+
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of ``kernel`` from the committed PMC passes (profiles/rNN_pmc.json, newest round; collected by
+    tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes), or None."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        return d[kernel]["traffic_bytes"], os.path.basename(files[-1])
+    except (KeyError, ValueError, OSError):
+        return None, None
 
 
 def cpu_baseline(cfg, n_rays: int, iters: int):
@@ -254,7 +278,7 @@ def main():
         }
         if not args.no_kernels:
             rows = kernel_table(tr, rays, cfg, max(10, args.steps))
-            dom = max(rows, key=lambda r: r["ms"])
+            dom = max((r for r in rows if r["bound"] is not None), key=lambda r: r["ms"])
             if dom["bound"] == "mfma":
                 roof = {"bound": "mfma", "achieved": dom["TFLOPs"], "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                         "frac": round(dom["TFLOPs"] / FP32_MFMA_PEAK_TF, 4), "traffic": None}
@@ -263,9 +287,14 @@ def main():
                         "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": None}
             roof["kernel"] = dom["kernel"]
             roof["kernel_ms"] = dom["ms"]
+            roof["alg_bytes"] = dom["alg_bytes"]
+            tb, src = pmc_traffic(dom["kernel"])
+            if tb is not None:
+                roof["traffic"] = tb                      # bytes per launch (FETCH_SIZE + WRITE_SIZE), same launch shape
+                roof["traffic_source"] = f"profiles/{src}"
             out["roofline"] = roof
             out["kernels"] = rows
-            out["kernels_ms_sum"] = round(sum(r["ms"] for r in rows), 4)
+            out["kernels_ms_sum"] = round(sum(r["ms"] for r in rows if r["bound"] is not None), 4)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, n_rays, args.cpu_iters)
         print(json.dumps(out), flush=True)

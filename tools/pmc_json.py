@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), as summarised by prof_summary.py.
+
+    python tools/pmc_json.py gpurun_out/r01_pmc_FETCH_SIZE.txt gpurun_out/r01_pmc_WRITE_SIZE.txt > profiles/r01_pmc.json
+
+Units and corrections (MI355X_MICROARCH.md, "HBM"): the counters report KiB per dispatch; on gfx950 FETCH_SIZE counts
+128-byte requests of wide coalesced streams as 64 bytes (x2 for those), other access widths are uncalibrated.  The
+kernels here read mostly through 8-byte gathers, so the raw value is kept and the x2 bound is given next to it.
+"""
+import json
+import re
+import sys
+
+NAMES = {"k_query_fwd<color>": ["k_query_fwdILb1"], "k_query_bwd": ["k_query_bwd"],
+         "k_hash_scatter+reduce+k_wgrad_reduce": ["k_hash_scatter_lds", "k_scatter_reduce", "k_hash_scatter_atomic", "k_bwd_post", "k_wgrad_reduce"], "k_tv_encode": ["k_tv_encode"],
+         "k_loss_stage": ["k_loss_stage"], "k_composite_bwd<loss>": ["k_composite_bwdILb1"], "k_adam_multi": ["k_adam_multi"]}
+
+
+def parse(path):
+    out = {}
+    on = False
+    for line in open(path):
+        if line.startswith("PMC counters"):
+            on = True
+            continue
+        if not on or line.startswith("kernel"):
+            continue
+        m = re.match(r"(\S+)\s+(\w+)\s+(\d+)\s+([0-9.]+)\s*$", line)
+        if m:
+            out[m.group(1)] = float(m.group(4))
+    return out
+
+
+fetch, write = parse(sys.argv[1]), parse(sys.argv[2])
+res = {"note": "per-dispatch averages, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over eager launches "
+               "(bench.py --no-graph); bytes = KiB * 1024.  fetch_bytes_x2 = the gfx950 wide-read correction applied (upper bound)."}
+for label, keys in NAMES.items():
+    f = sum(v for k, v in fetch.items() if any(("naruto" + str(len(x)) + x) in k or x in k for x in keys))
+    w = sum(v for k, v in write.items() if any(x in k for x in keys))
+    res[label] = {"fetch_bytes": int(f * 1024), "fetch_bytes_x2": int(2 * f * 1024), "write_bytes": int(w * 1024),
+                  "traffic_bytes": int((f + w) * 1024)}
+print(json.dumps(res, indent=1))

@@ -276,7 +276,6 @@ typedef struct NarutoTrainStep {
     float *losses;                                    /* [10]                                                 */
     float *d_raw;                                     /* [N,S,5]          (backward)                          */
     uint32_t *ray_count, *ray_offset, *active_idx, *n_active;  /* [N] [N] [N*S] [1]  (backward)               */
-    float *smooth_x, *smooth_d;                       /* [(P-1)^3,3] [(P-1)^3,32], with smooth_points         */
     void *workspace;                                  /* naruto_train_workspace() bytes                       */
 } NarutoTrainStep;
 size_t naruto_train_workspace(const NarutoField* f, const NarutoTrainStep* t);

@@ -67,7 +67,7 @@ class NarutoTrainStep(C.Structure):
         ("rgb", C.c_void_p), ("depth", C.c_void_p), ("uncert_map", C.c_void_p),
         ("sums", C.c_void_p), ("losses", C.c_void_p), ("d_raw", C.c_void_p),
         ("ray_count", C.c_void_p), ("ray_offset", C.c_void_p), ("active_idx", C.c_void_p), ("n_active", C.c_void_p),
-        ("smooth_x", C.c_void_p), ("smooth_d", C.c_void_p), ("workspace", C.c_void_p),
+        ("workspace", C.c_void_p),
     ]
 
 

@@ -259,7 +259,7 @@ int naruto_smoothness_fwd(const NarutoField* f, const float* table, uint32_t sam
     if (f == nullptr || table == nullptr || rand6 == nullptr || x_out == nullptr || d_feat == nullptr || loss == nullptr || workspace == nullptr)
         return fail(NARUTO_ERR_INVALID, "smoothness_fwd: NULL argument");
     if (sample_points < 3 || sample_points > 257) return fail(NARUTO_ERR_INVALID, "smoothness_fwd: sample_points must be in [3, 257]");
-    TvArgs a;
+    TvArgs a{};
     a.n = sample_points - 1;
     a.voxel = voxel_size;
     a.margin = margin;
@@ -310,13 +310,30 @@ size_t naruto_query_bwd_workspace(const NarutoField* f, uint32_t M) {
 }  // extern "C"
 
 namespace {
-// fused_post: weight-gradient reduction and lattice append share one launch; extra_scale: host factor on extra->scale
+struct BwdWs {
+    float* d_feat; float* x_soa; float* partials; float* scatter_ws; uint32_t* n_total;
+};
+// layout of naruto_query_bwd_workspace(): the scatter's point list (d_feat [16][cap][2], x [3][cap]), wgrad partials,
+// scatter partial tables, one count word
+BwdWs bwd_ws(const NarutoField* f, void* workspace, uint32_t cap) {
+    BwdWs w;
+    w.d_feat = reinterpret_cast<float*>(workspace);
+    w.x_soa = w.d_feat + (size_t)kLevels * 2u * (size_t)cap;
+    w.partials = w.x_soa + 3u * (size_t)cap;
+    w.scatter_ws = w.partials + (size_t)kBwdMaxBlocks * kAccFloats;
+    w.n_total = reinterpret_cast<uint32_t*>(w.scatter_ws + naruto_scatter_workspace(f) / sizeof(float));
+    return w;
+}
+
+// n_front > 0 (fused training path): list positions [0, n_front) were filled by the caller (smoothness lattice: points
+// and weighted feature cotangents), this launch's points follow; n_list_dev = device word holding n_front + n_active.
 int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, const NarutoPoints* pts, const float* feat_save,
                    const float* d_raw, const float* d_geo, const uint32_t* active_idx, const uint32_t* n_active, const NarutoExtraPoints* extra,
-                   uint32_t flags, const NarutoGrads* g, void* workspace, void* stream, bool fused_post, float extra_scale) {
+                   uint32_t flags, const NarutoGrads* g, void* workspace, void* stream, uint32_t n_front, const uint32_t* n_list_dev) {
     if ((active_idx == nullptr) != (n_active == nullptr)) return fail(NARUTO_ERR_INVALID, "query_bwd: active_idx and n_active go together");
-    const uint32_t E = (extra != nullptr && g != nullptr && g->table != nullptr) ? extra->n : 0u;
-    if (E > 0 && (extra->x == nullptr || extra->d_feat == nullptr)) return fail(NARUTO_ERR_INVALID, "query_bwd: extra points need x and d_feat");
+    if (n_front > 0 && (extra != nullptr || n_list_dev == nullptr)) return fail(NARUTO_ERR_INVALID, "query_bwd: front list excludes extra points");
+    const uint32_t E = n_front > 0 ? n_front : ((extra != nullptr && g != nullptr && g->table != nullptr) ? extra->n : 0u);
+    if (n_front == 0 && E > 0 && (extra->x == nullptr || extra->d_feat == nullptr)) return fail(NARUTO_ERR_INVALID, "query_bwd: extra points need x and d_feat");
     const uint32_t cap = M + E;                      // leading dimension of the scatter's point list
     if (f == nullptr || p == nullptr || g == nullptr || feat_save == nullptr || d_raw == nullptr || workspace == nullptr)
         return fail(NARUTO_ERR_INVALID, "query_bwd: NULL argument");
@@ -324,11 +341,9 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
         return fail(NARUTO_ERR_INVALID, "query_bwd: NULL parameter");
     if (int rc = check_points(pts)) return rc;
     if (M == 0) return NARUTO_OK;
-    float* d_feat = reinterpret_cast<float*>(workspace);
-    float* x_soa = d_feat + (size_t)kLevels * 2u * (size_t)cap;
-    float* partials = x_soa + 3u * (size_t)cap;
-    float* scatter_ws = partials + (size_t)kBwdMaxBlocks * kAccFloats;
-    uint32_t* n_total = reinterpret_cast<uint32_t*>(scatter_ws + naruto_scatter_workspace(f) / sizeof(float));
+    const BwdWs w = bwd_ws(f, workspace, cap);
+    float* d_feat = w.d_feat; float* x_soa = w.x_soa; float* partials = w.partials; float* scatter_ws = w.scatter_ws;
+    uint32_t* n_total = w.n_total;
     const uint32_t n_tiles = (M + 31u) / 32u;
     uint32_t blocks = (n_tiles + 3u) / 4u;
     uint32_t max_blocks = cu_count(f);
@@ -342,26 +357,22 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
         attr_set = true;
     }
     hipLaunchKernelGGL(k_query_bwd, dim3(blocks), dim3(256), sizeof(BwdLds), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, ps, M, cap, feat_save, d_raw,
-                       d_geo, d_feat, g->table != nullptr ? x_soa : nullptr, g->uncert_grid, partials, active_idx, n_active);
+                       d_geo, d_feat, g->table != nullptr ? x_soa : nullptr, g->uncert_grid, partials, active_idx, n_active, n_front);
     if (int rc = check_launch("query_bwd")) return rc;
     const bool want_w = g->sdf_w0 || g->sdf_w1 || g->col_w0 || g->col_w1;
-    if (fused_post && want_w && E > 0 && g->table != nullptr) {
-        const uint32_t nw = kAccFloats / 32, na = (E * kLevels + 255u) / 256u;
-        hipLaunchKernelGGL(k_bwd_post, dim3(nw + na), dim3(256), 0, (hipStream_t)stream, partials, blocks, *g, (int)(flags & NARUTO_BWD_OVERWRITE_WEIGHT_GRADS), nw,
-                           E, extra->x, extra->d_feat, extra->scale, extra_scale, n_active, M, cap, x_soa, d_feat, n_total);
-        if (int rc = check_launch("bwd_post")) return rc;
-        PointSrc pss{};
-        pss.xsoa = x_soa;
-        pss.M = cap;
-        pss.S = 1;
-        return launch_scatter(f, pss, cap, d_feat, (size_t)2, (size_t)2 * (size_t)cap, g->table, scatter_ws, (hipStream_t)stream, n_total, nullptr,
-                              (int)(flags & NARUTO_BWD_OVERWRITE_TABLE_GRAD));
-    }
-    if (extra_scale != 1.0f) return fail(NARUTO_ERR_INVALID, "query_bwd: host scale only on the fused path");
     if (want_w) {
         hipLaunchKernelGGL(k_wgrad_reduce, dim3(kAccFloats / 32), dim3(256), 0, (hipStream_t)stream, partials, blocks, *g,
                            (int)(flags & NARUTO_BWD_OVERWRITE_WEIGHT_GRADS));
         if (int rc = check_launch("wgrad_reduce")) return rc;
+    }
+    if (n_front > 0) {
+        if (g->table == nullptr) return NARUTO_OK;
+        PointSrc pss{};
+        pss.xsoa = x_soa;
+        pss.M = cap;
+        pss.S = 1;
+        return launch_scatter(f, pss, cap, d_feat, (size_t)2, (size_t)2 * (size_t)cap, g->table, scatter_ws, (hipStream_t)stream, n_list_dev, nullptr,
+                              (int)(flags & NARUTO_BWD_OVERWRITE_TABLE_GRAD));
     }
     if (g->table != nullptr) {
         PointSrc pss{};
@@ -388,7 +399,7 @@ extern "C" {
 int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, const NarutoPoints* pts, const float* feat_save,
                      const float* d_raw, const float* d_geo, const uint32_t* active_idx, const uint32_t* n_active, const NarutoExtraPoints* extra,
                      uint32_t flags, const NarutoGrads* g, void* workspace, void* stream) {
-    return query_bwd_impl(f, p, M, pts, feat_save, d_raw, d_geo, active_idx, n_active, extra, flags, g, workspace, stream, false, 1.0f);
+    return query_bwd_impl(f, p, M, pts, feat_save, d_raw, d_geo, active_idx, n_active, extra, flags, g, workspace, stream, 0u, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -431,8 +442,8 @@ int train_check(const NarutoField* f, const NarutoParams* p, const NarutoTrainSt
     if ((uint64_t)t->n_rays * S > 0x7FFFFFFFull) return fail(NARUTO_ERR_INVALID, "%s: too many samples for 32-bit indices", who);
     if (t->smooth_points != 0 && (t->smooth_points < 3 || t->smooth_points > 257)) return fail(NARUTO_ERR_INVALID, "%s: smooth_points must be 0 or in [3, 257]", who);
     if (t->perturb && t->rand == nullptr && t->rng == nullptr) return fail(NARUTO_ERR_INVALID, "%s: perturb needs rand or rng", who);
-    if (t->smooth_points != 0 && ((t->rand6 == nullptr && t->rng == nullptr) || t->smooth_x == nullptr || t->smooth_d == nullptr))
-        return fail(NARUTO_ERR_INVALID, "%s: the smoothness term needs rand6 (or rng), smooth_x and smooth_d", who);
+    if (t->smooth_points != 0 && t->rand6 == nullptr && t->rng == nullptr) return fail(NARUTO_ERR_INVALID, "%s: the smoothness term needs rand6 or rng", who);
+    if (t->smooth_points != 0 && t->loss_weights == nullptr) return fail(NARUTO_ERR_INVALID, "%s: the smoothness term needs loss_weights", who);
     return NARUTO_OK;
 }
 TvArgs tv_args(const NarutoTrainStep* t) {
@@ -465,11 +476,13 @@ int naruto_train_forward(const NarutoField* f, const NarutoParams* p, const Naru
     hipLaunchKernelGGL(k_sample_z, dim3(N), dim3(64), 0, st, N, t->target_d, t->near_, t->far_, t->n_samples_d, t->n_range_d, t->range_d, jitter, jitter_rng,
                        t->z_vals);
     if (int rc = check_launch("sample_z")) return rc;
-    // the smoothness lattice: points + hash features
-    const TvArgs tva = tv_args(t);
+    // the smoothness lattice: its points go straight to the FRONT of the backward's scatter list, features level-major
+    TvArgs tva = tv_args(t);
+    tva.cap = M + w.n3;
+    const BwdWs bw = bwd_ws(f, w.bwd, M + w.n3);
     if (t->smooth_points != 0) {
         hipLaunchKernelGGL(k_tv_encode, dim3(16u * ((w.n3 + 255u) / 256u)), dim3(256), 0, st, f->lt, f->bt, tva, t->rand6, t->rng,
-                           reinterpret_cast<const float2*>(p->table), t->smooth_x, w.tv_feat);
+                           reinterpret_cast<const float2*>(p->table), bw.x_soa, w.tv_feat);
         if (int rc = check_launch("tv_encode")) return rc;
     }
     // A2..A5
@@ -489,7 +502,9 @@ int naruto_train_forward(const NarutoField* f, const NarutoParams* p, const Naru
     a.rgb = t->rgb; a.depth = t->depth; a.uncert_map = t->uncert_map;
     a.partials = reinterpret_cast<double*>(w.terms);       // n_rays/4 x 16 doubles fit the n_rays x 16 floats of the modular path
     a.n_ray_blocks = (N + kRaysPerBlock - 1) / kRaysPerBlock;
-    a.tv = tva; a.tv_feat = w.tv_feat; a.tv_d_feat = t->smooth_d; a.tv_partial = w.tv_partial;
+    a.tv = tva; a.tv_feat = w.tv_feat; a.tv_d_list = bw.d_feat; a.tv_partial = w.tv_partial;
+    a.tv_scale_dev = t->loss_weights != nullptr ? t->loss_weights + 8 : nullptr;
+    a.tv_scale_host = t->smooth_grad_scale != 0.0f ? t->smooth_grad_scale : 1.0f;
     a.n_tv_blocks = t->smooth_points != 0 ? w.n_tv_blocks : 0u;
     hipLaunchKernelGGL(k_loss_stage, dim3(a.n_ray_blocks + a.n_tv_blocks), dim3(64 * kRaysPerBlock), 0, st, a);
     if (int rc = check_launch("loss_stage")) return rc;
@@ -526,19 +541,16 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
     hipLaunchKernelGGL(k_composite_bwd<true>, dim3((N + kRaysPerBlock - 1) / kRaysPerBlock), dim3(64 * kRaysPerBlock), 0, st, N, S, f->desc.trunc,
                        f->desc.sc_factor, f->desc.white_bkgd, t->raw, t->z_vals, cot, la, t->d_raw, 0, t->ray_count);
     if (int rc = check_launch("loss_bwd")) return rc;
-    if (N <= 8192u) {
-        hipLaunchKernelGGL(k_compact, dim3((N + 3u) / 4u), dim3(256), 0, st, N, S, t->ray_count, t->ray_offset, t->active_idx, t->n_active);
-        if (int rc = check_launch("compact")) return rc;
-    } else if (int rc = naruto_compact_active(N, S, t->ray_count, t->ray_offset, t->active_idx, t->n_active, stream)) {
-        return rc;
-    }
+    const bool smooth = t->smooth_points != 0 && g->table != nullptr;
+    const uint32_t n_front = smooth ? w.n3 : 0u;
+    const BwdWs bw = bwd_ws(f, w.bwd, M + w.n3);
+    hipLaunchKernelGGL(k_compact, dim3((N + 3u) / 4u), dim3(256), 0, st, N, S, t->ray_count, t->ray_offset, t->active_idx, t->n_active, n_front, bw.n_total);
+    if (int rc = check_launch("compact")) return rc;
     NarutoPoints pts{};
     pts.rays_o = t->rays_o; pts.rays_d = t->rays_d; pts.z_vals = t->z_vals; pts.n_samples = S;
-    NarutoExtraPoints ex{};
-    const bool smooth = t->smooth_points != 0 && g->table != nullptr;
-    if (smooth) { ex.x = t->smooth_x; ex.d_feat = t->smooth_d; ex.scale = t->loss_weights + 8; ex.n = w.n3; }
-    return query_bwd_impl(f, p, M, &pts, t->feat_save, t->d_raw, nullptr, t->active_idx, t->n_active, smooth ? &ex : nullptr, flags, g, w.bwd, stream, true,
-                          smooth ? (t->smooth_grad_scale != 0.0f ? t->smooth_grad_scale : 1.0f) : 1.0f);
+    if (n_front > 0) return query_bwd_impl(f, p, M, &pts, t->feat_save, t->d_raw, nullptr, t->active_idx, t->n_active, nullptr, flags, g, w.bwd, stream, n_front, bw.n_total);
+    // no smoothness term: the workspace was sized for cap = M + n3 with n3 = 0
+    return query_bwd_impl(f, p, M, &pts, t->feat_save, t->d_raw, nullptr, t->active_idx, t->n_active, nullptr, flags, g, w.bwd, stream, 0u, nullptr);
 }
 
 int naruto_composite_fwd(const NarutoField* f, uint32_t n_rays, uint32_t S, const float* raw, const float* z_vals, float* rgb, float* disp,

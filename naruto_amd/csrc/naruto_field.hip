@@ -78,6 +78,9 @@ __device__ __forceinline__ void stage_fwd_weights(FwdLds& L, const NarutoParams&
 struct TvArgs {
     uint32_t n;
     float voxel, margin, grid_size, inv_p3;
+    // cap != 0: "list" layout of the fused training path -- points go to rows of the scatter's SoA point list
+    // (x [3][cap]), features are level-major ([16][n^3][2]) so that every access is coalesced
+    uint32_t cap;
 };
 
 __device__ __forceinline__ void tv_encode_body(const LevelTab& lt, const BoxTab& bt, const TvArgs& a, const float* __restrict__ rand6,
@@ -102,9 +105,14 @@ __device__ __forceinline__ void tv_encode_body(const LevelTab& lt, const BoxTab&
         const float offset = r_off * offset_max + a.margin;
         const float p = ((float)ijk[d] + r_jit) * a.voxel + bt.bmin[d] + offset;
         xn[d] = __fdiv_rn(p - bt.bmin[d], bt.bext[d]);
-        if (level == 0) x_out[3 * (size_t)m + d] = xn[d];
+        if (level == 0) {
+            if (a.cap != 0) x_out[(size_t)d * a.cap + m] = xn[d];
+            else x_out[3 * (size_t)m + d] = xn[d];
+        }
     }
-    reinterpret_cast<float2*>(feat + (size_t)m * kFeat)[level] = hash_level_rt(lt, (int)level, table, xn[0], xn[1], xn[2]);
+    const float2 f = hash_level_rt(lt, (int)level, table, xn[0], xn[1], xn[2]);
+    if (a.cap != 0) reinterpret_cast<float2*>(feat)[(size_t)level * n3 + m] = f;
+    else reinterpret_cast<float2*>(feat + (size_t)m * kFeat)[level] = f;
 }
 
 #ifndef NARUTO_GATHER_GROUP
@@ -540,6 +548,39 @@ __device__ __forceinline__ void tv_loss_body(const TvArgs& a, const float* __res
     }
 }
 
+// list-layout variant (fused training path): feat [16][n^3][2]; the feature cotangent, already multiplied by the term's
+// weight scale_dev[0] * scale_host, goes straight into the scatter's d_feat rows [16][cap][2] at list positions 0..n^3
+__device__ __forceinline__ void tv_loss_list_body(const TvArgs& a, const float* __restrict__ feat, float* __restrict__ d_list,
+                                                  const float* __restrict__ scale_dev, float scale_host, double* __restrict__ partial, uint32_t block,
+                                                  uint32_t n_blocks, double* red) {
+    const uint32_t n = a.n, n3 = n * n * n, total = n3 * kFeat;
+    const float sc = 2.0f * a.inv_p3 * (scale_dev != nullptr ? scale_dev[0] : 1.0f) * scale_host;
+    double acc = 0.0;
+    for (uint32_t t = block * 256u + threadIdx.x; t < total; t += n_blocks * 256u) {          // (level, point, component)
+        const uint32_t level = t / (2u * n3), r = t % (2u * n3), m = r >> 1;
+        const uint32_t i = m / (n * n), j = (m / n) % n, k = m % n;
+        const float f = feat[t];
+        const uint32_t stride[3] = {2u * n * n, 2u * n, 2u};
+        const uint32_t pos[3] = {i, j, k};
+        float g = 0.0f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            if (pos[d] + 1 < n) {
+                const float df = feat[t + stride[d]] - f;
+                acc += (double)(df * df);
+                g -= df;
+            }
+            if (pos[d] > 0) g += f - feat[t - stride[d]];
+        }
+        d_list[((size_t)level * a.cap + m) * 2u + (r & 1u)] = g * sc;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[block] = red[0] + red[1] + red[2] + red[3];
+}
+
 __global__ __launch_bounds__(256) void k_tv_loss(TvArgs a, const float* __restrict__ feat, float* __restrict__ d_feat, double* __restrict__ partial) {
     __shared__ double red[4];
     tv_loss_body(a, feat, d_feat, partial, blockIdx.x, gridDim.x, red);
@@ -692,7 +733,8 @@ __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, Bo
                                                    const float* __restrict__ feat_save, const float* __restrict__ d_raw,
                                                    const float* __restrict__ d_geo, float* __restrict__ d_feat, float* __restrict__ x_out,
                                                    float* __restrict__ d_uncert_grid, float* __restrict__ partials,
-                                                   const uint32_t* __restrict__ active_idx, const uint32_t* __restrict__ n_active) {
+                                                   const uint32_t* __restrict__ active_idx, const uint32_t* __restrict__ n_active, uint32_t list_off) {
+    // list_off: position of this launch's first point in the scatter's point list (the smoothness lattice sits in front)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     BwdLds& L = *reinterpret_cast<BwdLds*>(smem_raw);
     stage_bwd_weights(L, p, threadIdx.x, blockDim.x);
@@ -715,9 +757,9 @@ __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, Bo
         float x, y, z;
         load_point(ps, bt, m, x, y, z);
         if (x_out != nullptr && valid && hh == 0) {      // normalised points [3][M] (list order) for the table scatter
-            x_out[i_pt] = x;
-            x_out[(size_t)cap + i_pt] = y;
-            x_out[2 * (size_t)cap + i_pt] = z;
+            x_out[list_off + i_pt] = x;
+            x_out[(size_t)cap + list_off + i_pt] = y;
+            x_out[2 * (size_t)cap + list_off + i_pt] = z;
         }
         float g_rgb[3], g_sdf, g_unc;
         {
@@ -853,7 +895,7 @@ __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, Bo
 #pragma unroll
                 for (int e2 = 0; e2 < 2; ++e2) {
                     const int level = e2 + 4 * q + 2 * hh;
-                    dfo[(size_t)level * cap + i_pt] = make_float2(df[4 * q + 2 * e2], df[4 * q + 2 * e2 + 1]);
+                    dfo[(size_t)level * cap + list_off + i_pt] = make_float2(df[4 * q + 2 * e2], df[4 * q + 2 * e2 + 1]);
                 }
             }
         }
@@ -885,7 +927,17 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part
     const int o = threadIdx.x & 31, slice = threadIdx.x >> 5;
     const uint32_t e = block * 32u + o;
     float s = 0.0f;
-    for (uint32_t b = slice; b < n_blocks; b += 8) s += partials[(size_t)b * kAccFloats + e];
+    // batches of 8 independent loads (each is an L2 / memory round trip), same summation order as a plain loop
+    for (uint32_t b0 = slice; b0 < n_blocks; b0 += 64u) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t b = b0 + 8u * u;
+            v[u] = b < n_blocks ? partials[(size_t)b * kAccFloats + e] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
     red[slice][o] = s;
     __syncthreads();
     if (slice != 0) return;

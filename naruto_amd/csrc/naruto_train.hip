@@ -7,7 +7,8 @@
 //   k_loss_stage = composite + per-ray loss terms (-> per-workgroup fp64 partials) | smoothness TV (-> partials)
 //   k_loss_tail  = one workgroup: partials -> sums, losses, total, iteration counter
 //   k_compact    = ray-count prefix + index write in one launch
-//   k_bwd_post   = weight-gradient reduction | append the lattice to the scatter's point list
+//   the smoothness lattice is written straight into the FRONT of the scatter's point list by the forward (points by
+//   k_tv_encode, weighted feature cotangents by the loss stage), the rendered samples follow: no append step
 //
 // Two things that were tried and measured slower on MI355X, so they are NOT done:
 //   * finishing the reductions in the last workgroup to retire (device-scope ticket): an agent-scope release fence per
@@ -34,7 +35,8 @@ struct LossStageArgs {
     uint32_t n_ray_blocks;
     // smoothness role (n_tv_blocks == 0: absent)
     TvArgs tv;
-    const float* tv_feat; float* tv_d_feat; double* tv_partial;
+    const float* tv_feat; float* tv_d_list; double* tv_partial;     // d_list: the scatter's d_feat rows [16][cap][2]
+    const float* tv_scale_dev; float tv_scale_host;                  // the term's weight: loss_weights[8] * grad scale
     uint32_t n_tv_blocks;
 };
 
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_stage(LossStageArgs
             a.partials[(size_t)blockIdx.x * 16 + k] = v;
         }
     } else {
-        tv_loss_body(a.tv, a.tv_feat, a.tv_d_feat, a.tv_partial, blockIdx.x - a.n_ray_blocks, a.n_tv_blocks, red);
+        tv_loss_list_body(a.tv, a.tv_feat, a.tv_d_list, a.tv_scale_dev, a.tv_scale_host, a.tv_partial, blockIdx.x - a.n_ray_blocks, a.n_tv_blocks, red);
     }
 }
 
@@ -208,7 +210,8 @@ __global__ void k_loss_finalize_total(const double* __restrict__ sums, uint64_t 
 // ray prefix lengths -> flat active list, one launch: every workgroup (4 rays, one wave each) sums the counts of the
 // rays before it (integer sums: any order gives the same result), then writes its rays' indices.
 __global__ __launch_bounds__(256) void k_compact(uint32_t n_rays, uint32_t S, const uint32_t* __restrict__ ray_count, uint32_t* __restrict__ ray_off,
-                                                 uint32_t* __restrict__ active_idx, uint32_t* __restrict__ n_active) {
+                                                 uint32_t* __restrict__ active_idx, uint32_t* __restrict__ n_active, uint32_t n_front,
+                                                 uint32_t* __restrict__ n_list) {
     __shared__ uint32_t red[4], cnt[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t r0 = blockIdx.x * 4u;
@@ -225,21 +228,12 @@ __global__ __launch_bounds__(256) void k_compact(uint32_t n_rays, uint32_t S, co
     if (n >= n_rays) return;
     if (lane == 0) {
         ray_off[n] = off;
-        if (n == n_rays - 1u) n_active[0] = off + c;
+        if (n == n_rays - 1u) {
+            n_active[0] = off + c;
+            if (n_list != nullptr) n_list[0] = n_front + off + c;          // length of the scatter's point list
+        }
     }
     for (uint32_t k = lane; k < c; k += 64) active_idx[off + k] = n * S + k;
-}
-
-// weight-gradient reduction | lattice append, one launch
-__global__ __launch_bounds__(256) void k_bwd_post(const float* __restrict__ partials, uint32_t n_blocks, NarutoGrads g, int overwrite, uint32_t n_wgrad_blocks,
-                                                  uint32_t E, const float* __restrict__ ex, const float* __restrict__ ed, const float* __restrict__ scale_dev,
-                                                  float scale_host, const uint32_t* __restrict__ n_base_dev, uint32_t n_base_host, uint32_t cap,
-                                                  float* __restrict__ x_soa, float* __restrict__ d_feat, uint32_t* __restrict__ n_total) {
-    if (blockIdx.x < n_wgrad_blocks) {
-        wgrad_reduce_body(partials, n_blocks, g, overwrite, blockIdx.x);
-        return;
-    }
-    append_points_body(E, ex, ed, scale_dev, scale_host, n_base_dev, n_base_host, cap, x_soa, d_feat, n_total, blockIdx.x - n_wgrad_blocks);
 }
 
 }  // namespace naruto

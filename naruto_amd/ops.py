@@ -611,10 +611,6 @@ class TrainStep:
         self.d_raw = torch.empty(N, S, 5, **f32)
         self.ray_count, self.ray_offset = torch.empty(N, **i32), torch.empty(N, **i32)
         self.active_idx, self.n_active = torch.empty(M, **i32), torch.zeros(1, **i32)
-        n3 = 0
-        if smooth is not None:
-            n3 = (int(smooth[0]) - 1) ** 3
-        self.smooth_x, self.smooth_d = (torch.empty(n3, 3, **f32), torch.empty(n3, 32, **f32)) if n3 else (None, None)
         self.flat_grad = torch.zeros(sum(self.params[n].numel() for n in self.FLAT_NAMES), **f32)
         self.grads, off = {}, 0
         for n in self.FLAT_NAMES:
@@ -634,7 +630,6 @@ class TrainStep:
         if smooth is not None:
             t.smooth_points, t.smooth_voxel, t.smooth_margin = int(smooth[0]), float(smooth[1]), float(smooth[2])
             t.smooth_grad_scale = 1.0 / world            # every rank adds the same lattice's gradient; the sum over ranks is one term
-            t.smooth_x, t.smooth_d = _p(self.smooth_x), _p(self.smooth_d)
         t.n_rays_total = int(n_rays_total) if n_rays_total else N * world
         self._set_rng_mode(self.device_rng)
         t.loss_weights = _p(self.loss_weights)

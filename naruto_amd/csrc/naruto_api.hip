@@ -417,8 +417,8 @@ TrainWs train_ws(const NarutoField* f, const NarutoTrainStep* t) {
     const size_t M = (size_t)t->n_rays * S;
     const uint32_t n = t->smooth_points > 1 ? t->smooth_points - 1 : 0;
     w.n3 = n * n * n;
-    w.n_tv_blocks = (w.n3 * (uint32_t)kFeat + 255u) / 256u;        // smoothness role blocks of the loss stage (grid-stride beyond 512)
-    if (w.n_tv_blocks > 512u) w.n_tv_blocks = 512u;
+    w.n_tv_blocks = (w.n3 * (uint32_t)kFeat + 255u) / 256u;        // smoothness role blocks of the loss stage (grid-stride beyond 512: more
+    if (w.n_tv_blocks > 512u) w.n_tv_blocks = 512u;                // blocks only move the time into the one-workgroup tail)
     auto al = [](size_t b) { return (b + 255u) / 256u * 256u; };
     size_t off = 0;
     char* base = reinterpret_cast<char*>(t->workspace);

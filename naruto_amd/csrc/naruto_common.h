@@ -324,16 +324,58 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// Wave-wide reductions on the VALU's DPP path (4 dependent DPP ops + 4 v_readlane) instead of six ds_bpermute round
+// trips through the LDS crossbar (what __shfl_xor compiles to): the per-ray kernels are chains of 10-20 of these.
+// Tree: pairs, quads (quad_perm), 8-groups (row_half_mirror), rows of 16 (row_mirror), then ((r0 + r1) + r2) + r3.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) { return __builtin_bit_cast(float, dpp_i32<CTRL>(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ float lane_f32(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
+
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f32<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);        // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);       // row_half_mirror
+    v += dpp_f32<0x140>(v);       // row_mirror
+    return ((lane_f32(v, 0) + lane_f32(v, 16)) + lane_f32(v, 32)) + lane_f32(v, 48);
 }
 
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fminf(v, dpp_f32<0xB1>(v));
+    v = fminf(v, dpp_f32<0x4E>(v));
+    v = fminf(v, dpp_f32<0x141>(v));
+    v = fminf(v, dpp_f32<0x140>(v));
+    return fminf(fminf(lane_f32(v, 0), lane_f32(v, 16)), fminf(lane_f32(v, 32), lane_f32(v, 48)));
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = min(v, (uint32_t)dpp_i32<0xB1>((int)v));
+    v = min(v, (uint32_t)dpp_i32<0x4E>((int)v));
+    v = min(v, (uint32_t)dpp_i32<0x141>((int)v));
+    v = min(v, (uint32_t)dpp_i32<0x140>((int)v));
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return min(min(a, b), min(c, d));
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = max(v, (uint32_t)dpp_i32<0xB1>((int)v));
+    v = max(v, (uint32_t)dpp_i32<0x4E>((int)v));
+    v = max(v, (uint32_t)dpp_i32<0x141>((int)v));
+    v = max(v, (uint32_t)dpp_i32<0x140>((int)v));
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return max(max(a, b), max(c, d));
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+    v += (uint32_t)dpp_i32<0xB1>((int)v);
+    v += (uint32_t)dpp_i32<0x4E>((int)v);
+    v += (uint32_t)dpp_i32<0x141>((int)v);
+    v += (uint32_t)dpp_i32<0x140>((int)v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) +
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }

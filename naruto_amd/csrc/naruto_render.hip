@@ -104,8 +104,7 @@ __device__ __forceinline__ RayWeights ray_weights(const RayScratch& rs, uint32_t
     for (uint32_t s = lane; s + 1 < S; s += 64) {
         if (rs.sdf[s] * rs.sdf[s + 1] < 0.0f) { first = s; break; }     // lane-local first; strided => global min below
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) first = min(first, (uint32_t)__shfl_xor((int)first, o, 64));
+    first = wave_min_u32(first);
     RayWeights rw;
     rw.z_min = rs.z[first == 0xFFFFFFFFu ? 0u : first];
     rw.limit = rw.z_min + sc_factor * trunc;
@@ -445,8 +444,7 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_composite_bwd(uint32_t n
         if (o0 != 0.0f || o1 != 0.0f || o2 != 0.0f || g_s != 0.0f || o4 != 0.0f) last_nz = s + 1u;
     }
     if (ray_count != nullptr) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) last_nz = max(last_nz, (uint32_t)__shfl_xor((int)last_nz, o, 64));
+        last_nz = wave_max_u32(last_nz);
         if (lane == 0) ray_count[n] = last_nz;
     }
 }

@@ -217,8 +217,7 @@ __global__ __launch_bounds__(256) void k_compact(uint32_t n_rays, uint32_t S, co
     const uint32_t r0 = blockIdx.x * 4u;
     uint32_t s = 0;
     for (uint32_t i = threadIdx.x; i < r0; i += 256u) s += ray_count[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += (uint32_t)__shfl_xor((int)s, o, 64);
+    s = wave_sum_u32(s);
     const uint32_t n = r0 + wave;
     const uint32_t c = n < n_rays ? ray_count[n] : 0u;
     if (lane == 0) { red[wave] = s; cnt[wave] = c; }

@@ -748,14 +748,39 @@ __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, Bo
     float* __restrict__ ga = L.ga[wave];
     float* __restrict__ gb = L.gb[wave];
     f32x16 dW0a = zero16(), dW0b = zero16(), dW0c = zero16(), dW1 = zero16(), dWc0a = zero16(), dWc0b = zero16(), dWc1 = zero16();
-    for (uint32_t tile = blockIdx.x * 4u + wave; tile < n_tiles; tile += gridDim.x * 4u) {
+    // Inputs of a tile (list index -> sample index -> point, cotangent, saved hash features): with one wave per SIMD
+    // nothing else hides these dependent trips to L2 / memory, so the NEXT tile's inputs are fetched while the current
+    // tile computes (software prefetch, ~30 registers).
+    struct TileIn {
+        uint32_t i_pt, m;
+        bool valid;
+        float x, y, z, g[5], feat[kLevels];
+    };
+    auto load_tile = [&](uint32_t tile) {
+        TileIn t;
         // lanes j and j+32 both work on list entry i = tile*32 + j (point m); hh selects the K-pair component
         const uint32_t i_raw = tile * 32u + j;
-        const bool valid = i_raw < M_eff;
-        const uint32_t i_pt = valid ? i_raw : M_eff - 1u;
-        const uint32_t m = active_idx != nullptr ? active_idx[i_pt] : i_pt;
-        float x, y, z;
-        load_point(ps, bt, m, x, y, z);
+        t.valid = i_raw < M_eff;
+        t.i_pt = t.valid ? i_raw : M_eff - 1u;
+        t.m = active_idx != nullptr ? active_idx[t.i_pt] : t.i_pt;
+        load_point(ps, bt, t.m, t.x, t.y, t.z);
+        const float* g = d_raw + (size_t)t.m * 5;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) t.g[q] = g[q];
+#pragma unroll
+        for (int T = 0; T < kLevels; ++T) t.feat[T] = feat_save[((size_t)T * M + t.m) * 2 + hh];
+        return t;
+    };
+    const uint32_t tile_stride = gridDim.x * 4u;
+    uint32_t tile = blockIdx.x * 4u + wave;
+    TileIn nxt;
+    if (tile < n_tiles) nxt = load_tile(tile);
+    for (; tile < n_tiles; tile += tile_stride) {
+        const TileIn cur = nxt;
+        if (tile + tile_stride < n_tiles) nxt = load_tile(tile + tile_stride);
+        const bool valid = cur.valid;
+        const uint32_t i_pt = cur.i_pt, m = cur.m;
+        const float x = cur.x, y = cur.y, z = cur.z;
         if (x_out != nullptr && valid && hh == 0) {      // normalised points [3][M] (list order) for the table scatter
             x_out[list_off + i_pt] = x;
             x_out[(size_t)cap + list_off + i_pt] = y;
@@ -763,10 +788,10 @@ __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, Bo
         }
         float g_rgb[3], g_sdf, g_unc;
         {
-            const float* g = d_raw + (size_t)m * 5;     // padding lanes: zero cotangent => zero contribution
-            g_rgb[0] = valid ? g[0] : 0.0f; g_rgb[1] = valid ? g[1] : 0.0f; g_rgb[2] = valid ? g[2] : 0.0f;
-            g_sdf = valid ? g[3] : 0.0f;
-            g_unc = valid ? g[4] : 0.0f;
+            // padding lanes: zero cotangent => zero contribution
+            g_rgb[0] = valid ? cur.g[0] : 0.0f; g_rgb[1] = valid ? cur.g[1] : 0.0f; g_rgb[2] = valid ? cur.g[2] : 0.0f;
+            g_sdf = valid ? cur.g[3] : 0.0f;
+            g_unc = valid ? cur.g[4] : 0.0f;
         }
         // uncertainty grid: raw[...,4] is the trilinear sample itself (the decoder passes it through)
         if (d_uncert_grid != nullptr && hh == 0 && g_unc != 0.0f) {
@@ -781,7 +806,7 @@ __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, Bo
         f32x16 h = zero16(), c = zero16();
         static_for<0, kLevels>([&](auto tc) {
             constexpr int T = decltype(tc)::value;
-            const float b = feat_save[((size_t)T * M + m) * 2 + hh];
+            const float b = cur.feat[T];
             xs[j * kStageLd + 2 * T + hh] = valid ? b : 0.0f;
             h = mfma32(L.f.s0[T * 64 + lane], b, h);
         });

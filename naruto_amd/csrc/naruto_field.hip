@@ -49,26 +49,45 @@ struct FwdLds {
     float c1[3 * 16 * 2];  // colour layer 1 (VALU): [c][r][hh] = col_w1[c][crow(r,hh)]
 };
 
-__device__ __forceinline__ void stage_fwd_weights(FwdLds& L, const NarutoParams& p, int tid, int nthreads) {
-    for (int e = tid; e < 40 * 64; e += nthreads) {
+// NT (threads per workgroup) is a compile-time constant so that the loops unroll completely and all of a thread's loads
+// (strided reads of the row-major weights: one cache line per lane) are in flight together; with a runtime stride the
+// 22 (forward) / 62 (backward) loads per thread were issued one L2 round trip after the other
+template <int NT>
+__device__ __forceinline__ void stage_fwd_weights(FwdLds& L, const NarutoParams& p, int tid) {
+    constexpr int nthreads = NT;
+#pragma unroll
+    for (int e0 = 0; e0 < 40 * 64; e0 += NT) {
+        const int e = e0 + tid;
         const int t = e >> 6, l = e & 63, i = l & 31, kk = l >> 5;
         const int col = t < 16 ? 2 * t + kk : kFeat + 2 * (t - 16) + kk;
         L.s0[e] = p.sdf_w0[i * kInSdf + col];
     }
-    for (int e = tid; e < 24 * 64; e += nthreads) {
+#pragma unroll
+    for (int e0 = 0; e0 < 24 * 64; e0 += nthreads) {
+        const int e = e0 + tid;
+        if (e >= 24 * 64) continue;
         const int t = e >> 6, l = e & 63, i = l & 31, kk = l >> 5;
         L.c0p[e] = p.col_w0[i * kInCol + 2 * t + kk];
     }
-    for (int e = tid; e < 16 * 64; e += nthreads) {
+#pragma unroll
+    for (int e0 = 0; e0 < 16 * 64; e0 += nthreads) {
+        const int e = e0 + tid;
+        if (e >= 16 * 64) continue;
         const int t = e >> 6, l = e & 63, i = l & 31, kk = l >> 5;
         L.s1[e] = i < kOut ? p.sdf_w1[i * kHidden + crow(t, kk)] : 0.0f;
     }
-    for (int e = tid; e < 8 * 64; e += nthreads) {
+#pragma unroll
+    for (int e0 = 0; e0 < 8 * 64; e0 += nthreads) {
+        const int e = e0 + tid;
+        if (e >= 8 * 64) continue;
         const int r = e >> 6, l = e & 63, i = l & 31, kk = l >> 5;
         const int row = crow(r, kk);                      // sdf-net output row 0..15; row 0 is the sdf
         L.c0g[e] = row >= 1 ? p.col_w0[i * kInCol + kPos + row - 1] : 0.0f;
     }
-    for (int e = tid; e < 3 * 16 * 2; e += nthreads) {
+#pragma unroll
+    for (int e0 = 0; e0 < 3 * 16 * 2; e0 += nthreads) {
+        const int e = e0 + tid;
+        if (e >= 3 * 16 * 2) continue;
         const int c = e / 32, r = (e >> 1) & 15, hh = e & 1;
         L.c1[e] = p.col_w1[c * kHidden + crow(r, hh)];
     }
@@ -128,7 +147,7 @@ __global__ __launch_bounds__(256, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab
                                                    uint32_t M, float* __restrict__ raw, float* __restrict__ sdf_uncert,
                                                    float* __restrict__ geo, float* __restrict__ feat_save) {
     __shared__ FwdLds L;
-    stage_fwd_weights(L, p, threadIdx.x, blockDim.x);
+    stage_fwd_weights<256>(L, p, threadIdx.x);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hh = lane >> 5, j = lane & 31;
@@ -644,17 +663,28 @@ struct BwdLds {
     float gb[4][32 * kGradLd];    // per wave: activation stage  [point][32]
 };
 
-__device__ __forceinline__ void stage_bwd_weights(BwdLds& L, const NarutoParams& p, int tid, int nthreads) {
-    stage_fwd_weights(L.f, p, tid, nthreads);
-    for (int e = tid; e < 16 * 64; e += nthreads) {
+template <int NT>
+__device__ __forceinline__ void stage_bwd_weights(BwdLds& L, const NarutoParams& p, int tid) {
+    constexpr int nthreads = NT;
+    stage_fwd_weights<NT>(L.f, p, tid);
+#pragma unroll
+    for (int e0 = 0; e0 < 16 * 64; e0 += nthreads) {
+        const int e = e0 + tid;
+        if (e >= 16 * 64) continue;
         const int t = e >> 6, l = e & 63, i = l & 31, kk = l >> 5;
         L.s0T[e] = p.sdf_w0[crow(t, kk) * kInSdf + i];
     }
-    for (int e = tid; e < 8 * 64; e += nthreads) {
+#pragma unroll
+    for (int e0 = 0; e0 < 8 * 64; e0 += nthreads) {
+        const int e = e0 + tid;
+        if (e >= 8 * 64) continue;
         const int r = e >> 6, l = e & 63, i = l & 31, kk = l >> 5;
         L.s1T[e] = p.sdf_w1[crow(r, kk) * kHidden + i];        // crow(r,kk) in 0..15 for r<8
     }
-    for (int e = tid; e < 16 * 64; e += nthreads) {
+#pragma unroll
+    for (int e0 = 0; e0 < 16 * 64; e0 += nthreads) {
+        const int e = e0 + tid;
+        if (e >= 16 * 64) continue;
         const int t = e >> 6, l = e & 63, i = l & 31, kk = l >> 5;
         L.c0gT[e] = (i >= 1 && i < kOut) ? p.col_w0[crow(t, kk) * kInCol + kPos + i - 1] : 0.0f;
     }
@@ -737,7 +767,7 @@ __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, Bo
     // list_off: position of this launch's first point in the scatter's point list (the smoothness lattice sits in front)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     BwdLds& L = *reinterpret_cast<BwdLds*>(smem_raw);
-    stage_bwd_weights(L, p, threadIdx.x, blockDim.x);
+    stage_bwd_weights<256>(L, p, threadIdx.x);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hh = lane >> 5, j = lane & 31;

@@ -295,10 +295,12 @@ int naruto_query_fwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
     const uint32_t cap = cu_count(f) * 4u;
     if (blocks > cap) blocks = cap;
     const PointSrc ps = make_points(pts);
+    const EarlyExit none{};
     if (color)
-        hipLaunchKernelGGL(k_query_fwd<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, f->lt, f->ut, f->bt, pp, ps, M, raw, sdf_uncert, geo, feat_save);
+        hipLaunchKernelGGL(k_query_fwd<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, f->lt, f->ut, f->bt, pp, ps, M, raw, sdf_uncert, geo, feat_save, none);
     else
-        hipLaunchKernelGGL(k_query_fwd<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, f->lt, f->ut, f->bt, pp, ps, M, raw, sdf_uncert, geo, feat_save);
+        hipLaunchKernelGGL(k_query_fwd<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, f->lt, f->ut, f->bt, pp, ps, M, raw, sdf_uncert, geo, feat_save,
+                           none);
     return check_launch("query_fwd");
 }
 
@@ -491,7 +493,16 @@ int naruto_train_forward(const NarutoField* f, const NarutoParams* p, const Naru
     const uint32_t n_tiles = (M + 63u) / 64u;
     uint32_t blocks = (n_tiles + 3u) / 4u;
     if (blocks > cu_count(f) * 4u) blocks = cu_count(f) * 4u;
-    hipLaunchKernelGGL(k_query_fwd<true>, dim3(blocks), dim3(256), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save);
+    EarlyExit ee{};
+    static const bool no_ee = getenv("NARUTO_DEBUG_NO_EARLY_EXIT") != nullptr;             // profiling knob
+    if (S % 64u == 0u && S > 64u && !no_ee) {      // depth-ordered early termination: one wave per ray, front to back
+        ee.target_d = t->target_d;
+        ee.trunc_sc = f->desc.trunc * f->desc.sc_factor;
+        ee.tiles_per_ray = S / 64u;
+        blocks = (N + 3u) / 4u;
+        if (blocks > cu_count(f) * 4u) blocks = cu_count(f) * 4u;
+    }
+    hipLaunchKernelGGL(k_query_fwd<true>, dim3(blocks), dim3(256), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
     if (int rc = check_launch("query_fwd")) return rc;
     // A6..A8 (+ the lattice's TV term), then the one-workgroup tail
     LossStageArgs a{};

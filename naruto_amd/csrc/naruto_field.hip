@@ -142,10 +142,23 @@ __device__ __forceinline__ void tv_encode_body(const LevelTab& lt, const BoxTab&
 #endif
 constexpr int kGatherGroup = NARUTO_GATHER_GROUP;
 
+// Depth-ordered early termination for the TRAINING forward (tiles_per_ray != 0: rays with depth-sorted samples, S a
+// multiple of 64, one wave walks one ray front to back).  What the losses, the compositing and the backward can see of
+// a ray ends at max(first sign change of the sdf, measured depth) + truncation: beyond that the compositing weight is
+// exactly 0 (sdf2weights masks z >= z_first + sc*trunc), the loss masks are exactly 0 (get_masks: z > d + trunc) and
+// the "first sign change" is already decided.  Once a 64-sample tile has found the sign change and its last sample is
+// past both limits, the ray's remaining tiles are not evaluated; their raw entries are written as zeros (which no
+// consumer can tell from the real values).  Same idea as the backward's active prefix; outputs are bit-identical.
+struct EarlyExit {
+    const float* target_d;
+    float trunc_sc;
+    uint32_t tiles_per_ray;
+};
+
 template <bool COLOR>
 __global__ __launch_bounds__(256, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps,
                                                    uint32_t M, float* __restrict__ raw, float* __restrict__ sdf_uncert,
-                                                   float* __restrict__ geo, float* __restrict__ feat_save) {
+                                                   float* __restrict__ geo, float* __restrict__ feat_save, EarlyExit ee) {
     __shared__ FwdLds L;
     stage_fwd_weights<256>(L, p, threadIdx.x);
     __syncthreads();
@@ -154,7 +167,13 @@ __global__ __launch_bounds__(256, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab
     const uint32_t n_tiles = (M + 63u) / 64u;
     const float2* __restrict__ table = reinterpret_cast<const float2*>(p.table);
     float2* __restrict__ feat_out = reinterpret_cast<float2*>(feat_save);
-    for (uint32_t tile = blockIdx.x * 4u + wave; tile < n_tiles; tile += gridDim.x * 4u) {
+    const uint32_t tpr = ee.tiles_per_ray;
+    const uint32_t n_tasks = tpr ? n_tiles / tpr : n_tiles;          // rays, or tiles of the flat point list
+    for (uint32_t task = blockIdx.x * 4u + wave; task < n_tasks; task += gridDim.x * 4u) {
+    bool ee_found = false;                       // per ray (wave-uniform): first sign change seen, its depth, the last sample so far
+    float ee_zfirst = 0.0f, ee_prev_sdf = 0.0f, ee_prev_z = 0.0f;
+    for (uint32_t tq = 0; tq < (tpr ? tpr : 1u); ++tq) {
+        const uint32_t tile = tpr ? task * tpr + tq : task;
         const uint32_t m_raw = tile * 64u + lane;
         const bool valid = m_raw < M;
         const uint32_t m = valid ? m_raw : M - 1u;       // padding lanes redo the last point, stores masked
@@ -257,6 +276,36 @@ __global__ __launch_bounds__(256, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab
                 o[0] = rgb[0]; o[1] = rgb[1]; o[2] = rgb[2]; o[3] = sdf; o[4] = u;
             }
         }
+        if (tpr != 0u && tq + 1u < tpr) {
+            const float zs = ps.z_vals[m];
+            if (!ee_found) {
+                if (tq > 0u && ee_prev_sdf * lane_f32(sdf, 0) < 0.0f) {          // the pair straddling the tile boundary
+                    ee_found = true;
+                    ee_zfirst = ee_prev_z;
+                } else {
+                    const float nb = __shfl_down(sdf, 1, 64);
+                    const uint32_t first = wave_min_u32((lane < 63 && sdf * nb < 0.0f) ? (uint32_t)lane : 0xFFFFFFFFu);
+                    if (first != 0xFFFFFFFFu) {
+                        ee_found = true;
+                        ee_zfirst = __shfl(zs, (int)first, 64);
+                    }
+                }
+            }
+            const float z_last = lane_f32(zs, 63);
+            ee_prev_sdf = lane_f32(sdf, 63);
+            ee_prev_z = z_last;
+            if (ee_found) {
+                // conservative margin: the consumers form z_first + sc*trunc and d + sc*trunc with their own rounding
+                const float lim = fmaxf(ee_zfirst, ee.target_d[task]) + ee.trunc_sc;
+                if (z_last > lim + 1e-5f * fabsf(lim) + 1e-6f) {
+                    if (raw != nullptr) {
+                        for (uint32_t k = (tile + 1u) * 64u * 5u + lane; k < (task + 1u) * tpr * 64u * 5u; k += 64u) raw[k] = 0.0f;
+                    }
+                    break;
+                }
+            }
+        }
+    }
     }
 }
 

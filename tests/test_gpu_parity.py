@@ -418,13 +418,16 @@ def test_train_node_with_fused_smoothness(gpu):
         grad_close(H.hip_grads(m)[k], 2 * go[k], f"fused.grad2.{k}")
 
 
-def test_train_step_direct_against_oracle(gpu):
+@pytest.mark.parametrize("n_samples_d", [32, 117, 181])
+def test_train_step_direct_against_oracle(gpu, n_samples_d):
     """naruto_train_forward / naruto_train_backward (the trainer's fast path: role blocks, last-workgroup reductions,
     no autograd) against the oracle, with the smoothness term, zero-depth rays and a given jitter draw; run twice to
     check that the self-resetting tickets and the written-not-accumulated gradients hold up, and that the
-    uncertainty-grid gradient accumulates."""
+    uncertainty-grid gradient accumulates.  n_samples_d = 117 / 181 make S = 128 / 192 = 2 / 3 tiles of 64 samples per
+    ray: the forward then walks each ray front to back and stops evaluating once nothing behind can matter (EarlyExit in
+    naruto_field.hip) -- losses and gradients must not change, and some rays must actually have stopped early."""
     from naruto_amd import ops
-    cfg = H.office_cfg(12, perturb=1.0)
+    cfg = H.office_cfg(12, perturb=1.0, n_samples_d=n_samples_d)
     tr, cam = cfg["training"], cfg["cam"]
     ora = H.make_oracle(cfg, 0.25, 43)
     m = H.make_hip_from_oracle(cfg, ora, gpu)
@@ -463,6 +466,10 @@ def test_train_step_direct_against_oracle(gpu):
         for k in ("table", "sdf_w0", "sdf_w1", "col_w0", "col_w1"):
             grad_close(ts.grads[k].reshape(-1), go[k].reshape(-1), f"direct.rep{rep}.grad.{k}")
         grad_close(ug.reshape(-1), (rep + 1) * ora.uncert_grid.grad.reshape(-1), f"direct.rep{rep}.grad.uncert_grid")
+    if S_tot % 64 == 0:
+        tail = ts.raw[:, 64:, :].reshape(N, -1)
+        n_stopped = int((tail.abs().sum(1) == 0).sum().item())
+        assert 0 < n_stopped < N, f"early termination: {n_stopped} of {N} rays stopped after the first tile"
 
 
 def test_train_step_device_rng(gpu):

@@ -278,11 +278,21 @@ typedef struct NarutoTrainStep {
     uint32_t *ray_count, *ray_offset, *active_idx, *n_active;  /* [N] [N] [N*S] [1]  (backward)               */
     void *workspace;                                  /* naruto_train_workspace() bytes                       */
 } NarutoTrainStep;
+/* Optimiser in the backward (single process): the launch that finishes the gradients applies torch.optim.Adam
+ * (amsgrad off, L2 weight decay; reference create_optimizer, coslam.py:409-419) to the table and the MLP weights in
+ * place.  Tensor order: table, sdf_w0, sdf_w1, col_w0, col_w1.  Needs every level LDS-tiled (log2_hashmap_size <= 16). */
+typedef struct NarutoFusedAdam {
+    float* param[5]; float* exp_avg[5]; float* exp_avg_sq[5];
+    float lr[5], eps[5], weight_decay[5];
+    float beta1, beta2;
+    const int32_t* step_dev;              /* device int32: this step's 1-based number                               */
+} NarutoFusedAdam;
 size_t naruto_train_workspace(const NarutoField* f, const NarutoTrainStep* t);
 int naruto_train_forward(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, int finalize, void* stream);
 int naruto_train_finalize(const NarutoField* f, const NarutoTrainStep* t, void* stream);
 int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, const NarutoGrads* g,
-                          uint32_t flags, void* stream);
+                          uint32_t flags, const NarutoFusedAdam* opt /* NULL: gradients only; else g's table / weight
+                          pointers may be NULL (gradients not materialised) */, void* stream);
 
 /* Hardware self-checks used by the GPU tests: the MFMA / permlane layouts the kernels rely on.
  * out: device buffer of 64*16 floats; returns 0 and fills out (see tests/test_gpu_intrinsics.py). */

@@ -55,6 +55,12 @@ ADAM_ADVANCE = 1
 ADAM_ZERO_GRAD = 2
 
 
+class NarutoFusedAdam(C.Structure):
+    _fields_ = [("param", C.c_void_p * 5), ("exp_avg", C.c_void_p * 5), ("exp_avg_sq", C.c_void_p * 5),
+                ("lr", C.c_float * 5), ("eps", C.c_float * 5), ("weight_decay", C.c_float * 5),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("step_dev", C.c_void_p)]
+
+
 class NarutoTrainStep(C.Structure):
     _fields_ = [
         ("n_rays", C.c_uint32), ("n_samples_d", C.c_uint32), ("n_range_d", C.c_uint32), ("perturb", C.c_uint32),
@@ -128,7 +134,8 @@ SIGNATURES = {
     "naruto_train_workspace": (C.c_size_t, [_V, C.POINTER(NarutoTrainStep)]),
     "naruto_train_forward": (_I, [_V, C.POINTER(NarutoParams), C.POINTER(NarutoTrainStep), _I, _V]),
     "naruto_train_finalize": (_I, [_V, C.POINTER(NarutoTrainStep), _V]),
-    "naruto_train_backward": (_I, [_V, C.POINTER(NarutoParams), C.POINTER(NarutoTrainStep), C.POINTER(NarutoGrads), _U32, _V]),
+    "naruto_train_backward": (_I, [_V, C.POINTER(NarutoParams), C.POINTER(NarutoTrainStep), C.POINTER(NarutoGrads), _U32,
+                                   C.POINTER(NarutoFusedAdam), _V]),
     "naruto_compact_active": (_I, [_U32, _U32, _V, _V, _V, _V, _V]),
     "naruto_composite_fwd": (_I, [_V, _U32, _U32, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V]),
     "naruto_composite_bwd": (_I, [_V, _U32, _U32, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V, _I, _V]),

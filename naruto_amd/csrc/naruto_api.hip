@@ -65,7 +65,8 @@ constexpr uint32_t kBwdMaxBlocks = 256;     // one 145 KB-LDS block per CU
 
 // table scatter: LDS-tiled units + k_scatter_reduce, and/or the global-atomic kernel for oversized levels
 int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const float* d_feat, size_t stride_m, size_t stride_l, float* d_table,
-                   float* partial, hipStream_t st, const uint32_t* m_dev = nullptr, const float* scale_dev = nullptr, int overwrite = 0) {
+                   float* partial, hipStream_t st, const uint32_t* m_dev = nullptr, const float* scale_dev = nullptr, int overwrite = 0,
+                   bool do_reduce = true) {
     if (overwrite && f->plan.atomic_levels != 0) return fail(NARUTO_ERR_INVALID, "scatter: overwrite mode needs every level LDS-tiled (log2_hashmap_size <= 17)");
     const size_t n_params = (size_t)f->n_entries * 2u;
     if (f->plan.n_dense + f->plan.n_hashed > 0) {
@@ -80,6 +81,7 @@ int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const f
         hipLaunchKernelGGL(k_hash_scatter_lds, dim3(blocks), dim3(kScatterThreads), lds, st, f->lt, f->bt, ps, M, d_feat, stride_m, stride_l, f->plan,
                            partial, n_params, m_dev, scale_dev);
         if (int rc = check_launch("hash_scatter_lds")) return rc;
+        if (!do_reduce) return NARUTO_OK;          // the caller finishes the gradient itself (k_bwd_finish)
         hipLaunchKernelGGL(k_scatter_reduce, dim3((uint32_t)((n_params / 4u + 255u) / 256u)), dim3(256), 0, st, f->lt, f->plan.atomic_levels, partial,
                            f->plan.s_dense, f->plan.s_hashed, n_params, d_table, overwrite);
         if (int rc = check_launch("scatter_reduce")) return rc;
@@ -331,7 +333,8 @@ BwdWs bwd_ws(const NarutoField* f, void* workspace, uint32_t cap) {
 // and weighted feature cotangents), this launch's points follow; n_list_dev = device word holding n_front + n_active.
 int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, const NarutoPoints* pts, const float* feat_save,
                    const float* d_raw, const float* d_geo, const uint32_t* active_idx, const uint32_t* n_active, const NarutoExtraPoints* extra,
-                   uint32_t flags, const NarutoGrads* g, void* workspace, void* stream, uint32_t n_front, const uint32_t* n_list_dev) {
+                   uint32_t flags, const NarutoGrads* g, void* workspace, void* stream, uint32_t n_front, const uint32_t* n_list_dev,
+                   const AdamFuse* adam = nullptr) {
     if ((active_idx == nullptr) != (n_active == nullptr)) return fail(NARUTO_ERR_INVALID, "query_bwd: active_idx and n_active go together");
     if (n_front > 0 && (extra != nullptr || n_list_dev == nullptr)) return fail(NARUTO_ERR_INVALID, "query_bwd: front list excludes extra points");
     const uint32_t E = n_front > 0 ? n_front : ((extra != nullptr && g != nullptr && g->table != nullptr) ? extra->n : 0u);
@@ -359,8 +362,24 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
         attr_set = true;
     }
     hipLaunchKernelGGL(k_query_bwd, dim3(blocks), dim3(256), sizeof(BwdLds), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, ps, M, cap, feat_save, d_raw,
-                       d_geo, d_feat, g->table != nullptr ? x_soa : nullptr, g->uncert_grid, partials, active_idx, n_active, n_front);
+                       d_geo, d_feat, (g->table != nullptr || adam != nullptr) ? x_soa : nullptr, g->uncert_grid, partials, active_idx, n_active, n_front);
     if (int rc = check_launch("query_bwd")) return rc;
+    if (adam != nullptr) {
+        // optimiser in the backward: scatter without its reduce, then ONE launch finishes table + weight gradients and steps
+        if (f->plan.atomic_levels != 0) return fail(NARUTO_ERR_INVALID, "query_bwd: the fused optimiser needs every level LDS-tiled (log2_hashmap_size <= 16)");
+        PointSrc pss{};
+        pss.xsoa = x_soa;
+        pss.M = cap;
+        pss.S = 1;
+        if (int rc = launch_scatter(f, pss, cap, d_feat, (size_t)2, (size_t)2 * (size_t)cap, nullptr, scatter_ws, (hipStream_t)stream,
+                                    n_front > 0 ? n_list_dev : n_active, nullptr, 1, false))
+            return rc;
+        const size_t n_params = (size_t)f->n_entries * 2u;
+        const uint32_t n_table_blocks = (uint32_t)((n_params / 4u + 255u) / 256u);
+        hipLaunchKernelGGL(k_bwd_finish, dim3(n_table_blocks + kAccFloats / 32), dim3(256), 0, (hipStream_t)stream, f->lt, scatter_ws, f->plan.s_dense,
+                           f->plan.s_hashed, n_params, partials, blocks, *g, *adam, n_table_blocks);
+        return check_launch("bwd_finish");
+    }
     const bool want_w = g->sdf_w0 || g->sdf_w1 || g->col_w0 || g->col_w1;
     if (want_w) {
         hipLaunchKernelGGL(k_wgrad_reduce, dim3(kAccFloats / 32), dim3(256), 0, (hipStream_t)stream, partials, blocks, *g,
@@ -538,8 +557,20 @@ int naruto_train_finalize(const NarutoField* f, const NarutoTrainStep* t, void* 
     return check_launch("loss_finalize_total");
 }
 
-int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, const NarutoGrads* g, uint32_t flags, void* stream) {
+int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, const NarutoGrads* g, uint32_t flags,
+                          const NarutoFusedAdam* opt, void* stream) {
     if (int rc = train_check(f, p, t, "train_backward")) return rc;
+    AdamFuse adam{};
+    if (opt != nullptr) {
+        if (opt->step_dev == nullptr) return fail(NARUTO_ERR_INVALID, "train_backward: the fused optimiser needs step_dev");
+        for (int k = 0; k < 5; ++k) {
+            if (opt->param[k] == nullptr || opt->exp_avg[k] == nullptr || opt->exp_avg_sq[k] == nullptr)
+                return fail(NARUTO_ERR_INVALID, "train_backward: NULL tensor %d in NarutoFusedAdam", k);
+            adam.p[k] = opt->param[k]; adam.m[k] = opt->exp_avg[k]; adam.v[k] = opt->exp_avg_sq[k];
+            adam.lr[k] = opt->lr[k]; adam.eps[k] = opt->eps[k]; adam.wd[k] = opt->weight_decay[k];
+        }
+        adam.b1 = opt->beta1; adam.b2 = opt->beta2; adam.step_dev = opt->step_dev; adam.on = 1;
+    }
     if (g == nullptr || t->loss_weights == nullptr || t->feat_save == nullptr || t->d_raw == nullptr || t->ray_count == nullptr || t->ray_offset == nullptr ||
         t->active_idx == nullptr || t->n_active == nullptr)
         return fail(NARUTO_ERR_INVALID, "train_backward: NULL buffer");
@@ -552,16 +583,18 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
     hipLaunchKernelGGL(k_composite_bwd<true>, dim3((N + kRaysPerBlock - 1) / kRaysPerBlock), dim3(64 * kRaysPerBlock), 0, st, N, S, f->desc.trunc,
                        f->desc.sc_factor, f->desc.white_bkgd, t->raw, t->z_vals, cot, la, t->d_raw, 0, t->ray_count);
     if (int rc = check_launch("loss_bwd")) return rc;
-    const bool smooth = t->smooth_points != 0 && g->table != nullptr;
+    const bool smooth = t->smooth_points != 0 && (g->table != nullptr || opt != nullptr);
     const uint32_t n_front = smooth ? w.n3 : 0u;
     const BwdWs bw = bwd_ws(f, w.bwd, M + w.n3);
     hipLaunchKernelGGL(k_compact, dim3((N + 3u) / 4u), dim3(256), 0, st, N, S, t->ray_count, t->ray_offset, t->active_idx, t->n_active, n_front, bw.n_total);
     if (int rc = check_launch("compact")) return rc;
     NarutoPoints pts{};
     pts.rays_o = t->rays_o; pts.rays_d = t->rays_d; pts.z_vals = t->z_vals; pts.n_samples = S;
-    if (n_front > 0) return query_bwd_impl(f, p, M, &pts, t->feat_save, t->d_raw, nullptr, t->active_idx, t->n_active, nullptr, flags, g, w.bwd, stream, n_front, bw.n_total);
+    const AdamFuse* ad = opt != nullptr ? &adam : nullptr;
+    if (n_front > 0)
+        return query_bwd_impl(f, p, M, &pts, t->feat_save, t->d_raw, nullptr, t->active_idx, t->n_active, nullptr, flags, g, w.bwd, stream, n_front, bw.n_total, ad);
     // no smoothness term: the workspace was sized for cap = M + n3 with n3 = 0
-    return query_bwd_impl(f, p, M, &pts, t->feat_save, t->d_raw, nullptr, t->active_idx, t->n_active, nullptr, flags, g, w.bwd, stream, 0u, nullptr);
+    return query_bwd_impl(f, p, M, &pts, t->feat_save, t->d_raw, nullptr, t->active_idx, t->n_active, nullptr, flags, g, w.bwd, stream, 0u, nullptr, ad);
 }
 
 int naruto_composite_fwd(const NarutoField* f, uint32_t n_rays, uint32_t S, const float* raw, const float* z_vals, float* rgb, float* disp,

@@ -1026,7 +1026,33 @@ __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, Bo
 
 // partials [n_blocks][7][32][32] -> += into the four weight gradients.  Block = 32 outputs x 8 slices of the
 // block range; fixed summation order (deterministic for a given grid).
-__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ partials, uint32_t n_blocks, const NarutoGrads& g, int overwrite, uint32_t block) {
+// Fused torch.optim.Adam update (amsgrad off, L2 weight decay; the arithmetic of k_adam_multi) applied by the kernels
+// that FINISH a gradient, for the five tensors of the mapping optimiser: 0 table, 1 sdf_w0, 2 sdf_w1, 3 col_w0, 4 col_w1.
+struct AdamFuse {
+    float* p[5]; float* m[5]; float* v[5];
+    float lr[5], eps[5], wd[5];
+    float b1, b2;
+    const int32_t* step_dev;      // this step's 1-based number
+    int on;
+};
+struct AdamCoef { float bc1, bc2_sqrt; };
+__device__ __forceinline__ AdamCoef adam_coef(const AdamFuse& a) {
+    const float t = (float)a.step_dev[0];
+    return {1.0f - powf(a.b1, t), sqrtf(1.0f - powf(a.b2, t))};
+}
+__device__ __forceinline__ void adam_apply(const AdamFuse& a, const AdamCoef& c, int tensor, size_t i, float g) {
+    const float pi = a.p[tensor][i], wd = a.wd[tensor];
+    if (wd != 0.0f) g = fmaf(wd, pi, g);
+    const float m0 = a.m[tensor][i];
+    const float mi = m0 + (g - m0) * (1.0f - a.b1);
+    const float vi = a.b2 * a.v[tensor][i] + (1.0f - a.b2) * g * g;
+    a.m[tensor][i] = mi;
+    a.v[tensor][i] = vi;
+    a.p[tensor][i] = pi - (a.lr[tensor] / c.bc1) * (mi / (sqrtf(vi) / c.bc2_sqrt + a.eps[tensor]));
+}
+
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ partials, uint32_t n_blocks, const NarutoGrads& g, int overwrite, uint32_t block,
+                                                  const AdamFuse* __restrict__ adam = nullptr) {
     __shared__ float red[8][32];
     const int o = threadIdx.x & 31, slice = threadIdx.x >> 5;
     const uint32_t e = block * 32u + o;
@@ -1048,27 +1074,80 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part
 #pragma unroll
     for (int k = 1; k < 8; ++k) s += red[k][o];
     const int tile = e >> 10, row = (e >> 5) & 31, col = e & 31;
-    float* dst = nullptr;
+    int tensor = -1;             // 1 sdf_w0, 2 sdf_w1, 3 col_w0, 4 col_w1
+    int off = 0;
     if (tile <= 2) {
         const int c = tile * 32 + col;
-        if (c < kInSdf && g.sdf_w0) dst = g.sdf_w0 + row * kInSdf + c;
+        if (c < kInSdf) { tensor = 1; off = row * kInSdf + c; }
     } else if (tile == 3) {
-        if (row < kOut && g.sdf_w1) dst = g.sdf_w1 + row * kHidden + col;
+        if (row < kOut) { tensor = 2; off = row * kHidden + col; }
     } else if (tile == 4) {
-        if (g.col_w0) dst = g.col_w0 + row * kInCol + col;                             // OneBlob 0..31
+        tensor = 3; off = row * kInCol + col;                                        // OneBlob 0..31
     } else if (tile == 5) {
-        if (g.col_w0) {
-            if (col < 16) dst = g.col_w0 + row * kInCol + 32 + col;                     // OneBlob 32..47
-            else if (col >= 17) dst = g.col_w0 + row * kInCol + kPos + (col - 17);      // out row col-16 >= 1 -> geo col-17
-        }
+        if (col < 16) { tensor = 3; off = row * kInCol + 32 + col; }                  // OneBlob 32..47
+        else if (col >= 17) { tensor = 3; off = row * kInCol + kPos + (col - 17); }   // out row col-16 >= 1 -> geo col-17
     } else {
-        if (row < 3 && g.col_w1) dst = g.col_w1 + row * kHidden + col;
+        if (row < 3) { tensor = 4; off = row * kHidden + col; }
     }
-    if (dst != nullptr) *dst = overwrite ? s : *dst + s;
+    if (tensor < 0) return;
+    float* gt = tensor == 1 ? g.sdf_w0 : (tensor == 2 ? g.sdf_w1 : (tensor == 3 ? g.col_w0 : g.col_w1));
+    if (gt != nullptr) {
+        if (!overwrite) s += gt[off];
+        gt[off] = s;
+    }
+    if (adam != nullptr && adam->on && adam->p[tensor] != nullptr) adam_apply(*adam, adam_coef(*adam), tensor, (size_t)off, s);
 }
 
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partials, uint32_t n_blocks, NarutoGrads g, int overwrite) {
     wgrad_reduce_body(partials, n_blocks, g, overwrite, blockIdx.x);
+}
+
+// Optimiser in the backward: the launch that finishes the gradients (table: sum of the scatter's per-split partial
+// tables; MLP weights: sum of the per-workgroup dW partials) applies the Adam step in place -- the gradients need not be
+// written (g pointers may be NULL), k_adam_multi and one more pass over parameters + moments disappear.
+// Single process only: data parallelism needs the gradients all-reduced first.
+__global__ __launch_bounds__(256) void k_bwd_finish(LevelTab lt, const float* __restrict__ partial, uint32_t s_dense, uint32_t s_hashed, size_t n_params,
+                                                    const float* __restrict__ wpartials, uint32_t n_wblocks, NarutoGrads g, AdamFuse adam,
+                                                    uint32_t n_table_blocks) {
+    if (blockIdx.x >= n_table_blocks) {
+        wgrad_reduce_body(wpartials, n_wblocks, g, 1, blockIdx.x - n_table_blocks, &adam);
+        return;
+    }
+    const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // float4 index = entries 2 i4, 2 i4 + 1
+    if (i4 * 4 >= n_params) return;
+    const uint32_t entry = (uint32_t)(i4 * 2);
+    int level = 0;
+#pragma unroll
+    for (int l = 1; l < kLevels; ++l) level += entry >= lt.off[l] ? 1 : 0;
+    const uint32_t n_splits = ((lt.hashed >> level) & 1u) ? s_hashed : s_dense;
+    const size_t n_entries = n_params / 2u;
+    float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (uint32_t k = 0; k < n_splits; ++k) {
+        const float2 f0 = *reinterpret_cast<const float2*>(partial + ((size_t)k * 2u) * n_entries + entry);
+        const float2 f1 = *reinterpret_cast<const float2*>(partial + ((size_t)k * 2u + 1u) * n_entries + entry);
+        s.x += f0.x; s.y += f1.x; s.z += f0.y; s.w += f1.y;
+    }
+    if (g.table != nullptr) reinterpret_cast<float4*>(g.table)[i4] = s;
+    if (adam.on && adam.p[0] != nullptr) {
+        // float4-wide version of adam_apply for tensor 0
+        const AdamCoef c = adam_coef(adam);
+        const float step_size = adam.lr[0] / c.bc1, eps = adam.eps[0], wd = adam.wd[0];
+        float4 pv = reinterpret_cast<float4*>(adam.p[0])[i4], mv = reinterpret_cast<float4*>(adam.m[0])[i4], vv = reinterpret_cast<float4*>(adam.v[0])[i4];
+        float* pp = &pv.x; float* mm = &mv.x; float* vw = &vv.x; const float* gg = &s.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float gi = gg[k];
+            if (wd != 0.0f) gi = fmaf(wd, pp[k], gi);
+            const float mi = mm[k] + (gi - mm[k]) * (1.0f - adam.b1);
+            const float vi = adam.b2 * vw[k] + (1.0f - adam.b2) * gi * gi;
+            mm[k] = mi;
+            vw[k] = vi;
+            pp[k] = pp[k] - step_size * (mi / (sqrtf(vi) / c.bc2_sqrt + eps));
+        }
+        reinterpret_cast<float4*>(adam.p[0])[i4] = pv;
+        reinterpret_cast<float4*>(adam.m[0])[i4] = mv;
+        reinterpret_cast<float4*>(adam.v[0])[i4] = vv;
+    }
 }
 
 }  // namespace naruto

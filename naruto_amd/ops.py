@@ -645,10 +645,37 @@ class TrainStep:
         for n in PARAM_NAMES:
             setattr(self.gs, n, _p(self.grads[n]))
         self.flags = _lib.BWD_OVERWRITE_WEIGHT_GRADS | (_lib.BWD_OVERWRITE_TABLE_GRAD if handle_supports_overwrite(handle) else 0)
-        if not handle_supports_overwrite(handle):
-            self._zero_table = True
-        else:
-            self._zero_table = False
+        self._zero_table = not handle_supports_overwrite(handle)
+        self.opt = None                      # NarutoFusedAdam: set by fuse_adam()
+        self._gs_nograd = None
+
+    def fuse_adam(self, entries: Dict[str, tuple], betas, step_dev: torch.Tensor, write_grads: bool = False):
+        """Optimiser in the backward (single process): ``entries[name] = (exp_avg, exp_avg_sq, lr, eps, weight_decay)`` for the
+        five FLAT_NAMES tensors; ``step_dev``: int32 device word holding the current step's 1-based number when the backward
+        runs.  The launch that finishes the gradients then applies the Adam step in place; with ``write_grads=False`` the
+        table / weight gradients are not materialised at all."""
+        assert self.group is None, "the fused optimiser is single-process: data-parallel ranks must all-reduce gradients first"
+        assert handle_supports_overwrite(self.handle), "the fused optimiser needs every level LDS-tiled (log2_hashmap_size <= 16)"
+        o = _lib.NarutoFusedAdam()
+        self._opt_keep = []
+        for k, name in enumerate(self.FLAT_NAMES):
+            m, v, lr, eps, wd = entries[name]
+            for t_ in (m, v):
+                assert t_.is_cuda and t_.dtype == torch.float32 and t_.is_contiguous() and t_.numel() == self.params[name].numel()
+            o.param[k], o.exp_avg[k], o.exp_avg_sq[k] = self.params[name].data_ptr(), m.data_ptr(), v.data_ptr()
+            o.lr[k], o.eps[k], o.weight_decay[k] = float(lr), float(eps), float(wd)
+            self._opt_keep += [m, v]
+        o.beta1, o.beta2 = float(betas[0]), float(betas[1])
+        assert step_dev.dtype == torch.int32 and step_dev.is_cuda
+        o.step_dev = step_dev.data_ptr()
+        self._opt_keep.append(step_dev)
+        self.opt = o
+        gs = NarutoGrads()
+        gs.uncert_grid = _p(self.grads["uncert_grid"])
+        if write_grads:
+            for n in self.FLAT_NAMES:
+                setattr(gs, n, _p(self.grads[n]))
+        self._gs_nograd = gs
 
     def _set_rng_mode(self, device_rng: bool):
         t, M = self.t, self.N * self.S
@@ -686,7 +713,12 @@ class TrainStep:
                 from . import parallel
                 parallel.allreduce_loss_sums(self.sums, self.group)
                 check(lib.naruto_train_finalize(self.handle.ptr, C.byref(t), st), "naruto_train_finalize")
-            check(lib.naruto_train_backward(self.handle.ptr, C.byref(self.ps), C.byref(t), C.byref(self.gs), self.flags, st), "naruto_train_backward")
+            if self.opt is not None:
+                check(lib.naruto_train_backward(self.handle.ptr, C.byref(self.ps), C.byref(t), C.byref(self._gs_nograd), self.flags, C.byref(self.opt), st),
+                      "naruto_train_backward")
+            else:
+                check(lib.naruto_train_backward(self.handle.ptr, C.byref(self.ps), C.byref(t), C.byref(self.gs), self.flags, None, st),
+                      "naruto_train_backward")
         return self.losses
 
 

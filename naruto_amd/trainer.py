@@ -173,6 +173,7 @@ class MappingTrainer:
         self._static = None
         # fast path: forward + backward as two C calls on persistent buffers (ops.TrainStep) instead of the autograd node
         self.direct = bool(fused_adam)
+        self.fuse_optimizer = bool(fused_adam)          # single process: apply the mapping Adam inside the backward
         self._train_steps = {}
         if self.direct:
             # {seed, iteration counter}: the kernels' own random numbers are keyed by it, the forward advances the counter,
@@ -202,6 +203,17 @@ class MappingTrainer:
                                rgb_missing=tr['rgb_missing'], perturb=tr['perturb'] > 0., loss_weights=self._loss_w,
                                smooth=(tr['smooth_pts'], tr['smooth_vox'], tr['smooth_margin']) if use_smooth else None,
                                group=self.group, n_rays_total=self.model.n_rays_total, rng_state=self.iter_state)
+            if self.fuse_optimizer and self.group is None and ops.handle_supports_overwrite(m._handle()):
+                # optimiser in the backward: the mapping Adam is applied by the launch that finishes the gradients
+                names = {id(p): n for n, p in m._params().items()}
+                entries = {}
+                for gp in self.map_optimizer.param_groups:
+                    for p in gp['params']:
+                        mm, vv = self.map_optimizer.state[p]
+                        entries[names[id(p)]] = (mm, vv, gp['lr'], gp['eps'], gp['weight_decay'])
+                betas = self.map_optimizer.param_groups[0]['betas']
+                assert all(tuple(gp['betas']) == tuple(betas) for gp in self.map_optimizer.param_groups)
+                ts.fuse_adam(entries, betas, self.map_optimizer.external_step)
             self._train_steps[key] = ts
         return ts
 
@@ -216,11 +228,14 @@ class MappingTrainer:
         ts = self._train_step(rays_o.shape[0], use_smooth)
         with torch.no_grad():
             losses = ts.run(rays_o, rays_d, target_rgb, target_d.reshape(-1))
-            for name, p in model._params().items():
-                p.grad = ts.grads[name]
-            if self.group is not None:
-                torch.distributed.all_reduce(ts.flat_grad, op=torch.distributed.ReduceOp.SUM, group=self.group)
-            self.map_optimizer.step()
+            if ts.opt is None:
+                for name, p in model._params().items():
+                    p.grad = ts.grads[name]
+                if self.group is not None:
+                    torch.distributed.all_reduce(ts.flat_grad, op=torch.distributed.ReduceOp.SUM, group=self.group)
+                self.map_optimizer.step()
+            else:
+                model.uncert_grid.grad = ts.grads["uncert_grid"]          # table / weight gradients are consumed inside the backward
             if uncert_step:
                 if self.group is not None:
                     parallel.allreduce_grads([model.uncert_grid], self.group)

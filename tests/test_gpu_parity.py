@@ -390,6 +390,32 @@ def test_graph_replay_equals_eager(gpu):
         H.assert_close(q, p, 1e-6, f"param {n}", rel=1e-5)
 
 
+def test_optimizer_in_backward_equals_separate_adam(gpu):
+    """k_bwd_finish (gradient reduction + Adam in one launch, gradients never materialised) walks the same trajectory as
+    the backward followed by k_adam_multi, incl. the smoothness term and the uncertainty-grid optimiser."""
+    from naruto_amd import trainer
+    cfg = H.office_cfg(12, perturb=1.0)
+    bound = torch.tensor(cfg["mapping"]["bound"])
+    torch.manual_seed(9)
+    a = trainer.MappingTrainer(cfg, bound, gpu, fused_adam=True)
+    b = trainer.MappingTrainer(cfg, bound, gpu, fused_adam=True)
+    b.model.load_state_dict(a.model.state_dict())
+    b.iter_state.copy_(a.iter_state)                 # same in-kernel random numbers
+    a.fuse_optimizer = False
+    assert b.fuse_optimizer
+    for it in range(6):
+        rays = syn.random_rays(160, cfg["mapping"]["bound"], seed=300 + it, zero_depth_frac=0.1)
+        t = [torch.from_numpy(rays[k]).to(gpu) for k in ("rays_o", "rays_d", "target_rgb", "target_d")]
+        ra, la = a.step(*t, smooth=True)
+        rb, lb = b.step(*t, smooth=True)
+        H.assert_close(lb.reshape(-1), la.reshape(-1), 1e-7, f"iter{it}.loss", rel=1e-6)
+    assert next(iter(b._train_steps.values())).opt is not None and next(iter(a._train_steps.values())).opt is None
+    for (n, p), (_, q) in zip(a.model.named_parameters(), b.model.named_parameters()):
+        # same formulas in two kernels: fused-multiply-add contraction may differ by an ulp, Adam's normalisation carries that
+        # into the parameters at the 1e-6 level over six steps
+        H.assert_close(q, p, 5e-6, f"param {n}", rel=1e-5)
+
+
 def test_train_node_with_fused_smoothness(gpu):
     """The training node with the smoothness term riding along (one scatter pass, written-not-accumulated
     gradients) against the oracle: rendering losses + smooth_weight * TV(hash features)."""

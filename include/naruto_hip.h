@@ -233,6 +233,23 @@ int naruto_active_ray_select(uint32_t n_total, uint32_t base, uint32_t K, uint32
 int naruto_rays_to_world(uint32_t n, const float* d_cam, const int64_t* pose_id, const float* poses, float* rays_o,
                          float* rays_d, void* stream);
 
+/* N3 ("next" row) -- the planner's uncertainty aggregation in goal space (reference src/planner/naruto_planner.py,
+ * NarutoPlanner.uncertainty_aggregation_v2 :596-735), consuming the volumes of naruto_map_volumes.
+ * naruto_goal_targets: the target observations (:629-632) -- the top_k largest uncertainty voxels (ties: lower flat index),
+ *   listed in flat-index order and thinned to top_k_subset entries at positions floor(i*top_k/subset); targets int32
+ *   [subset,3] voxel indices.  (The reference takes whatever numpy's argpartition leaves in the last `subset` slots: an
+ *   unspecified subset of the top_k.)  dims: HOST array {X,Y,Z}; workspace naruto_goal_targets_workspace() bytes.
+ * naruto_goal_aggregate (:637-710): collections[g][k] = uncert[target k] if min_dist < |goal g - target k| < max_dist
+ *   (voxels), goal g is not on the border and sdf >= safe_sdf at the goal and its 6 neighbours, and the sdf is > 0 at the
+ *   30 points of the segment goal -> target (truncated to voxels); else 0.  aggregated[g] = sum_k collections[g][k].
+ *   goal_idx int32 [G,3], targets int32 [k,3]. */
+size_t naruto_goal_targets_workspace(uint32_t n_voxels, uint32_t top_k);
+int naruto_goal_targets(const uint32_t* dims, const float* uncert_vol, uint32_t top_k, uint32_t top_k_subset,
+                        int32_t* targets, void* workspace, void* stream);
+int naruto_goal_aggregate(const uint32_t* dims, const float* uncert_vol, const float* sdf_vol, uint32_t n_goals,
+                          const int32_t* goal_idx, uint32_t n_targets, const int32_t* targets, float min_dist,
+                          float max_dist, float safe_sdf, float* collections, float* aggregated, void* stream);
+
 /* All parameter tensors of one optimiser in a single launch (<= 8 segments, per-segment lr / eps / weight_decay,
  * shared betas and step). */
 typedef struct NarutoAdamSeg {

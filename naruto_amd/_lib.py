@@ -14,7 +14,7 @@ from typing import List, Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnaruto_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["naruto_api.hip", "naruto_field.hip", "naruto_render.hip", "naruto_rays.hip", "naruto_train.hip", "naruto_common.h"]
+SOURCES = ["naruto_api.hip", "naruto_field.hip", "naruto_render.hip", "naruto_rays.hip", "naruto_train.hip", "naruto_planner.hip", "naruto_common.h"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "naruto_hip.h")
 
 MAX_LEVELS = 16
@@ -130,6 +130,9 @@ SIGNATURES = {
     "naruto_active_ray_select": (_I, [_U32, _U32, _U32, _U32, _V, _V, _V, _V, _V, C.POINTER(_U32), C.POINTER(_F), _F, _V, _V, _V, _V, _V, _V]),
     "naruto_rays_to_world": (_I, [_U32, _V, _V, _V, _V, _V, _V]),
     "naruto_map_volumes": (_I, [_U32, _V, _V, _V]),
+    "naruto_goal_targets_workspace": (C.c_size_t, [_U32, _U32]),
+    "naruto_goal_targets": (_I, [C.POINTER(_U32), _V, _U32, _U32, _V, _V, _V]),
+    "naruto_goal_aggregate": (_I, [C.POINTER(_U32), _V, _V, _U32, _V, _U32, _V, _F, _F, _F, _V, _V, _V]),
     "naruto_adam_multi": (_I, [C.POINTER(NarutoAdamSeg), _U32, _F, _F, _U32, _V, _U32, _V]),
     "naruto_train_workspace": (C.c_size_t, [_V, C.POINTER(NarutoTrainStep)]),
     "naruto_train_forward": (_I, [_V, C.POINTER(NarutoParams), C.POINTER(NarutoTrainStep), _I, _V]),

@@ -10,6 +10,7 @@
 #include "naruto_render.hip"
 #include "naruto_rays.hip"
 #include "naruto_train.hip"
+#include "naruto_planner.hip"
 
 using namespace naruto;
 
@@ -714,6 +715,39 @@ int naruto_rays_to_world(uint32_t n, const float* d_cam, const int64_t* pose_id,
     if (n == 0) return NARUTO_OK;
     hipLaunchKernelGGL(k_rays_to_world, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, n, d_cam, pose_id, poses, rays_o, rays_d);
     return check_launch("rays_to_world");
+}
+
+size_t naruto_goal_targets_workspace(uint32_t n_voxels, uint32_t top_k) { return ((size_t)n_voxels + top_k + 64u) * sizeof(uint32_t); }
+
+int naruto_goal_targets(const uint32_t* dims, const float* uncert_vol, uint32_t top_k, uint32_t top_k_subset, int32_t* targets, void* workspace, void* stream) {
+    if (dims == nullptr || uncert_vol == nullptr || targets == nullptr || workspace == nullptr) return fail(NARUTO_ERR_INVALID, "goal_targets: NULL argument");
+    const uint64_t n64 = (uint64_t)dims[0] * dims[1] * dims[2];
+    if (n64 == 0 || n64 > 0x7FFFFFFFull) return fail(NARUTO_ERR_INVALID, "goal_targets: bad volume dimensions");
+    const uint32_t n = (uint32_t)n64;
+    if (top_k == 0 || top_k > n || top_k_subset == 0 || top_k_subset > top_k) return fail(NARUTO_ERR_INVALID, "goal_targets: need 1 <= subset <= top_k <= voxels");
+    uint32_t* keys = reinterpret_cast<uint32_t*>(workspace);
+    uint32_t* sel = keys + n;
+    const VolDims d{(int)dims[0], (int)dims[1], (int)dims[2]};
+    hipLaunchKernelGGL(k_topk_keys, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, n, uncert_vol, keys);
+    if (int rc = check_launch("topk_keys")) return rc;
+    hipLaunchKernelGGL(k_ars_select, dim3(1), dim3(1024), 0, (hipStream_t)stream, n, top_k, keys, sel);
+    if (int rc = check_launch("topk_select")) return rc;
+    hipLaunchKernelGGL(k_topk_thin, dim3((top_k_subset + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, sel, top_k, top_k_subset, d, targets);
+    return check_launch("topk_thin");
+}
+
+int naruto_goal_aggregate(const uint32_t* dims, const float* uncert_vol, const float* sdf_vol, uint32_t n_goals, const int32_t* goal_idx, uint32_t n_targets,
+                          const int32_t* targets, float min_dist, float max_dist, float safe_sdf, float* collections, float* aggregated, void* stream) {
+    if (dims == nullptr || uncert_vol == nullptr || sdf_vol == nullptr || goal_idx == nullptr || targets == nullptr || collections == nullptr ||
+        aggregated == nullptr)
+        return fail(NARUTO_ERR_INVALID, "goal_aggregate: NULL argument");
+    if ((uint64_t)dims[0] * dims[1] * dims[2] == 0 || (uint64_t)dims[0] * dims[1] * dims[2] > 0x7FFFFFFFull)
+        return fail(NARUTO_ERR_INVALID, "goal_aggregate: bad volume dimensions");
+    if (n_goals == 0 || n_targets == 0) return NARUTO_OK;
+    const VolDims d{(int)dims[0], (int)dims[1], (int)dims[2]};
+    hipLaunchKernelGGL(k_goal_aggregate, dim3((n_goals + 3u) / 4u), dim3(256), 0, (hipStream_t)stream, d, uncert_vol, sdf_vol, n_goals, goal_idx, n_targets,
+                       targets, min_dist, max_dist, safe_sdf, collections, aggregated);
+    return check_launch("goal_aggregate");
 }
 
 int naruto_map_volumes(uint32_t M, const float* sdf_uncert, float* out, void* stream) {

@@ -281,6 +281,48 @@ def case_active_ray(name, seed):
     print(f"{name}: ok, {n_total} rays -> {out[0].shape[0]}")
 
 
+def case_planner_aggregation(name, seed):
+    """N3: the reference's own NarutoPlanner.init_data + uncertainty_aggregation_v2, called unbound on a stand-in ``self``
+    (the planner class needs the simulator stack to construct; these two methods only touch the attributes set here)."""
+    from types import SimpleNamespace
+    from src.planner.naruto_planner import NarutoPlanner                     # the reference
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    bbox = [[-1.2, 1.2], [-1.4, 1.4], [-0.4, 1.3]]                           # 25 x 29 x 18 voxels of 0.1 m: a small fixture
+
+    class Cfg(dict):
+        __getattr__ = dict.__getitem__
+    pcfg = Cfg(uncert_top_k=400, uncert_top_k_subset=60, gs_sensing_range=[0.5, 2], safe_sdf=0.8, gs_z_levels=[5, 9, 13])
+    me = SimpleNamespace(planner_cfg=pcfg, main_cfg=SimpleNamespace(planner=SimpleNamespace(voxel_size=0.1)), step=0,
+                         info_printer=lambda *a, **k: None)
+    NarutoPlanner.init_data(me, bbox)
+    dims, ranges, goal_idx = S.goal_space(bbox, 0.1, pcfg["gs_z_levels"])
+    assert (me.Nx, me.Ny, me.Nz) == dims and torch.equal(me.goal_space_pts, goal_idx.float())
+    rs = np.random.RandomState(seed)
+    X, Y, Z = np.meshgrid(np.arange(dims[0]), np.arange(dims[1]), np.arange(dims[2]), indexing="ij")
+    # sdf in voxel-ish units: a room (positive inside) with a wall slab and a pillar (negative), so that safety and
+    # visibility both bite; uncertainty: positive near surfaces, many exact zeros elsewhere
+    room = np.minimum.reduce([X - 1.5, dims[0] - 2.5 - X, Y - 1.5, dims[1] - 2.5 - Y, Z - 1.5, dims[2] - 2.5 - Z]).astype(np.float32)
+    wall = (np.abs(X - 12.3) - 0.9).astype(np.float32)
+    wall[(Y > 17) & (Y < 23)] = 5.0                                           # a doorway
+    pillar = (np.sqrt((X - 19.2) ** 2 + (Y - 8.7) ** 2) - 1.6).astype(np.float32)
+    sdf = (np.minimum.reduce([room, wall, pillar]) * 0.5 + rs.normal(0, 0.02, X.shape)).astype(np.float32)
+    uncert = (rs.uniform(0.01, 3.0, X.shape) * ((sdf >= 0) & (sdf < 0.5))).astype(np.float32)
+    ok, out = NarutoPlanner.uncertainty_aggregation_v2(me, [uncert, sdf], force_running=True)
+    assert ok
+    tgt = out["topk_uncert_vxl"].numpy().astype(np.int64)
+    assert np.array_equal(tgt, S.topk_targets_reference(uncert, 400, 60))
+    coll, agg, valid = S.uncert_aggregation(uncert, sdf, tgt, goal_idx, dims, 0.1, (0.5, 2.0), 0.8)
+    assert torch.equal(coll, out["gs_uncert_collections"]), "oracle != reference (gs_uncert_collections)"
+    assert torch.equal(agg.reshape(out["gs_aggre_uncerts"].shape), out["gs_aggre_uncerts"]), "oracle != reference (gs_aggre_uncerts)"
+    n_valid = int(valid.sum())
+    assert 0 < n_valid < valid.numel()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), bbox=np.asarray(bbox, np.float32), uncert=uncert, sdf=sdf, targets=tgt,
+                        gs_z_levels=np.asarray(pcfg["gs_z_levels"], np.int64), collections=coll.numpy(),
+                        aggregated=out["gs_aggre_uncerts"].numpy(), top_k=np.int64(400), top_k_subset=np.int64(60))
+    print(f"{name}: ok, {goal_idx.shape[0]} goals x {tgt.shape[0]} targets, {n_valid} valid pairs, "
+          f"{int((agg > 0).sum())} goals with uncertainty in view")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -293,6 +335,7 @@ def main():
     case_query_volume("g3_query_volume_t16", 16, 0.25, 6)
     case_composite_edges("g5_composite_edges", 7)
     case_active_ray("g8_active_ray", 8)
+    case_planner_aggregation("g9_planner_aggregation", 9)
 
 
 if __name__ == "__main__":

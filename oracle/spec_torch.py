@@ -517,3 +517,70 @@ def rays_to_world(rays_d_cam, ids_all, poses_all):
     rays_d = torch.sum(rays_d_cam[..., None, None, :] * poses_all[ids_all, None, :3, :3], -1)
     rays_o = poses_all[ids_all, None, :3, -1].repeat(1, rays_d.shape[1], 1).reshape(-1, 3)
     return rays_o, rays_d.reshape(-1, 3)
+
+
+# ---------------------------------------------------------------------------------------------------
+# N3 ("next" row): the planner's uncertainty aggregation in goal space
+# (reference src/planner/naruto_planner.py: init_data :110-137, uncertainty_aggregation_v2 :596-735)
+# ---------------------------------------------------------------------------------------------------
+def goal_space(bbox, voxel_size: float = 0.1, gs_z_levels=(5, 11, 17)):
+    """naruto_planner.py:116-137 -> (dims (Nx,Ny,Nz), ranges (gs_x_range, gs_y_range, gs_z_range), goal_idx int64 [G,3])."""
+    Nx = round((bbox[0][1] - bbox[0][0]) / voxel_size + 0.0005) + 1
+    Ny = round((bbox[1][1] - bbox[1][0]) / voxel_size + 0.0005) + 1
+    Nz = round((bbox[2][1] - bbox[2][0]) / voxel_size + 0.0005) + 1
+    gx = torch.arange(0, Nx, 2)
+    gy = torch.arange(0, Ny, 2)
+    gz = torch.arange(int(1 / voxel_size), Nz, int(1 / voxel_size)) if gs_z_levels is None else torch.tensor(list(gs_z_levels))
+    X, Y, Z = torch.meshgrid(gx, gy, gz, indexing="ij")
+    return (Nx, Ny, Nz), (gx, gy, gz), torch.stack([X.reshape(-1), Y.reshape(-1), Z.reshape(-1)], 1)
+
+
+def topk_targets_reference(uncert: np.ndarray, top_k: int, top_k_subset: int) -> np.ndarray:
+    """naruto_planner.py:629-632: np.argpartition(uncert, -top_k)[-top_k_subset:] -> voxel indices int64 [k,3].  WHICH subset
+    of the top_k comes out is an artefact of numpy's introselect; only 'a subset of the top_k largest' is specified."""
+    idx = np.argpartition(uncert, -top_k, axis=None)[-top_k_subset:]
+    return np.column_stack(np.unravel_index(idx, uncert.shape)).astype(np.int64)
+
+
+def topk_targets_deterministic(uncert: np.ndarray, top_k: int, top_k_subset: int) -> np.ndarray:
+    """What the HIP path selects: the top_k largest values (ties: lower flat index first), listed in flat-index order,
+    thinned to top_k_subset entries at positions floor(i * top_k / top_k_subset) -- spread over the volume, which is what
+    the reference's comment asks of the subset ("avoid Uncertainty Point Concentration", configs/default.py:94)."""
+    flat = uncert.reshape(-1)
+    order = np.lexsort((np.arange(flat.size), -flat.astype(np.float64)))      # by value descending, then index ascending
+    top = np.sort(order[:top_k])
+    pick = top[(np.arange(top_k_subset, dtype=np.int64) * top_k) // top_k_subset]
+    return np.column_stack(np.unravel_index(pick, uncert.shape)).astype(np.int64)
+
+
+def uncert_aggregation(uncert: np.ndarray, sdf: np.ndarray, targets: np.ndarray, goal_idx: torch.Tensor, dims, voxel_size: float,
+                       sensing_range=(0.5, 2.0), safe_sdf: float = 0.8):
+    """naruto_planner.py:637-710 for given target voxels -> (collections [G,k] fp32, aggregated [G] fp32, valid mask [G,k]).
+    A (goal, target) pair counts iff min < |goal - target| < max (voxels), the goal is not on the volume border and the sdf
+    at the goal and its six neighbours is >= safe_sdf, and the sdf at 30 points of the segment goal -> target (truncated
+    to voxel indices) is > 0 everywhere."""
+    Nx, Ny, Nz = dims
+    unc = torch.from_numpy(np.ascontiguousarray(uncert))
+    sd = torch.from_numpy(np.ascontiguousarray(sdf))
+    tgt = torch.from_numpy(np.asarray(targets)).float()                       # [k,3]
+    gp = goal_idx.float()                                                     # [G,3]
+    k = tgt.shape[0]
+    goal_pts = gp[:, None, :].repeat(1, k, 1)
+    view = goal_pts - tgt
+    dist = torch.norm(view, dim=2)
+    valid = (dist < sensing_range[1] / voxel_size) * (dist > sensing_range[0] / voxel_size)
+    x, y, z = goal_idx[:, 0], goal_idx[:, 1], goal_idx[:, 2]
+    unsafe = (x < 1) + (x + 1 >= Nx) + (y < 1) + (y + 1 >= Ny) + (z < 1) + (z + 1 >= Nz)
+    for dx, dy, dz in ((0, 0, 0), (1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)):
+        unsafe = unsafe + (sd[(x + dx).clamp(0, Nx - 1), (y + dy).clamp(0, Ny - 1), (z + dz).clamp(0, Nz - 1)] < safe_sdf)
+    valid[unsafe.reshape(-1) > 0, :] = False
+    near = view[valid]
+    t = torch.linspace(0, 1, 30)
+    pts = (goal_pts[valid][..., None] - t * near[..., None]).permute(0, 2, 1).long()
+    vis = sd[pts[:, :, 0], pts[:, :, 1], pts[:, :, 2]].min(dim=1)[0] > 0 if near.shape[0] else torch.zeros(0, dtype=torch.bool)
+    valid = valid.masked_scatter(valid.clone(), vis)
+    ti = tgt.long()
+    ku = unc[ti[:, 0], ti[:, 1], ti[:, 2]][None, :].repeat(gp.shape[0], 1)
+    coll = torch.zeros_like(ku)
+    coll[valid] = ku[valid]
+    return coll, coll.sum(dim=1), valid

@@ -568,3 +568,32 @@ def test_rays_to_world_golden(gpu):
     o, d = rays_to_world(torch.from_numpy(g["dcam"]).to(gpu), ids.to(gpu), torch.from_numpy(g["poses"]).to(gpu))
     assert np.array_equal(o.cpu().numpy(), g["world_o"])
     H.assert_close(d, g["world_d"], 1e-6, "rays_to_world.d")
+
+
+# --------------------------------------------------------------------------------------------- N3 ("next" row)
+def test_planner_aggregation_golden(gpu):
+    """GoalSpaceAggregatorHIP against the reference's uncertainty_aggregation_v2 (golden, the reference's own targets) and the
+    oracle's deterministic target selection."""
+    from naruto_amd.planner_aggregation import GoalSpaceAggregatorHIP
+    g = H.load_golden("g9_planner_aggregation")
+    bbox = [list(map(float, b)) for b in g["bbox"]]
+    top_k, sub = int(g["top_k"]), int(g["top_k_subset"])
+    ag = GoalSpaceAggregatorHIP(bbox, 0.1, uncert_top_k=top_k, uncert_top_k_subset=sub, gs_sensing_range=(0.5, 2.0), safe_sdf=0.8,
+                                gs_z_levels=list(g["gs_z_levels"]), device=gpu)
+    dims, ranges, goal_idx = S.goal_space(bbox, 0.1, list(g["gs_z_levels"]))
+    assert (ag.Nx, ag.Ny, ag.Nz) == dims and torch.equal(ag.goal_space_pts.cpu(), goal_idx.float())
+    ok, out = ag.uncertainty_aggregation_v2([g["uncert"], g["sdf"]], targets=g["targets"])
+    assert ok
+    assert np.array_equal(out["gs_uncert_collections"].cpu().numpy(), g["collections"])          # exact: pure selection
+    H.assert_close(out["gs_aggre_uncerts"], g["aggregated"], 1e-6, "gs_aggre_uncerts", rel=1e-6)   # summation order differs
+    assert torch.equal(out["topk_uncert_vxl"].cpu(), torch.from_numpy(g["targets"]))
+    # own target selection == the oracle's deterministic rule; aggregation on those targets == oracle
+    ok, out2 = ag.uncertainty_aggregation_v2([torch.from_numpy(g["uncert"]).to(gpu), torch.from_numpy(g["sdf"]).to(gpu)])
+    det = S.topk_targets_deterministic(g["uncert"], top_k, sub)
+    assert ok and np.array_equal(out2["topk_uncert_vxl"].cpu().numpy(), det)
+    coll, agg, _ = S.uncert_aggregation(g["uncert"], g["sdf"], det, goal_idx, dims, 0.1, (0.5, 2.0), 0.8)
+    assert np.array_equal(out2["gs_uncert_collections"].cpu().numpy(), coll.numpy())
+    H.assert_close(out2["gs_aggre_uncerts"].reshape(-1), agg, 1e-6, "gs_aggre_uncerts (own targets)", rel=1e-6)
+    # an all-solid sdf volume: nothing is safe or visible -> invalid goal space, as in the reference
+    ok3, out3 = ag.uncertainty_aggregation_v2([g["uncert"], -np.ones_like(g["sdf"])])
+    assert ok3 is False and out3 == {}

@@ -255,3 +255,24 @@ def test_oracle_rays_to_world_golden():
     g = H.load_golden("g8_active_ray")
     o, d = S.rays_to_world(torch.from_numpy(g["dcam"]), torch.from_numpy(g["ids"]), torch.from_numpy(g["poses"]))
     assert np.array_equal(o.numpy(), g["world_o"]) and np.allclose(d.numpy(), g["world_d"], atol=1e-7)
+
+
+def test_oracle_planner_aggregation_golden():
+    """N3: the restatement of NarutoPlanner.uncertainty_aggregation_v2 reproduces the reference's outputs exactly for the
+    reference's own target selection; the deterministic selection (what the HIP path does) picks from the same top_k."""
+    g = H.load_golden("g9_planner_aggregation")
+    bbox = [list(map(float, b)) for b in g["bbox"]]
+    dims, ranges, goal_idx = S.goal_space(bbox, 0.1, list(g["gs_z_levels"]))
+    assert dims == g["uncert"].shape
+    coll, agg, valid = S.uncert_aggregation(g["uncert"], g["sdf"], g["targets"], goal_idx, dims, 0.1, (0.5, 2.0), 0.8)
+    assert np.array_equal(coll.numpy(), g["collections"])
+    assert np.array_equal(agg.numpy().reshape(g["aggregated"].shape), g["aggregated"])
+    top_k, sub = int(g["top_k"]), int(g["top_k_subset"])
+    assert np.array_equal(S.topk_targets_reference(g["uncert"], top_k, sub), g["targets"])
+    det = S.topk_targets_deterministic(g["uncert"], top_k, sub)
+    flat = g["uncert"].reshape(-1)
+    kth = np.sort(flat)[-top_k]
+    vals = g["uncert"][det[:, 0], det[:, 1], det[:, 2]]
+    assert det.shape == (sub, 3) and (vals >= kth).all() and len({tuple(r) for r in det}) == sub
+    ref_vals = g["uncert"][g["targets"][:, 0], g["targets"][:, 1], g["targets"][:, 2]]
+    assert (ref_vals >= kth).all()                       # both selections are subsets of the top_k

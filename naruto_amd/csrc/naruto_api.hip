@@ -286,8 +286,8 @@ int naruto_query_fwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
     if (f == nullptr || p == nullptr) return fail(NARUTO_ERR_INVALID, "query_fwd: NULL argument");
     if (p->table == nullptr || p->uncert_grid == nullptr || p->sdf_w0 == nullptr || p->sdf_w1 == nullptr)
         return fail(NARUTO_ERR_INVALID, "query_fwd: NULL parameter");
+    if (M == 0) return NARUTO_OK;                     // empty batch: its (NULL) point pointers are not an error
     if (int rc = check_points(pts)) return rc;
-    if (M == 0) return NARUTO_OK;
     const bool color = raw != nullptr;
     if (color && (p->col_w0 == nullptr || p->col_w1 == nullptr)) return fail(NARUTO_ERR_INVALID, "query_fwd: colour net parameters missing");
     if (!color && sdf_uncert == nullptr && geo == nullptr && feat_save == nullptr) return fail(NARUTO_ERR_INVALID, "query_fwd: no output requested");
@@ -345,8 +345,8 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
         return fail(NARUTO_ERR_INVALID, "query_bwd: NULL argument");
     if (p->table == nullptr || p->uncert_grid == nullptr || p->sdf_w0 == nullptr || p->sdf_w1 == nullptr || p->col_w0 == nullptr || p->col_w1 == nullptr)
         return fail(NARUTO_ERR_INVALID, "query_bwd: NULL parameter");
-    if (int rc = check_points(pts)) return rc;
     if (M == 0) return NARUTO_OK;
+    if (int rc = check_points(pts)) return rc;
     const BwdWs w = bwd_ws(f, workspace, cap);
     float* d_feat = w.d_feat; float* x_soa = w.x_soa; float* partials = w.partials; float* scatter_ws = w.scatter_ws;
     uint32_t* n_total = w.n_total;

@@ -597,3 +597,83 @@ def test_planner_aggregation_golden(gpu):
     # an all-solid sdf volume: nothing is safe or visible -> invalid goal space, as in the reference
     ok3, out3 = ag.uncertainty_aggregation_v2([g["uncert"], -np.ones_like(g["sdf"])])
     assert ok3 is False and out3 == {}
+
+
+# --------------------------------------------------------------------------------------------- edge cases
+def test_edge_sizes_and_degenerate_inputs(gpu):
+    """Empty and minimal inputs, the per-ray sample limit, depths that are zero / negative / beyond depth_trunc.  (A NaN
+    depth is treated like a missing one here; the reference lets it poison every loss of the batch -- INTEGRATION.md.)"""
+    from naruto_amd import _lib, ops
+    cfg = H.office_cfg(12)
+    ora = H.make_oracle(cfg, 0.25, 51)
+    m = H.make_hip_from_oracle(cfg, ora, gpu)
+    # empty and single-point queries
+    assert m.query_color_sdf(torch.zeros(0, 3, device=gpu)).shape == (0, 5)
+    one = torch.tensor([[0.31, 0.72, 0.55]])
+    H.assert_close(m.query_color_sdf(one.to(gpu)), ora.query_color_sdf(one), TOL_OUT, "raw(1 point)")
+    # one ray; rays with zero / NaN / over-range depth: the masks of get_masks and the near-far fallback of render_rays
+    m.train(), ora.train()
+    rays = syn.random_rays(5, cfg["mapping"]["bound"], seed=51)
+    t = {k: torch.from_numpy(v) for k, v in rays.items()}
+    t["target_d"][1] = 0.0
+    t["target_d"][2] = -1.0                      # negative depth: the near-far fallback as well (target_d <= 0)
+    t["target_d"][3] = 150.0                     # > cam.depth_trunc = 100: excluded from the depth / uncertainty losses
+    for n in (1, 5):
+        a = {k: v[:n] for k, v in t.items()}
+        ret_o = ora.forward(a["rays_o"], a["rays_d"], a["target_rgb"], a["target_d"])
+        ret_h = m.forward(*(a[k].to(gpu) for k in ("rays_o", "rays_d", "target_rgb", "target_d")))
+        for k in ("rgb_loss", "depth_loss", "sdf_loss", "fs_loss", "uncert_loss"):
+            H.assert_close(ret_h[k].reshape(-1), ret_o[k].reshape(-1), 1e-5, f"{n} rays.{k}", rel=1e-4)
+    # the per-ray sample limit (kMaxSamples = 1024) and one past it
+    lib = _lib.load()
+    N = 3
+    td = torch.tensor([1.3, 0.0, 2.2])
+    z_o = S.sample_z(N, td.view(-1, 1), 0.0, 5.0, 1013, 11, 0.1, 0.0)
+    z_h = ops.sample_z(N, td.to(gpu), 0.0, 5.0, 1013, 11, 0.1, 0, None, device=gpu)
+    H.assert_close(z_h, z_o, 1e-6, "z_vals S=1024", rel=1e-6)
+    with pytest.raises(_lib.NarutoError):
+        ops.sample_z(N, td.to(gpu), 0.0, 5.0, 1014, 11, 0.1, 0, None, device=gpu)
+    raw = torch.randn(N, 1024, 5, generator=torch.Generator().manual_seed(3))
+    out_o = S.raw2outputs(raw, z_o, cfg["training"]["trunc"], cfg["data"]["sc_factor"])
+    out_h = ops.composite(m._handle(), raw.to(gpu), z_h)             # rgb, disp, acc, weights, depth, depth_var, uncert_map
+    for a, b, name in zip(out_h, out_o, ("rgb", "disp", "acc", "weights", "depth", "depth_var", "uncert_map")):
+        H.assert_close(a, b, 2e-5, f"{name} S=1024", rel=1e-4)
+
+
+def test_scatter_collisions(gpu):
+    """Every point in ONE cell (all updates of a level collide on eight entries, the worst case for the LDS accumulators) plus a
+    block of distinct points: the table gradient of hash_encode equals the oracle's."""
+    from naruto_amd import ops
+    cfg = H.office_cfg(12)
+    ora = H.make_oracle(cfg, 0.25, 52)
+    m = H.make_hip_from_oracle(cfg, ora, gpu)
+    rs = np.random.RandomState(52)
+    same = np.tile(np.array([[0.4137, 0.2871, 0.6312]], np.float32), (3000, 1)) + rs.uniform(0, 1e-5, (3000, 3)).astype(np.float32)
+    x = np.concatenate([same, rs.uniform(0, 1, (1500, 3)).astype(np.float32)])
+    c = rs.normal(size=(x.shape[0], 32)).astype(np.float32)
+    f_o = S.hash_encode(torch.from_numpy(x), ora.table, ora.meta)
+    (f_o * torch.from_numpy(c)).sum().backward()
+    f_h = m.query_sdf(torch.from_numpy(x).to(gpu), embed=True)
+    H.assert_close(f_h, f_o, 5e-6, "features")
+    (f_h * torch.from_numpy(c).to(gpu)).sum().backward()
+    grad_close(m.embed_fn.params.grad, ora.table.grad, "collisions.grad.table")
+
+
+def test_active_ray_sampler_ties(gpu):
+    """An all-zero cached uncertainty volume (the state before the first planner query): every candidate ties, the K
+    lowest-index candidates are taken, exactly as the oracle's deterministic rule."""
+    from naruto_amd.active_ray_sampler import ActiveRaySamplerHIP
+    cfg = H.office_cfg(16)
+    cfg["mapping"]["sample"], cfg["mapping"]["min_pixels_cur"] = 128, 20
+    smp = ActiveRaySamplerHIP(config=cfg, num_uncert_sample=40, oversample_mul=4)
+    n_cur = 33
+    n = smp.oversample_num + n_cur
+    rays = syn.random_rays(n, cfg["mapping"]["bound"], seed=53)
+    t = {k: torch.from_numpy(v) for k, v in rays.items()}
+    vol = np.zeros((49, 56, 35), np.float32)
+    got = smp.sample_rays(*(t[k].to(gpu) for k in ("rays_o", "rays_d", "target_rgb", "target_d")), list(range(n_cur)), vol, cfg["mapping"]["bound"])
+    want, vals, sel = S.active_ray_sample(t["rays_o"], t["rays_d"], t["target_rgb"], t["target_d"], n_cur, vol, cfg["mapping"]["bound"], 128, 40, 4,
+                                          deterministic=True)
+    assert np.array_equal(sel, np.arange(40))
+    for a, b in zip(got, want):
+        assert torch.equal(a.cpu(), b)

@@ -170,23 +170,27 @@ def pmc_traffic(kernel: str):
         return None, None
 
 
-def cpu_baseline(cfg, n_rays: int, iters: int):
-    """The oracle's mapping iteration (CPU PyTorch), same body, on a bounded sample."""
+def cpu_baseline(cfg, n_rays: int, iters: int, device=None):
+    """The oracle's mapping iteration (plain PyTorch ops), same body, on a bounded sample: on the host cores (the reported
+    ``cpu_baseline``), or -- device given -- as unfused torch ops on the GPU, the stand-in for "the reference in single-GPU
+    PyTorch" (SURVEY.md 8(d); the reference itself needs the CUDA-only tiny-cuda-nn)."""
     from oracle import spec_torch as S
     torch.manual_seed(0)
+    on_gpu = device is not None
+    dev = device if on_gpu else torch.device("cpu")
     bbox = torch.tensor(cfg["mapping"]["bound"], dtype=torch.float32)
-    ora = S.OracleField(cfg, bbox, 0.1)
+    ora = S.OracleField(cfg, bbox, 0.1).to(dev)
     g1, g2 = ora.param_groups()
     o_map = torch.optim.Adam(g1, betas=(0.9, 0.99))
     o_unc = torch.optim.Adam(g2, lr=1)
-    rays = {k: torch.from_numpy(v) for k, v in syn.random_rays(n_rays, cfg["mapping"]["bound"], seed=0).items()}
+    rays = {k: torch.from_numpy(v).to(dev) for k, v in syn.random_rays(n_rays, cfg["mapping"]["bound"], seed=0).items()}
     trc = cfg["training"]
     ora.train()
 
     def step(i):
         o_map.zero_grad()
         ret = ora.forward(rays["rays_o"], rays["rays_d"], rays["target_rgb"], rays["target_d"])
-        sm = S.smoothness(ora, trc["smooth_pts"], trc["smooth_vox"], trc["smooth_margin"], torch.rand(3), torch.rand(3))
+        sm = S.smoothness(ora, trc["smooth_pts"], trc["smooth_vox"], trc["smooth_margin"], torch.rand(3).to(dev), torch.rand(3).to(dev))
         S.total_loss(ret, trc, smooth_term=sm).backward()
         o_map.step()
         if (i + 1) % 5 == 0:
@@ -194,11 +198,18 @@ def cpu_baseline(cfg, n_rays: int, iters: int):
             o_unc.zero_grad()
 
     step(0)
+    if on_gpu:
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(iters):
         step(i + 1)
+    if on_gpu:
+        torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
     S_tot = trc["n_samples_d"] + trc["n_range_d"]
+    if on_gpu:
+        return {"value": round(n_rays / dt, 1), "unit": "rays/s", "kind": "port, unfused torch ops on the same GPU",
+                "sample": f"{iters} mapping iterations of {n_rays} rays x {S_tot} samples after 1 warm-up, {dt * 1e3:.1f} ms/iter"}
     return {"value": round(n_rays / dt, 1), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{iters} mapping iterations of {n_rays} rays x {S_tot} samples after 1 warm-up (oracle/spec_torch.py, "
                       f"forward+losses+smoothness+backward+Adam), {dt * 1e3:.0f} ms/iter"}
@@ -297,6 +308,10 @@ def main():
             out["kernels_ms_sum"] = round(sum(r["ms"] for r in rows if r["bound"] is not None), 4)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, n_rays, args.cpu_iters)
+            try:
+                out["torch_gpu_baseline"] = cpu_baseline(cfg, n_rays, 10, device=dev)
+            except Exception as e:                               # informational: never fail the bench line over it
+                out["torch_gpu_baseline"] = {"error": repr(e)[:200]}
         print(json.dumps(out), flush=True)
     if group is not None:
         torch.distributed.barrier(group)

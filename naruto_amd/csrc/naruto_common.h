@@ -170,6 +170,60 @@ __device__ __forceinline__ float2 hash_level_rt(const LevelTab& lt, int T, const
     return acc;
 }
 
+// Half of a level's interpolation: the four corners with x offset ``xh`` (0 or 1), i.e. sum over (dy,dz) of w * table[idx].
+// Used with the two halves of a wave working on the SAME 32 points (lanes j and j+32, xh = lane >> 5): the x-neighbour
+// corners idx(x) and idx(x+1) differ only in their low bits (hashed: (gx ^ h) vs ((gx+1) ^ h); dense: consecutive), so in
+// 7 of 8 cases they lie in the same 64-byte line and the load instruction touches ~36 distinct lines instead of 64.
+// Measured on MI355X (tools/gather_coalesce_bench.hip): gather cost is proportional to the distinct lines per instruction,
+// wherever in the wave the sharing lanes sit (173 -> 343 G lane-gathers/s for pairs l / l+32).
+__device__ __forceinline__ float2 hash_level_half_rt(const LevelTab& lt, int T, const float2* __restrict__ table, float x, float y, float z, uint32_t xh) {
+    const float scale = lt.scale[T];
+    const uint32_t res = lt.res[T];
+    const uint32_t size = lt.size[T];
+    const float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
+    const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+    const uint32_t gx = (uint32_t)(int)fx + xh, gy = (uint32_t)(int)fy, gz = (uint32_t)(int)fz;
+    const float wx = px - fx, wy = py - fy, wz = pz - fz;
+    const float wxh = xh ? wx : 1.0f - wx, uy = 1.0f - wy, uz = 1.0f - wz;
+    uint32_t idx[4];
+    if ((lt.hashed >> T) & 1u) {
+        const uint32_t mask = size - 1u;
+        const uint32_t hy0 = gy * kPrime1, hy1 = hy0 + kPrime1;
+        const uint32_t hz0 = gz * kPrime2, hz1 = hz0 + kPrime2;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) idx[c] = (gx ^ ((c & 1) ? hy1 : hy0) ^ ((c & 2) ? hz1 : hz0)) & mask;
+    } else {
+        const uint32_t r2 = res * res;
+        const uint32_t base = gx + gy * res + gz * r2;
+        const uint32_t magic = 0xFFFFFFFFu / size;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint32_t i = base + ((c & 1) ? res : 0u) + ((c & 2) ? r2 : 0u);
+            i -= __umulhi(i, magic) * size;
+            if (i >= size) i -= size;
+            idx[c] = i;
+        }
+    }
+    const float2* __restrict__ tl = table + lt.off[T];
+    float2 v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#ifdef NARUTO_ABLATE_GATHER
+        v[c] = make_float2(__uint_as_float(idx[c] | 0x3f000000u), 0.25f);
+#else
+        v[c] = tl[idx[c]];
+#endif
+    }
+    float2 acc = make_float2(0.0f, 0.0f);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float w = (wxh * ((c & 1) ? wy : uy)) * ((c & 2) ? wz : uz);         // same association as hash_corners
+        acc.x = fmaf(w, v[c].x, acc.x);
+        acc.y = fmaf(w, v[c].y, acc.y);
+    }
+    return acc;
+}
+
 template <int T>
 __device__ __forceinline__ float2 hash_level(const LevelTab& lt, const float2* __restrict__ table, float x, float y, float z) {
     uint32_t idx[8];

@@ -196,14 +196,27 @@ __global__ __launch_bounds__(256, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab
         });
 #else
         // levels in a real loop (unrolled by kGatherGroup): the gathers of a group are in flight together, the code
-        // stays an order of magnitude smaller than the fully unrolled form
+        // stays an order of magnitude smaller than the fully unrolled form.
+        // Lane layout of the gathers: both halves of the wave work on the same 32 points -- round A on points 0..31,
+        // round B on points 32..63 -- and lane half hh fetches the four corners with x offset hh (hash_level_half_rt).
+        // One v_permlane32_swap then adds the two x halves AND leaves (f0 | f1) in the (low | high) half: exactly the
+        // B operand of the MFMA tile.
+        float xa = x, xb = x, ya = y, yb = y, za = z, zb = z;
+        swap32(xa, xb); swap32(ya, yb); swap32(za, zb);        // xa = x of points (0..31 | 0..31), xb = (32..63 | 32..63)
+        const uint32_t mA = tile * 64u + (uint32_t)j, mB = mA + 32u;
 #pragma unroll NARUTO_GATHER_GROUP
         for (int T = 0; T < kLevels; ++T) {
-            const float2 f = hash_level_rt(lt, T, table, x, y, z);
-            if (feat_out != nullptr && valid) feat_out[(size_t)T * M + m] = f;
+            const float2 pa = hash_level_half_rt(lt, T, table, xa, ya, za, (uint32_t)hh);
+            const float2 pb = hash_level_half_rt(lt, T, table, xb, yb, zb, (uint32_t)hh);
+            float ua = pa.x, wa = pa.y, ub = pb.x, wb = pb.y;
+            swap32(ua, wa);                      // low half: (own x-part of f0, partner's) ; high half: (partner's f1 part, own)
+            swap32(ub, wb);
+            const float b0 = ua + wa, b1 = ub + wb;       // feature hh of point j (tile A) / j+32 (tile B)
+            if (feat_save != nullptr) {
+                if (mA < M) feat_save[((size_t)T * M + mA) * 2u + hh] = b0;
+                if (mB < M) feat_save[((size_t)T * M + mB) * 2u + hh] = b1;
+            }
             const float a = L.s0[T * 64 + lane];
-            float b0 = f.x, b1 = f.y;
-            swap32(b0, b1);                      // b0: tile A operand, b1: tile B operand
             hA = mfma32(a, b0, hA);
             hB = mfma32(a, b1, hB);
         }

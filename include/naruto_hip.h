@@ -233,6 +233,33 @@ int naruto_active_ray_select(uint32_t n_total, uint32_t base, uint32_t K, uint32
 int naruto_rays_to_world(uint32_t n, const float* d_cam, const int64_t* pose_id, const float* poses, float* rays_o,
                          float* rays_d, void* stream);
 
+/* N2, store side -- one BA batch from a device-resident keyframe ray store (coslam.py:310-344 + Co-SLAM
+ * KeyFrameDatabase.sample_global_rays [not in tree]): n_global DISTINCT rays drawn from the n_kf*rays_per_kf stored rows
+ * (python random.sample semantics: without replacement), n_cur distinct pixels of the current frame (all pixels, or those
+ * listed in cur_list = the valid-depth pixels), rotated to world with the pose of their keyframe
+ * (frame_ids[kf] / keyframe_every; the current frame uses the LAST pose).  The distinct draw is a keyed Feistel
+ * permutation of [0, n) with cycle walking: sample element i = perm(i); key = (seed, counter).
+ * naruto_perm_index is the same permutation on the host (salt 2: store draw, 3: current-frame draw, 1: naruto_sample_distinct). */
+typedef struct NarutoRayBatch {
+    const float* store;        /* [n_kf*rays_per_kf, 7] (direction 3, rgb 3, depth 1), device                       */
+    uint32_t n_kf, rays_per_kf;
+    const int64_t* frame_ids;  /* [n_kf] device                                                                     */
+    int64_t keyframe_every;
+    uint32_t n_global;
+    const float* current;      /* [pixels, 7] rays of the current frame                                             */
+    const uint32_t* cur_list;  /* optional [n_cur_pop] admissible pixel indices; NULL: pixels 0..n_cur_pop-1         */
+    uint64_t n_cur_pop;
+    uint32_t n_cur;
+    const float* poses;        /* [n_poses,4,4] camera-to-world                                                      */
+    uint32_t n_poses;
+    uint64_t seed, counter;
+    float *rays_o, *rays_d, *target_s, *target_d;   /* [n_global+n_cur,3] x3, [n_global+n_cur]                      */
+    int64_t* ids_out;          /* optional [n_global+n_cur]: pose index per ray, -1 for current-frame rays           */
+} NarutoRayBatch;
+int naruto_assemble_rays(const NarutoRayBatch* b, void* stream);
+int naruto_sample_distinct(uint64_t n, uint32_t count, uint64_t seed, uint64_t counter, int64_t* out, void* stream);
+uint64_t naruto_perm_index(uint64_t i, uint64_t n, uint64_t seed, uint64_t counter, uint64_t salt);
+
 /* N3 ("next" row) -- the planner's uncertainty aggregation in goal space (reference src/planner/naruto_planner.py,
  * NarutoPlanner.uncertainty_aggregation_v2 :596-735), consuming the volumes of naruto_map_volumes.
  * naruto_goal_targets: the target observations (:629-632) -- the top_k largest uncertainty voxels (ties: lower flat index),

@@ -55,6 +55,14 @@ ADAM_ADVANCE = 1
 ADAM_ZERO_GRAD = 2
 
 
+class NarutoRayBatch(C.Structure):
+    _fields_ = [("store", C.c_void_p), ("n_kf", C.c_uint32), ("rays_per_kf", C.c_uint32), ("frame_ids", C.c_void_p),
+                ("keyframe_every", C.c_int64), ("n_global", C.c_uint32), ("current", C.c_void_p), ("cur_list", C.c_void_p),
+                ("n_cur_pop", C.c_uint64), ("n_cur", C.c_uint32), ("poses", C.c_void_p), ("n_poses", C.c_uint32),
+                ("seed", C.c_uint64), ("counter", C.c_uint64), ("rays_o", C.c_void_p), ("rays_d", C.c_void_p),
+                ("target_s", C.c_void_p), ("target_d", C.c_void_p), ("ids_out", C.c_void_p)]
+
+
 class NarutoFusedAdam(C.Structure):
     _fields_ = [("param", C.c_void_p * 5), ("exp_avg", C.c_void_p * 5), ("exp_avg_sq", C.c_void_p * 5),
                 ("lr", C.c_float * 5), ("eps", C.c_float * 5), ("weight_decay", C.c_float * 5),
@@ -130,6 +138,9 @@ SIGNATURES = {
     "naruto_active_ray_select": (_I, [_U32, _U32, _U32, _U32, _V, _V, _V, _V, _V, C.POINTER(_U32), C.POINTER(_F), _F, _V, _V, _V, _V, _V, _V]),
     "naruto_rays_to_world": (_I, [_U32, _V, _V, _V, _V, _V, _V]),
     "naruto_map_volumes": (_I, [_U32, _V, _V, _V]),
+    "naruto_assemble_rays": (_I, [C.POINTER(NarutoRayBatch), _V]),
+    "naruto_sample_distinct": (_I, [_U64, _U32, _U64, _U64, _V, _V]),
+    "naruto_perm_index": (_U64, [_U64, _U64, _U64, _U64, _U64]),
     "naruto_goal_targets_workspace": (C.c_size_t, [_U32, _U32]),
     "naruto_goal_targets": (_I, [C.POINTER(_U32), _V, _U32, _U32, _V, _V, _V]),
     "naruto_goal_aggregate": (_I, [C.POINTER(_U32), _V, _V, _U32, _V, _U32, _V, _F, _F, _F, _V, _V, _V]),

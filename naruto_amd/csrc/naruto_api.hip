@@ -750,6 +750,56 @@ int naruto_goal_aggregate(const uint32_t* dims, const float* uncert_vol, const f
     return check_launch("goal_aggregate");
 }
 
+namespace {
+uint32_t half_bits_for(uint64_t n) {             // smallest h with 2^(2h) >= n
+    uint32_t h = 1;
+    while (h < 32u && (1ull << (2u * h)) < n) ++h;
+    return h;
+}
+uint64_t mix_key(uint64_t seed, uint64_t counter, uint64_t salt) {
+    uint64_t x = seed ^ (counter * 0x9E3779B97F4A7C15ull) ^ (salt * 0xD1342543DE82EF95ull);
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+    return x;
+}
+}  // namespace
+
+int naruto_sample_distinct(uint64_t n, uint32_t count, uint64_t seed, uint64_t counter, int64_t* out, void* stream) {
+    if (out == nullptr) return fail(NARUTO_ERR_INVALID, "sample_distinct: NULL output");
+    if (count == 0) return NARUTO_OK;
+    if (n == 0 || count > n) return fail(NARUTO_ERR_INVALID, "sample_distinct: cannot draw %u distinct indices out of %llu", count, (unsigned long long)n);
+    hipLaunchKernelGGL(k_sample_distinct, dim3((count + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, n, count, (uint64_t)0, half_bits_for(n),
+                       mix_key(seed, counter, 1), out);
+    return check_launch("sample_distinct");
+}
+
+int naruto_assemble_rays(const NarutoRayBatch* b, void* stream) {
+    if (b == nullptr) return fail(NARUTO_ERR_INVALID, "assemble_rays: NULL argument");
+    if (b->poses == nullptr || b->n_poses == 0 || b->rays_o == nullptr || b->rays_d == nullptr || b->target_s == nullptr || b->target_d == nullptr)
+        return fail(NARUTO_ERR_INVALID, "assemble_rays: NULL pose / output buffer");
+    if (b->n_global > 0 && (b->store == nullptr || b->frame_ids == nullptr || b->rays_per_kf == 0 || b->n_kf == 0 || b->keyframe_every <= 0))
+        return fail(NARUTO_ERR_INVALID, "assemble_rays: the keyframe store is incomplete");
+    const uint64_t n_pop = (uint64_t)b->n_kf * b->rays_per_kf;
+    if (b->n_global > n_pop) return fail(NARUTO_ERR_INVALID, "assemble_rays: %u distinct rays out of %llu stored", b->n_global, (unsigned long long)n_pop);
+    if (b->n_cur > 0 && (b->current == nullptr || b->n_cur_pop == 0 || b->n_cur > b->n_cur_pop))
+        return fail(NARUTO_ERR_INVALID, "assemble_rays: %u distinct current-frame rays out of %llu", b->n_cur, (unsigned long long)b->n_cur_pop);
+    const uint32_t n = b->n_global + b->n_cur;
+    if (n == 0) return NARUTO_OK;
+    AssembleArgs a{};
+    a.store = b->store; a.n_pop = n_pop ? n_pop : 1; a.rays_per_kf = b->rays_per_kf ? b->rays_per_kf : 1; a.frame_ids = b->frame_ids;
+    a.keyframe_every = b->keyframe_every; a.n_global = b->n_global;
+    a.current = b->current; a.cur_list = b->cur_list; a.n_cur_pop = b->n_cur_pop ? b->n_cur_pop : 1; a.n_cur = b->n_cur;
+    a.poses = b->poses; a.n_poses = b->n_poses;
+    a.key_global = mix_key(b->seed, b->counter, 2); a.key_cur = mix_key(b->seed, b->counter, 3);
+    a.hb_global = half_bits_for(a.n_pop); a.hb_cur = half_bits_for(a.n_cur_pop);
+    a.rays_o = b->rays_o; a.rays_d = b->rays_d; a.target_s = b->target_s; a.target_d = b->target_d; a.ids_out = b->ids_out;
+    hipLaunchKernelGGL(k_assemble_rays, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("assemble_rays");
+}
+
+uint64_t naruto_perm_index(uint64_t i, uint64_t n, uint64_t seed, uint64_t counter, uint64_t salt) {
+    return n ? perm_index(i, n, half_bits_for(n), mix_key(seed, counter, salt)) : 0;
+}
+
 int naruto_map_volumes(uint32_t M, const float* sdf_uncert, float* out, void* stream) {
     if (sdf_uncert == nullptr || out == nullptr) return fail(NARUTO_ERR_INVALID, "map_volumes: NULL argument");
     if (M == 0) return NARUTO_OK;

@@ -139,4 +139,89 @@ __global__ __launch_bounds__(256) void k_rays_to_world(uint32_t n, const float* 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// N2, the store side: batch assembly from a device-resident keyframe ray store.
+//
+// The reference keeps the keyframe rays on the host side of a Python `random.sample` (Co-SLAM
+// KeyFrameDatabase.sample_global_rays [not in tree]; coslam.py:310-344): every BA iteration draws `bs` DISTINCT ray indices
+// out of n_kf * rays_per_kf, gathers [bs,7] rows, appends distinct current-frame pixels, and rotates to world.  Here the
+// distinct draw is a keyed Feistel permutation of [0, n) with cycle walking -- element i of the sample is perm(i): no
+// state, no rejection bookkeeping, one kernel for draw + gather + rotation.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t feistel_f(uint32_t r, uint32_t k) {
+    uint32_t x = r * 0x9E3779B1u + k;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+
+// bijection on [0, n): 4-round balanced Feistel on 2*half_bits bits (2^(2*half_bits) >= n), cycle-walked into range
+__host__ __device__ __forceinline__ uint64_t perm_index(uint64_t i, uint64_t n, uint32_t half_bits, uint64_t key) {
+    const uint32_t mask = half_bits >= 32 ? 0xFFFFFFFFu : ((1u << half_bits) - 1u);
+    const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+    do {
+        uint32_t l = (uint32_t)(i >> half_bits) & mask, r = (uint32_t)i & mask;
+#pragma unroll
+        for (uint32_t round = 0; round < 4u; ++round) {
+            const uint32_t t = l ^ (feistel_f(r, (round & 1u ? k1 : k0) + round * 0x85EBCA6Bu) & mask);
+            l = r;
+            r = t;
+        }
+        i = ((uint64_t)l << half_bits) | r;
+    } while (i >= n);
+    return i;
+}
+
+struct AssembleArgs {
+    const float* store;          // [n_pop, 7] = (direction 3, rgb 3, depth 1) of the stored keyframe rays
+    uint64_t n_pop;              // n_kf * rays_per_kf
+    uint32_t rays_per_kf;
+    const int64_t* frame_ids;    // [n_kf]
+    int64_t keyframe_every;
+    uint32_t n_global;           // rays drawn from the store
+    const float* current;        // [n_cur_pop, 7] rays of the current frame
+    const uint32_t* cur_list;    // optional [n_cur_pop_list]: pixels allowed (valid depth); NULL: all n_cur_pop pixels
+    uint64_t n_cur_pop;          // population the current-frame draw is over (length of cur_list, or pixel count)
+    uint32_t n_cur;              // rays drawn from the current frame
+    const float* poses;          // [P,4,4] row-major camera-to-world; the current frame uses the LAST pose (index -1)
+    uint32_t n_poses;
+    uint64_t key_global, key_cur;
+    uint32_t hb_global, hb_cur;
+    float* rays_o; float* rays_d; float* target_s; float* target_d;
+    int64_t* ids_out;            // optional [n_global + n_cur]: pose index used per ray (-1 for current-frame rays)
+};
+
+__global__ __launch_bounds__(256) void k_assemble_rays(AssembleArgs a) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_global + a.n_cur) return;
+    const float* src;
+    int64_t pose_id;
+    if (r < a.n_global) {
+        const uint64_t idx = perm_index(r, a.n_pop, a.hb_global, a.key_global);
+        src = a.store + idx * 7u;
+        pose_id = a.frame_ids[idx / a.rays_per_kf] / a.keyframe_every;          // torch.div(..., rounding_mode='trunc'), ids >= 0
+        if (a.ids_out) a.ids_out[r] = pose_id;
+    } else {
+        uint64_t j = perm_index(r - a.n_global, a.n_cur_pop, a.hb_cur, a.key_cur);
+        if (a.cur_list != nullptr) j = a.cur_list[j];
+        src = a.current + j * 7u;
+        pose_id = (int64_t)a.n_poses - 1;
+        if (a.ids_out) a.ids_out[r] = -1;
+    }
+    const float* P = a.poses + 16 * (size_t)pose_id;
+    const float dx = src[0], dy = src[1], dz = src[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        a.rays_d[3 * (size_t)r + i] = __fadd_rn(__fadd_rn(__fmul_rn(dx, P[4 * i + 0]), __fmul_rn(dy, P[4 * i + 1])), __fmul_rn(dz, P[4 * i + 2]));
+        a.rays_o[3 * (size_t)r + i] = P[4 * i + 3];
+        a.target_s[3 * (size_t)r + i] = src[3 + i];
+    }
+    a.target_d[r] = src[6];
+}
+
+// out[i] = perm(first + i): `count` distinct pseudo-random indices in [0, n)
+__global__ __launch_bounds__(256) void k_sample_distinct(uint64_t n, uint32_t count, uint64_t first, uint32_t half_bits, uint64_t key, int64_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = (int64_t)perm_index(first + i, n, half_bits, key);
+}
+
 }  // namespace naruto

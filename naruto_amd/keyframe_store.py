@@ -1,0 +1,125 @@
+"""N2, store side ("next" row of SURVEY.md section 8f): a device-resident keyframe ray store and the BA batch assembly.
+
+Mirror of what the mapping loop needs from ``KeyFrameDatabaseNaruto`` (reference src/slam/coslam/model/keyframe.py:16-60,
+on top of Co-SLAM's ``KeyFrameDatabase`` [not in tree]) and of the ray assembly in ``CoSLAMNaruto.global_BA``
+(src/slam/coslam/coslam.py:293-344):
+
+  * ``add_keyframe(batch, filter_depth)``  -- keep ``num_rays_to_save`` distinct (valid-depth) pixels of the frame as
+    [direction 3 | rgb 3 | depth 1] rows, tiled when the frame has fewer (keyframe.py:38-60);
+  * ``sample_global_rays(bs)``             -- ``bs`` distinct stored rays + their frame ids (Co-SLAM; ``random.sample``);
+  * ``assemble_batch(...)``                -- the fused form of coslam.py:310-344: global rays + distinct current-frame
+    pixels, rotated to world with the pose of their keyframe, in ONE kernel; the result feeds ``ActiveRaySamplerHIP`` /
+    ``MappingTrainer.step`` without leaving the device.
+
+Everything lives on the GPU; the "random.sample" draws are keyed Feistel permutations (``naruto_assemble_rays``), so a
+batch is reproducible from (seed, counter) and the whole BA iteration can be captured in a hipGraph.  The reference keeps
+the store on the host and draws with Python's ``random`` -- the drawn SETS differ, their distribution (uniform, without
+replacement) does not.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class KeyFrameStoreHIP:
+    def __init__(self, config: Dict, H: int, W: int, num_kf: int, num_rays_to_save: int, device, seed: int = 0):
+        self.config = config
+        self.H, self.W = int(H), int(W)
+        self.total_pixels = self.H * self.W
+        self.num_rays_to_save = int(num_rays_to_save)
+        self.device = torch.device(device)
+        self.rays = torch.zeros(int(num_kf), self.num_rays_to_save, 7, dtype=torch.float32, device=self.device)   # Co-SLAM: self.rays
+        self.frame_ids: Optional[torch.Tensor] = None          # int64 [n_kf] on the device (Co-SLAM keeps it on the host)
+        self.seed, self.counter = int(seed), 0
+
+    def __len__(self):
+        return 0 if self.frame_ids is None else int(self.frame_ids.shape[0])
+
+    def attach_ids(self, frame_ids: torch.Tensor):
+        """Co-SLAM KeyFrameDatabase.attach_ids."""
+        frame_ids = frame_ids.to(self.device, torch.int64).reshape(-1)
+        self.frame_ids = frame_ids if self.frame_ids is None else torch.cat([self.frame_ids, frame_ids], dim=0)
+
+    def _distinct(self, n: int, count: int) -> torch.Tensor:
+        lib = _lib.load()
+        out = torch.empty(count, dtype=torch.int64, device=self.device)
+        self.counter += 1
+        with torch.cuda.device(self.device):
+            check(lib.naruto_sample_distinct(n, count, self.seed, self.counter, out.data_ptr(), _stream()), "naruto_sample_distinct")
+        return out
+
+    def add_keyframe(self, batch: Dict, filter_depth: bool = False):
+        """keyframe.py:38-60.  batch: 'direction' [1,H,W,3] (or [H*W,3]), 'rgb' likewise, 'depth' [1,H,W], 'frame_id'."""
+        rays = torch.cat([batch['direction'], batch['rgb'], batch['depth'][..., None]], dim=-1).to(self.device, torch.float32)
+        rays = rays.reshape(-1, rays.shape[-1])                                         # [H*W, 7]
+        if filter_depth:
+            valid = (rays[:, -1] > 0.0) & (rays[:, -1] <= self.config["cam"]["depth_trunc"])
+            pool = torch.nonzero(valid).reshape(-1)
+            n_take = min(int(pool.shape[0]), self.num_rays_to_save)
+            sel = pool[self._distinct(int(pool.shape[0]), n_take)] if n_take > 0 else pool[:0]
+        else:
+            sel = self._distinct(rays.shape[0], self.num_rays_to_save)
+        fid = batch['frame_id']
+        self.attach_ids(fid if isinstance(fid, torch.Tensor) else torch.tensor([fid]))
+        if sel.shape[0] == 0:                        # as in the reference: the id is attached, no rays are stored
+            return
+        kept = rays[sel]
+        if kept.shape[0] < self.num_rays_to_save:    # "while rays.shape[1] < n: rays = cat([rays, rays])" then truncate = periodic tiling
+            reps = -(-self.num_rays_to_save // kept.shape[0])
+            kept = kept.repeat(reps, 1)[:self.num_rays_to_save]
+        self.rays[len(self) - 1] = kept
+
+    def sample_global_rays(self, bs: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Co-SLAM KeyFrameDatabase.sample_global_rays: bs distinct stored rays [bs,7] and their frame ids [bs]."""
+        n_kf = len(self)
+        idx = self._distinct(n_kf * self.num_rays_to_save, bs)
+        rays = self.rays[:n_kf].reshape(-1, 7)[idx]
+        return rays, self.frame_ids[idx // self.num_rays_to_save]
+
+    def assemble_batch(self, sample_num: int, current_rays: torch.Tensor, poses_all: torch.Tensor, min_pixels_cur: int,
+                       filter_depth: bool = False, return_ids: bool = False):
+        """coslam.py:310-344 fused: -> rays_o [N,3], rays_d [N,3], target_s [N,3], target_d [N,1], n_cur (and ids_all).
+        N = sample_num + n_cur, n_cur = max(sample_num // n_kf, min_pixels_cur) (capped by the valid pixels).
+        current_rays [H*W,7]; poses_all [P,4,4] camera-to-world with the current frame's pose LAST (index -1)."""
+        lib = _lib.load()
+        n_kf = len(self)
+        assert n_kf > 0, "no keyframe stored yet"
+        cur = current_rays.to(self.device, torch.float32).reshape(-1, 7).contiguous()
+        poses = poses_all.to(self.device, torch.float32).contiguous()
+        n_cur = max(sample_num // n_kf, int(min_pixels_cur))
+        cur_list = None
+        n_cur_pop = cur.shape[0]
+        if filter_depth:
+            valid = (cur[:, -1] > 0.0) & (cur[:, -1] <= self.config["cam"]["depth_trunc"])
+            cur_list = torch.nonzero(valid).reshape(-1).to(torch.int32).contiguous()
+            n_cur_pop = int(cur_list.shape[0])
+            n_cur = min(n_cur_pop, n_cur)
+        n = sample_num + n_cur
+        f32 = dict(dtype=torch.float32, device=self.device)
+        rays_o, rays_d, target_s = torch.empty(n, 3, **f32), torch.empty(n, 3, **f32), torch.empty(n, 3, **f32)
+        target_d = torch.empty(n, 1, **f32)
+        ids = torch.empty(n, dtype=torch.int64, device=self.device) if return_ids else None
+        self.counter += 1
+        b = _lib.NarutoRayBatch()
+        b.store, b.n_kf, b.rays_per_kf = self.rays.data_ptr(), n_kf, self.num_rays_to_save
+        b.frame_ids, b.keyframe_every, b.n_global = self.frame_ids.data_ptr(), int(self.config['mapping']['keyframe_every']), int(sample_num)
+        b.current, b.cur_list = cur.data_ptr(), (cur_list.data_ptr() if cur_list is not None and n_cur_pop > 0 else None)
+        b.n_cur_pop, b.n_cur = max(n_cur_pop, 1), n_cur
+        b.poses, b.n_poses, b.seed, b.counter = poses.data_ptr(), poses.shape[0], self.seed, self.counter
+        b.rays_o, b.rays_d, b.target_s, b.target_d = rays_o.data_ptr(), rays_d.data_ptr(), target_s.data_ptr(), target_d.data_ptr()
+        b.ids_out = ids.data_ptr() if ids is not None else None
+        with torch.cuda.device(self.device):
+            check(lib.naruto_assemble_rays(C.byref(b), _stream()), "naruto_assemble_rays")
+        out = (rays_o, rays_d, target_s, target_d, n_cur)
+        return out + (ids,) if return_ids else out

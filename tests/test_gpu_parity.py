@@ -677,3 +677,69 @@ def test_active_ray_sampler_ties(gpu):
     assert np.array_equal(sel, np.arange(40))
     for a, b in zip(got, want):
         assert torch.equal(a.cpu(), b)
+
+
+# --------------------------------------------------------------------------------------------- N2, store side
+def test_keyframe_store_batch_assembly(gpu):
+    """KeyFrameStoreHIP: add_keyframe keeps distinct (valid) pixels and tiles short frames; assemble_batch draws distinct
+    stored rays + distinct current-frame pixels (exactly the host permutation naruto_perm_index), gathers them and rotates
+    them to world bit for bit like coslam.py:337-344 (oracle rays_to_world)."""
+    from naruto_amd import _lib
+    from naruto_amd.keyframe_store import KeyFrameStoreHIP
+    lib = _lib.load()
+    cfg = H.office_cfg(16)
+    cfg["mapping"]["keyframe_every"] = 5
+    Hh, Ww, R = 24, 32, 200
+    st = KeyFrameStoreHIP(cfg, Hh, Ww, num_kf=6, num_rays_to_save=R, device=gpu, seed=77)
+    rs = np.random.RandomState(61)
+    frames = []
+    for k in range(4):
+        depth = rs.uniform(0.3, 4.0, (1, Hh, Ww)).astype(np.float32)
+        if k == 2:
+            depth[:] = 0.0
+            depth[0, :3, :20] = 1.5                       # only 60 valid pixels: the stored rows are a periodic tiling of them
+        depth[0, rs.uniform(size=(Hh, Ww)) < 0.2] = 0.0
+        b = {"direction": torch.from_numpy(rs.normal(size=(1, Hh, Ww, 3)).astype(np.float32)), "rgb": torch.from_numpy(rs.uniform(size=(1, Hh, Ww, 3)).astype(np.float32)),
+             "depth": torch.from_numpy(depth), "frame_id": 5 * k}
+        frames.append(torch.cat([b["direction"], b["rgb"], b["depth"][..., None]], -1).reshape(-1, 7))
+        st.add_keyframe(b, filter_depth=True)
+    assert len(st) == 4 and st.frame_ids.cpu().tolist() == [0, 5, 10, 15]
+    for k in range(4):
+        rows = st.rays[k].cpu()
+        src = frames[k]
+        assert (rows[:, 6] > 0).all()                                                 # filter_depth: only valid pixels
+        keys = {tuple(r.tolist()) for r in src}
+        assert all(tuple(r.tolist()) in keys for r in rows)                           # every stored row is a pixel of that frame
+        n_valid = int(((src[:, 6] > 0) & (src[:, 6] <= cfg["cam"]["depth_trunc"])).sum())
+        uniq = len({tuple(r.tolist()) for r in rows})
+        assert uniq == min(n_valid, R)                                                # distinct pixels, tiled when the frame is short
+        if n_valid < R:
+            assert torch.equal(rows[:n_valid], rows[n_valid:2 * n_valid][:n_valid]) or R < 2 * n_valid
+    # batch assembly
+    cur = frames[3].to(gpu)
+    poses = torch.eye(4).repeat(4, 1, 1)
+    for i in range(4):
+        a = 0.4 * i + 0.2
+        poses[i, :3, :3] = torch.tensor([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], dtype=torch.float32)
+        poses[i, :3, 3] = torch.tensor(rs.uniform(-1, 1, 3), dtype=torch.float32)
+    bs = 300
+    o, d, s, t, n_cur, ids = st.assemble_batch(bs, cur, poses, min_pixels_cur=40, filter_depth=True, return_ids=True)
+    assert n_cur == max(bs // 4, 40) and o.shape == (bs + n_cur, 3) and t.shape == (bs + n_cur, 1)
+    ctr = st.counter
+    n_pop = 4 * R
+    gidx = np.array([lib.naruto_perm_index(i, n_pop, 77, ctr, 2) for i in range(bs)])
+    assert len(np.unique(gidx)) == bs
+    flat = st.rays[:4].reshape(-1, 7).cpu()
+    valid_list = torch.nonzero((frames[3][:, 6] > 0) & (frames[3][:, 6] <= cfg["cam"]["depth_trunc"])).reshape(-1)
+    cidx = valid_list[[lib.naruto_perm_index(i, int(valid_list.shape[0]), 77, ctr, 3) for i in range(n_cur)]]
+    assert len(set(cidx.tolist())) == n_cur
+    rows = torch.cat([flat[gidx], frames[3][cidx]], 0)
+    want_ids = torch.cat([st.frame_ids.cpu()[gidx // R] // 5, -torch.ones(n_cur, dtype=torch.int64)])
+    assert torch.equal(ids.cpu(), want_ids)
+    w_o, w_d = S.rays_to_world(rows[:, :3], want_ids, poses)
+    assert torch.equal(o.cpu(), w_o)
+    H.assert_close(d, w_d, 1e-6, "assemble.rays_d", rel=1e-6)           # torch.sum's association over the 3 products differs by an ulp
+    assert torch.equal(s.cpu(), rows[:, 3:6]) and torch.equal(t.cpu(), rows[:, 6:7])
+    # sample_global_rays: distinct rows with their frame ids
+    r2, f2 = st.sample_global_rays(128)
+    assert r2.shape == (128, 7) and set(f2.cpu().tolist()) <= {0, 5, 10, 15}

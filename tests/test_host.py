@@ -127,3 +127,22 @@ def test_reference_workload_config0_on_oracle():
     loss.backward()
     assert torch.isfinite(loss) and ret["rgb"].shape == (4096, 3)
     assert float(ora.table.grad.abs().sum()) > 0
+
+
+def test_feistel_permutation_is_a_bijection(built_lib):
+    """naruto_perm_index (host build of the device function behind naruto_assemble_rays / naruto_sample_distinct): a bijection
+    of [0, n) for every n, different for different keys -- i.e. the first k values are k DISTINCT indices, which is what
+    python's random.sample guarantees in the reference."""
+    from naruto_amd import _lib
+    lib = _lib.load()
+    for n in (1, 2, 3, 7, 64, 100, 1000, 4097, 40800):
+        p = np.array([lib.naruto_perm_index(i, n, 11, 5, 2) for i in range(n)], dtype=np.int64)
+        assert p.min() == 0 and p.max() == n - 1 and len(np.unique(p)) == n, n
+    a = [lib.naruto_perm_index(i, 40800, 11, 5, 2) for i in range(64)]
+    b = [lib.naruto_perm_index(i, 40800, 11, 6, 2) for i in range(64)]
+    c = [lib.naruto_perm_index(i, 40800, 11, 5, 3) for i in range(64)]
+    assert a != b and a != c and len(set(a)) == 64
+    # no gross bias: the first 4096 draws of 163 200 spread over all 16 sixteenths of the range
+    q = np.array([lib.naruto_perm_index(i, 163200, 3, 1, 2) for i in range(4096)]) * 16 // 163200
+    counts = np.bincount(q, minlength=16)
+    assert counts.min() > 180 and counts.max() < 340, counts

@@ -351,7 +351,7 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
     float* d_feat = w.d_feat; float* x_soa = w.x_soa; float* partials = w.partials; float* scatter_ws = w.scatter_ws;
     uint32_t* n_total = w.n_total;
     const uint32_t n_tiles = (M + 31u) / 32u;
-    uint32_t blocks = (n_tiles + 3u) / 4u;
+    uint32_t blocks = (n_tiles + (uint32_t)kBwdWaves - 1u) / (uint32_t)kBwdWaves;
     uint32_t max_blocks = cu_count(f);
     if (max_blocks > kBwdMaxBlocks) max_blocks = kBwdMaxBlocks;
     if (blocks > max_blocks) blocks = max_blocks;
@@ -362,7 +362,7 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
             return fail(NARUTO_ERR_LAUNCH, "query_bwd: cannot reserve %zu bytes of LDS: %s", sizeof(BwdLds), hipGetErrorString(hipGetLastError()));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_query_bwd, dim3(blocks), dim3(256), sizeof(BwdLds), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, ps, M, cap, feat_save, d_raw,
+    hipLaunchKernelGGL(k_query_bwd, dim3(blocks), dim3(64 * kBwdWaves), sizeof(BwdLds), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, ps, M, cap, feat_save, d_raw,
                        d_geo, d_feat, (g->table != nullptr || adam != nullptr) ? x_soa : nullptr, g->uncert_grid, partials, active_idx, n_active, n_front);
     if (int rc = check_launch("query_bwd")) return rc;
     if (adam != nullptr) {

@@ -58,6 +58,7 @@ __device__ __forceinline__ void stage_fwd_weights(FwdLds& L, const NarutoParams&
 #pragma unroll
     for (int e0 = 0; e0 < 40 * 64; e0 += NT) {
         const int e = e0 + tid;
+        if (e >= 40 * 64) continue;
         const int t = e >> 6, l = e & 63, i = l & 31, kk = l >> 5;
         const int col = t < 16 ? 2 * t + kk : kFeat + 2 * (t - 16) + kk;
         L.s0[e] = p.sdf_w0[i * kInSdf + col];
@@ -714,15 +715,24 @@ constexpr int kGradLd = 33;    // row stride of the per-wave [32][32] stages
 constexpr int kAccTiles = 7;
 constexpr int kAccFloats = kAccTiles * 1024;
 
+// Waves per workgroup: 33 KB of weight images + 20.4 KB of stages per wave <= 160 KB of LDS allows up to 6.  Measured on
+// MI355X: 4 waves (one per SIMD, 396 registers, software prefetch) 68 us; 6 waves (2,2,1,1 per SIMD, 256 registers with
+// 42 spilled, no prefetch) 82 us -- the two SIMDs that hold two waves set the pace.  PMC at 4 waves: MFMA pipe 35 % busy,
+// 39 % of the wave cycles parked in s_waitcnt, 36 % issue-stalled: two waves on EVERY SIMD (8 per workgroup) would hide
+// most of it but need <= 15.8 KB of stages per wave.
+#ifndef NARUTO_BWD_WAVES
+#define NARUTO_BWD_WAVES 4
+#endif
+constexpr int kBwdWaves = NARUTO_BWD_WAVES;
 struct BwdLds {
     FwdLds f;
     float s0T[16 * 64];   // dgrad sdf0 -> feats:   A[i=feat][K pair t]       = sdf_w0[crow(t,k)][i]
     float s1T[8 * 64];    // dgrad sdf1 -> hidden:  A[i=hidden][K pair r]     = sdf_w1[crow(r,k)][i]
     float c0gT[16 * 64];  // dgrad col0 -> sdf-net outputs: A[i=out row][K pair t] = col_w0[crow(t,k)][48+i-1]
-    float acc[kAccFloats];
-    float xs[4][32 * kStageLd];   // per wave: layer inputs  [point][feat32 | oneblob48 | sdf-net out16]
-    float ga[4][32 * kGradLd];    // per wave: "G" operand stage [point][32]
-    float gb[4][32 * kGradLd];    // per wave: activation stage  [point][32]
+    float xs[kBwdWaves][32 * kStageLd];   // per wave: layer inputs  [point][feat32 | oneblob48 | sdf-net out16]
+    float ga[kBwdWaves][32 * kGradLd];    // per wave: "G" operand stage [point][32]
+    float gb[kBwdWaves][32 * kGradLd];    // per wave: activation stage  [point][32]
+    // the block-level dW image (kAccFloats floats) reuses the xs stages once the tile loop is over
 };
 
 template <int NT>
@@ -760,20 +770,26 @@ __device__ __forceinline__ void stage_ctile(float* __restrict__ buf, int ld, int
 
 // one 32x32 dW tile over this wave's 32 points: D[i][c] += sum_pt G[pt][i] * X[pt][c0 + c].  The tile lives in
 // this wave's registers for the whole kernel (ds_add_f32 is ~25x too slow on gfx950 to accumulate in LDS).
+// Operands are read kWgradBatch K-pairs at a time (one lgkmcnt wait per batch, then the dependent MFMAs back to back):
+// large batches hide the LDS round trip when a SIMD holds a single wave, small ones keep the kernel inside the 256
+// registers that two waves per SIMD leave to each.
+constexpr int kWgradBatch = kBwdWaves > 4 ? 4 : 16;
+
 __device__ __forceinline__ void wgrad_tile(const float* __restrict__ gbuf, int gld, const float* __restrict__ xbuf, int xld, int c0,
                                            f32x16& d, int lane) {
     const int i = lane & 31, kk = lane >> 5;
-    // all 32 operand reads first (one lgkmcnt wait), then the 16 dependent MFMAs back to back: with one wave per
-    // SIMD nothing else hides an LDS round trip in front of every MFMA
-    float gv[16], xv[16];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const int pt = 2 * t + kk;
-        gv[t] = gbuf[pt * gld + i];
-        xv[t] = xbuf[pt * xld + c0 + i];
+    for (int t0 = 0; t0 < 16; t0 += kWgradBatch) {
+        float gv[kWgradBatch], xv[kWgradBatch];
+#pragma unroll
+        for (int t = 0; t < kWgradBatch; ++t) {
+            const int pt = 2 * (t0 + t) + kk;
+            gv[t] = gbuf[pt * gld + i];
+            xv[t] = xbuf[pt * xld + c0 + i];
+        }
+#pragma unroll
+        for (int t = 0; t < kWgradBatch; ++t) d = mfma32(gv[t], xv[t], d);
     }
-#pragma unroll
-    for (int t = 0; t < 16; ++t) d = mfma32(gv[t], xv[t], d);
 }
 
 // three tiles sharing the G operand (dW of one layer, 96 input columns): G is read once, the three accumulators
@@ -781,24 +797,23 @@ __device__ __forceinline__ void wgrad_tile(const float* __restrict__ gbuf, int g
 __device__ __forceinline__ void wgrad_tile3(const float* __restrict__ gbuf, int gld, const float* __restrict__ xbuf, int xld, f32x16& d0,
                                             f32x16& d1, f32x16& d2, int lane) {
     const int i = lane & 31, kk = lane >> 5;
-    float gv[16];
+    constexpr int B = kWgradBatch > 8 ? 8 : kWgradBatch;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) gv[t] = gbuf[(2 * t + kk) * gld + i];
+    for (int t0 = 0; t0 < 16; t0 += B) {
+        float gv[B], x0[B], x1[B], x2[B];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        float x0[8], x1[8], x2[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int pt = 2 * (8 * h + t) + kk;
+        for (int t = 0; t < B; ++t) {
+            const int pt = 2 * (t0 + t) + kk;
+            gv[t] = gbuf[pt * gld + i];
             x0[t] = xbuf[pt * xld + i];
             x1[t] = xbuf[pt * xld + 32 + i];
             x2[t] = xbuf[pt * xld + 64 + i];
         }
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            d0 = mfma32(gv[8 * h + t], x0[t], d0);
-            d1 = mfma32(gv[8 * h + t], x1[t], d1);
-            d2 = mfma32(gv[8 * h + t], x2[t], d2);
+        for (int t = 0; t < B; ++t) {
+            d0 = mfma32(gv[t], x0[t], d0);
+            d1 = mfma32(gv[t], x1[t], d1);
+            d2 = mfma32(gv[t], x2[t], d2);
         }
     }
 }
@@ -806,22 +821,25 @@ __device__ __forceinline__ void wgrad_tile3(const float* __restrict__ gbuf, int 
 __device__ __forceinline__ void wgrad_tile2(const float* __restrict__ gbuf, int gld, const float* __restrict__ xbuf, int xld, int c0, f32x16& d0,
                                             f32x16& d1, int lane) {
     const int i = lane & 31, kk = lane >> 5;
-    float gv[16], x0[16], x1[16];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const int pt = 2 * t + kk;
-        gv[t] = gbuf[pt * gld + i];
-        x0[t] = xbuf[pt * xld + c0 + i];
-        x1[t] = xbuf[pt * xld + c0 + 32 + i];
-    }
+    for (int t0 = 0; t0 < 16; t0 += kWgradBatch) {
+        float gv[kWgradBatch], x0[kWgradBatch], x1[kWgradBatch];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        d0 = mfma32(gv[t], x0[t], d0);
-        d1 = mfma32(gv[t], x1[t], d1);
+        for (int t = 0; t < kWgradBatch; ++t) {
+            const int pt = 2 * (t0 + t) + kk;
+            gv[t] = gbuf[pt * gld + i];
+            x0[t] = xbuf[pt * xld + c0 + i];
+            x1[t] = xbuf[pt * xld + c0 + 32 + i];
+        }
+#pragma unroll
+        for (int t = 0; t < kWgradBatch; ++t) {
+            d0 = mfma32(gv[t], x0[t], d0);
+            d1 = mfma32(gv[t], x1[t], d1);
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps, uint32_t M, uint32_t cap,
+__global__ __launch_bounds__(64 * kBwdWaves) void k_query_bwd(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps, uint32_t M, uint32_t cap,
                                                    const float* __restrict__ feat_save, const float* __restrict__ d_raw,
                                                    const float* __restrict__ d_geo, float* __restrict__ d_feat, float* __restrict__ x_out,
                                                    float* __restrict__ d_uncert_grid, float* __restrict__ partials,
@@ -829,7 +847,7 @@ __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, Bo
     // list_off: position of this launch's first point in the scatter's point list (the smoothness lattice sits in front)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     BwdLds& L = *reinterpret_cast<BwdLds*>(smem_raw);
-    stage_bwd_weights<256>(L, p, threadIdx.x);
+    stage_bwd_weights<64 * kBwdWaves>(L, p, threadIdx.x);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hh = lane >> 5, j = lane & 31;
@@ -863,13 +881,14 @@ __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, Bo
         for (int T = 0; T < kLevels; ++T) t.feat[T] = feat_save[((size_t)T * M + t.m) * 2 + hh];
         return t;
     };
-    const uint32_t tile_stride = gridDim.x * 4u;
-    uint32_t tile = blockIdx.x * 4u + wave;
+    const uint32_t tile_stride = gridDim.x * (uint32_t)kBwdWaves;
+    uint32_t tile = blockIdx.x * (uint32_t)kBwdWaves + wave;
+    constexpr bool kPrefetch = kBwdWaves <= 4;         // with two waves per SIMD the other wave hides the latency; the registers are needed
     TileIn nxt;
-    if (tile < n_tiles) nxt = load_tile(tile);
+    if (kPrefetch && tile < n_tiles) nxt = load_tile(tile);
     for (; tile < n_tiles; tile += tile_stride) {
-        const TileIn cur = nxt;
-        if (tile + tile_stride < n_tiles) nxt = load_tile(tile + tile_stride);
+        const TileIn cur = kPrefetch ? nxt : load_tile(tile);
+        if (kPrefetch && tile + tile_stride < n_tiles) nxt = load_tile(tile + tile_stride);
         const bool valid = cur.valid;
         const uint32_t i_pt = cur.i_pt, m = cur.m;
         const float x = cur.x, y = cur.y, z = cur.z;
@@ -1019,14 +1038,17 @@ __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, Bo
     }
     // block-level sum of the four waves' register tiles through the LDS image (plain stores / adds: every
     // (tile,row,col) belongs to exactly one lane of a wave), then one coalesced write of the partial
-    for (int w = 0; w < 4; ++w) {
+    static_assert(sizeof(L.xs) >= kAccFloats * sizeof(float), "the dW image must fit the xs stages");
+    float* __restrict__ acc = &L.xs[0][0];
+    __syncthreads();                     // every wave is done with its stages
+    for (int w = 0; w < kBwdWaves; ++w) {
         if (wave == w) {
             const f32x16* tiles[kAccTiles] = {&dW0a, &dW0b, &dW0c, &dW1, &dWc0a, &dWc0b, &dWc1};
 #pragma unroll
             for (int t = 0; t < kAccTiles; ++t) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float* a = &L.acc[t * 1024 + crow(r, hh) * 32 + j];
+                    float* a = &acc[t * 1024 + crow(r, hh) * 32 + j];
                     *a = (w == 0 ? 0.0f : *a) + (*tiles[t])[r];
                 }
             }
@@ -1034,7 +1056,7 @@ __global__ __launch_bounds__(256) void k_query_bwd(LevelTab lt, UncertTab ut, Bo
         __syncthreads();
     }
     float* __restrict__ out = partials + (size_t)blockIdx.x * kAccFloats;
-    for (int e = threadIdx.x; e < kAccFloats; e += blockDim.x) out[e] = L.acc[e];
+    for (int e = threadIdx.x; e < kAccFloats; e += blockDim.x) out[e] = acc[e];
 }
 
 // partials [n_blocks][7][32][32] -> += into the four weight gradients.  Block = 32 outputs x 8 slices of the

@@ -691,6 +691,18 @@ class TrainStep:
         """One forward + backward.  Afterwards: self.losses[10], self.rgb / depth / uncert_map, gradients in self.grads.
         ``rand`` ([N,S], only with device_rng=False): the depth jitter to use instead of a fresh draw; the six lattice
         numbers in self.rand[N*S:] are then left as they are."""
+        self.run_forward(rays_o, rays_d, target_rgb, target_d, rand)
+        if self.group is not None:
+            from . import parallel
+            parallel.allreduce_loss_sums(self.sums, self.group)
+        self.run_backward()
+        return self.losses
+
+    # The two halves of run(), split where data-parallel ranks exchange the loss sums: run_forward stops at this rank's
+    # sums (a process group is set) or at the final losses (single process); run_backward finishes the losses from the
+    # (all-reduced) sums if needed and runs the backward.  MappingTrainer captures them as separate hipGraph segments so
+    # that the collectives stay ordinary eager RCCL calls between graph launches.
+    def run_forward(self, rays_o, rays_d, target_rgb, target_d, rand: Optional[torch.Tensor] = None):
         lib = _lib.load()
         t = self.t
         for a, n in ((rays_o, "rays_o"), (rays_d, "rays_d"), (target_rgb, "target_rgb"), (target_d, "target_d")):
@@ -709,9 +721,13 @@ class TrainStep:
                 self.grads["table"].zero_()
             check(lib.naruto_train_forward(self.handle.ptr, C.byref(self.ps), C.byref(t), 0 if self.group is not None else 1, st),
                   "naruto_train_forward")
+
+    def run_backward(self):
+        lib = _lib.load()
+        t = self.t
+        with torch.cuda.device(self.device):
+            st = _stream()
             if self.group is not None:
-                from . import parallel
-                parallel.allreduce_loss_sums(self.sums, self.group)
                 check(lib.naruto_train_finalize(self.handle.ptr, C.byref(t), st), "naruto_train_finalize")
             if self.opt is not None:
                 check(lib.naruto_train_backward(self.handle.ptr, C.byref(self.ps), C.byref(t), C.byref(self._gs_nograd), self.flags, C.byref(self.opt), st),
@@ -719,7 +735,6 @@ class TrainStep:
             else:
                 check(lib.naruto_train_backward(self.handle.ptr, C.byref(self.ps), C.byref(t), C.byref(self.gs), self.flags, None, st),
                       "naruto_train_backward")
-        return self.losses
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -304,6 +304,17 @@ class MappingTrainer:
                 st['rays_d'].copy_(rays_d, non_blocking=True)
                 st['target_rgb'].copy_(target_rgb, non_blocking=True)
                 st['target_d'].copy_(target_d.reshape(st['target_d'].shape), non_blocking=True)
+            if st.get('segments') is not None:
+                # data parallel: three graph segments with the collectives as ordinary eager RCCL calls in between
+                seg, ts = st['segments'], st['ts']
+                seg['fwd'].replay()
+                parallel.allreduce_loss_sums(ts.sums, self.group)
+                seg['bwd'].replay()
+                torch.distributed.all_reduce(ts.flat_grad, op=torch.distributed.ReduceOp.SUM, group=self.group)
+                if uncert_step:
+                    parallel.allreduce_grads([self.model.uncert_grid], self.group)
+                seg['opt'][1 if uncert_step else 0].replay()
+                return st['ret'][0], st['loss'][0]
             self._graphs[1 if uncert_step else 0].replay()
             return st['ret'][1 if uncert_step else 0], st['loss'][1 if uncert_step else 0]
         return self._iteration(rays_o, rays_d, target_rgb, target_d, smooth, uncert_step)
@@ -330,7 +341,44 @@ class MappingTrainer:
         torch.cuda.synchronize(dev)
         graphs = []
         pool = None
-        for variant in (False, True):
+        import os
+        segmented = self.group is not None and self.direct and os.environ.get("NARUTO_GRAPH_DIST", "segmented") != "whole"
+        # (bench.py runs data-parallel jobs eagerly unless NARUTO_GRAPH_DIST is set: same speed, nothing to capture)
+        if segmented:
+            # Data parallel: forward | backward | optimiser as three graph segments; the two all-reduces (loss sums, flat
+            # gradient) run between them as eager RCCL calls on the same stream.  (Capturing the collectives inside one graph
+            # also works -- NARUTO_GRAPH_DIST=whole, 0.47 ms at world size 1 -- but a multi-rank capture cannot be
+            # exercised on the single-GPU test boxes, so the default does not depend on it.)
+            tr_cfg = self.config['training']
+            ts = self._train_step(n_rays, bool(smooth and tr_cfg['smooth_weight'] > 0))
+            args = (st['rays_o'], st['rays_d'], st['target_rgb'], st['target_d'].reshape(-1))
+            seg = {'opt': [None, None]}
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool), torch.no_grad():
+                ts.run_forward(*args)
+            pool = g.pool()
+            seg['fwd'] = g
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool), torch.no_grad():
+                ts.run_backward()
+            seg['bwd'] = g
+            for name, p in self.model._params().items():
+                p.grad = ts.grads[name]
+            for variant in (False, True):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool), torch.no_grad():
+                    self.map_optimizer.step()
+                    if variant:
+                        self.uncert_optim.step(zero_grad=True)
+                seg['opt'][1 if variant else 0] = g
+            losses = ts.losses
+            self.model._pending_min_uncert = losses[6]
+            st['segments'], st['ts'] = seg, ts
+            st['ret'][0] = {"rgb": ts.rgb, "depth": ts.depth, "rgb_loss": losses[0], "depth_loss": losses[1], "sdf_loss": losses[2],
+                            "fs_loss": losses[3], "psnr": losses[4], "uncert_loss": losses[5], "_losses": losses, "_smooth_loss": losses[8]}
+            st['loss'][0] = losses[9]
+            graphs = [seg['fwd']]
+        for variant in (() if segmented else (False, True)):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool):
                 ret, loss = self._iteration(st['rays_o'], st['rays_d'], st['target_rgb'], st['target_d'], smooth, variant, check=False)

@@ -434,6 +434,17 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// a / d and a % d for a < 2^24 with a divisor that is only known at run time: float estimate + one correction step
+// (the generic 32-bit division sequence is ~40 instructions; index decoding was most of the smoothness kernels' time)
+__device__ __forceinline__ uint32_t fast_divmod(uint32_t a, uint32_t d, float inv_d, uint32_t& rem) {
+    uint32_t q = (uint32_t)((float)a * inv_d);
+    int32_t r = (int32_t)(a - q * d);
+    if (r < 0) { --q; r += (int32_t)d; }
+    if (r >= (int32_t)d) { ++q; r -= (int32_t)d; }
+    rem = (uint32_t)r;
+    return q;
+}
+
 // Counter-based uniform numbers for the depth jitter / lattice placement when the caller does not supply its own:
 // rng = {seed, iteration counter} in device memory; value(idx) = top 24 bits of splitmix64 keyed by (seed, counter).
 // (The reference draws the jitter with torch.rand on the host, scene_rep.py:180: any uniform stream is equivalent.)

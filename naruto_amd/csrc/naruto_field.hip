@@ -114,7 +114,10 @@ __device__ __forceinline__ void tv_encode_body(const LevelTab& lt, const BoxTab&
     const uint32_t level = block / per_level;
     const uint32_t m = (block % per_level) * 256u + threadIdx.x;
     if (m >= n3) return;
-    const uint32_t ijk[3] = {m / (a.n * a.n), (m / a.n) % a.n, m % a.n};
+    uint32_t ijk[3], jk;
+    const float inv_n = 1.0f / (float)a.n;
+    ijk[0] = fast_divmod(m, a.n * a.n, inv_n * inv_n, jk);
+    ijk[1] = fast_divmod(jk, a.n, inv_n, ijk[2]);
     const uint64_t key = rand6 == nullptr ? rng_key(rng) : 0ull;
     float xn[3];
 #pragma unroll
@@ -636,25 +639,52 @@ __device__ __forceinline__ void tv_loss_list_body(const TvArgs& a, const float* 
                                                   const float* __restrict__ scale_dev, float scale_host, double* __restrict__ partial, uint32_t block,
                                                   uint32_t n_blocks, double* red) {
     const uint32_t n = a.n, n3 = n * n * n, total = n3 * kFeat;
+    const float inv_n = 1.0f / (float)n, inv_2n3 = 1.0f / (float)(2u * n3);
     const float sc = 2.0f * a.inv_p3 * (scale_dev != nullptr ? scale_dev[0] : 1.0f) * scale_host;
     double acc = 0.0;
-    for (uint32_t t = block * 256u + threadIdx.x; t < total; t += n_blocks * 256u) {          // (level, point, component)
-        const uint32_t level = t / (2u * n3), r = t % (2u * n3), m = r >> 1;
-        const uint32_t i = m / (n * n), j = (m / n) % n, k = m % n;
-        const float f = feat[t];
-        const uint32_t stride[3] = {2u * n * n, 2u * n, 2u};
-        const uint32_t pos[3] = {i, j, k};
-        float g = 0.0f;
+    // kTvBatch elements per thread and step: the 7 loads of each (own value + 6 lattice neighbours) are issued for all of them
+    // before the first use -- one element at a time the loop is a chain of memory round trips
+    constexpr int kTvBatch = 4;
+    const uint32_t stride[3] = {2u * n * n, 2u * n, 2u};
+    for (uint32_t t0 = block * 256u + threadIdx.x; t0 < total; t0 += n_blocks * 256u * kTvBatch) {          // (level, point, component)
+        float f[kTvBatch], fp[kTvBatch][3], fm[kTvBatch][3];
+        uint32_t lvl[kTvBatch], mm[kTvBatch], rr[kTvBatch];
+        bool hp[kTvBatch][3], hm[kTvBatch][3], live[kTvBatch];
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            if (pos[d] + 1 < n) {
-                const float df = feat[t + stride[d]] - f;
-                acc += (double)(df * df);
-                g -= df;
+        for (int q = 0; q < kTvBatch; ++q) {
+            const uint32_t t_raw = t0 + (uint32_t)q * n_blocks * 256u;
+            live[q] = t_raw < total;
+            const uint32_t t = live[q] ? t_raw : total - 1u;
+            uint32_t r, jk, k;
+            lvl[q] = fast_divmod(t, 2u * n3, inv_2n3, r);
+            rr[q] = r;
+            mm[q] = r >> 1;
+            const uint32_t i = fast_divmod(mm[q], n * n, inv_n * inv_n, jk), j = fast_divmod(jk, n, inv_n, k);
+            const uint32_t pos[3] = {i, j, k};
+            f[q] = feat[t];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                hp[q][d] = pos[d] + 1 < n;
+                hm[q][d] = pos[d] > 0;
+                fp[q][d] = feat[hp[q][d] ? t + stride[d] : t];
+                fm[q][d] = feat[hm[q][d] ? t - stride[d] : t];
             }
-            if (pos[d] > 0) g += f - feat[t - stride[d]];
         }
-        d_list[((size_t)level * a.cap + m) * 2u + (r & 1u)] = g * sc;
+#pragma unroll
+        for (int q = 0; q < kTvBatch; ++q) {
+            if (!live[q]) continue;
+            float g = 0.0f;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                if (hp[q][d]) {
+                    const float df = fp[q][d] - f[q];
+                    acc += (double)(df * df);
+                    g -= df;
+                }
+                if (hm[q][d]) g += f[q] - fm[q][d];
+            }
+            d_list[((size_t)lvl[q] * a.cap + mm[q]) * 2u + (rr[q] & 1u)] = g * sc;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);

@@ -62,6 +62,20 @@ int check_points(const NarutoPoints* pts) {
 
 uint32_t cu_count(const NarutoField* f) { return f->n_cu > 0 ? (uint32_t)f->n_cu : 256u; }
 
+// the per-ray kernels keep one ray per wave in dynamic LDS (kRayFields x S floats): allow the kMaxSamples case (128 KB)
+int ray_lds_attr() {
+    static bool done = false;
+    if (done) return NARUTO_OK;
+    const int bytes = (int)ray_scratch_bytes(kMaxSamples);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_composite_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_composite_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_composite_bwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_loss_stage), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+        return fail(NARUTO_ERR_LAUNCH, "per-ray kernels: cannot reserve %d bytes of LDS: %s", bytes, hipGetErrorString(hipGetLastError()));
+    done = true;
+    return NARUTO_OK;
+}
+
 constexpr uint32_t kBwdMaxBlocks = 256;     // one 145 KB-LDS block per CU
 
 // table scatter: LDS-tiled units + k_scatter_reduce, and/or the global-atomic kernel for oversized levels
@@ -537,7 +551,8 @@ int naruto_train_forward(const NarutoField* f, const NarutoParams* p, const Naru
     a.tv_scale_dev = t->loss_weights != nullptr ? t->loss_weights + 8 : nullptr;
     a.tv_scale_host = t->smooth_grad_scale != 0.0f ? t->smooth_grad_scale : 1.0f;
     a.n_tv_blocks = t->smooth_points != 0 ? w.n_tv_blocks : 0u;
-    hipLaunchKernelGGL(k_loss_stage, dim3(a.n_ray_blocks + a.n_tv_blocks), dim3(64 * kRaysPerBlock), 0, st, a);
+    if (int rc = ray_lds_attr()) return rc;
+    hipLaunchKernelGGL(k_loss_stage, dim3(a.n_ray_blocks + a.n_tv_blocks), dim3(64 * kRaysPerBlock), ray_scratch_bytes(S), st, a);
     if (int rc = check_launch("loss_stage")) return rc;
     LossTailArgs tl{};
     tl.partials = a.partials; tl.n_ray_blocks = a.n_ray_blocks;
@@ -581,7 +596,8 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
     CompositeCot cot{};
     LossArgs la{t->target_rgb, t->target_d, t->sums, t->loss_weights, t->n_rays_total ? t->n_rays_total : N, t->depth_trunc, t->rgb_missing,
                 f->desc.trunc * f->desc.sc_factor};
-    hipLaunchKernelGGL(k_composite_bwd<true>, dim3((N + kRaysPerBlock - 1) / kRaysPerBlock), dim3(64 * kRaysPerBlock), 0, st, N, S, f->desc.trunc,
+    if (int rc = ray_lds_attr()) return rc;
+    hipLaunchKernelGGL(k_composite_bwd<true>, dim3((N + kRaysPerBlock - 1) / kRaysPerBlock), dim3(64 * kRaysPerBlock), ray_scratch_bytes(S), st, N, S, f->desc.trunc,
                        f->desc.sc_factor, f->desc.white_bkgd, t->raw, t->z_vals, cot, la, t->d_raw, 0, t->ray_count);
     if (int rc = check_launch("loss_bwd")) return rc;
     const bool smooth = t->smooth_points != 0 && (g->table != nullptr || opt != nullptr);
@@ -603,7 +619,8 @@ int naruto_composite_fwd(const NarutoField* f, uint32_t n_rays, uint32_t S, cons
     if (f == nullptr || raw == nullptr || z_vals == nullptr) return fail(NARUTO_ERR_INVALID, "composite_fwd: NULL argument");
     if (S < 1 || S > (uint32_t)kMaxSamples) return fail(NARUTO_ERR_INVALID, "composite_fwd: samples per ray must be in [1, %d]", kMaxSamples);
     if (n_rays == 0) return NARUTO_OK;
-    hipLaunchKernelGGL(k_composite_fwd, dim3((n_rays + kRaysPerBlock - 1) / kRaysPerBlock), dim3(64 * kRaysPerBlock), 0, (hipStream_t)stream, n_rays, S,
+    if (int rc = ray_lds_attr()) return rc;
+    hipLaunchKernelGGL(k_composite_fwd, dim3((n_rays + kRaysPerBlock - 1) / kRaysPerBlock), dim3(64 * kRaysPerBlock), ray_scratch_bytes(S), (hipStream_t)stream, n_rays, S,
                        f->desc.trunc, f->desc.sc_factor, f->desc.white_bkgd, raw, z_vals, rgb, disp, acc, weights, depth, depth_var, uncert_map);
     return check_launch("composite_fwd");
 }
@@ -616,7 +633,8 @@ int naruto_composite_bwd(const NarutoField* f, uint32_t n_rays, uint32_t S, cons
     if (n_rays == 0) return NARUTO_OK;
     CompositeCot cot{d_rgb, d_disp, d_acc, d_weights, d_depth, d_depth_var, d_uncert_map};
     LossArgs la{};
-    hipLaunchKernelGGL(k_composite_bwd<false>, dim3((n_rays + kRaysPerBlock - 1) / kRaysPerBlock), dim3(64 * kRaysPerBlock), 0, (hipStream_t)stream,
+    if (int rc = ray_lds_attr()) return rc;
+    hipLaunchKernelGGL(k_composite_bwd<false>, dim3((n_rays + kRaysPerBlock - 1) / kRaysPerBlock), dim3(64 * kRaysPerBlock), ray_scratch_bytes(S), (hipStream_t)stream,
                        n_rays, S, f->desc.trunc, f->desc.sc_factor, f->desc.white_bkgd, raw, z_vals, cot, la, d_raw, accumulate, (uint32_t*)nullptr);
     return check_launch("composite_bwd");
 }
@@ -654,7 +672,8 @@ int naruto_loss_bwd(const NarutoField* f, uint32_t n_rays, uint32_t S, const flo
     if (n_rays == 0) return NARUTO_OK;
     CompositeCot cot{};
     LossArgs la{target_rgb, target_d, sums, loss_grad, n_rays_total, depth_trunc, rgb_missing, f->desc.trunc * f->desc.sc_factor};
-    hipLaunchKernelGGL(k_composite_bwd<true>, dim3((n_rays + kRaysPerBlock - 1) / kRaysPerBlock), dim3(64 * kRaysPerBlock), 0, (hipStream_t)stream,
+    if (int rc = ray_lds_attr()) return rc;
+    hipLaunchKernelGGL(k_composite_bwd<true>, dim3((n_rays + kRaysPerBlock - 1) / kRaysPerBlock), dim3(64 * kRaysPerBlock), ray_scratch_bytes(S), (hipStream_t)stream,
                        n_rays, S, f->desc.trunc, f->desc.sc_factor, f->desc.white_bkgd, raw, z_vals, cot, la, d_raw, 0, ray_count);
     return check_launch("loss_bwd");
 }

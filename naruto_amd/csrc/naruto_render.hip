@@ -77,10 +77,21 @@ __global__ __launch_bounds__(64) void k_sample_z(uint32_t n_rays, const float* _
 // ------------------------------------------------------------------------------------------------
 // Shared per-ray compositing core.  Works on this wave's ray; sdf / z / raw live in per-wave LDS.
 // ------------------------------------------------------------------------------------------------
+// Per-wave LDS image of one ray: every per-sample quantity the passes below touch more than once -- the raw channels
+// (read 3-4 times by forward + backward) and the unnormalised compositing weight (two sigmoids per evaluation, needed by
+// five passes).  Dynamic shared memory: kRayFields x S floats per wave.
 struct RayScratch {
-    float sdf[kMaxSamples];
-    float z[kMaxSamples];
+    float* sdf; float* z;           // raw[...,3], z_vals
+    float* c0; float* c1; float* c2; float* u;      // raw[...,0..2] (pre-sigmoid colour), raw[...,4] (uncertainty, pre-softplus)
+    float* wb;                      // (z < limit ? bell(sdf) : 0), filled by ray_weights
+    float* gw;                      // backward: cotangent of the normalised weight (pass 1 -> pass 2)
 };
+constexpr int kRayFields = 8;
+__device__ __forceinline__ RayScratch ray_scratch(float* __restrict__ base, int wave, uint32_t S) {
+    float* p = base + (size_t)wave * kRayFields * S;
+    return {p, p + S, p + 2 * (size_t)S, p + 3 * (size_t)S, p + 4 * (size_t)S, p + 5 * (size_t)S, p + 6 * (size_t)S, p + 7 * (size_t)S};
+}
+inline size_t ray_scratch_bytes(uint32_t S) { return (size_t)kRaysPerBlock * kRayFields * S * sizeof(float); }
 
 __device__ __forceinline__ float softplus_(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float softplus_grad_(float x) {
@@ -109,15 +120,22 @@ __device__ __forceinline__ RayWeights ray_weights(const RayScratch& rs, uint32_t
     rw.z_min = rs.z[first == 0xFFFFFFFFu ? 0u : first];
     rw.limit = rw.z_min + sc_factor * trunc;
     float t = 0.0f;
-    for (uint32_t s = lane; s < S; s += 64) t += rs.z[s] < rw.limit ? bell(rs.sdf[s], trunc) : 0.0f;
+    for (uint32_t s = lane; s < S; s += 64) {
+        const float wb = rs.z[s] < rw.limit ? bell(rs.sdf[s], trunc) : 0.0f;
+        rs.wb[s] = wb;                                          // own lane's entries only: no sync needed before the strided re-reads
+        t += wb;
+    }
     rw.t_eps = wave_sum(t) + 1e-8f;
     return rw;
 }
 
-__device__ __forceinline__ void load_ray(RayScratch& rs, const float* __restrict__ raw, const float* __restrict__ z_vals, uint32_t n,
+__device__ __forceinline__ void load_ray(const RayScratch& rs, const float* __restrict__ raw, const float* __restrict__ z_vals, uint32_t n,
                                          uint32_t S, int lane) {
     for (uint32_t s = lane; s < S; s += 64) {
-        rs.sdf[s] = raw[((size_t)n * S + s) * 5 + 3];
+        const float* p = raw + ((size_t)n * S + s) * 5;
+        rs.c0[s] = p[0]; rs.c1[s] = p[1]; rs.c2[s] = p[2];
+        rs.sdf[s] = p[3];
+        rs.u[s] = p[4];
         rs.z[s] = z_vals[(size_t)n * S + s];
     }
     wave_lds_sync();
@@ -127,19 +145,18 @@ struct RayOut {
     float rgb[3], depth, acc, depth_var, uncert, disp;
 };
 
-__device__ __forceinline__ RayOut ray_composite(const RayScratch& rs, const RayWeights& rw, const float* __restrict__ raw, uint32_t n,
-                                                uint32_t S, float trunc, int white_bkgd, float* __restrict__ weights_out, int lane) {
+__device__ __forceinline__ RayOut ray_composite(const RayScratch& rs, const RayWeights& rw, uint32_t n,
+                                                uint32_t S, int white_bkgd, float* __restrict__ weights_out, int lane) {
     float r = 0.0f, g = 0.0f, b = 0.0f, dep = 0.0f, acc = 0.0f, unc = 0.0f;
     for (uint32_t s = lane; s < S; s += 64) {
         const float z = rs.z[s];
-        const float w = (z < rw.limit ? bell(rs.sdf[s], trunc) : 0.0f) / rw.t_eps;
-        const float* p = raw + ((size_t)n * S + s) * 5;
-        r = fmaf(w, sigmoid_(p[0]), r);
-        g = fmaf(w, sigmoid_(p[1]), g);
-        b = fmaf(w, sigmoid_(p[2]), b);
+        const float w = rs.wb[s] / rw.t_eps;
+        r = fmaf(w, sigmoid_(rs.c0[s]), r);
+        g = fmaf(w, sigmoid_(rs.c1[s]), g);
+        b = fmaf(w, sigmoid_(rs.c2[s]), b);
         dep = fmaf(w, z, dep);
         acc += w;
-        unc = fmaf(w * w, softplus_(p[4]) + 0.01f, unc);
+        unc = fmaf(w * w, softplus_(rs.u[s]) + 0.01f, unc);
         if (weights_out != nullptr) weights_out[(size_t)n * S + s] = w;
     }
     RayOut o;
@@ -149,9 +166,8 @@ __device__ __forceinline__ RayOut ray_composite(const RayScratch& rs, const RayW
     o.uncert = wave_sum(unc);
     float var = 0.0f;
     for (uint32_t s = lane; s < S; s += 64) {
-        const float z = rs.z[s];
-        const float w = (z < rw.limit ? bell(rs.sdf[s], trunc) : 0.0f) / rw.t_eps;
-        const float dz = z - o.depth;
+        const float w = rs.wb[s] / rw.t_eps;
+        const float dz = rs.z[s] - o.depth;
         var = fmaf(w, dz * dz, var);
     }
     o.depth_var = wave_sum(var);
@@ -170,14 +186,14 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_composite_fwd(uint32_t n
                                                                       float* __restrict__ disp, float* __restrict__ acc,
                                                                       float* __restrict__ weights, float* __restrict__ depth,
                                                                       float* __restrict__ depth_var, float* __restrict__ uncert_map) {
-    __shared__ RayScratch scratch[kRaysPerBlock];
+    extern __shared__ float ray_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t n = blockIdx.x * kRaysPerBlock + wave;
     if (n >= n_rays) return;
-    RayScratch& rs = scratch[wave];
+    const RayScratch rs = ray_scratch(ray_lds, wave, S);
     load_ray(rs, raw, z_vals, n, S, lane);
     const RayWeights rw = ray_weights(rs, S, trunc, sc_factor, lane);
-    const RayOut o = ray_composite(rs, rw, raw, n, S, trunc, white_bkgd, weights, lane);
+    const RayOut o = ray_composite(rs, rw, n, S, white_bkgd, weights, lane);
     if (lane == 0) {
         if (rgb) { rgb[3 * (size_t)n] = o.rgb[0]; rgb[3 * (size_t)n + 1] = o.rgb[1]; rgb[3 * (size_t)n + 2] = o.rgb[2]; }
         if (disp) disp[n] = o.disp;
@@ -350,14 +366,14 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_composite_bwd(uint32_t n
                                                                       const float* __restrict__ raw, const float* __restrict__ z_vals,
                                                                       CompositeCot cot, LossArgs la, float* __restrict__ d_raw, int accumulate,
                                                                       uint32_t* __restrict__ ray_count) {
-    __shared__ RayScratch scratch[kRaysPerBlock];
+    extern __shared__ float ray_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t n = blockIdx.x * kRaysPerBlock + wave;
     if (n >= n_rays) return;
-    RayScratch& rs = scratch[wave];
+    const RayScratch rs = ray_scratch(ray_lds, wave, S);
     load_ray(rs, raw, z_vals, n, S, lane);
     const RayWeights rw = ray_weights(rs, S, trunc, sc_factor, lane);
-    const RayOut o = ray_composite(rs, rw, raw, n, S, trunc, 0, nullptr, lane);     // rgb WITHOUT the white background term
+    const RayOut o = ray_composite(rs, rw, n, S, 0, nullptr, lane);     // rgb WITHOUT the white background term
 
     float g_rgb[3] = {0.0f, 0.0f, 0.0f}, g_depth = 0.0f, g_acc = 0.0f, g_var = 0.0f, g_unc = 0.0f, g_disp = 0.0f;
     float td = 0.0f, dm = 0.0f, c_fs = 0.0f, c_sdf = 0.0f;
@@ -395,19 +411,24 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_composite_bwd(uint32_t n
         const float q = o.depth / o.acc;
         if (q > 1e-10f) { gd_depth = -g_disp * o.acc / (o.depth * o.depth); gd_acc = g_disp / o.depth; }
     }
-    // pass 1: gw_i (cotangent of the normalised weight) and sum_i gw_i w_i
+    // pass 1: gw_i (cotangent of the normalised weight) and sum_i gw_i w_i.  The sigmoids / softplus terms evaluated here are
+    // parked in the ray's LDS image (over the raw values they came from) for pass 2.
     float dot = 0.0f;
     for (uint32_t s = lane; s < S; s += 64) {
         const float z = rs.z[s];
-        const float w = (z < rw.limit ? bell(rs.sdf[s], trunc) : 0.0f) / rw.t_eps;
-        const float* p = raw + ((size_t)n * S + s) * 5;
+        const float w = rs.wb[s] / rw.t_eps;
+        const float u_raw = rs.u[s];
+        const float c0 = sigmoid_(rs.c0[s]), c1 = sigmoid_(rs.c1[s]), c2 = sigmoid_(rs.c2[s]);
         const float dz = z - o.depth;
-        float gw = g_rgb[0] * sigmoid_(p[0]) + g_rgb[1] * sigmoid_(p[1]) + g_rgb[2] * sigmoid_(p[2]);
+        float gw = g_rgb[0] * c0 + g_rgb[1] * c1 + g_rgb[2] * c2;
         gw += (g_depth + gd_depth) * z + (g_acc + gd_acc);
-        gw += g_unc * 2.0f * w * (softplus_(p[4]) + 0.01f);
+        gw += g_unc * 2.0f * w * (softplus_(u_raw) + 0.01f);
         gw += g_var * (dz * dz - 2.0f * z * (o.depth - o.depth * o.acc));
         if (!LOSS && cot.d_weights) gw += cot.d_weights[(size_t)n * S + s];
         dot = fmaf(gw, w, dot);
+        rs.c0[s] = c0; rs.c1[s] = c1; rs.c2[s] = c2;
+        rs.u[s] = softplus_grad_(u_raw);
+        rs.gw[s] = gw;
     }
     dot = wave_sum(dot);
     // pass 2: write d_raw
@@ -415,20 +436,12 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_composite_bwd(uint32_t n
     for (uint32_t s = lane; s < S; s += 64) {
         const float z = rs.z[s];
         const float sdf = rs.sdf[s];
-        const float m = z < rw.limit ? 1.0f : 0.0f;
+        const float wb = rs.wb[s];                               // mask * bell
         const float sg = sigmoid_(sdf / trunc);
-        const float bl = sg * sigmoid_(-sdf / trunc);
-        const float w = m * bl / rw.t_eps;
-        const float* p = raw + ((size_t)n * S + s) * 5;
-        const float c0 = sigmoid_(p[0]), c1 = sigmoid_(p[1]), c2 = sigmoid_(p[2]);
-        const float dz = z - o.depth;
-        float gw = g_rgb[0] * c0 + g_rgb[1] * c1 + g_rgb[2] * c2;
-        gw += (g_depth + gd_depth) * z + (g_acc + gd_acc);
-        gw += g_unc * 2.0f * w * (softplus_(p[4]) + 0.01f);
-        gw += g_var * (dz * dz - 2.0f * z * (o.depth - o.depth * o.acc));
-        if (!LOSS && cot.d_weights) gw += cot.d_weights[(size_t)n * S + s];
-        const float dbell = bl * (1.0f - 2.0f * sg) / trunc;
-        float g_s = m * dbell / rw.t_eps * (gw - dot);
+        const float w = wb / rw.t_eps;
+        const float c0 = rs.c0[s], c1 = rs.c1[s], c2 = rs.c2[s];
+        const float gw = rs.gw[s];
+        float g_s = wb * (1.0f - 2.0f * sg) / trunc / rw.t_eps * (gw - dot);       // mask * d bell / d sdf / t_eps * (gw - dot)
         if constexpr (LOSS) {
             const float front = z < (td - la.trunc_sc) ? 1.0f : 0.0f;
             const float back = z > (td + la.trunc_sc) ? 1.0f : 0.0f;
@@ -438,7 +451,7 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_composite_bwd(uint32_t n
         }
         float* q = d_raw + ((size_t)n * S + s) * 5;
         const float o0 = g_rgb[0] * w * c0 * (1.0f - c0), o1 = g_rgb[1] * w * c1 * (1.0f - c1), o2 = g_rgb[2] * w * c2 * (1.0f - c2);
-        const float o4 = g_unc * w * w * softplus_grad_(p[4]);
+        const float o4 = g_unc * w * w * rs.u[s];
         if (accumulate) { q[0] += o0; q[1] += o1; q[2] += o2; q[3] += g_s; q[4] += o4; }
         else { q[0] = o0; q[1] = o1; q[2] = o2; q[3] = g_s; q[4] = o4; }
         if (o0 != 0.0f || o1 != 0.0f || o2 != 0.0f || g_s != 0.0f || o4 != 0.0f) last_nz = s + 1u;

@@ -60,7 +60,7 @@ __device__ __forceinline__ void loss_total(float* __restrict__ losses, const flo
 }
 
 __global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_stage(LossStageArgs a) {
-    __shared__ RayScratch scratch[kRaysPerBlock];
+    extern __shared__ float ray_lds[];
     __shared__ double red[4];
     __shared__ float terms[kRaysPerBlock][10];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -68,10 +68,10 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_stage(LossStageArgs
         const uint32_t n = blockIdx.x * kRaysPerBlock + wave;
         if (n < a.n_rays) {
             const uint32_t S = a.S;
-            RayScratch& rs = scratch[wave];
+            const RayScratch rs = ray_scratch(ray_lds, wave, S);
             load_ray(rs, a.raw, a.z_vals, n, S, lane);
             const RayWeights rw = ray_weights(rs, S, a.trunc, a.sc_factor, lane);
-            const RayOut o = ray_composite(rs, rw, a.raw, n, S, a.trunc, a.white_bkgd, nullptr, lane);
+            const RayOut o = ray_composite(rs, rw, n, S, a.white_bkgd, nullptr, lane);
             const float td = a.target_d[n];
             const bool valid = depth_valid(td, a.depth_trunc);
             const float dm = td > 0.0f ? 1.0f : 0.0f;

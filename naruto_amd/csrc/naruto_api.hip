@@ -509,17 +509,19 @@ int naruto_train_forward(const NarutoField* f, const NarutoParams* p, const Naru
     // A1
     const float* jitter = t->perturb ? t->rand : nullptr;
     const uint64_t* jitter_rng = (t->perturb && t->rand == nullptr) ? t->rng : nullptr;
-    hipLaunchKernelGGL(k_sample_z, dim3(N), dim3(64), 0, st, N, t->target_d, t->near_, t->far_, t->n_samples_d, t->n_range_d, t->range_d, jitter, jitter_rng,
-                       t->z_vals);
-    if (int rc = check_launch("sample_z")) return rc;
-    // the smoothness lattice: its points go straight to the FRONT of the backward's scatter list, features level-major
+    // A1 (+ the smoothness lattice: its points go straight to the FRONT of the backward's scatter list, features level-major)
     TvArgs tva = tv_args(t);
     tva.cap = M + w.n3;
     const BwdWs bw = bwd_ws(f, w.bwd, M + w.n3);
     if (t->smooth_points != 0) {
-        hipLaunchKernelGGL(k_tv_encode, dim3(16u * ((w.n3 + 255u) / 256u)), dim3(256), 0, st, f->lt, f->bt, tva, t->rand6, t->rng,
-                           reinterpret_cast<const float2*>(p->table), bw.x_soa, w.tv_feat);
-        if (int rc = check_launch("tv_encode")) return rc;
+        SampleArgs sa{N, t->target_d, t->near_, t->far_, t->n_samples_d, t->n_range_d, t->range_d, jitter, jitter_rng, t->z_vals, (N + 3u) / 4u};
+        hipLaunchKernelGGL(k_sample_encode, dim3(sa.n_ray_blocks + 16u * ((w.n3 + 255u) / 256u)), dim3(256), (size_t)4u * 2u * S * sizeof(float), st, sa, f->lt,
+                           f->bt, tva, t->rand6, t->rng, reinterpret_cast<const float2*>(p->table), bw.x_soa, w.tv_feat);
+        if (int rc = check_launch("sample_encode")) return rc;
+    } else {
+        hipLaunchKernelGGL(k_sample_z, dim3(N), dim3(64), 0, st, N, t->target_d, t->near_, t->far_, t->n_samples_d, t->n_range_d, t->range_d, jitter, jitter_rng,
+                           t->z_vals);
+        if (int rc = check_launch("sample_z")) return rc;
     }
     // A2..A5
     PointSrc ps{};

@@ -25,14 +25,12 @@ __device__ __forceinline__ float linspace_at(float start, float end, uint32_t st
 // linspace(near, far, nr) where d <= 0; then the stratified jitter.  Both lists are already sorted, so the
 // "sort" is a rank computation (merge), not a sort.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_sample_z(uint32_t n_rays, const float* __restrict__ target_d, float near_, float far_,
-                                                 uint32_t nu, uint32_t nr, float range_d, const float* __restrict__ rand,
-                                                 const uint64_t* __restrict__ rng, float* __restrict__ z_vals) {
-    __shared__ float zs[kMaxSamples];      // merged list
-    __shared__ float us[kMaxSamples];      // the two sorted input lists: uniform [0, nu) then near-surface [nu, nu+nr)
-    const uint32_t n = blockIdx.x;
+// one wave = one ray; zs / us: this wave's LDS, S floats each (merged list; the two sorted input lists: uniform [0, nu) then
+// near-surface [nu, nu+nr))
+__device__ __forceinline__ void sample_z_ray(uint32_t n, const float* __restrict__ target_d, float near_, float far_, uint32_t nu, uint32_t nr,
+                                             float range_d, const float* __restrict__ rand, const uint64_t* __restrict__ rng,
+                                             float* __restrict__ z_vals, float* __restrict__ zs, float* __restrict__ us, int lane) {
     const uint32_t S = nu + nr;
-    const int lane = threadIdx.x;
     if (target_d == nullptr) {
         for (uint32_t s = lane; s < S; s += 64) zs[s] = linspace_at(near_, far_, S, s);     // S == n_samples, nr == 0
     } else {
@@ -42,7 +40,7 @@ __global__ __launch_bounds__(64) void k_sample_z(uint32_t n_rays, const float* _
             if (s < nu) us[s] = linspace_at(near_, far_, nu, s);
             else us[s] = use_near_far ? linspace_at(near_, far_, nr, s - nu) : __fadd_rn(linspace_at(-range_d, range_d, nr, s - nu), d);
         }
-        __syncthreads();
+        wave_lds_sync();
         for (uint32_t s = lane; s < S; s += 64) {
             const float v = us[s];
             uint32_t rank;
@@ -60,7 +58,7 @@ __global__ __launch_bounds__(64) void k_sample_z(uint32_t n_rays, const float* _
             zs[rank] = v;
         }
     }
-    __syncthreads();
+    wave_lds_sync();
     const uint64_t key = rng != nullptr ? rng_key(rng) : 0ull;
     for (uint32_t s = lane; s < S; s += 64) {
         float v = zs[s];
@@ -72,6 +70,16 @@ __global__ __launch_bounds__(64) void k_sample_z(uint32_t n_rays, const float* _
         }
         z_vals[(size_t)n * S + s] = v;
     }
+}
+
+
+__global__ __launch_bounds__(64) void k_sample_z(uint32_t n_rays, const float* __restrict__ target_d, float near_, float far_,
+                                                 uint32_t nu, uint32_t nr, float range_d, const float* __restrict__ rand,
+                                                 const uint64_t* __restrict__ rng, float* __restrict__ z_vals) {
+    __shared__ float zs[kMaxSamples];
+    __shared__ float us[kMaxSamples];
+    (void)n_rays;
+    sample_z_ray(blockIdx.x, target_d, near_, far_, nu, nr, range_d, rand, rng, z_vals, zs, us, (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -130,6 +130,27 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_stage(LossStageArgs
     }
 }
 
+// A1 | the smoothness lattice's points + hash features, one launch: workgroups [0, n_ray_blocks) sample the depths of four
+// rays each (one per wave, 2 S floats of dynamic LDS per wave), the rest are k_tv_encode's workgroups
+struct SampleArgs {
+    uint32_t n_rays; const float* target_d; float near_, far_; uint32_t nu, nr; float range_d;
+    const float* rand; const uint64_t* rng; float* z_vals;
+    uint32_t n_ray_blocks;
+};
+__global__ __launch_bounds__(256) void k_sample_encode(SampleArgs sa, LevelTab lt, BoxTab bt, TvArgs a, const float* __restrict__ rand6,
+                                                       const uint64_t* __restrict__ rng, const float2* __restrict__ table, float* __restrict__ x_out,
+                                                       float* __restrict__ feat) {
+    extern __shared__ float ray_lds[];
+    if (blockIdx.x < sa.n_ray_blocks) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const uint32_t n = blockIdx.x * 4u + wave, S = sa.nu + sa.nr;
+        if (n < sa.n_rays) sample_z_ray(n, sa.target_d, sa.near_, sa.far_, sa.nu, sa.nr, sa.range_d, sa.rand, sa.rng, sa.z_vals,
+                                        ray_lds + (size_t)wave * 2u * S, ray_lds + (size_t)wave * 2u * S + S, lane);
+        return;
+    }
+    tv_encode_body(lt, bt, a, rand6, rng, table, x_out, feat, blockIdx.x - sa.n_ray_blocks);
+}
+
 // one workgroup: per-workgroup partials -> sums[16], smoothness term, losses[10], iteration counter
 __global__ __launch_bounds__(256) void k_loss_tail(LossTailArgs a) {
     __shared__ double red[4];

@@ -62,6 +62,10 @@ int check_points(const NarutoPoints* pts) {
 
 uint32_t cu_count(const NarutoField* f) { return f->n_cu > 0 ? (uint32_t)f->n_cu : 256u; }
 
+// leading dimension of the scatter's point list: a multiple of 4 so that every row (x [3][cap], d_feat [16][cap][2]) starts
+// 16-byte aligned and the scatter can stream it with 16-byte loads
+inline uint32_t list_cap(uint32_t n) { return (n + 3u) & ~3u; }
+
 // the per-ray kernels keep one ray per wave in dynamic LDS (kRayFields x S floats): allow the kMaxSamples case (128 KB)
 int ray_lds_attr() {
     static bool done = false;
@@ -92,7 +96,7 @@ int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const f
                 return fail(NARUTO_ERR_LAUNCH, "hash_scatter: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(hipGetLastError()));
             attr_set = true;
         }
-        const uint32_t blocks = f->plan.n_dense * f->plan.s_dense + f->plan.n_hashed * f->plan.s_hashed;
+        const uint32_t blocks = (f->plan.n_dense * f->plan.s_dense + f->plan.n_hashed * f->plan.s_hashed + 7u) / 8u * 8u;      // XCD-aware order: multiple of 8
         hipLaunchKernelGGL(k_hash_scatter_lds, dim3(blocks), dim3(kScatterThreads), lds, st, f->lt, f->bt, ps, M, d_feat, stride_m, stride_l, f->plan,
                            partial, n_params, m_dev, scale_dev);
         if (int rc = check_launch("hash_scatter_lds")) return rc;
@@ -322,7 +326,8 @@ int naruto_query_fwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
 }
 
 size_t naruto_query_bwd_workspace(const NarutoField* f, uint32_t M) {
-    // M here = points + extra points.  d_feat [16][M][2] | x [3][M] | wgrad partials | scatter partials | count word
+    // M here = points + extra points.  d_feat [16][cap][2] | x [3][cap] | wgrad partials | scatter partials | count word
+    M = list_cap(M);
     return ((size_t)kLevels * 2u + 3u) * sizeof(float) * (size_t)M + (size_t)kBwdMaxBlocks * kAccFloats * sizeof(float) + naruto_scatter_workspace(f) + 64;
 }
 
@@ -354,7 +359,7 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
     if (n_front > 0 && (extra != nullptr || n_list_dev == nullptr)) return fail(NARUTO_ERR_INVALID, "query_bwd: front list excludes extra points");
     const uint32_t E = n_front > 0 ? n_front : ((extra != nullptr && g != nullptr && g->table != nullptr) ? extra->n : 0u);
     if (n_front == 0 && E > 0 && (extra->x == nullptr || extra->d_feat == nullptr)) return fail(NARUTO_ERR_INVALID, "query_bwd: extra points need x and d_feat");
-    const uint32_t cap = M + E;                      // leading dimension of the scatter's point list
+    const uint32_t cap = list_cap(M + E);            // leading dimension of the scatter's point list
     if (f == nullptr || p == nullptr || g == nullptr || feat_save == nullptr || d_raw == nullptr || workspace == nullptr)
         return fail(NARUTO_ERR_INVALID, "query_bwd: NULL argument");
     if (p->table == nullptr || p->uncert_grid == nullptr || p->sdf_w0 == nullptr || p->sdf_w1 == nullptr || p->col_w0 == nullptr || p->col_w1 == nullptr)
@@ -386,8 +391,9 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
         pss.xsoa = x_soa;
         pss.M = cap;
         pss.S = 1;
-        if (int rc = launch_scatter(f, pss, cap, d_feat, (size_t)2, (size_t)2 * (size_t)cap, nullptr, scatter_ws, (hipStream_t)stream,
-                                    n_front > 0 ? n_list_dev : n_active, nullptr, 1, false))
+        const uint32_t* cnt = n_front > 0 ? n_list_dev : n_active;
+        if (int rc = launch_scatter(f, pss, cnt != nullptr ? cap : M, d_feat, (size_t)2, (size_t)2 * (size_t)cap, nullptr, scatter_ws, (hipStream_t)stream, cnt,
+                                    nullptr, 1, false))
             return rc;
         const size_t n_params = (size_t)f->n_entries * 2u;
         const uint32_t n_table_blocks = (uint32_t)((n_params / 4u + 255u) / 256u);
@@ -422,7 +428,8 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
             if (int rc = check_launch("append_points")) return rc;
             count_dev = n_total;
         }
-        if (int rc = launch_scatter(f, pss, cap, d_feat, (size_t)2, (size_t)2 * (size_t)cap, g->table, scatter_ws, (hipStream_t)stream, count_dev, nullptr,
+        // host-side point count: the padded capacity only bounds a device-side count; without one the list holds exactly M points
+        if (int rc = launch_scatter(f, pss, count_dev != nullptr ? cap : M, d_feat, (size_t)2, (size_t)2 * (size_t)cap, g->table, scatter_ws, (hipStream_t)stream, count_dev, nullptr,
                                     (int)(flags & NARUTO_BWD_OVERWRITE_TABLE_GRAD)))
             return rc;
     }
@@ -511,8 +518,8 @@ int naruto_train_forward(const NarutoField* f, const NarutoParams* p, const Naru
     const uint64_t* jitter_rng = (t->perturb && t->rand == nullptr) ? t->rng : nullptr;
     // A1 (+ the smoothness lattice: its points go straight to the FRONT of the backward's scatter list, features level-major)
     TvArgs tva = tv_args(t);
-    tva.cap = M + w.n3;
-    const BwdWs bw = bwd_ws(f, w.bwd, M + w.n3);
+    tva.cap = list_cap(M + w.n3);
+    const BwdWs bw = bwd_ws(f, w.bwd, list_cap(M + w.n3));
     if (t->smooth_points != 0) {
         SampleArgs sa{N, t->target_d, t->near_, t->far_, t->n_samples_d, t->n_range_d, t->range_d, jitter, jitter_rng, t->z_vals, (N + 3u) / 4u};
         hipLaunchKernelGGL(k_sample_encode, dim3(sa.n_ray_blocks + 16u * ((w.n3 + 255u) / 256u)), dim3(256), (size_t)4u * 2u * S * sizeof(float), st, sa, f->lt,
@@ -604,7 +611,7 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
     if (int rc = check_launch("loss_bwd")) return rc;
     const bool smooth = t->smooth_points != 0 && (g->table != nullptr || opt != nullptr);
     const uint32_t n_front = smooth ? w.n3 : 0u;
-    const BwdWs bw = bwd_ws(f, w.bwd, M + w.n3);
+    const BwdWs bw = bwd_ws(f, w.bwd, list_cap(M + w.n3));
     hipLaunchKernelGGL(k_compact, dim3((N + 3u) / 4u), dim3(256), 0, st, N, S, t->ray_count, t->ray_offset, t->active_idx, t->n_active, n_front, bw.n_total);
     if (int rc = check_launch("compact")) return rc;
     NarutoPoints pts{};

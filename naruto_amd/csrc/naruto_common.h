@@ -57,10 +57,10 @@ struct PointSrc {
 // reference's eager torch ops), then (p - bmin) / (bmax - bmin)   [Co-SLAM run_network].
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void load_point(const PointSrc& ps, const BoxTab& bt, uint32_t m, float& x, float& y, float& z) {
-    if (ps.xsoa) {
+    if (ps.xsoa) {                     // 32-bit element offsets: 3 * M < 2^32 (checked where the list is built)
         x = ps.xsoa[m];
-        y = ps.xsoa[(size_t)ps.M + m];
-        z = ps.xsoa[2 * (size_t)ps.M + m];
+        y = ps.xsoa[ps.M + m];
+        z = ps.xsoa[2u * ps.M + m];
     } else if (ps.x) {
         x = ps.x[3 * (size_t)m + 0];
         y = ps.x[3 * (size_t)m + 1];

@@ -419,29 +419,61 @@ constexpr int kScatterBatch = 4;   // independent point loads in flight per thre
 
 constexpr int kScatterRun = 8;     // consecutive points per thread on the dense (coarse) levels
 
-// float -> two's-complement fixed point with 40 fractional bits, in six VALU ops instead of the generic f32 -> i64
-// conversion: v * 2^40 = H * 2^32 + L,  H = floor(v * 2^8) (int32),  L = (v * 2^8 - H) * 2^32 (uint32, exact in fp32
-// apart from the final truncation: error < 2^-40).  Valid for |v| < 2^23.
-__device__ __forceinline__ unsigned long long to_fix40(float v) {
-    const float t = v * 256.0f;
-    const float fh = floorf(t);
-    const uint32_t lo = (uint32_t)((t - fh) * 4294967296.0f);
-    const uint32_t hi = (uint32_t)(int)fh;
+// float -> two's-complement fixed point with 40 fractional bits in four VALU ops instead of the generic f32 -> i64
+// conversion: v * 2^40 = H * 2^32 + L,  H = floor(v * 2^8) (int32, v_cvt_flr_i32_f32),  L = fract(v * 2^8) * 2^32
+// (uint32; v_fract_f32 stays below 1, so L never wraps).  The argument is t = v * 2^8 -- callers fold the 2^8 into the
+// per-point cotangent.  Valid for |v| < 2^23; error < 2^-40 (2^-32 in the measure-zero case fract(t) rounds to 1 - 2^-24).
+__device__ __forceinline__ unsigned long long to_fix40_scaled(float t) {
+    const uint32_t lo = (uint32_t)(__builtin_amdgcn_fractf(t) * 4294967296.0f);
+    const uint32_t hi = (uint32_t)(int)floorf(t);
     return ((unsigned long long)hi << 32) | lo;
 }
+__device__ __forceinline__ unsigned long long to_fix40(float v) { return to_fix40_scaled(v * 256.0f); }
 
+// rel = entry index relative to this workgroup's chunk; in the chunk iff rel < kChunk (unsigned compare: entries below the
+// chunk wrap to huge values).  t256 = contribution * 2^8.
+__device__ __forceinline__ void fix_add_rel(unsigned long long* __restrict__ acc, uint32_t rel, float t256) {
+    if (rel < kChunk) atomicAdd(acc + rel, to_fix40_scaled(t256));          // ds_add_u64
+}
 __device__ __forceinline__ void fix_add(unsigned long long* __restrict__ acc, uint32_t idx, uint32_t chunk, float v) {
-    if ((idx >> kChunkLog2) == chunk) atomicAdd(acc + (idx & (kChunk - 1u)), to_fix40(v));          // ds_add_u64
+    fix_add_rel(acc, idx - chunk * kChunk, v * 256.0f);
 }
 
 template <int T>
 __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const BoxTab& bt, const PointSrc& ps, const float* __restrict__ d_feat,
                                                     size_t stride_m, size_t stride_l, uint32_t m_lo, uint32_t m_hi, uint32_t chunk,
-                                                    unsigned long long* __restrict__ acc) {
+                                                    unsigned long long* __restrict__ acc, uint32_t feat) {
     // d_feat already points at this unit's feature (0 or 1)
+    const uint32_t sm32 = (uint32_t)stride_m, sl32 = (uint32_t)stride_l, chunk_base = chunk * kChunk;
     if ((lt.hashed >> T) & 1u) {
-        // hashed (fine) levels: neighbouring points land in unrelated entries; one point per thread per step,
-        // kScatterBatch independent loads in flight
+        // hashed (fine) levels: neighbouring points land in unrelated entries.  With 256 workgroups re-streaming the point
+        // list at once the kernel is bound by that stream (measured: time linear in the number of workgroups, 2.8 TB/s with
+        // 4-byte loads), so the list layout of the training path (x [3][cap], d_feat [16][cap][2], cap % 4 == 0) is read
+        // four consecutive points per thread with 16-byte loads.
+        if (ps.xsoa != nullptr && stride_m == 2 && (ps.M & 3u) == 0u && (m_lo & 3u) == 0u && (stride_l & 3u) == 0u) {
+            const float* __restrict__ pair = d_feat - feat + (size_t)T * stride_l;          // (f0, f1) pairs of this level
+            for (uint32_t base = m_lo + threadIdx.x * 4u; base < m_hi; base += kScatterThreads * 4u) {
+                const float4 X = *reinterpret_cast<const float4*>(ps.xsoa + base);
+                const float4 Y = *reinterpret_cast<const float4*>(ps.xsoa + ps.M + base);
+                const float4 Z = *reinterpret_cast<const float4*>(ps.xsoa + 2u * ps.M + base);
+                const float4 G0 = *reinterpret_cast<const float4*>(pair + 2u * base);         // points base, base+1
+                const float4 G1 = *reinterpret_cast<const float4*>(pair + 2u * base + 4u);    // points base+2, base+3
+                const float px[4] = {X.x, X.y, X.z, X.w}, py[4] = {Y.x, Y.y, Y.z, Y.w}, pz[4] = {Z.x, Z.y, Z.z, Z.w};
+                const float gg[4] = {feat ? G0.y : G0.x, feat ? G0.w : G0.z, feat ? G1.y : G1.x, feat ? G1.w : G1.z};
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (base + (uint32_t)b >= m_hi || gg[b] == 0.0f) continue;
+                    uint32_t idx[8];
+                    float w[8];
+                    hash_corners<T>(lt, px[b], py[b], pz[b], idx, w);
+                    const float g256 = gg[b] * 256.0f;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) fix_add_rel(acc, idx[c] - chunk_base, w[c] * g256);
+                }
+            }
+            return;
+        }
+        // generic layouts: one point per thread per step, kScatterBatch independent loads in flight
         for (uint32_t base = m_lo + threadIdx.x; base < m_hi; base += kScatterThreads * kScatterBatch) {
             float g[kScatterBatch];
             float px[kScatterBatch], py[kScatterBatch], pz[kScatterBatch];
@@ -449,7 +481,8 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
             for (int b = 0; b < kScatterBatch; ++b) {
                 const uint32_t m = base + b * kScatterThreads;
                 const uint32_t mm = m < m_hi ? m : m_hi - 1u;
-                g[b] = d_feat[(size_t)mm * stride_m + (size_t)T * stride_l];
+                // 32-bit element offsets (the launcher checks that the point list is < 2^32 floats): one shift-add per load
+                g[b] = d_feat[mm * sm32 + (uint32_t)T * sl32];
                 load_point(ps, bt, mm, px[b], py[b], pz[b]);
                 if (m >= m_hi) g[b] = 0.0f;
             }
@@ -459,8 +492,9 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
                 uint32_t idx[8];
                 float w[8];
                 hash_corners<T>(lt, px[b], py[b], pz[b], idx, w);
+                const float g256 = g[b] * 256.0f;                  // the 2^8 of to_fix40 folded in once per point
 #pragma unroll
-                for (int c = 0; c < 8; ++c) fix_add(acc, idx[c], chunk, w[c] * g[b]);
+                for (int c = 0; c < 8; ++c) fix_add_rel(acc, idx[c] - chunk_base, w[c] * g256);
             }
         }
     } else {
@@ -520,15 +554,23 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];
     if (m_dev != nullptr) M = m_dev[0];          // compacted point list: the count lives on the device
     const float gscale = scale_dev != nullptr ? scale_dev[0] : 1.0f;     // cotangent of a scalar loss (smoothness term)
+    // XCD-aware placement: workgroups go to the 8 XCDs round-robin by id, and every workgroup streams the point list of ITS
+    // level (x [3][M] + one d_feat slice, ~2.5 MB), so the workgroups of a level should share an XCD -- then its 4 MB L2
+    // serves the 16..30 re-reads of that level's slice.  Position pos in the level-sorted unit list <-> workgroup id:
+    // pos = (id % 8) * (grid / 8) + id / 8.  (Measured: a single level alone 20-24 us, all levels together 78 us with the
+    // naive order -- the kernel was bound by re-streaming the list through the fabric, not by its arithmetic.)
     uint32_t unit, split, n_splits;
     const uint32_t dense_blocks = plan.n_dense * plan.s_dense;
-    if (blockIdx.x < dense_blocks) {
+    const uint32_t n_blocks = dense_blocks + plan.n_hashed * plan.s_hashed;
+    const uint32_t pos = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (pos >= n_blocks) return;
+    if (pos < dense_blocks) {
         n_splits = plan.s_dense;
-        unit = blockIdx.x / n_splits;
-        split = blockIdx.x % n_splits;
+        unit = pos / n_splits;
+        split = pos % n_splits;
     } else {
         n_splits = plan.s_hashed;
-        const uint32_t b = blockIdx.x - dense_blocks;
+        const uint32_t b = pos - dense_blocks;
         unit = plan.n_dense + b / n_splits;
         split = b % n_splits;
     }
@@ -537,11 +579,11 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
     d_feat += feat;
     for (uint32_t i = threadIdx.x; i < kChunk; i += kScatterThreads) acc[i] = 0ull;
     __syncthreads();
-    const uint32_t per = (M + n_splits - 1u) / n_splits;
-    const uint32_t m_lo = split * per;
+    const uint32_t per = ((M + n_splits - 1u) / n_splits + 3u) & ~3u;         // multiple of 4: 16-byte aligned shares
+    const uint32_t m_lo = split * per < M ? split * per : M;
     const uint32_t m_hi = m_lo + per < M ? m_lo + per : M;
     switch (level) {
-#define NARUTO_CASE(T) case T: scatter_tile_points<T>(lt, bt, ps, d_feat, stride_m, stride_l, m_lo, m_hi, chunk, acc); break;
+#define NARUTO_CASE(T) case T: scatter_tile_points<T>(lt, bt, ps, d_feat, stride_m, stride_l, m_lo, m_hi, chunk, acc, feat); break;
         NARUTO_CASE(0) NARUTO_CASE(1) NARUTO_CASE(2) NARUTO_CASE(3) NARUTO_CASE(4) NARUTO_CASE(5) NARUTO_CASE(6) NARUTO_CASE(7)
         NARUTO_CASE(8) NARUTO_CASE(9) NARUTO_CASE(10) NARUTO_CASE(11) NARUTO_CASE(12) NARUTO_CASE(13) NARUTO_CASE(14) NARUTO_CASE(15)
 #undef NARUTO_CASE

@@ -418,6 +418,10 @@ __global__ __launch_bounds__(256) void k_hash_scatter_atomic(LevelTab lt, BoxTab
 constexpr int kScatterBatch = 4;   // independent point loads in flight per thread (the loop is latency-bound otherwise)
 
 constexpr int kScatterRun = 8;     // consecutive points per thread on the dense (coarse) levels
+#ifndef NARUTO_LIST_VEC
+#define NARUTO_LIST_VEC 2
+#endif
+constexpr uint32_t kListVec = NARUTO_LIST_VEC;      // 2 or 4 consecutive points per lane in the hashed levels' list stream
 
 // float -> two's-complement fixed point with 40 fractional bits in four VALU ops instead of the generic f32 -> i64
 // conversion: v * 2^40 = H * 2^32 + L,  H = floor(v * 2^8) (int32, v_cvt_flr_i32_f32),  L = fract(v * 2^8) * 2^32
@@ -452,21 +456,44 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
         // four consecutive points per thread with 16-byte loads.
         if (ps.xsoa != nullptr && stride_m == 2 && (ps.M & 3u) == 0u && (m_lo & 3u) == 0u && (stride_l & 3u) == 0u) {
             const float* __restrict__ pair = d_feat - feat + (size_t)T * stride_l;          // (f0, f1) pairs of this level
-            for (uint32_t base = m_lo + threadIdx.x * 4u; base < m_hi; base += kScatterThreads * 4u) {
-                const float4 X = *reinterpret_cast<const float4*>(ps.xsoa + base);
-                const float4 Y = *reinterpret_cast<const float4*>(ps.xsoa + ps.M + base);
-                const float4 Z = *reinterpret_cast<const float4*>(ps.xsoa + 2u * ps.M + base);
-                const float4 G0 = *reinterpret_cast<const float4*>(pair + 2u * base);         // points base, base+1
-                const float4 G1 = *reinterpret_cast<const float4*>(pair + 2u * base + 4u);    // points base+2, base+3
-                const float px[4] = {X.x, X.y, X.z, X.w}, py[4] = {Y.x, Y.y, Y.z, Y.w}, pz[4] = {Z.x, Z.y, Z.z, Z.w};
-                const float gg[4] = {feat ? G0.y : G0.x, feat ? G0.w : G0.z, feat ? G1.y : G1.x, feat ? G1.w : G1.z};
+            // kListVec consecutive points per lane and load.  Wider loads stream the list faster (4-byte loads: 2.8 TB/s over
+            // 256 workgroups), narrower ones keep the lanes of a wave on neighbouring points, whose corners agree on
+            // "in my chunk or not" so that whole-wave branches skip most corner bodies.
+            constexpr uint32_t V = kListVec;
+            struct Vec { float x[V], y[V], z[V], g[V]; };
+            auto load_vec = [&](uint32_t base) {
+                Vec q;
+                if constexpr (V == 4) {
+                    const float4 X = *reinterpret_cast<const float4*>(ps.xsoa + base), Y = *reinterpret_cast<const float4*>(ps.xsoa + ps.M + base);
+                    const float4 Z = *reinterpret_cast<const float4*>(ps.xsoa + 2u * ps.M + base);
+                    const float4 G0 = *reinterpret_cast<const float4*>(pair + 2u * base), G1 = *reinterpret_cast<const float4*>(pair + 2u * base + 4u);
+                    q.x[0] = X.x; q.x[1] = X.y; q.x[2] = X.z; q.x[3] = X.w;
+                    q.y[0] = Y.x; q.y[1] = Y.y; q.y[2] = Y.z; q.y[3] = Y.w;
+                    q.z[0] = Z.x; q.z[1] = Z.y; q.z[2] = Z.z; q.z[3] = Z.w;
+                    q.g[0] = feat ? G0.y : G0.x; q.g[1] = feat ? G0.w : G0.z; q.g[2] = feat ? G1.y : G1.x; q.g[3] = feat ? G1.w : G1.z;
+                } else {
+                    const float2 X = *reinterpret_cast<const float2*>(ps.xsoa + base), Y = *reinterpret_cast<const float2*>(ps.xsoa + ps.M + base);
+                    const float2 Z = *reinterpret_cast<const float2*>(ps.xsoa + 2u * ps.M + base);
+                    const float4 G = *reinterpret_cast<const float4*>(pair + 2u * base);
+                    q.x[0] = X.x; q.x[1] = X.y; q.y[0] = Y.x; q.y[1] = Y.y; q.z[0] = Z.x; q.z[1] = Z.y;
+                    q.g[0] = feat ? G.y : G.x; q.g[1] = feat ? G.w : G.z;
+                }
+                return q;
+            };
+            // software prefetch: the next loads are in flight while this batch is scattered
+            uint32_t base = m_lo + threadIdx.x * V;
+            Vec nxt{};
+            if (base < m_hi) nxt = load_vec(base);
+            for (; base < m_hi; base += kScatterThreads * V) {
+                const Vec q = nxt;
+                if (base + kScatterThreads * V < m_hi) nxt = load_vec(base + kScatterThreads * V);
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    if (base + (uint32_t)b >= m_hi || gg[b] == 0.0f) continue;
+                for (uint32_t b = 0; b < V; ++b) {
+                    if (base + b >= m_hi || q.g[b] == 0.0f) continue;
                     uint32_t idx[8];
                     float w[8];
-                    hash_corners<T>(lt, px[b], py[b], pz[b], idx, w);
-                    const float g256 = gg[b] * 256.0f;
+                    hash_corners<T>(lt, q.x[b], q.y[b], q.z[b], idx, w);
+                    const float g256 = q.g[b] * 256.0f;
 #pragma unroll
                     for (int c = 0; c < 8; ++c) fix_add_rel(acc, idx[c] - chunk_base, w[c] * g256);
                 }
@@ -519,13 +546,37 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
                     a0[c] = 0.0f;
                 }
             };
+            // the whole run's inputs up front (list layout: ten 16-byte loads; otherwise 32 scalar loads, all independent): one
+            // point at a time the run is a chain of kScatterRun memory round trips
+            float rg[kScatterRun], rx[kScatterRun], ry[kScatterRun], rz[kScatterRun];
+            if (ps.xsoa != nullptr && stride_m == 2 && (ps.M & 3u) == 0u && (m_lo & 3u) == 0u && (stride_l & 3u) == 0u && kScatterRun == 8) {
+                const float* __restrict__ pair = d_feat - feat + (size_t)T * stride_l;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t b4 = r0 + 4u * h;
+                    const float4 X = *reinterpret_cast<const float4*>(ps.xsoa + b4), Y = *reinterpret_cast<const float4*>(ps.xsoa + ps.M + b4);
+                    const float4 Z = *reinterpret_cast<const float4*>(ps.xsoa + 2u * ps.M + b4);
+                    const float4 G0 = *reinterpret_cast<const float4*>(pair + 2u * b4), G1 = *reinterpret_cast<const float4*>(pair + 2u * b4 + 4u);
+                    rx[4 * h] = X.x; rx[4 * h + 1] = X.y; rx[4 * h + 2] = X.z; rx[4 * h + 3] = X.w;
+                    ry[4 * h] = Y.x; ry[4 * h + 1] = Y.y; ry[4 * h + 2] = Y.z; ry[4 * h + 3] = Y.w;
+                    rz[4 * h] = Z.x; rz[4 * h + 1] = Z.y; rz[4 * h + 2] = Z.z; rz[4 * h + 3] = Z.w;
+                    rg[4 * h] = feat ? G0.y : G0.x; rg[4 * h + 1] = feat ? G0.w : G0.z; rg[4 * h + 2] = feat ? G1.y : G1.x; rg[4 * h + 3] = feat ? G1.w : G1.z;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < kScatterRun; ++k) {
+                    const uint32_t m = r0 + k < m_hi ? r0 + k : m_hi - 1u;
+                    rg[k] = d_feat[m * sm32 + (uint32_t)T * sl32];
+                    load_point(ps, bt, m, rx[k], ry[k], rz[k]);
+                }
+            }
+#pragma unroll
             for (int k = 0; k < kScatterRun; ++k) {
                 const uint32_t m = r0 + k;
                 if (m >= m_hi) break;
-                const float g = d_feat[(size_t)m * stride_m + (size_t)T * stride_l];
+                const float g = rg[k];
                 if (g == 0.0f) continue;
-                float x, y, z;
-                load_point(ps, bt, m, x, y, z);
+                const float x = rx[k], y = ry[k], z = rz[k];
                 const float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
                 const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
                 const uint32_t cell = (uint32_t)(int)fx + (uint32_t)(int)fy * res + (uint32_t)(int)fz * r2;

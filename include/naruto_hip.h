@@ -277,6 +277,26 @@ int naruto_goal_aggregate(const uint32_t* dims, const float* uncert_vol, const f
                           const int32_t* goal_idx, uint32_t n_targets, const int32_t* targets, float min_dist,
                           float max_dist, float safe_sdf, float* collections, float* aggregated, void* stream);
 
+/* N4 ("next" row) -- the dense volume -> mesh path (reference src/slam/coslam/coslam_utils.py:100-226 extract_mesh,
+ * callers coslam.py:421-492).  The reference pushes a host-built lattice through query_sdf in 65 536-point chunks with a
+ * copy per chunk and runs the third-party `marching_cubes` module on the CPU (coslam_utils.py:26,145).
+ * naruto_lattice_points: x[(i*Y + j)*Z + k] = (tx[i], ty[j], tz[k]) -- the (already normalised) lattice of
+ *   coslam_utils.py:124-133 expanded on the device; feed x to naruto_query_fwd.  dims: HOST array {X,Y,Z}.
+ * naruto_mesh_count: marching cubes over sdf_vol [X,Y,Z] (z fastest), pass 1: counts[0] = vertices, counts[1] =
+ *   triangles (device uint64[2]); bit c of a cell's case = (double)value < isolevel at corner (c&1, (c>>1)&1, (c>>2)&1);
+ *   cells with a corner |value| > truncation emit nothing; workspace: naruto_mesh_workspace(dims) bytes, kept for
+ * naruto_mesh_emit: pass 2: vertices float64 [V,3] in lattice-index coordinates (one per crossed lattice edge, at
+ *   t = (isolevel - v0) / (v1 - v0) in float64, ordered by (owner voxel, axis)), triangles int32 [F,3] ordered by
+ *   (cell, case-table order), normals towards larger values.  At most cap_* entries are written. */
+int naruto_lattice_points(const uint32_t* dims, const float* tx, const float* ty, const float* tz, float* x,
+                          void* stream);
+size_t naruto_mesh_workspace(const uint32_t* dims);
+int naruto_mesh_count(const uint32_t* dims, const float* sdf_vol, double isolevel, double truncation,
+                      void* workspace, uint64_t* counts, void* stream);
+int naruto_mesh_emit(const uint32_t* dims, const float* sdf_vol, double isolevel, const void* workspace,
+                     uint64_t cap_vertices, uint64_t cap_triangles, double* vertices, int32_t* triangles,
+                     void* stream);
+
 /* All parameter tensors of one optimiser in a single launch (<= 8 segments, per-segment lr / eps / weight_decay,
  * shared betas and step). */
 typedef struct NarutoAdamSeg {

@@ -14,7 +14,8 @@ from typing import List, Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnaruto_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["naruto_api.hip", "naruto_field.hip", "naruto_render.hip", "naruto_rays.hip", "naruto_train.hip", "naruto_planner.hip", "naruto_common.h"]
+SOURCES = ["naruto_api.hip", "naruto_field.hip", "naruto_render.hip", "naruto_rays.hip", "naruto_train.hip", "naruto_planner.hip", "naruto_mesh.hip",
+           "naruto_mc_table.inc", "naruto_common.h"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "naruto_hip.h")
 
 MAX_LEVELS = 16
@@ -144,6 +145,10 @@ SIGNATURES = {
     "naruto_goal_targets_workspace": (C.c_size_t, [_U32, _U32]),
     "naruto_goal_targets": (_I, [C.POINTER(_U32), _V, _U32, _U32, _V, _V, _V]),
     "naruto_goal_aggregate": (_I, [C.POINTER(_U32), _V, _V, _U32, _V, _U32, _V, _F, _F, _F, _V, _V, _V]),
+    "naruto_lattice_points": (_I, [C.POINTER(_U32), _V, _V, _V, _V, _V]),
+    "naruto_mesh_workspace": (C.c_size_t, [C.POINTER(_U32)]),
+    "naruto_mesh_count": (_I, [C.POINTER(_U32), _V, C.c_double, C.c_double, _V, _V, _V]),
+    "naruto_mesh_emit": (_I, [C.POINTER(_U32), _V, C.c_double, _V, _U64, _U64, _V, _V, _V]),
     "naruto_adam_multi": (_I, [C.POINTER(NarutoAdamSeg), _U32, _F, _F, _U32, _V, _U32, _V]),
     "naruto_train_workspace": (C.c_size_t, [_V, C.POINTER(NarutoTrainStep)]),
     "naruto_train_forward": (_I, [_V, C.POINTER(NarutoParams), C.POINTER(NarutoTrainStep), _I, _V]),

@@ -11,6 +11,7 @@
 #include "naruto_rays.hip"
 #include "naruto_train.hip"
 #include "naruto_planner.hip"
+#include "naruto_mesh.hip"
 
 using namespace naruto;
 
@@ -776,6 +777,81 @@ int naruto_goal_aggregate(const uint32_t* dims, const float* uncert_vol, const f
     hipLaunchKernelGGL(k_goal_aggregate, dim3((n_goals + 3u) / 4u), dim3(256), 0, (hipStream_t)stream, d, uncert_vol, sdf_vol, n_goals, goal_idx, n_targets,
                        targets, min_dist, max_dist, safe_sdf, collections, aggregated);
     return check_launch("goal_aggregate");
+}
+
+// ---- N4: dense volume -> mesh (naruto_mesh.hip) ----------------------------------------------------------------------
+namespace {
+struct McWs {
+    uint8_t* cases;
+    uint8_t* flags;
+    uint2* prefix;
+    unsigned long long* block_total;
+    uint32_t n, n_blocks;
+};
+size_t mc_align(size_t v) { return (v + 255u) & ~(size_t)255u; }
+int mc_dims(const uint32_t* dims, const char* who, McDims* d, uint32_t* n) {
+    if (dims == nullptr) return fail(NARUTO_ERR_INVALID, "%s: NULL dims", who);
+    const uint64_t n64 = (uint64_t)dims[0] * dims[1] * dims[2];
+    if (n64 == 0 || n64 > (1ull << 30) || dims[0] > (1u << 30) || dims[1] > (1u << 30) || dims[2] > (1u << 30))
+        return fail(NARUTO_ERR_INVALID, "%s: volume must have 1 .. 2^30 voxels", who);
+    *d = McDims{dims[0], dims[1], dims[2]};
+    *n = (uint32_t)n64;
+    return NARUTO_OK;
+}
+McWs mc_ws(void* workspace, uint32_t n) {
+    McWs w;
+    char* p = reinterpret_cast<char*>(workspace);
+    w.n = n;
+    w.n_blocks = (n + kMcBlockItems - 1u) / kMcBlockItems;
+    w.cases = reinterpret_cast<uint8_t*>(p); p += mc_align(n);
+    w.flags = reinterpret_cast<uint8_t*>(p); p += mc_align(n);
+    w.prefix = reinterpret_cast<uint2*>(p); p += mc_align((size_t)n * sizeof(uint2));
+    w.block_total = reinterpret_cast<unsigned long long*>(p);
+    return w;
+}
+}  // namespace
+
+int naruto_lattice_points(const uint32_t* dims, const float* tx, const float* ty, const float* tz, float* x, void* stream) {
+    McDims d; uint32_t n;
+    if (int rc = mc_dims(dims, "lattice_points", &d, &n)) return rc;
+    if (tx == nullptr || ty == nullptr || tz == nullptr || x == nullptr) return fail(NARUTO_ERR_INVALID, "lattice_points: NULL argument");
+    hipLaunchKernelGGL(k_lattice_points, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, d, tx, ty, tz, x);
+    return check_launch("lattice_points");
+}
+
+size_t naruto_mesh_workspace(const uint32_t* dims) {
+    McDims d; uint32_t n;
+    if (mc_dims(dims, "mesh_workspace", &d, &n)) return 0;
+    const size_t n_blocks = (n + kMcBlockItems - 1u) / kMcBlockItems;
+    return 2u * mc_align(n) + mc_align((size_t)n * sizeof(uint2)) + mc_align(n_blocks * sizeof(unsigned long long));
+}
+
+int naruto_mesh_count(const uint32_t* dims, const float* sdf_vol, double isolevel, double truncation, void* workspace, uint64_t* counts, void* stream) {
+    McDims d; uint32_t n;
+    if (int rc = mc_dims(dims, "mesh_count", &d, &n)) return rc;
+    if (sdf_vol == nullptr || workspace == nullptr || counts == nullptr) return fail(NARUTO_ERR_INVALID, "mesh_count: NULL argument");
+    const McWs w = mc_ws(workspace, n);
+    hipLaunchKernelGGL(k_mc_cases, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, d, sdf_vol, isolevel, truncation, w.cases);
+    if (int rc = check_launch("mc_cases")) return rc;
+    hipLaunchKernelGGL(k_mc_count, dim3(w.n_blocks), dim3(kMcThreads), 0, (hipStream_t)stream, d, sdf_vol, w.cases, isolevel, w.flags, w.prefix, w.block_total);
+    if (int rc = check_launch("mc_count")) return rc;
+    hipLaunchKernelGGL(k_mc_scan_blocks, dim3(1), dim3(1024), 0, (hipStream_t)stream, w.n_blocks, w.block_total, reinterpret_cast<unsigned long long*>(counts));
+    return check_launch("mc_scan_blocks");
+}
+
+int naruto_mesh_emit(const uint32_t* dims, const float* sdf_vol, double isolevel, const void* workspace, uint64_t cap_vertices, uint64_t cap_triangles,
+                     double* vertices, int32_t* triangles, void* stream) {
+    McDims d; uint32_t n;
+    if (int rc = mc_dims(dims, "mesh_emit", &d, &n)) return rc;
+    if (sdf_vol == nullptr || workspace == nullptr) return fail(NARUTO_ERR_INVALID, "mesh_emit: NULL argument");
+    if ((cap_vertices != 0 && vertices == nullptr) || (cap_triangles != 0 && triangles == nullptr))
+        return fail(NARUTO_ERR_INVALID, "mesh_emit: NULL output with a non-zero capacity");
+    if (cap_vertices > 0x7FFFFFFFull) return fail(NARUTO_ERR_INVALID, "mesh_emit: triangles index vertices with int32");
+    if (cap_vertices == 0 && cap_triangles == 0) return NARUTO_OK;
+    const McWs w = mc_ws(const_cast<void*>(workspace), n);
+    hipLaunchKernelGGL(k_mc_emit, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, d, sdf_vol, w.cases, w.flags, w.prefix, w.block_total, isolevel,
+                       cap_vertices, cap_triangles, vertices, triangles);
+    return check_launch("mc_emit");
 }
 
 namespace {

@@ -323,6 +323,77 @@ def case_planner_aggregation(name, seed):
           f"{int((agg > 0).sum())} goals with uncertainty in view")
 
 
+def case_extract_mesh(name, hash_size, table_amp, seed, voxel):
+    """N4: the reference's own extract_mesh (coslam_utils.py:100-226), both colour branches the shipped configs use.
+    Its third-party imports are stand-ins: ``marching_cubes`` = oracle/mesh_numpy.marching_cubes (parity unpinned, see
+    that file), ``trimesh.Trimesh`` = a recorder; matplotlib is the real one.  Pins the lattice, the chunked query, the
+    vertex transforms and the colour branches; the oracle's restatement of the whole function is asserted equal."""
+    import tempfile
+    from oracle import mesh_numpy as MN
+    table = dict(np.load(os.path.join(OUT, "mc_table.npz")))
+    cfg = C.office0_config()
+    cfg["grid"]["hash_size"] = hash_size
+    cfg["data"]["sc_factor"], cfg["data"]["translation"] = 2.0, 0.25           # non-trivial metric transform
+    ref, ora, w, dims = build_pair(cfg, table_amp, seed)
+    ref.eval()
+    bbox = torch.tensor(cfg["mapping"]["bound"], dtype=torch.float32)
+    mcb = torch.tensor([[-2.0, 2.4], [-3.1, 1.9], [-1.2, 1.7]], dtype=torch.float32)     # inside the mapping bound, like the configs' marching_cubes_bound
+    seen = {}
+
+    def mc(vol, iso, truncation):
+        seen["vol"], seen["trunc"] = np.array(vol, copy=True), truncation
+        v, f = MN.marching_cubes(vol, iso, truncation, table)
+        seen["verts_index"], seen["faces"] = v.copy(), f.copy()
+        return v, f
+
+    class Recorder:
+        def __init__(self, vertices, faces, process=True, vertex_colors=None):
+            self.vertices, self.faces, self.vertex_colors = np.array(vertices), np.array(faces), None if vertex_colors is None else np.array(vertex_colors)
+
+        def export(self, path):
+            open(path, "wb").close()
+
+    ref_utils.mcubes.marching_cubes = mc
+    ref_utils.trimesh.Trimesh = Recorder
+    # the isolevel: near the median of the volume (the closed-form field then certainly has a surface), in the widest gap
+    # between lattice values there, so that fp32 noise in a re-implementation cannot flip a corner
+    with torch.no_grad():
+        probe = MN.extract_mesh(ora.query_sdf, cfg, bbox, table, marching_cube_bound=mcb, voxel_size=voxel, isolevel=1e9, render_uncert=False)
+    srt = np.sort(probe["vol"].reshape(-1).astype(np.float64))
+    mid = srt[int(0.4 * len(srt)):int(0.6 * len(srt))]
+    at = int(np.argmax(np.diff(mid)))                                         # the widest gap between lattice values near the median
+    iso = float(np.float32(0.5 * (mid[at] + mid[at + 1])))
+    gap = float(np.abs(probe["vol"] - iso).min())
+    assert gap > 2e-5, f"a lattice value lies {gap} from the isolevel: pick another seed (the GPU test compares topology)"
+    out = {"bound": np.asarray(cfg["mapping"]["bound"], np.float32), "mcb": mcb.numpy(), "hash_size": np.int64(hash_size), "table_amp": np.float64(table_amp),
+           "seed": np.int64(seed), "uncert_dims": np.asarray(dims, np.int64), "voxel": np.float64(voxel), "isolevel": np.float64(iso),
+           "sc_factor": np.float64(2.0), "translation": np.float64(0.25)}
+    out.update(w)
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag, color_func in (("color", ref.query_color), ("uncert", None)):
+            mesh = ref_utils.extract_mesh(ref.query_sdf, cfg, bbox, marching_cube_bound=mcb, color_func=color_func, voxel_size=voxel, isolevel=iso,
+                                          mesh_savepath=os.path.join(tmp, "m", "mesh.ply"), render_uncert=True)
+            o = MN.extract_mesh(ora.query_sdf, cfg, bbox, table, marching_cube_bound=mcb, color_func=None if color_func is None else ora.query_color,
+                                voxel_size=voxel, isolevel=iso, render_uncert=True)
+            assert seen["trunc"] == 3.0
+            close(torch.from_numpy(o["vol"]), torch.from_numpy(seen["vol"].astype(np.float32)), f"{name}.{tag}.vol")
+            assert np.array_equal(o["faces"], mesh.faces), f"{name}.{tag}: faces differ"
+            close(torch.from_numpy(o["vertices"]), torch.from_numpy(mesh.vertices), f"{name}.{tag}.vertices", tol=1e-9)
+            col = np.asarray(mesh.vertex_colors, dtype=np.float64)
+            assert col.shape == (len(mesh.vertices), 3)
+            if tag == "color":
+                close(torch.from_numpy(o["colors"].astype(np.float64)), torch.from_numpy(col), f"{name}.{tag}.colors")
+            else:
+                assert np.array_equal(o["colors"], col), f"{name}.{tag}: jet colours differ (oracle LUT vs matplotlib)"
+            out[f"{tag}_vertices"], out[f"{tag}_colors"] = mesh.vertices, col
+        out["vol"], out["verts_index"], out["faces"] = seen["vol"].astype(np.float32), seen["verts_index"], seen["faces"]
+    import matplotlib.pyplot as plt
+    out["jet_lut"] = plt.get_cmap("jet")(np.arange(256))[:, :3]
+    assert np.array_equal(out["jet_lut"], MN.jet_lut()), "oracle jet LUT != matplotlib"
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: ok, volume {out['vol'].shape}, {len(out['verts_index'])} vertices, {len(out['faces'])} triangles, isolevel {iso:.4f}, gap {gap:.2e}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -336,6 +407,7 @@ def main():
     case_composite_edges("g5_composite_edges", 7)
     case_active_ray("g8_active_ray", 8)
     case_planner_aggregation("g9_planner_aggregation", 9)
+    case_extract_mesh("g10_extract_mesh", 12, 0.25, 10, 0.3)
 
 
 if __name__ == "__main__":

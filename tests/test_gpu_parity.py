@@ -743,3 +743,98 @@ def test_keyframe_store_batch_assembly(gpu):
     # sample_global_rays: distinct rows with their frame ids
     r2, f2 = st.sample_global_rays(128)
     assert r2.shape == (128, 7) and set(f2.cpu().tolist()) <= {0, 5, 10, 15}
+
+
+# --------------------------------------------------------------------------------------------- N4: dense volume -> mesh
+def _mc_volumes():
+    rs = np.random.RandomState(3)
+    n = 23
+    g = np.stack(np.meshgrid(*[np.linspace(-1, 1, n)] * 3, indexing="ij"), -1)
+    sphere = (np.linalg.norm(g - np.array([0.05, -0.03, 0.02]), axis=-1) - 0.6).astype(np.float32)
+    noise = rs.standard_normal((17, 9, 31)).astype(np.float32)
+    planes = np.round(rs.standard_normal((12, 13, 14)) * 2).astype(np.float32) * 0.5          # many values exactly on the isolevel
+    thin = rs.standard_normal((2, 2, 70)).astype(np.float32)
+    big = (np.sin(np.arange(70 * 65 * 61, dtype=np.float64).reshape(70, 65, 61) * 0.37) +
+           0.3 * np.cos(np.arange(70)[:, None, None] * 0.2)).astype(np.float32)               # > 1 scan block, > 1024 blocks would need 2M+ voxels
+    return {"sphere": (sphere, 0.0, 3.0), "noise": (noise, 0.1, 1e9), "noise_trunc": (noise, 0.0, 1.2), "on_isolevel": (planes, 0.0, 3.0),
+            "thin": (thin, 0.0, 3.0), "single_voxel": (np.zeros((1, 1, 1), np.float32), 0.0, 3.0), "no_cells": (noise[:1], 0.0, 3.0),
+            "empty_surface": (np.ones((5, 6, 7), np.float32), 0.0, 3.0), "multi_block": (big, 0.05, 3.0)}
+
+
+@pytest.mark.parametrize("name", list(_mc_volumes()))
+def test_marching_cubes_vs_oracle(gpu, name):
+    """bit-exact vertices (float64) and triangles against the numpy restatement, through naruto_mesh_count / naruto_mesh_emit"""
+    from naruto_amd import mesh as M
+    from oracle import mesh_numpy as MN
+    vol, iso, trunc = _mc_volumes()[name]
+    v, f = M.marching_cubes(torch.from_numpy(vol).to(gpu), iso, trunc)
+    ov, of = MN.marching_cubes(vol, iso, trunc, H.load_golden("mc_table"))
+    assert v.dtype == torch.float64 and f.dtype == torch.int32
+    assert v.shape == ov.shape and f.shape == of.shape, (v.shape, ov.shape, f.shape, of.shape)
+    assert np.array_equal(f.cpu().numpy(), of)
+    assert np.array_equal(v.cpu().numpy(), ov)
+    if name in ("single_voxel", "no_cells", "empty_surface"):
+        assert len(ov) == 0 and len(of) == 0
+    else:
+        assert len(of) > 0
+
+
+def test_marching_cubes_large_volume_properties(gpu):
+    """a volume with > 1024 scan blocks (the block-total scan loops): closed surface of a sphere, vertex count = crossed edges"""
+    from naruto_amd import mesh as M
+    n = 160
+    t = torch.linspace(-1, 1, n, device=gpu)
+    g = torch.stack(torch.meshgrid(t, t, t, indexing="ij"), -1)
+    vol = (torch.linalg.norm(g - torch.tensor([0.01, 0.02, -0.03], device=gpu), dim=-1) - 0.7).float().contiguous()
+    assert vol.numel() > 1024 * 2048
+    v, f = M.marching_cubes(vol, 0.0, 3.0)
+    inside = vol.double() < 0
+    n_cross = int((inside[1:] != inside[:-1]).sum() + (inside[:, 1:] != inside[:, :-1]).sum() + (inside[:, :, 1:] != inside[:, :, :-1]).sum())
+    assert len(v) == n_cross and len(v) - len(f) // 2 == 2                       # Euler: V - E + F = V - 3F/2 + F = 2
+    fl = f.long()
+    e = torch.cat([fl[:, [0, 1]], fl[:, [1, 2]], fl[:, [2, 0]]])
+    key = e[:, 0] * len(v) + e[:, 1]
+    rkey = e[:, 1] * len(v) + e[:, 0]
+    assert len(torch.unique(key)) == len(key) and torch.equal(torch.sort(key).values, torch.sort(rkey).values)     # closed, oriented
+    p = v / (n - 1) * 2 - 1 - torch.tensor([0.01, 0.02, -0.03], device=gpu, dtype=torch.float64)
+    assert (torch.linalg.norm(p, dim=-1) - 0.7).abs().max() < 1e-3
+    nrm = torch.cross(p[fl[:, 1]] - p[fl[:, 0]], p[fl[:, 2]] - p[fl[:, 0]], dim=-1)
+    assert ((nrm * p[fl].mean(1)).sum(-1) > 0).all()
+
+
+def test_lattice_points(gpu):
+    from naruto_amd import mesh as M
+    tx, ty, tz = torch.linspace(0, 1, 7), torch.linspace(-2, 3, 5), torch.linspace(0.25, 0.5, 11)
+    want = torch.stack(torch.meshgrid(tx, ty, tz, indexing="ij"), -1).reshape(-1, 3)
+    got = M.lattice_points(tx.to(gpu), ty.to(gpu), tz.to(gpu))
+    assert torch.equal(got.cpu(), want)
+
+
+def test_extract_mesh_golden(gpu, tmp_path):
+    """N4 end to end against what the reference's own extract_mesh returned (tests/golden/g10_extract_mesh.npz)."""
+    from naruto_amd import mesh as M
+    g = H.load_golden("g10_extract_mesh")
+    cfg = H.office_cfg(int(g["hash_size"]))
+    cfg["data"]["sc_factor"], cfg["data"]["translation"] = float(g["sc_factor"]), float(g["translation"])
+    w = {k: g[k] for k in ("sdf_w0", "sdf_w1", "col_w0", "col_w1")}
+    ora = H.make_oracle(cfg, float(g["table_amp"]), int(g["seed"]), weights=w)
+    m = H.make_hip_from_oracle(cfg, ora, gpu).eval()
+    mcb = torch.from_numpy(g["mcb"])
+    # marching cubes on the golden's own volume: exact
+    v, f = M.marching_cubes(torch.from_numpy(g["vol"]).to(gpu), float(g["isolevel"]), 3.0)
+    assert np.array_equal(v.cpu().numpy(), g["verts_index"]) and np.array_equal(f.cpu().numpy(), g["faces"])
+    for tag, color_func in (("color", m.query_color), ("uncert", None)):
+        path = tmp_path / tag / "mesh.ply"
+        mesh = M.extract_mesh(m.query_sdf, cfg, m.bounding_box, marching_cube_bound=mcb, color_func=color_func, voxel_size=float(g["voxel"]),
+                              isolevel=float(g["isolevel"]), mesh_savepath=str(path))
+        assert path.exists() and path.stat().st_size > 0
+        # the fixture's isolevel keeps every lattice value 1e-4 away, so fp32 noise cannot change the topology
+        assert np.array_equal(mesh.faces, g["faces"])
+        H.assert_close(mesh.vertices, g[f"{tag}_vertices"], 2e-3 * float(g["voxel"]), f"{tag}.vertices")
+        want = np.round(np.clip(g[f"{tag}_colors"], 0, 1) * 255.0)
+        got = mesh.vertex_colors[:, :3].astype(np.float64)
+        assert mesh.vertex_colors.shape == (len(mesh.vertices), 4) and (mesh.vertex_colors[:, 3] == 255).all()
+        if tag == "color":
+            assert np.abs(got - want).max() <= 1.0
+        else:
+            assert (np.abs(got - want).max(-1) > 0).mean() < 0.02          # a jet bin edge may flip with the 1e-6 noise of the uncertainty

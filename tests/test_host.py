@@ -146,3 +146,47 @@ def test_feistel_permutation_is_a_bijection(built_lib):
     q = np.array([lib.naruto_perm_index(i, 163200, 3, 1, 2) for i in range(4096)]) * 16 // 163200
     counts = np.bincount(q, minlength=16)
     assert counts.min() > 180 and counts.max() < 340, counts
+
+
+# --------------------------------------------------------------------------------------------- N4: mesh host side
+def test_mesh_host_helpers(tmp_path):
+    from naruto_amd import mesh as M
+    g = H.load_golden("g10_extract_mesh")
+    assert np.array_equal(M.jet_lut().numpy(), g["jet_lut"])                       # == matplotlib's table (oracle/make_golden.py)
+    mcb = g["mcb"]
+    tx, ty, tz = M.get_voxels(mcb[0, 1], mcb[0, 0], mcb[1, 1], mcb[1, 0], mcb[2, 1], mcb[2, 0], float(g["voxel"]))
+    assert (tx.numel(), ty.numel(), tz.numel()) == g["vol"].shape
+    ox, oy, oz = S.get_voxels(torch.from_numpy(mcb).double(), float(g["voxel"]))
+    assert torch.equal(tx, ox) and torch.equal(ty, oy) and torch.equal(tz, oz)
+    rx, _, _ = M.get_voxels(1.0, 0.0, 1.0, 0.0, 1.0, 0.0, None, 9)
+    assert rx.numel() == 9
+    # PLY round trip
+    col = M._float_colors_to_rgba8(g["color_colors"])
+    assert col.shape == (len(g["color_colors"]), 4) and (col[:, 3] == 255).all()
+    mesh = M.Mesh(g["color_vertices"], g["faces"], col)
+    path = tmp_path / "m.ply"
+    mesh.export(str(path))
+    blob = open(path, "rb").read()
+    head, body = blob.split(b"end_header\n", 1)
+    assert b"element vertex %d" % len(mesh.vertices) in head and b"element face %d" % len(mesh.faces) in head
+    vdt = np.dtype([("p", "<f4", (3,)), ("c", "u1", (4,))])
+    v = np.frombuffer(body, dtype=vdt, count=len(mesh.vertices))
+    assert np.array_equal(v["p"], mesh.vertices.astype(np.float32)) and np.array_equal(v["c"], col)
+    f = np.frombuffer(body, dtype=np.dtype([("n", "u1"), ("i", "<i4", (3,))]), count=len(mesh.faces), offset=vdt.itemsize * len(mesh.vertices))
+    assert (f["n"] == 3).all() and np.array_equal(f["i"], mesh.faces)
+    assert len(body) == vdt.itemsize * len(mesh.vertices) + 13 * len(mesh.faces)
+
+
+def test_mesh_entry_points_validate_arguments(built_lib):
+    lib = built_lib
+    dims = (C.c_uint32 * 3)(0, 4, 4)
+    assert lib.naruto_mesh_workspace(dims) == 0
+    assert lib.naruto_mesh_count(dims, None, 0.0, 3.0, None, None, None) < 0
+    dims = (C.c_uint32 * 3)(4, 4, 4)
+    assert lib.naruto_mesh_workspace(dims) >= 64 * 10
+    assert lib.naruto_mesh_count(dims, None, 0.0, 3.0, None, None, None) < 0
+    assert b"NULL" in lib.naruto_last_error()
+    assert lib.naruto_mesh_emit(dims, None, 0.0, None, 0, 0, None, None, None) < 0
+    assert lib.naruto_lattice_points(dims, None, None, None, None, None) < 0
+    big = (C.c_uint32 * 3)(2048, 2048, 2048)
+    assert lib.naruto_mesh_workspace(big) == 0

@@ -276,3 +276,95 @@ def test_oracle_planner_aggregation_golden():
     assert det.shape == (sub, 3) and (vals >= kth).all() and len({tuple(r) for r in det}) == sub
     ref_vals = g["uncert"][g["targets"][:, 0], g["targets"][:, 1], g["targets"][:, 2]]
     assert (ref_vals >= kth).all()                       # both selections are subsets of the top_k
+
+
+# --------------------------------------------------------------------------------------------- N4: mesh path
+def _mesh_cfg(g):
+    cfg = H.office_cfg(int(g["hash_size"]))
+    cfg["data"]["sc_factor"], cfg["data"]["translation"] = float(g["sc_factor"]), float(g["translation"])
+    return cfg
+
+
+def test_mc_table_is_what_the_generator_derives():
+    """tests/golden/mc_table.npz == tools/gen_mc_table.py's derivation == the table compiled into the HIP library."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_mc_table", os.path.join(root, "tools", "gen_mc_table.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    n_tris, tris, edge_mask = gen.build()
+    t = H.load_golden("mc_table")
+    assert np.array_equal(t["n_tris"], n_tris) and np.array_equal(t["tris"], tris) and np.array_equal(t["edge_mask"], edge_mask)
+    inc = open(os.path.join(root, "naruto_amd", "csrc", "naruto_mc_table.inc")).read()
+    rows = [r for r in inc.split("kMcTris")[1].split("\n") if r.strip().startswith("{")]
+    compiled = np.array([[int(v) for v in r.strip().strip("{},").split(",")] for r in rows], dtype=np.int8)
+    assert np.array_equal(compiled.reshape(256, -1, 3), tris)
+    # every case: triangles use exactly the crossed edges (corner states differ), no triangle without a crossing
+    for c in range(256):
+        crossed = 0
+        for e in range(12):
+            a, q = e >> 2, e & 3
+            u, w = [i for i in range(3) if i != a]
+            off = [0, 0, 0]
+            off[u], off[w] = q & 1, q >> 1
+            lo = off[0] | (off[1] << 1) | (off[2] << 2)
+            if ((c >> lo) & 1) != ((c >> (lo | (1 << a))) & 1):
+                crossed |= 1 << e
+        assert crossed == int(edge_mask[c]), c
+    assert n_tris[0] == 0 and n_tris[255] == 0 and int(n_tris.max()) == 5
+
+
+def test_oracle_marching_cubes_properties():
+    from oracle import mesh_numpy as MN
+    table = H.load_golden("mc_table")
+    n = 21
+    g = np.stack(np.meshgrid(*[np.linspace(-1, 1, n)] * 3, indexing="ij"), -1)
+    c0 = np.array([0.05, -0.03, 0.02])
+    vol = (np.linalg.norm(g - c0, axis=-1) - 0.6).astype(np.float32)
+    v, f = MN.marching_cubes(vol, 0.0, 3.0, table)
+    assert MN.check_closed(f) and len(v) - len(f) * 3 // 2 + len(f) == 2             # closed, Euler characteristic of a sphere
+    p = v / (n - 1) * 2 - 1 - c0
+    nrm = np.cross(p[f[:, 1]] - p[f[:, 0]], p[f[:, 2]] - p[f[:, 0]])
+    assert ((nrm * p[f].mean(1)).sum(-1) > 0).all()                                   # normals towards larger values (outside)
+    assert np.abs(np.linalg.norm(p, axis=-1) - 0.6).max() < 0.01                      # vertices on the surface
+    # the vertex set is exactly the set of crossed lattice edges
+    vol64 = vol.astype(np.float64)
+    n_cross = sum(int(((np.take(vol64, range(0, n - 1), a) < 0) != (np.take(vol64, range(1, n), a) < 0)).sum()) for a in range(3))
+    assert n_cross == len(v)
+    # a noisy volume (all 256 cases, ambiguous faces everywhere): still no directed edge twice, holes only on the boundary
+    rs = np.random.RandomState(0)
+    vol = rs.standard_normal((11, 12, 13)).astype(np.float32)
+    v, f = MN.marching_cubes(vol, 0.0, 1e9, table)
+    e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+    es = set(map(tuple, e))
+    assert len(es) == len(e)
+    open_edges = np.array([(a, b) for (a, b) in es if (b, a) not in es])
+    vv = v[open_edges]
+    assert ((vv <= 0) | (vv >= np.array(vol.shape) - 1)).any(-1).all()
+    # truncation removes cells, never adds
+    v2, f2 = MN.marching_cubes(vol, 0.0, 1.5, table)
+    assert 0 < len(f2) < len(f) and len(v2) < len(v)
+
+
+def test_oracle_extract_mesh_golden():
+    """N4: the restatement of extract_mesh reproduces what the reference's own function returned (oracle/make_golden.py
+    case_extract_mesh), both colour branches."""
+    from oracle import mesh_numpy as MN
+    g = H.load_golden("g10_extract_mesh")
+    table = H.load_golden("mc_table")
+    cfg = _mesh_cfg(g)
+    w = {k: g[k] for k in ("sdf_w0", "sdf_w1", "col_w0", "col_w1")}
+    ora = H.make_oracle(cfg, float(g["table_amp"]), int(g["seed"]), weights=w).eval()
+    assert np.array_equal(MN.jet_lut(), g["jet_lut"])
+    for tag, color_func in (("color", ora.query_color), ("uncert", None)):
+        o = MN.extract_mesh(ora.query_sdf, cfg, ora.bounding_box, table, marching_cube_bound=torch.from_numpy(g["mcb"]), color_func=color_func,
+                            voxel_size=float(g["voxel"]), isolevel=float(g["isolevel"]))
+        H.assert_close(o["vol"], g["vol"], 3e-6, f"{tag}.vol")
+        assert np.array_equal(o["faces"], g["faces"])
+        H.assert_close(o["vertices"], g[f"{tag}_vertices"], 1e-5, f"{tag}.vertices")
+        if tag == "color":
+            H.assert_close(o["colors"], g["color_colors"], 3e-6, "colors")
+        else:
+            assert (np.abs(o["colors"] - g["uncert_colors"]).max(-1) > 1e-6).mean() < 0.01       # a bin edge may flip with 1-ulp noise
+    v, f = MN.marching_cubes(g["vol"], float(g["isolevel"]), 3.0, table)
+    assert np.array_equal(v, g["verts_index"]) and np.array_equal(f, g["faces"])

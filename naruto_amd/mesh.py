@@ -92,12 +92,13 @@ class Mesh:
             f.write(face.tobytes())
 
 
-def _float_colors_to_rgba8(color: np.ndarray) -> np.ndarray:
-    """trimesh.visual.color.to_rgba for float input in [0,1]: round(c * 255), opaque alpha."""
-    c = np.clip(np.asarray(color, dtype=np.float64), 0.0, 1.0)
-    rgba = np.full((len(c), 4), 255, dtype=np.uint8)
-    rgba[:, :c.shape[1]] = np.round(c * 255.0).astype(np.uint8)
-    return rgba
+def _float_colors_to_rgba8(color) -> np.ndarray:
+    """trimesh.visual.color.to_rgba for float input in [0,1]: round(c * 255) (half to even), opaque alpha.
+    Device tensors are converted on the device: only the bytes cross PCIe."""
+    c = torch.as_tensor(color)
+    rgba = torch.full((c.shape[0], 4), 255, dtype=torch.uint8, device=c.device)
+    rgba[:, :c.shape[1]] = torch.round(c.to(torch.float64).clamp(0.0, 1.0) * 255.0).to(torch.uint8)
+    return rgba.cpu().numpy()
 
 
 def lattice_points(tx: torch.Tensor, ty: torch.Tensor, tz: torch.Tensor) -> torch.Tensor:
@@ -172,7 +173,7 @@ def extract_mesh(query_fn: Callable, config, bounding_box: torch.Tensor, marchin
             vert_flat = (vert_flat - bounding_box[:, 0]) / (bounding_box[:, 1] - bounding_box[:, 0])         # :165-166 / :198-199
     if color_func is not None and not config["mesh"]["render_color"]:
         color = color_func(vert_flat[:, None, :]) if len(vert_flat) else torch.zeros(0, 3, device=device)    # :169-176
-        colors = _float_colors_to_rgba8(torch.reshape(color, (len(vert_flat), -1)).float().cpu().numpy())
+        colors = _float_colors_to_rgba8(torch.reshape(color, (len(vert_flat), -1)))
     elif color_func is not None:
         raise NotImplementedError("config['mesh']['render_color'] = True (render_surface_color with trimesh vertex normals) is not built: "
                                   "no shipped config enables it")
@@ -184,7 +185,7 @@ def extract_mesh(query_fn: Callable, config, bounding_box: torch.Tensor, marchin
             idx = torch.where(torch.isnan(x), torch.zeros_like(x), x).clamp(0.0, 255.0).to(torch.int64)
             rgb = jet_lut().to(device)[idx]
             rgb = torch.where(torch.isnan(x)[:, None], torch.zeros_like(rgb), rgb)
-            colors = _float_colors_to_rgba8(rgb.cpu().numpy())
+            colors = _float_colors_to_rgba8(rgb)
         else:
             colors = np.zeros((0, 4), dtype=np.uint8)
 

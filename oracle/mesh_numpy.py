@@ -19,7 +19,7 @@ What is restated (paths under /root/reference):
     - ``getVoxels`` / ``get_batch_query_fn`` (third_parties/coslam/utils.py, same Co-SLAM commit): restated in
       oracle/spec_torch.py (get_voxels) and inline below.
     - matplotlib's ``jet`` colormap (coslam_utils.py:211): matplotlib IS importable in the build container, the
-      fixture tests/golden/g10_jet_lut.npz holds its 256-entry lookup table (oracle/make_golden.py).
+      fixture tests/golden/g10_extract_mesh.npz holds its 256-entry lookup table (key jet_lut, oracle/make_golden.py).
 """
 
 from __future__ import annotations

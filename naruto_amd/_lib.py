@@ -12,7 +12,7 @@ import subprocess
 from typing import List, Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnaruto_hip.so")
+LIB_PATH = os.environ.get("NARUTO_HIP_LIB") or os.path.join(_HERE, "libnaruto_hip.so")      # override: kernel experiments only
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["naruto_api.hip", "naruto_field.hip", "naruto_render.hip", "naruto_rays.hip", "naruto_train.hip", "naruto_planner.hip", "naruto_mesh.hip",
            "naruto_mc_table.inc", "naruto_common.h"]

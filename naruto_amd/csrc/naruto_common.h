@@ -194,14 +194,24 @@ __device__ __forceinline__ float2 hash_level_half_rt(const LevelTab& lt, int T, 
         for (int c = 0; c < 4; ++c) idx[c] = (gx ^ ((c & 1) ? hy1 : hy0) ^ ((c & 2) ? hz1 : hz0)) & mask;
     } else {
         const uint32_t r2 = res * res;
-        const uint32_t base = gx + gy * res + gz * r2;
-        const uint32_t magic = 0xFFFFFFFFu / size;
+        // every corner of every lane inside the level's grid (all but the last half voxel at the upper faces, and points
+        // outside the box): the index needs no wrap and the products fit the full-rate 24-bit multiplier; the wrap costs
+        // two quarter-rate 32-bit multiplies per corner
+        const uint32_t gmax = max(max(gx - xh, gy), gz);
+        if (__all(gmax <= res - 2u)) {                          // res >= 2; a negative coordinate wraps to a huge gmax
+            const uint32_t base = gx + __umul24(gy, res) + __umul24(gz, r2);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            uint32_t i = base + ((c & 1) ? res : 0u) + ((c & 2) ? r2 : 0u);
-            i -= __umulhi(i, magic) * size;
-            if (i >= size) i -= size;
-            idx[c] = i;
+            for (int c = 0; c < 4; ++c) idx[c] = base + ((c & 1) ? res : 0u) + ((c & 2) ? r2 : 0u);
+        } else {
+            const uint32_t base = gx + gy * res + gz * r2;
+            const uint32_t magic = 0xFFFFFFFFu / size;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                uint32_t i = base + ((c & 1) ? res : 0u) + ((c & 2) ? r2 : 0u);
+                i -= __umulhi(i, magic) * size;
+                if (i >= size) i -= size;
+                idx[c] = i;
+            }
         }
     }
     const float2* __restrict__ tl = table + lt.off[T];

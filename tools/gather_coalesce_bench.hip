@@ -46,11 +46,15 @@ double run(const float2* t, uint32_t n_lines, float* out) {
 }
 
 int main() {
-    const uint32_t n_lines = 65536 * 8 / 8 * 1;          // 65536 entries x 8 B = 512 KB per level ... use 6.5 MB total
-    const uint32_t lines = 6u * 1024u * 1024u / 64u;
+    const uint32_t lines = 6u * 1024u * 1024u / 64u;                  // ~ the 6.5 MB table
     float2* t; float* out;
-    CK(hipMalloc(&t, (size_t)lines * 64)); CK(hipMemset(t, 0, (size_t)lines * 64)); CK(hipMalloc(&out, 4));
-    (void)n_lines;
+    CK(hipMalloc(&t, (size_t)256u << 20)); CK(hipMemset(t, 0, (size_t)256u << 20)); CK(hipMalloc(&out, 4));
     run<0>(t, lines, out); run<1>(t, lines, out); run<2>(t, lines, out); run<3>(t, lines, out);
+    // the layout in use (mode 2) against the size of the region the gathers fall in: L1 / L2 (4 MB per XCD) / beyond
+    const double mb[] = {0.0625, 0.25, 0.5, 1, 2, 3, 4, 6.5, 16, 64, 256};
+    for (double m : mb) {
+        printf("region %.4g MB: ", m);
+        run<2>(t, (uint32_t)(m * 1024 * 1024 / 64), out);
+    }
     return 0;
 }

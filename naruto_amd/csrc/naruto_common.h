@@ -328,7 +328,8 @@ __device__ __forceinline__ float oneblob_cq(float u) {
 
 __device__ __forceinline__ bool oneblob_sparse_ok(float x) { return x > -0.93f && x < 1.93f; }
 
-__device__ __forceinline__ void oneblob16_sparse(float x, float (&e)[kBins]) {
+// pairs: bit Q set = bin 2Q or 2Q+1 may be non-zero (every other bin is an exact 0.0f)
+__device__ __forceinline__ void oneblob16_sparse(float x, float (&e)[kBins], uint32_t& pairs) {
     const float y = x * 16.0f;
     const float yw = y - 16.0f * floorf(y * 0.0625f);
     const float fb = floorf(yw);
@@ -339,12 +340,17 @@ __device__ __forceinline__ void oneblob16_sparse(float x, float (&e)[kBins]) {
     const float mid = q - p, hi = 1.0f - q;
 #pragma unroll
     for (int b = 0; b < kBins; ++b) e[b] = b == bm ? p : (b == b0 ? mid : (b == bp ? hi : 0.0f));
+    pairs = (1u << (bm >> 1)) | (1u << (b0 >> 1)) | (1u << (bp >> 1));
 }
 
 // wave-uniform choice: the closed form when every lane's coordinate allows it, the dense form otherwise
+__device__ __forceinline__ void oneblob16_auto(float x, bool all_sparse_ok, float (&e)[kBins], uint32_t& pairs) {
+    if (all_sparse_ok) oneblob16_sparse(x, e, pairs);
+    else { oneblob16(x, e); pairs = 0xFFu; }
+}
 __device__ __forceinline__ void oneblob16_auto(float x, bool all_sparse_ok, float (&e)[kBins]) {
-    if (all_sparse_ok) oneblob16_sparse(x, e);
-    else oneblob16(x, e);
+    uint32_t pairs;
+    oneblob16_auto(x, all_sparse_ok, e, pairs);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -431,6 +437,15 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
     const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
     return max(max(a, b), max(c, d));
+}
+
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
+    v |= (uint32_t)dpp_i32<0xB1>((int)v);
+    v |= (uint32_t)dpp_i32<0x4E>((int)v);
+    v |= (uint32_t)dpp_i32<0x141>((int)v);
+    v |= (uint32_t)dpp_i32<0x140>((int)v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) | (uint32_t)__builtin_amdgcn_readlane((int)v, 16) |
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
 }
 
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {

@@ -225,23 +225,35 @@ __global__ __launch_bounds__(256, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab
             hB = mfma32(a, b1, hB);
         }
 #endif
+        // OneBlob: three of a coordinate's 16 bins are non-zero, and the 64 points of a tile are neighbours on a ray, so
+        // most of the 24 K pairs are exact zeros for every point of the tile: those matrix steps are skipped (a product
+        // with 0.0f adds nothing to a finite accumulator; fp32 MFMA runs at the vector rate, every one skipped is 16 slots).
         const bool blob_fast = __all(oneblob_sparse_ok(x) && oneblob_sparse_ok(y) && oneblob_sparse_ok(z));
+        float eb[3][kBins];
+        uint32_t pairs = 0;
         static_for<0, 3>([&](auto dc) {
             constexpr int D = decltype(dc)::value;
-            float e[kBins];
-            oneblob16_auto(D == 0 ? x : (D == 1 ? y : z), blob_fast, e);
+            uint32_t pd;
+            oneblob16_auto(D == 0 ? x : (D == 1 ? y : z), blob_fast, eb[D], pd);
+            pairs |= pd << (8 * D);
+        });
+        pairs = blob_fast ? wave_or_u32(pairs) : 0xFFFFFFu;
+        static_for<0, 3>([&](auto dc) {
+            constexpr int D = decltype(dc)::value;
             static_for<0, 8>([&](auto qc) {
                 constexpr int Q = decltype(qc)::value;
                 constexpr int P = D * 8 + Q;
-                float b0 = e[2 * Q], b1 = e[2 * Q + 1];
-                swap32(b0, b1);
-                const float as = L.s0[(16 + P) * 64 + lane];
-                hA = mfma32(as, b0, hA);
-                hB = mfma32(as, b1, hB);
-                if constexpr (COLOR) {
-                    const float ac = L.c0p[P * 64 + lane];
-                    cA = mfma32(ac, b0, cA);
-                    cB = mfma32(ac, b1, cB);
+                if ((pairs >> P) & 1u) {
+                    float b0 = eb[D][2 * Q], b1 = eb[D][2 * Q + 1];
+                    swap32(b0, b1);
+                    const float as = L.s0[(16 + P) * 64 + lane];
+                    hA = mfma32(as, b0, hA);
+                    hB = mfma32(as, b1, hB);
+                    if constexpr (COLOR) {
+                        const float ac = L.c0p[P * 64 + lane];
+                        cA = mfma32(ac, b0, cA);
+                        cB = mfma32(ac, b1, cB);
+                    }
                 }
             });
         });

@@ -261,7 +261,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    tr.model.check_asserts()
+    tr.model.check_asserts(block=True)
     if group is not None:
         torch.distributed.barrier(group)
     torch.cuda.synchronize()
@@ -276,7 +276,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
         dt = float(t.item())
-    tr.model.check_asserts()
+    tr.model.check_asserts(block=True)
 
     if rank == 0:
         trc = cfg["training"]

@@ -104,6 +104,7 @@ class NarutoFieldHIP(nn.Module):
         self.n_rays_total = 0
         self.strict_assert = False
         self._pending_min_uncert = None
+        self._min_uncert_host, self._min_uncert_queue, self._min_uncert_slot = None, [], 0
 
     # ------------------------------------------------------------------ construction helpers
     def get_resolution(self):
@@ -227,13 +228,36 @@ class NarutoFieldHIP(nn.Module):
                 'z_vals': z_vals, 'raw': raw, 'uncert_map': uncert_map}
 
     # ------------------------------------------------------------------ A8
-    def check_asserts(self):
-        """The reference asserts ``uncert_map.min() > 0`` inside forward (scene_rep.py:280), which costs a
-        device sync per iteration.  Here the value is produced on the device and checked lazily: at the next
-        forward (one iteration late) or on demand; ``strict_assert = True`` restores the in-line check."""
+    def note_min_uncert(self, value: torch.Tensor):
+        """Queue this iteration's ``uncert_map.min()`` (a device scalar) for the deferred check: an asynchronous copy into
+        pinned host memory and an event; nothing waits.  (Skipped while a hipGraph is being captured.)"""
+        if not value.is_cuda or torch.cuda.is_current_stream_capturing():
+            self._pending_min_uncert = value
+            return
+        if self._min_uncert_host is None:
+            self._min_uncert_host = torch.empty(16, dtype=torch.float32, pin_memory=True)
+        if len(self._min_uncert_queue) >= 16:
+            self.check_asserts(block=True)
+        slot = self._min_uncert_slot
+        self._min_uncert_slot = (slot + 1) % 16
+        self._min_uncert_host[slot:slot + 1].copy_(value.detach().reshape(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._min_uncert_queue.append((slot, ev))
+
+    def check_asserts(self, block: bool = False):
+        """The reference asserts ``uncert_map.min() > 0`` inside forward (scene_rep.py:280), which costs a device sync
+        per iteration -- with eager launches the host then never runs ahead of the GPU.  Here the value is produced on
+        the device, copied to the host asynchronously and checked when its copy has landed (a few iterations late);
+        ``block=True`` (or ``strict_assert = True``: the reference's in-line behaviour) waits for everything queued."""
         if self._pending_min_uncert is not None:
             v = float(self._pending_min_uncert.item())
             self._pending_min_uncert = None
+            assert v > 0, "uncert_map.min() > 0 violated (scene_rep.py:280)"
+        while self._min_uncert_queue and (block or self._min_uncert_queue[0][1].query()):
+            slot, ev = self._min_uncert_queue.pop(0)
+            ev.synchronize()
+            v = float(self._min_uncert_host[slot])
             assert v > 0, "uncert_map.min() > 0 violated (scene_rep.py:280)"
 
     def forward(self, rays_o, rays_d, target_rgb, target_d, global_step=0, rand=None, _check=True, _smooth=None):
@@ -247,9 +271,9 @@ class NarutoFieldHIP(nn.Module):
         rgb, depth, _disp, _acc, _var, _um, _raw, losses = ops.render_train(
             self._handle(), self._params(), rays_o, rays_d, z_vals, target_rgb, target_d, cfg['cam']['depth_trunc'],
             cfg['training']['rgb_missing'], group=self.process_group, n_rays_total=self.n_rays_total, smooth=_smooth)
-        self._pending_min_uncert = losses[6].detach()
+        self.note_min_uncert(losses[6])
         if self.strict_assert:
-            self.check_asserts()
+            self.check_asserts(block=True)
         return {"rgb": rgb, "depth": depth, "rgb_loss": losses[0], "depth_loss": losses[1], "sdf_loss": losses[2],
                 "fs_loss": losses[3], "psnr": losses[4].detach(), "uncert_loss": losses[5], "_losses": losses, "_smooth_loss": losses[8]}
 

@@ -240,9 +240,9 @@ class MappingTrainer:
                 if self.group is not None:
                     parallel.allreduce_grads([model.uncert_grid], self.group)
                 self.uncert_optim.step(zero_grad=True)
-        model._pending_min_uncert = losses[6]
+        model.note_min_uncert(losses[6])
         if model.strict_assert:
-            model.check_asserts()
+            model.check_asserts(block=True)
         ret = {"rgb": ts.rgb, "depth": ts.depth, "rgb_loss": losses[0], "depth_loss": losses[1], "sdf_loss": losses[2], "fs_loss": losses[3],
                "psnr": losses[4], "uncert_loss": losses[5], "_losses": losses, "_smooth_loss": losses[8]}
         return ret, losses[9]

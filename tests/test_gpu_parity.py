@@ -838,3 +838,24 @@ def test_extract_mesh_golden(gpu, tmp_path):
             assert np.abs(got - want).max() <= 1.0
         else:
             assert (np.abs(got - want).max(-1) > 0).mean() < 0.02          # a jet bin edge may flip with the 1e-6 noise of the uncertainty
+
+
+def test_deferred_min_uncert_assert(gpu):
+    """scene_rep.py:280 asserts uncert_map.min() > 0 inside forward; here the value is copied to the host asynchronously and
+    checked when it has landed: no sync per iteration, and a violation is still reported (within a few iterations, or at once
+    with check_asserts(block=True) / strict_assert)."""
+    from naruto_amd.trainer import MappingTrainer, pack_rays
+    cfg = H.office_cfg(12, perturb=1.0)
+    tr = MappingTrainer(cfg, torch.tensor(cfg["mapping"]["bound"], dtype=torch.float32), gpu, 0.1, fused_adam=True)
+    rays = {k: torch.from_numpy(v).to(gpu) for k, v in syn.random_rays(64, cfg["mapping"]["bound"], seed=5).items()}
+    o, d, s, t = pack_rays(rays["rays_o"], rays["rays_d"], rays["target_rgb"], rays["target_d"])
+    for _ in range(3):
+        tr.step(o, d, s, t, smooth=True, n_rays_total=64)
+    tr.model.check_asserts(block=True)                                   # healthy so far
+    assert not tr.model._min_uncert_queue
+    with torch.no_grad():
+        tr.model.uncert_grid.fill_(float("nan"))                         # every ray's uncert_map becomes NaN: "min() > 0" is false
+    tr.step(o, d, s, t, smooth=True, n_rays_total=64)                    # queues the bad value; may or may not have landed yet
+    with pytest.raises(AssertionError, match="uncert_map.min"):
+        tr.step(o, d, s, t, smooth=True, n_rays_total=64)
+        tr.model.check_asserts(block=True)

@@ -172,13 +172,9 @@ int naruto_field_create(const NarutoFieldDesc* d, NarutoField** out) {
     // scatter plan: levels of up to kMaxChunksPerLevel 16 384-entry chunks are LDS-tiled, one unit per (chunk, feature),
     // dense levels first; larger levels use global atomics
     memset(&f->plan, 0, sizeof(f->plan));
-    // profiling knobs (not part of the contract): restrict the scatter to some levels / force the split counts
-    const char* env_mask = getenv("NARUTO_DEBUG_SCATTER_LEVELS");
-    const uint32_t dbg_mask = env_mask ? (uint32_t)strtoul(env_mask, nullptr, 0) : 0xFFFFu;
     uint32_t n_units = 0;
     for (int pass = 0; pass < 2; ++pass) {
         for (uint32_t l = 0; l < d->n_levels; ++l) {
-            if (!((dbg_mask >> l) & 1u)) continue;
             const bool hashed = (f->lt.hashed >> l) & 1u;
             if ((pass == 1) != hashed) continue;
             const uint32_t chunks = (f->lt.size[l] + kChunk - 1u) / kChunk;
@@ -205,8 +201,9 @@ int naruto_field_create(const NarutoFieldDesc* d, NarutoField** out) {
         sd = sd < 1u ? 1u : (sd > 8u ? 8u : sd);
         f->plan.s_hashed = sh;
         f->plan.s_dense = sd;
-        if (const char* e1 = getenv("NARUTO_DEBUG_SCATTER_SPLITS_HASHED")) f->plan.s_hashed = (uint32_t)atoi(e1);
-        if (const char* e2 = getenv("NARUTO_DEBUG_SCATTER_SPLITS_DENSE")) f->plan.s_dense = (uint32_t)atoi(e2);
+        // profiling knobs (performance only: the split counts change the summation order, nothing else)
+        if (const char* e1 = getenv("NARUTO_DEBUG_SCATTER_SPLITS_HASHED")) f->plan.s_hashed = (uint32_t)atoi(e1) < 1 ? 1u : ((uint32_t)atoi(e1) > 8u ? 8u : (uint32_t)atoi(e1));
+        if (const char* e2 = getenv("NARUTO_DEBUG_SCATTER_SPLITS_DENSE")) f->plan.s_dense = (uint32_t)atoi(e2) < 1 ? 1u : ((uint32_t)atoi(e2) > 8u ? 8u : (uint32_t)atoi(e2));
     }
     *out = f;
     return NARUTO_OK;

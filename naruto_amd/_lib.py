@@ -177,6 +177,10 @@ def load() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
                 "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). There is no fallback path.")
+        # The device pointers and streams handed to the library are PyTorch's, so both must talk to ONE HIP runtime: the
+        # one PyTorch-ROCm brings along.  Loaded first, libnaruto_hip.so would pull in /opt/rocm's libamdhip64 and the
+        # process would end up with two runtimes (the second one reports "no ROCm-capable device").  Import torch first.
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol

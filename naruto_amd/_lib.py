@@ -108,10 +108,16 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     if force or needs_build():
-        cmd = build_command()
+        tmp = f"{LIB_PATH}.{os.getpid()}.tmp"               # never a half-written library under the final name
+        cmd = build_command(tmp)
         if verbose:
             print(" ".join(cmd))
-        subprocess.run(cmd, check=True)
+        try:
+            subprocess.run(cmd, check=True)
+            os.replace(tmp, LIB_PATH)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     return LIB_PATH
 
 

@@ -307,6 +307,7 @@ int naruto_query_fwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
     const bool color = raw != nullptr;
     if (color && (p->col_w0 == nullptr || p->col_w1 == nullptr)) return fail(NARUTO_ERR_INVALID, "query_fwd: colour net parameters missing");
     if (!color && sdf_uncert == nullptr && geo == nullptr && feat_save == nullptr) return fail(NARUTO_ERR_INVALID, "query_fwd: no output requested");
+    if (feat_save != nullptr && M > (1u << 29)) return fail(NARUTO_ERR_INVALID, "query_fwd: feat_save is addressed with 32-bit byte offsets: at most 2^29 points per call");
     NarutoParams pp = *p;
     if (!color) { pp.col_w0 = p->sdf_w0; pp.col_w1 = p->sdf_w0; }       // staged but unused; keep the loads in bounds
     const uint32_t n_tiles = (M + 63u) / 64u;

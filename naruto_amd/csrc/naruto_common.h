@@ -214,14 +214,16 @@ __device__ __forceinline__ float2 hash_level_half_rt(const LevelTab& lt, int T, 
             }
         }
     }
-    const float2* __restrict__ tl = table + lt.off[T];
+    // uniform base + 32-bit byte offset (level sizes are < 2^28 entries): the load takes its base from SGPRs and the lane
+    // offset from ONE VGPR, instead of a zero-extended 64-bit address built per lane
+    const char* __restrict__ tl = reinterpret_cast<const char*>(table + lt.off[T]);
     float2 v[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
 #ifdef NARUTO_ABLATE_GATHER
         v[c] = make_float2(__uint_as_float(idx[c] | 0x3f000000u), 0.25f);
 #else
-        v[c] = tl[idx[c]];
+        v[c] = *reinterpret_cast<const float2*>(tl + (idx[c] << 3));
 #endif
     }
     float2 acc = make_float2(0.0f, 0.0f);

@@ -217,8 +217,10 @@ __global__ __launch_bounds__(256, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab
             swap32(ub, wb);
             const float b0 = ua + wa, b1 = ub + wb;       // feature hh of point j (tile A) / j+32 (tile B)
             if (feat_save != nullptr) {
-                if (mA < M) feat_save[((size_t)T * M + mA) * 2u + hh] = b0;
-                if (mB < M) feat_save[((size_t)T * M + mB) * 2u + hh] = b1;
+                // uniform per-level base + 32-bit lane offset (the launcher bounds the point list at 2^29 points)
+                char* __restrict__ fs = reinterpret_cast<char*>(feat_save + (size_t)T * M * 2u);
+                if (mA < M) *reinterpret_cast<float*>(fs + ((mA * 2u + (uint32_t)hh) << 2)) = b0;
+                if (mB < M) *reinterpret_cast<float*>(fs + ((mB * 2u + (uint32_t)hh) << 2)) = b1;
             }
             const float a = L.s0[T * 64 + lane];
             hA = mfma32(a, b0, hA);

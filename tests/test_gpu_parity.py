@@ -18,10 +18,10 @@ pytestmark = pytest.mark.gpu
 TOL_OUT = 1e-4
 
 
-def grad_close(got, want, what):
+def grad_close(got, want, what, frac=1e-4):
     want = torch.as_tensor(want).detach().double().cpu()
     scale = max(want.abs().max().item(), 1e-12)
-    H.assert_close(got, want, 1e-4 * scale, what, rel=1e-3)
+    H.assert_close(got, want, frac * scale, what, rel=1e-3)
 
 
 # --------------------------------------------------------------------------------------------- hardware layout probes
@@ -495,6 +495,67 @@ def test_train_step_direct_against_oracle(gpu, n_samples_d):
     if S_tot % 64 == 0:
         tail = ts.raw[:, 64:, :].reshape(N, -1)
         n_stopped = int((tail.abs().sum(1) == 0).sum().item())
+        assert 0 < n_stopped < N, f"early termination: {n_stopped} of {N} rays stopped after the first tile"
+
+
+@pytest.mark.parametrize("workload", ["office0_2048x128", "office0_8192x43", "mp3d_2048x256"])
+def test_train_step_full_size_against_oracle(gpu, workload):
+    """BASELINE.json's configurations at their full per-GPU sizes -- configs[1] 2048 rays x 128 samples, configs[2] 8192
+    rays with the shipped sampling, configs[3]'s per-GPU shard 2048 rays x 256 samples on the MP3D volume; 2^16-entry
+    tables, smoothness term, the trainer's fast path (early termination, active-sample compaction, LDS-tiled scatter over
+    all CUs) -- against the CPU oracle on the same jitter draw: every loss, the rendered maps and every gradient."""
+    from naruto_amd import ops
+    from naruto_amd import config as C
+    if workload == "office0_2048x128":
+        cfg, N = H.office_cfg(16, perturb=1.0, n_samples_d=117), 2048
+    elif workload == "office0_8192x43":
+        cfg, N = H.office_cfg(16, perturb=1.0), 8192
+    else:
+        cfg, N = C.mp3d_large_config(perturb=1.0, n_samples_d=245), 2048
+    tr, cam = cfg["training"], cfg["cam"]
+    ora = H.make_oracle(cfg, 0.05, 77)
+    m = H.make_hip_from_oracle(cfg, ora, gpu)
+    S_tot = tr["n_samples_d"] + tr["n_range_d"]
+    rays = syn.random_rays(N, cfg["mapping"]["bound"], seed=77, zero_depth_frac=0.05)
+    t = {k: torch.from_numpy(v) for k, v in rays.items()}
+    r6 = torch.tensor([0.15, 0.8, 0.45, 0.6, 0.05, 0.9])
+    rand = torch.rand(N, S_tot, generator=torch.Generator().manual_seed(11))
+    w_s = 0.05
+    w = torch.tensor([tr["rgb_weight"], tr["depth_weight"], tr["sdf_weight"], tr["fs_weight"], 0.0, tr["uncert_weight"], 0.0, 0.0, w_s, 0.0])
+    ora.train()
+    ret_o = ora.forward(t["rays_o"], t["rays_d"], t["target_rgb"], t["target_d"], rand=rand)
+    sm_o = S.smoothness(ora, tr["smooth_pts"], tr["smooth_vox"], tr["smooth_margin"], r6[:3], r6[3:])
+    total_o = S.total_loss(ret_o, tr) + w_s * sm_o
+    total_o.backward()
+    go = H.ora_grads(ora)
+    ug = torch.zeros_like(m.uncert_grid)
+    ts = ops.TrainStep(m._handle(), m._params(), ug, N, n_samples_d=tr["n_samples_d"], n_range_d=tr["n_range_d"], near=cam["near"], far=cam["far"],
+                       range_d=tr["range_d"], depth_trunc=cam["depth_trunc"], rgb_missing=tr["rgb_missing"], perturb=True,
+                       loss_weights=w.to(gpu), smooth=(tr["smooth_pts"], tr["smooth_vox"], tr["smooth_margin"]), device_rng=False)
+    args = [t[k].to(gpu).contiguous() for k in ("rays_o", "rays_d", "target_rgb")] + [t["target_d"].to(gpu).reshape(-1).contiguous()]
+    ts.rand[N * S_tot:].copy_(r6)
+    losses = ts.run(*args, rand=rand.to(gpu))
+    torch.cuda.synchronize()
+    for i, k in enumerate(("rgb_loss", "depth_loss", "sdf_loss", "fs_loss")):
+        H.assert_close(losses[i].reshape(-1), ret_o[k].reshape(-1), 1e-6, f"full.{k}", rel=1e-4)
+    H.assert_close(losses[5].reshape(-1), ret_o["uncert_loss"].reshape(-1), 1e-5, "full.uncert_loss", rel=1e-4)
+    H.assert_close(losses[8].reshape(-1), sm_o.reshape(-1), 1e-7, "full.smooth", rel=1e-4)
+    H.assert_close(losses[9].reshape(-1), total_o.detach().reshape(-1), 1e-5, "full.total", rel=1e-4)
+    H.assert_close(ts.rgb, ret_o["rgb"], TOL_OUT, "full.rgb")
+    H.assert_close(ts.depth, ret_o["depth"], TOL_OUT, "full.depth", rel=1e-4)
+    # Gradient entries are sums over up to 10^5 samples with heavy cancellation; at these sizes the fp32 reference itself
+    # moves by up to 4e-3 of max|grad| when it is evaluated in fp64 (table; 9e-4 for col_w0 -- measured on the oracle, 8192 x
+    # 43), so the small-batch bound of 1e-4 of max|grad| is below the reference's own arithmetic noise here.  Measured
+    # HIP-vs-oracle at full size: <= 6e-4 of max|grad| on < 0.1 % of the table entries; a handful of the 2016 col_w0 entries
+    # at 1e-4 .. 1e-3 (the fp32 oracle has 6 of those against its own fp64 run).
+    for k in ("table", "sdf_w0", "sdf_w1", "col_w0", "col_w1"):
+        grad_close(ts.grads[k].reshape(-1), go[k].reshape(-1), f"full.grad.{k}", frac=1e-3)
+        if k == "table":
+            err = (ts.grads[k].reshape(-1).double().cpu() - go[k].reshape(-1).double()).abs()
+            assert float((err > 1e-4 * go[k].abs().max().double()).float().mean()) < 2e-3, "full.grad.table: too many entries beyond 1e-4 of the scale"
+    grad_close(ug.reshape(-1), ora.uncert_grid.grad.reshape(-1), "full.grad.uncert_grid", frac=1e-3)
+    if S_tot % 64 == 0 and S_tot > 64:
+        n_stopped = int((ts.raw[:, 64:, :].reshape(N, -1).abs().sum(1) == 0).sum().item())
         assert 0 < n_stopped < N, f"early termination: {n_stopped} of {N} rays stopped after the first tile"
 
 

@@ -50,6 +50,8 @@ def workload(name: str):
         return C.mp3d_large_config(perturb=1.0, n_samples_d=245), 2048
     if name == "office0_8192x43":
         return C.office0_config(perturb=1.0), 8192
+    if name == "unit1024_131072x43":              # configs[4]: 2^20 rays over 8 GPUs, unit cube, 1024^3 finest level
+        return C.unit_cube_config(1024, 16, perturb=1.0), 131072
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -282,12 +284,13 @@ def main():
         trc = cfg["training"]
         S_tot = trc["n_samples_d"] + trc["n_range_d"]
         ms = dt / args.steps * 1e3
+        volume = "MP3D 1LXtFkjw3qL bbox" if args.workload.startswith("mp3d") else ("unit cube, finest level 1024^3" if args.workload.startswith("unit") else "office_0 bbox")
         out = {
             "metric": "rendered rays/sec (train step), Replica office_0",
             "value": round(n_total * args.steps / dt, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: office_0 bbox, {n_rays} rays x {S_tot} samples per GPU, hash L16 F2 T2^16, "
+            "config": {"workload": f"{args.workload}: {volume}, {n_rays} rays x {S_tot} samples per GPU, hash L16 F2 T2^{cfg['grid']['hash_size']}, "
                                    "MLP 2x32, uncert grid; one global_BA mapping iteration incl. smoothness + Adam",
                        "rays_per_gpu": n_rays, "samples_per_ray": S_tot, "parallelism": f"ray-sharded dp{world}",
                        "optimizer": "torch.optim.Adam" if args.torch_adam else "fused HIP Adam", "hip_graph": bool(use_graph)},

@@ -437,14 +437,18 @@ constexpr int kScatterRun = 8;     // consecutive points per thread on the dense
 #endif
 constexpr uint32_t kListVec = NARUTO_LIST_VEC;      // 2 or 4 consecutive points per lane in the hashed levels' list stream
 
-// float -> two's-complement fixed point with 40 fractional bits in four VALU ops instead of the generic f32 -> i64
-// conversion: v * 2^40 = H * 2^32 + L,  H = floor(v * 2^8) (int32, v_cvt_flr_i32_f32),  L = fract(v * 2^8) * 2^32
-// (uint32; v_fract_f32 stays below 1, so L never wraps).  The argument is t = v * 2^8 -- callers fold the 2^8 into the
-// per-point cotangent.  Valid for |v| < 2^23; error < 2^-40 (2^-32 in the measure-zero case fract(t) rounds to 1 - 2^-24).
+// float -> two's-complement fixed point with 40 fractional bits without the generic f32 -> i64 conversion:
+// t = v * 2^8 (callers fold the 2^8 into the per-point cotangent) = H + r with H = rint(t) and r = t - H in [-1/2, 1/2]
+// EXACT in fp32; v * 2^40 = H * 2^32 + L with L = trunc(r * 2^32) a SIGNED 32-bit number (the high word borrows one when
+// L < 0).  Error < 2^-40 of v for |v| < 2^22.  (Splitting with floor / fract instead looks cheaper and is wrong: for a small
+// negative t, fract(t) = 1 + t is rounded to fp32 next to 1.0 and the contribution is off by up to 2^-33 -- a relative
+// 1e-4 for a typical 1e-6 contribution, every time.)
 __device__ __forceinline__ unsigned long long to_fix40_scaled(float t) {
-    const uint32_t lo = (uint32_t)(__builtin_amdgcn_fractf(t) * 4294967296.0f);
-    const uint32_t hi = (uint32_t)(int)floorf(t);
-    return ((unsigned long long)hi << 32) | lo;
+    const float hf = rintf(t);
+    const float r = t - hf;
+    const int lo = (int)(r * 4294967296.0f);                 // v_cvt_i32_f32 saturates at r = +1/2: one unit of 2^-40
+    const int hi = (int)hf + (lo >> 31);
+    return ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;
 }
 __device__ __forceinline__ unsigned long long to_fix40(float v) { return to_fix40_scaled(v * 256.0f); }
 

@@ -111,6 +111,38 @@ def test_query_golden(gpu, hash_size):
     H.assert_close(um, g["map_uncert"], TOL_OUT, "map.uncert")
 
 
+@pytest.mark.parametrize("hash_size", [12, 16])
+def test_query_boundary_sweeps(gpu, hash_size):
+    """Lines through the unit cube and well beyond it on every axis (-1.2 .. 2.2, 4001 steps, incl. the exact values 0, 1,
+    the bin edges k/16 and the switch-over points of the kernels' fast paths: the closed-form OneBlob inside (-0.93, 1.93),
+    the wrap-free dense-level indices inside the grid): every output against the oracle."""
+    cfg = H.office_cfg(hash_size)
+    ora = H.make_oracle(cfg, 0.25, 61).eval()
+    m = H.make_hip_from_oracle(cfg, ora, gpu).eval()
+    rs = np.random.RandomState(61)
+    sweep = np.unique(np.concatenate([np.linspace(-1.2, 2.2, 4001), np.arange(-19, 36) / 16.0, [-0.93, 1.93, -0.9375, 1.9375],
+                                      1.0 - 2.0 ** -np.arange(1, 24), 2.0 ** -np.arange(1, 24)])).astype(np.float32)
+    pts = []
+    for axis in range(3):
+        p = np.tile(rs.uniform(0.05, 0.95, (1, 3)).astype(np.float32), (len(sweep), 1))
+        p[:, axis] = sweep
+        pts.append(p)
+        q = rs.uniform(-0.3, 1.3, (len(sweep), 3)).astype(np.float32)         # the other two coordinates anywhere, some outside
+        q[:, axis] = sweep
+        pts.append(q)
+    x = torch.from_numpy(np.concatenate(pts))
+    with torch.no_grad():
+        want_raw = ora.query_color_sdf(x)
+        want_su, want_geo = ora.query_sdf(x, return_geo=True)
+        want_emb = ora.query_sdf(x, embed=True)
+        xg = x.to(gpu)
+        H.assert_close(m.query_sdf(xg, embed=True), want_emb, 2e-6, "sweep.embed")
+        H.assert_close(m.query_color_sdf(xg), want_raw.reshape(-1, 5), TOL_OUT, "sweep.raw")
+        got_su, got_geo = m.query_sdf(xg, return_geo=True)
+        H.assert_close(got_su, want_su, TOL_OUT, "sweep.sdf")
+        H.assert_close(got_geo, want_geo, TOL_OUT, "sweep.geo")
+
+
 @pytest.mark.parametrize("kind", ["office_t16", "mp3d", "unit1024"])
 def test_hash_encode_vs_oracle(gpu, kind):
     from naruto_amd import config as C

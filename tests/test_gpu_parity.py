@@ -751,6 +751,52 @@ def test_planner_aggregation_golden(gpu):
     assert ok3 is False and out3 == {}
 
 
+def test_planner_aggregation_full_size(gpu):
+    """N3 at the office_0 size the planner runs (49 x 56 x 35 volumes of 0.1 m, 2 100 goal candidates, top 4000 -> 300 targets;
+    configs/default.py:93-98) on random-walk volumes, against the oracle: selections exact, sums to 1e-6."""
+    from naruto_amd import config as C
+    from naruto_amd.planner_aggregation import GoalSpaceAggregatorHIP
+    bbox = C.office0_config()["mapping"]["bound"]
+    ag = GoalSpaceAggregatorHIP(bbox, 0.1, device=gpu)
+    dims, ranges, goal_idx = S.goal_space(bbox, 0.1, [5, 11, 17])
+    assert (ag.Nx, ag.Ny, ag.Nz) == dims == (49, 56, 35) and goal_idx.shape[0] == 25 * 28 * 3
+    rs = np.random.RandomState(71)
+    X, Y, Z = np.meshgrid(*[np.arange(d) for d in dims], indexing="ij")
+    room = np.minimum.reduce([X - 1.5, dims[0] - 2.5 - X, Y - 1.5, dims[1] - 2.5 - Y, Z - 1.5, dims[2] - 2.5 - Z]).astype(np.float32)
+    blobs = np.minimum.reduce([np.sqrt((X - cx) ** 2 + (Y - cy) ** 2 + (Z - cz) ** 2) - r for cx, cy, cz, r in
+                               zip(rs.uniform(5, 44, 9), rs.uniform(5, 50, 9), rs.uniform(3, 30, 9), rs.uniform(1.5, 5, 9))]).astype(np.float32)
+    sdf = (np.minimum(room, blobs) * 0.5 + rs.normal(0, 0.03, dims)).astype(np.float32)
+    uncert = (rs.uniform(0.01, 3.0, dims) * ((sdf >= 0) & (sdf < 0.5))).astype(np.float32)
+    ok, out = ag.uncertainty_aggregation_v2([torch.from_numpy(uncert).to(gpu), torch.from_numpy(sdf).to(gpu)])
+    det = S.topk_targets_deterministic(uncert, 4000, 300)
+    assert ok and np.array_equal(out["topk_uncert_vxl"].cpu().numpy(), det)
+    coll, agg, valid = S.uncert_aggregation(uncert, sdf, det, goal_idx, dims, 0.1, (0.5, 2.0), 0.8)
+    assert 0 < int(valid.sum()) < valid.numel()
+    assert np.array_equal(out["gs_uncert_collections"].cpu().numpy(), coll.numpy())
+    H.assert_close(out["gs_aggre_uncerts"].reshape(-1), agg, 1e-5, "gs_aggre_uncerts (full size)", rel=1e-6)
+
+
+def test_active_ray_sampler_full_size(gpu):
+    """N1 at the size of a mapping iteration (2048 + 4 x 2048 oversampled + 100 current rays, K = 500) against the
+    deterministic oracle: identical batches."""
+    from naruto_amd import config as C
+    from naruto_amd.active_ray_sampler import ActiveRaySamplerHIP
+    cfg = C.office0_config()
+    cfg["mapping"]["sample"] = 2048
+    bound = cfg["mapping"]["bound"]
+    smp = ActiveRaySamplerHIP(config=cfg, num_uncert_sample=500, oversample_mul=4)
+    n_cur = 100
+    n = smp.oversample_num + n_cur
+    rays = syn.random_rays(n, bound, seed=72)
+    t = {k: torch.from_numpy(v) for k, v in rays.items()}
+    rs = np.random.RandomState(72)
+    vol = (rs.uniform(0, 3, (49, 56, 35)) * (rs.uniform(size=(49, 56, 35)) < 0.3)).astype(np.float32)     # many exact zeros: ties
+    got = smp.sample_rays(t["rays_o"].to(gpu), t["rays_d"].to(gpu), t["target_rgb"].to(gpu), t["target_d"].to(gpu), list(range(n_cur)), vol, bound)
+    want, vals, sel = S.active_ray_sample(t["rays_o"], t["rays_d"], t["target_rgb"], t["target_d"], n_cur, vol, bound, 2048, 500, 4, deterministic=True)
+    for a, b, k in zip(got, want, ("rays_o", "rays_d", "target_rgb", "target_d")):
+        assert a.shape == b.shape and torch.equal(a.cpu(), b), f"{k}: HIP sampler != deterministic oracle"
+
+
 # --------------------------------------------------------------------------------------------- edge cases
 def test_edge_sizes_and_degenerate_inputs(gpu):
     """Empty and minimal inputs, the per-ray sample limit, depths that are zero / negative / beyond depth_trunc.  (A NaN

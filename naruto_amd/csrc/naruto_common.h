@@ -77,6 +77,38 @@ __device__ __forceinline__ void load_point(const PointSrc& ps, const BoxTab& bt,
     }
 }
 
+// The same in two steps, for software prefetch: the loads only (no arithmetic on their results, so nothing waits), and
+// the arithmetic one tile later.
+struct PointRaw { float v[7]; };
+__device__ __forceinline__ PointRaw load_point_raw(const PointSrc& ps, uint32_t m) {
+    PointRaw r;
+    if (ps.xsoa) {
+        r.v[0] = ps.xsoa[m]; r.v[1] = ps.xsoa[ps.M + m]; r.v[2] = ps.xsoa[2u * ps.M + m];
+        r.v[3] = r.v[4] = r.v[5] = r.v[6] = 0.0f;
+    } else if (ps.x) {
+        r.v[0] = ps.x[3 * (size_t)m + 0]; r.v[1] = ps.x[3 * (size_t)m + 1]; r.v[2] = ps.x[3 * (size_t)m + 2];
+        r.v[3] = r.v[4] = r.v[5] = r.v[6] = 0.0f;
+    } else {
+        const uint32_t n = m / ps.S;
+        r.v[6] = ps.z_vals[m];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { r.v[c] = ps.rays_o[3 * n + c]; r.v[3 + c] = ps.rays_d[3 * n + c]; }
+    }
+    return r;
+}
+__device__ __forceinline__ void finish_point(const PointSrc& ps, const BoxTab& bt, const PointRaw& r, float& x, float& y, float& z) {
+    if (ps.xsoa || ps.x) {
+        x = r.v[0]; y = r.v[1]; z = r.v[2];
+    } else {                                                    // same arithmetic as load_point
+        const float px = __fadd_rn(r.v[0], __fmul_rn(r.v[3], r.v[6]));
+        const float py = __fadd_rn(r.v[1], __fmul_rn(r.v[4], r.v[6]));
+        const float pz = __fadd_rn(r.v[2], __fmul_rn(r.v[5], r.v[6]));
+        x = __fdiv_rn(__fsub_rn(px, bt.bmin[0]), bt.bext[0]);
+        y = __fdiv_rn(__fsub_rn(py, bt.bmin[1]), bt.bext[1]);
+        z = __fdiv_rn(__fsub_rn(pz, bt.bmin[2]), bt.bext[2]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // One hash-grid level: 8 corner indices + trilinear weights (tcnn kernel_grid / grid_index /
 // pos_fract, linear interpolation, coherent prime hash).  Weight order is tcnn's:

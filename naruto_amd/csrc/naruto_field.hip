@@ -1005,16 +1005,27 @@ __global__ __launch_bounds__(64 * kBwdWaves) void k_query_bwd(LevelTab lt, Uncer
     struct TileIn {
         uint32_t i_pt, m;
         bool valid;
-        float x, y, z, g[5], feat[kLevels];
+        PointRaw pr;
+        float g[5], feat[kLevels];
     };
-    auto load_tile = [&](uint32_t tile) {
+    // Software prefetch, two deep: the list entry -> sample index of the tile AFTER next and all inputs of the next tile
+    // (which depend on its index, loaded one tile earlier) are issued at the top of a tile; nothing computes on the loaded
+    // values before the next iteration, so no wait is exposed.  Tile numbers are clamped instead of branched on: the last
+    // iterations reload the last tile, and the loop-carried registers are plain load destinations (a conditional
+    // assignment made the compiler copy them, which waits for the loads right after issuing them).
+    auto load_index = [&](uint32_t tile) -> uint32_t {
+        const uint32_t i_raw = tile * 32u + j;
+        const uint32_t i_pt = i_raw < M_eff ? i_raw : M_eff - 1u;
+        return active_idx != nullptr ? active_idx[i_pt] : i_pt;
+    };
+    auto load_tile = [&](uint32_t tile, uint32_t m_of_tile) {
         TileIn t;
         // lanes j and j+32 both work on list entry i = tile*32 + j (point m); hh selects the K-pair component
         const uint32_t i_raw = tile * 32u + j;
         t.valid = i_raw < M_eff;
         t.i_pt = t.valid ? i_raw : M_eff - 1u;
-        t.m = active_idx != nullptr ? active_idx[t.i_pt] : t.i_pt;
-        load_point(ps, bt, t.m, t.x, t.y, t.z);
+        t.m = m_of_tile;
+        t.pr = load_point_raw(ps, t.m);
         const float* g = d_raw + (size_t)t.m * 5;
 #pragma unroll
         for (int q = 0; q < 5; ++q) t.g[q] = g[q];
@@ -1025,14 +1036,26 @@ __global__ __launch_bounds__(64 * kBwdWaves) void k_query_bwd(LevelTab lt, Uncer
     const uint32_t tile_stride = gridDim.x * (uint32_t)kBwdWaves;
     uint32_t tile = blockIdx.x * (uint32_t)kBwdWaves + wave;
     constexpr bool kPrefetch = kBwdWaves <= 4;         // with two waves per SIMD the other wave hides the latency; the registers are needed
+    const uint32_t last_tile = n_tiles > 0 ? n_tiles - 1u : 0u;
     TileIn nxt;
-    if (kPrefetch && tile < n_tiles) nxt = load_tile(tile);
+    uint32_t m_ahead = 0;
+    if (kPrefetch && tile < n_tiles) {
+        nxt = load_tile(tile, load_index(tile));
+        m_ahead = load_index(min(tile + tile_stride, last_tile));
+    }
     for (; tile < n_tiles; tile += tile_stride) {
-        const TileIn cur = kPrefetch ? nxt : load_tile(tile);
-        if (kPrefetch && tile + tile_stride < n_tiles) nxt = load_tile(tile + tile_stride);
+        TileIn cur;
+        if constexpr (kPrefetch) {
+            cur = nxt;
+            nxt = load_tile(min(tile + tile_stride, last_tile), m_ahead);
+            m_ahead = load_index(min(tile + 2u * tile_stride, last_tile));
+        } else {
+            cur = load_tile(tile, load_index(tile));
+        }
         const bool valid = cur.valid;
         const uint32_t i_pt = cur.i_pt, m = cur.m;
-        const float x = cur.x, y = cur.y, z = cur.z;
+        float x, y, z;
+        finish_point(ps, bt, cur.pr, x, y, z);
         if (x_out != nullptr && valid && hh == 0) {      // normalised points [3][M] (list order) for the table scatter
             x_out[list_off + i_pt] = x;
             x_out[(size_t)cap + list_off + i_pt] = y;
@@ -1099,17 +1122,21 @@ __global__ __launch_bounds__(64 * kBwdWaves) void k_query_bwd(LevelTab lt, Uncer
             dcv[r] = c[r] > 0.0f ? a : 0.0f;
             cact[r] = fmaxf(c[r], 0.0f);
         }
-        // ---- dW(col_w1)[q][i] = sum_pt d_rgb[q] * relu(c)[i]   (tile 6; G rows q<3 read from d_raw)
+        // ---- dW(col_w1)[q][i] = sum_pt d_rgb[q] * relu(c)[i]   (tile 6; G rows q<3 = this tile's rgb cotangents, which the
+        // lanes already hold: passed through the free "G" stage instead of being read back from d_raw -- that was an index
+        // load + a dependent cotangent load, two exposed round trips to memory in the middle of every tile)
         stage_ctile(gb, kGradLd, 0, cact, j, hh);
+        if (hh == 0) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) ga[j * kGradLd + q] = g_rgb[q];             // padding points carry zeros
+        }
         wave_lds_sync();
         {
             const int i = lane & 31;
             float gv[16], xv[16];
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                const uint32_t pt = tile * 32u + 2 * t + hh;
-                gv[t] = 0.0f;
-                if (i < 3 && pt < M_eff) gv[t] = d_raw[(size_t)(active_idx != nullptr ? active_idx[pt] : pt) * 5 + i];
+                gv[t] = i < 3 ? ga[(2 * t + hh) * kGradLd + i] : 0.0f;
                 xv[t] = gb[(2 * t + hh) * kGradLd + i];
             }
 #pragma unroll

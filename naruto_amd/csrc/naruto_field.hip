@@ -498,13 +498,15 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
                 }
                 return q;
             };
-            // software prefetch: the next loads are in flight while this batch is scattered
+            // software prefetch: the next loads are in flight while this batch is scattered.  The position is clamped, not
+            // branched on: a conditionally assigned loop-carried register gets copied, and the copy waits for its load.
             uint32_t base = m_lo + threadIdx.x * V;
+            const uint32_t last = m_hi >= V ? ((m_hi - 1u) & ~(V - 1u)) : m_lo;       // m_lo, m_hi are multiples of 4 here; V | 4
             Vec nxt{};
             if (base < m_hi) nxt = load_vec(base);
             for (; base < m_hi; base += kScatterThreads * V) {
                 const Vec q = nxt;
-                if (base + kScatterThreads * V < m_hi) nxt = load_vec(base + kScatterThreads * V);
+                nxt = load_vec(min(base + kScatterThreads * V, last));
 #pragma unroll
                 for (uint32_t b = 0; b < V; ++b) {
                     if (base + b >= m_hi || q.g[b] == 0.0f) continue;

@@ -234,8 +234,6 @@ int naruto_sample_z(uint32_t n_rays, const float* target_d, float near_, float f
     else { nu = n_samples; nr = 0; }
     const uint32_t S = nu + nr;
     if (S < 2 || S > (uint32_t)kMaxSamples) return fail(NARUTO_ERR_INVALID, "sample_z: need 2 <= samples per ray <= %d (got %u)", kMaxSamples, S);
-    if (target_d != nullptr && nr < 2) return fail(NARUTO_ERR_INVALID, "sample_z: n_range_d must be >= 2");
-    if (target_d != nullptr && nu == 1) return fail(NARUTO_ERR_INVALID, "sample_z: n_samples_d must be 0 or >= 2");
     hipLaunchKernelGGL(k_sample_z, dim3(n_rays), dim3(64), 0, (hipStream_t)stream, n_rays, target_d, near_, far_, nu, nr, range_d, rand,
                        static_cast<const uint64_t*>(nullptr), z_vals);
     return check_launch("sample_z");
@@ -480,7 +478,6 @@ int train_check(const NarutoField* f, const NarutoParams* p, const NarutoTrainSt
         return fail(NARUTO_ERR_INVALID, "%s: NULL buffer in NarutoTrainStep", who);
     const uint32_t S = t->n_samples_d + t->n_range_d;
     if (t->n_rays == 0 || S < 2 || S > (uint32_t)kMaxSamples) return fail(NARUTO_ERR_INVALID, "%s: need rays and 2..%d samples per ray", who, kMaxSamples);
-    if (t->n_range_d < 2 || t->n_samples_d == 1) return fail(NARUTO_ERR_INVALID, "%s: n_range_d must be >= 2 and n_samples_d 0 or >= 2", who);
     if ((uint64_t)t->n_rays * S > 0x7FFFFFFFull) return fail(NARUTO_ERR_INVALID, "%s: too many samples for 32-bit indices", who);
     if (t->smooth_points != 0 && (t->smooth_points < 3 || t->smooth_points > 257)) return fail(NARUTO_ERR_INVALID, "%s: smooth_points must be 0 or in [3, 257]", who);
     if (t->perturb && t->rand == nullptr && t->rng == nullptr) return fail(NARUTO_ERR_INVALID, "%s: perturb needs rand or rng", who);

@@ -15,6 +15,7 @@ constexpr int kRaysPerBlock = 4;       // 4 waves per block, one ray each
 
 // torch.linspace (aten RangeFactoriesKernel.cpp): symmetric two-sided formula
 __device__ __forceinline__ float linspace_at(float start, float end, uint32_t steps, uint32_t i) {
+    if (steps == 1u) return start;                          // torch.linspace(a, b, 1) == [a]
     const float step = __fdiv_rn(__fsub_rn(end, start), (float)(steps - 1u));
     if (i < steps / 2u) return __fadd_rn(start, __fmul_rn(step, (float)i));
     return __fsub_rn(end, __fmul_rn(step, (float)(steps - i - 1u)));

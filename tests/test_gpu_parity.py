@@ -612,14 +612,14 @@ def _relu_kink_distance(ora, cfg, rays_o, rays_d, z_vals, active):
 def test_train_step_random_shapes(gpu, case):
     """The trainer's fast path against the oracle over odd batch shapes: ray counts around the 4-rays-per-workgroup and
     64-sample-tile boundaries (1, 3, 5, 63 .. 257), sample counts that make S = 64 (one tile, flat mode), 128 / 192 (ray mode)
-    or nothing in particular, 5 / 11 / 21 samples around the depth, jitter on / off, many or no depth-less rays.  (A draw in
+    or nothing in particular, 0 / 1 / 5 / 11 / 21 samples around the depth, jitter on / off, many or no depth-less rays.  (A draw in
     which a small batch has a hidden unit of an active sample within 2e-6 of the ReLU kink is re-drawn: there the gradient is decided by
     fp32 rounding -- one such sample moved 12 % of a sdf_w0 row in a single-ray batch, in the oracle's fp32 as well.)"""
     from naruto_amd import ops
     for attempt in range(8):
         rs = np.random.RandomState(1000 + case + 100 * attempt)
         N = int(rs.choice([1, 3, 5, 63, 64, 65, 130, 257]))
-        n_range = int(rs.choice([5, 11, 21]))
+        n_range = int(rs.choice([0, 1, 5, 11, 21]))
         S_tot = int(rs.choice([43, 64, 100, 128, 192]))
         n_d = S_tot - n_range
         perturb = bool(case % 2)

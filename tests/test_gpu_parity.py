@@ -143,6 +143,48 @@ def test_query_boundary_sweeps(gpu, hash_size):
         H.assert_close(got_geo, want_geo, TOL_OUT, "sweep.geo")
 
 
+@pytest.mark.parametrize("case", list(range(10)))
+def test_random_field_configs(gpu, case):
+    """Drawn scene boxes (anisotropic, 1 .. 25 m), finest voxel sizes and table sizes 2^10 .. 2^18 (18: larger than the LDS-tiled
+    scatter takes, global atomics): level tables, features, outputs and every gradient of the fused query against the oracle, on
+    points inside and outside the box."""
+    from naruto_amd import config as C
+    rs = np.random.RandomState(500 + case)
+    ext = rs.uniform(1.0, 25.0, 3)
+    lo = rs.uniform(-10.0, 5.0, 3)
+    cfg = C.office0_config()
+    cfg["mapping"]["bound"] = [[float(lo[i]), float(lo[i] + ext[i])] for i in range(3)]
+    cfg["mapping"]["marching_cubes_bound"] = cfg["mapping"]["bound"]
+    cfg["grid"]["voxel_sdf"] = float(rs.choice([0.02, 0.04, 0.1]))
+    cfg["grid"]["hash_size"] = int(rs.choice([10, 12, 14, 16, 17, 18]))
+    ora = H.make_oracle(cfg, 0.25, 500 + case)
+    m = H.make_hip_from_oracle(cfg, ora, gpu)
+    sc, res, size, off = m._handle().levels()
+    assert [int(v) for v in res] == [int(v) for v in ora.meta.resolution] and [int(v) for v in size] == [int(v) for v in ora.meta.size]
+    n = int(rs.choice([1, 31, 64, 333, 1500]))
+    x = torch.from_numpy(rs.uniform(-0.3, 1.3, (n, 3)).astype(np.float32))
+    c = torch.from_numpy(rs.normal(size=(n, 5)).astype(np.float32))
+    raw_o = ora.query_color_sdf(x)
+    (raw_o * c).sum().backward()
+    H.assert_close(m.query_sdf(x.to(gpu), embed=True), ora.query_sdf(x, embed=True).detach(), 2e-6, f"case {case}: embed")
+    raw_h = m.query_color_sdf(x.to(gpu))
+    H.assert_close(raw_h, raw_o.detach().reshape(-1, 5), TOL_OUT, f"case {case}: raw")
+    (raw_h * c.to(gpu)).sum().backward()
+    # a sample on a ReLU kink may move its 128 table entries and one row of each first layer (see test_train_step_random_shapes)
+    with torch.no_grad():
+        feats, pos = S.hash_encode(x, ora.table, ora.meta).double(), S.oneblob_encode(x, 16).double()
+        h = torch.cat([feats, pos], -1) @ ora.sdf_w0.double().T
+        cc = torch.cat([pos, (torch.relu(h) @ ora.sdf_w1.double().T)[:, 1:]], -1) @ ora.col_w0.double().T
+        n_kink = int(((h.abs() < 2e-6).any(1) | (cc.abs() < 2e-6).any(1)).sum())
+    gh, go = H.hip_grads(m), H.ora_grads(ora)
+    budget = {"table": 128 * n_kink, "sdf_w0": 80 * n_kink, "col_w0": 63 * n_kink}
+    for k in gh:
+        got, want = gh[k].reshape(-1).double().cpu(), go[k].reshape(-1).double()
+        scale = max(float(want.abs().max()), 1e-12)
+        bad = (got - want).abs() > 1e-4 * scale + 1e-3 * want.abs()
+        assert int(bad.sum()) <= budget.get(k, 0), f"case {case} (T=2^{cfg['grid']['hash_size']}, n={n}): grad.{k}: {int(bad.sum())} entries off, max err {float((got - want).abs().max()):.3e}, scale {scale:.3e}"
+
+
 @pytest.mark.parametrize("kind", ["office_t16", "mp3d", "unit1024"])
 def test_hash_encode_vs_oracle(gpu, kind):
     from naruto_amd import config as C

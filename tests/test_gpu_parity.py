@@ -923,6 +923,63 @@ def test_active_ray_sampler_full_size(gpu):
         assert a.shape == b.shape and torch.equal(a.cpu(), b), f"{k}: HIP sampler != deterministic oracle"
 
 
+@pytest.mark.parametrize("case", list(range(6)))
+def test_next_rows_random_configs(gpu, case):
+    """N1 and N3 over drawn configurations (scene box, voxel size, batch / K / oversampling, top-k sizes, sensing range, safety
+    margin, goal levels) against the oracle: identical batches, identical collections."""
+    from naruto_amd import config as C
+    from naruto_amd.active_ray_sampler import ActiveRaySamplerHIP
+    from naruto_amd.planner_aggregation import GoalSpaceAggregatorHIP
+    rs = np.random.RandomState(700 + case)
+    ext = rs.uniform(2.0, 7.0, 3)
+    lo = rs.uniform(-4.0, 1.0, 3)
+    bbox = [[float(lo[i]), float(lo[i] + ext[i])] for i in range(3)]
+    # ---- N3
+    vox = float(rs.choice([0.1, 0.2]))
+    levels = sorted(int(v) for v in rs.choice(np.arange(2, int(ext[2] / vox) - 1), size=min(3, int(ext[2] / vox) - 3), replace=False))
+    top_k, sub = int(rs.choice([50, 400, 3000])), int(rs.choice([7, 60, 300]))
+    rng_lo, rng_hi, safe = float(rs.uniform(0.2, 0.8)), float(rs.uniform(1.2, 3.0)), float(rs.uniform(0.2, 1.0))
+    dims, ranges, goal_idx = S.goal_space(bbox, vox, levels)
+    top_k = min(top_k, int(np.prod(dims)))
+    sub = min(sub, top_k)
+    ag = GoalSpaceAggregatorHIP(bbox, vox, uncert_top_k=top_k, uncert_top_k_subset=sub, gs_sensing_range=(rng_lo, rng_hi), safe_sdf=safe, gs_z_levels=levels,
+                                device=gpu)
+    assert (ag.Nx, ag.Ny, ag.Nz) == dims
+    X, Y, Z = np.meshgrid(*[np.arange(d) for d in dims], indexing="ij")
+    room = np.minimum.reduce([X - 1.5, dims[0] - 2.5 - X, Y - 1.5, dims[1] - 2.5 - Y, Z - 1.5, dims[2] - 2.5 - Z]).astype(np.float32)
+    blob = (np.sqrt((X - dims[0] * 0.4) ** 2 + (Y - dims[1] * 0.6) ** 2 + (Z - dims[2] * 0.5) ** 2) - min(dims) * 0.15).astype(np.float32)
+    sdf = (np.minimum(room, blob) * 0.5 + rs.normal(0, 0.03, dims)).astype(np.float32)
+    uncert = (rs.uniform(0.01, 3.0, dims) * ((sdf >= 0) & (sdf < 0.5))).astype(np.float32)
+    ok, out = ag.uncertainty_aggregation_v2([torch.from_numpy(uncert).to(gpu), torch.from_numpy(sdf).to(gpu)], force_running=True)
+    det = S.topk_targets_deterministic(uncert, top_k, sub)
+    coll, agg, valid = S.uncert_aggregation(uncert, sdf, det, goal_idx, dims, vox, (rng_lo, rng_hi), safe)
+    if ok:
+        assert np.array_equal(out["topk_uncert_vxl"].cpu().numpy(), det)
+        assert np.array_equal(out["gs_uncert_collections"].cpu().numpy(), coll.numpy())
+        H.assert_close(out["gs_aggre_uncerts"].reshape(-1), agg, 1e-5, f"case {case}: gs_aggre_uncerts", rel=1e-6)
+    else:
+        assert float(agg.abs().sum()) == 0.0                   # the reference reports an invalid goal space when nothing is in view
+    # ---- N1
+    cfg = C.office0_config()
+    cfg["mapping"]["bound"] = bbox
+    cfg["mapping"]["sample"] = int(rs.choice([256, 1024, 2048]))
+    cfg["mapping"]["min_pixels_cur"] = int(rs.choice([10, 25, 100]))
+    mul, K = int(rs.choice([2, 4])), int(rs.choice([50, 200, 500]))
+    K = min(K, cfg["mapping"]["sample"] - 1)
+    smp = ActiveRaySamplerHIP(config=cfg, num_uncert_sample=K, oversample_mul=mul)
+    n_cur = int(rs.choice([3, 40, 100]))                        # 0 is rejected: the reference then appends rays[-0:] = every ray
+    n = smp.oversample_num + n_cur
+    rays = syn.random_rays(n, bbox, seed=700 + case)
+    t = {k: torch.from_numpy(v) for k, v in rays.items()}
+    vdims = S.goal_space(bbox, 0.1)[0]
+    vol = (rs.uniform(0, 3, vdims) * (rs.uniform(size=vdims) < 0.4)).astype(np.float32)
+    got = smp.sample_rays(t["rays_o"].to(gpu), t["rays_d"].to(gpu), t["target_rgb"].to(gpu), t["target_d"].to(gpu), list(range(n_cur)), vol, bbox)
+    want, vals, sel = S.active_ray_sample(t["rays_o"], t["rays_d"], t["target_rgb"], t["target_d"], n_cur, vol, bbox, cfg["mapping"]["sample"], K, mul,
+                                          deterministic=True)
+    for a, b, k in zip(got, want, ("rays_o", "rays_d", "target_rgb", "target_d")):
+        assert a.shape == b.shape and torch.equal(a.cpu(), b), f"case {case}: {k}: HIP sampler != deterministic oracle"
+
+
 # --------------------------------------------------------------------------------------------- edge cases
 def test_edge_sizes_and_degenerate_inputs(gpu):
     """Empty and minimal inputs, the per-ray sample limit, depths that are zero / negative / beyond depth_trunc.  (A NaN

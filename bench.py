@@ -243,10 +243,9 @@ def main():
     torch.manual_seed(0)                                     # identical replicas on every rank
     tr = MappingTrainer(cfg, torch.tensor(cfg["mapping"]["bound"], dtype=torch.float32), dev, 0.1, group=group,
                         fused_adam=not args.torch_adam)
-    # Single process: the whole iteration replays from one hipGraph.  Data parallel: eager launches by default -- the direct
-    # path is 12 launches, the host keeps ahead of the GPU (0.346 ms eager vs 0.345 ms as graph segments around eager RCCL
-    # calls vs 0.311 ms with the collectives captured, all at world size 1), and nothing depends on capturing a multi-rank
-    # collective.  NARUTO_GRAPH_DIST=segmented|whole opts in.
+    # Single process: the whole iteration replays from one hipGraph.  Data parallel: eager launches by default -- 14 launches
+    # and two collectives with no host sync in between, so the host runs ahead of the GPU (0.284 ms at world size 1 with
+    # NARUTO_FORCE_DIST=1), and nothing depends on capturing a multi-rank collective.  NARUTO_GRAPH_DIST=segmented|whole opts in.
     use_graph = (not args.no_graph) and (group is None or os.environ.get("NARUTO_GRAPH_DIST", "") in ("segmented", "whole"))
     if use_graph:
         tr.capture(n_rays, smooth=True, n_rays_total=n_rays * world)

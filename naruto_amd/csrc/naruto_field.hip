@@ -859,7 +859,7 @@ constexpr int kAccTiles = 7;
 constexpr int kAccFloats = kAccTiles * 1024;
 
 // Waves per workgroup: 33 KB of weight images + 20.4 KB of stages per wave <= 160 KB of LDS allows up to 6.  Measured on
-// MI355X: 4 waves (one per SIMD, 396 registers, software prefetch) 68 us; 6 waves (2,2,1,1 per SIMD, 256 registers with
+// MI355X: 4 waves (one per SIMD, 389 registers, software prefetch) 64 us (68 before the prefetch was made wait-free); 6 waves (2,2,1,1 per SIMD, 256 registers with
 // 42 spilled, no prefetch) 82 us -- the two SIMDs that hold two waves set the pace.  PMC at 4 waves: MFMA pipe 35 % busy,
 // 39 % of the wave cycles parked in s_waitcnt, 36 % issue-stalled: two waves on EVERY SIMD (8 per workgroup) would hide
 // most of it but need <= 15.8 KB of stages per wave.

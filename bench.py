@@ -231,6 +231,15 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON result.  RCCL writes its version banner to the C-level stdout (it lands in
+    # libc's buffer and would come out after the result); route file descriptor 1 to stderr for the whole run and give it
+    # back only for the result line.
+    import ctypes
+    libc = ctypes.CDLL(None)
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     group = parallel.init_from_env("nccl") if (args.gpus > 1 or os.environ.get("NARUTO_FORCE_DIST") == "1") else None
     world, rank = parallel.world_size(group), parallel.rank(group)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE is {world}"
@@ -319,7 +328,11 @@ def main():
                 out["torch_gpu_baseline"] = cpu_baseline(cfg, n_rays, 10, device=dev)
             except Exception as e:                               # informational: never fail the bench line over it
                 out["torch_gpu_baseline"] = {"error": repr(e)[:200]}
+        sys.stdout.flush()
+        libc.fflush(None)
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if group is not None:
         torch.distributed.barrier(group)
         torch.distributed.destroy_process_group()

@@ -28,8 +28,12 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# multi-process GPU work on this pool needs dmabuf IPC (the host driver has no legacy IPC): RCCL's peer-to-peer setup
+# fails with "hipIpcGetMemHandle: invalid argument" otherwise.  Already exported on the boxes; kept here for any other launcher.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -1260,6 +1260,50 @@ def test_extract_mesh_golden(gpu, tmp_path):
             assert (np.abs(got - want).max(-1) > 0).mean() < 0.02          # a jet bin edge may flip with the 1e-6 noise of the uncertainty
 
 
+@pytest.mark.parametrize("case", list(range(4)))
+def test_extract_mesh_random_configs(gpu, case):
+    """N4 over drawn scene boxes, marching-cubes bounds, voxel sizes / resolutions, metric transforms and isolevels: the SDF
+    volume against the oracle, marching cubes on the device's own volume bit-exact against the numpy restatement, the vertex
+    transform and the colour branch against the oracle's restatement of extract_mesh."""
+    from naruto_amd import config as C, mesh as M
+    from oracle import mesh_numpy as MN
+    table = H.load_golden("mc_table")
+    rs = np.random.RandomState(800 + case)
+    ext, lo = rs.uniform(2.0, 6.0, 3), rs.uniform(-3.0, 1.0, 3)
+    cfg = C.office0_config()
+    cfg["mapping"]["bound"] = [[float(lo[i]), float(lo[i] + ext[i])] for i in range(3)]
+    cfg["grid"]["hash_size"] = 12
+    cfg["data"]["sc_factor"], cfg["data"]["translation"] = float(rs.choice([1.0, 2.0])), float(rs.choice([0.0, 0.5]))
+    ora = H.make_oracle(cfg, 0.25, 800 + case).eval()
+    m = H.make_hip_from_oracle(cfg, ora, gpu).eval()
+    shrink = rs.uniform(0.0, 0.15, (3, 2)) * ext[:, None]
+    mcb = torch.tensor([[lo[i] + shrink[i, 0], lo[i] + ext[i] - shrink[i, 1]] for i in range(3)], dtype=torch.float32)
+    voxel = float(rs.choice([0.25, 0.4]))
+    # the volume the device meshes
+    tx, ty, tz = M.get_voxels(mcb[0, 1], mcb[0, 0], mcb[1, 1], mcb[1, 0], mcb[2, 1], mcb[2, 0], voxel)
+    bb = m.bounding_box.cpu()
+    axes = [((t - bb[i, 0]) / (bb[i, 1] - bb[i, 0])).to(gpu) for i, t in enumerate((tx, ty, tz))]
+    with torch.no_grad():
+        vol = m.query_sdf(M.lattice_points(*axes)[:, None, :]).reshape(tx.numel(), ty.numel(), tz.numel()).contiguous()
+    o = MN.extract_mesh(ora.query_sdf, cfg, ora.bounding_box, table, marching_cube_bound=mcb, voxel_size=voxel, isolevel=1e9, render_uncert=False)
+    H.assert_close(vol, o["vol"], TOL_OUT, f"case {case}: sdf volume")
+    srt = np.sort(o["vol"].reshape(-1).astype(np.float64))
+    mid = srt[int(0.3 * len(srt)):int(0.7 * len(srt))]
+    at = int(np.argmax(np.diff(mid)))
+    iso = float(np.float32(0.5 * (mid[at] + mid[at + 1])))                      # in the widest gap between lattice values: same topology on both sides
+    v, f = M.marching_cubes(vol, iso, 3.0)
+    ov, of = MN.marching_cubes(vol.cpu().numpy(), iso, 3.0, table)
+    assert np.array_equal(v.cpu().numpy(), ov) and np.array_equal(f.cpu().numpy(), of) and len(of) > 0
+    mesh = M.extract_mesh(m.query_sdf, cfg, m.bounding_box, marching_cube_bound=mcb, color_func=m.query_color, voxel_size=voxel, isolevel=iso)
+    want = MN.extract_mesh(ora.query_sdf, cfg, ora.bounding_box, table, marching_cube_bound=mcb, color_func=ora.query_color, voxel_size=voxel, isolevel=iso)
+    if float(np.abs(o["vol"] - iso).min()) > 2e-5:                               # otherwise fp32 noise may flip a corner: compare the surface loosely
+        assert np.array_equal(mesh.faces, want["faces"])
+        H.assert_close(mesh.vertices, want["vertices"], 5e-3 * voxel, f"case {case}: vertices")
+        assert np.abs(mesh.vertex_colors[:, :3].astype(np.float64) - np.round(np.clip(want["colors"], 0, 1) * 255.0)).max() <= 1.0
+    else:
+        assert abs(len(mesh.faces) - len(want["faces"])) <= 0.02 * len(want["faces"]) + 8
+
+
 def test_deferred_min_uncert_assert(gpu):
     """scene_rep.py:280 asserts uncert_map.min() > 0 inside forward; here the value is copied to the host asynchronously and
     checked when it has landed: no sync per iteration, and a violation is still reported (within a few iterations, or at once

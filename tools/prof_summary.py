@@ -19,6 +19,24 @@ print(f"{'kernel':96s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'min_us'
 for n, cnt, s, a, mn, mx in rows[:48]:
     print(f"{n[:96]:96s} {cnt:7d} {s/1e6:10.3f} {a/1e3:10.2f} {mn/1e3:9.2f} {mx/1e3:9.2f} {100*s/tot:6.2f}")
 print(f"total kernel time {tot/1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches")
+# The same kernel is launched in more than one shape (e.g. k_query_fwd: 1024 workgroups over all samples in bench.py's kernel
+# table, 512 = one wave per ray in the training forward): split the big ones by grid size.
+dcols = [r[1] for r in c.execute("pragma table_info(rocpd_kernel_dispatch)")]
+gcol = next((g for g in ("grid_size_x", "grid_x", "grid_size") if g in dcols), None)
+wcol = next((w for w in ("workgroup_size_x", "workgroup_x", "workgroup_size") if w in dcols), None)
+if gcol and wcol:
+    q = f"""select s.{name_col}, d.{gcol} / max(d.{wcol}, 1), count(*), avg(d.end-d.start), min(d.end-d.start), max(d.end-d.start)
+            from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id
+            group by s.{name_col}, d.{gcol} / max(d.{wcol}, 1) order by 1, 2"""
+    by_shape = {}
+    for n, g, cnt, a, mn, mx in c.execute(q):
+        by_shape.setdefault(n, []).append((g, cnt, a, mn, mx))
+    print("\nby launch shape (kernels launched in more than one grid size):")
+    print(f"{'kernel':64s} {'workgroups':>10s} {'calls':>7s} {'avg_us':>10s} {'min_us':>9s} {'max_us':>9s}")
+    for n, cnt, s_, a, mn, mx in rows[:12]:
+        if len(by_shape.get(n, [])) > 1:
+            for g, k, av, mn2, mx2 in by_shape[n]:
+                print(f"{n[:64]:64s} {g:10d} {k:7d} {av/1e3:10.2f} {mn2/1e3:9.2f} {mx2/1e3:9.2f}")
 n_pmc = c.execute("select count(*) from rocpd_pmc_event").fetchone()[0]
 if n_pmc:
     q = f"""select s.{name_col}, p.name, count(*), avg(e.value), sum(e.value)

@@ -17,17 +17,29 @@ NAMES = {"k_query_fwd<color>": ["k_query_fwdILb1"], "k_query_bwd": ["k_query_bwd
 
 
 def parse(path):
-    out = {}
-    on = False
+    """kernel -> per-dispatch average.  A kernel launched in several grid sizes is taken at its LARGEST one (the "by launch
+    shape" table of prof_summary.py): for k_query_fwd that is the launch over all samples, the one bench.py's roofline times."""
+    out, shaped = {}, {}
+    section = None
     for line in open(path):
+        if line.startswith("PMC counters by launch shape"):
+            section = "shape"
+            continue
         if line.startswith("PMC counters"):
-            on = True
+            section = "all"
             continue
-        if not on or line.startswith("kernel"):
+        if section is None or line.startswith("kernel"):
             continue
-        m = re.match(r"(\S+)\s+(\w+)\s+(\d+)\s+([0-9.]+)\s*$", line)
-        if m:
-            out[m.group(1)] = float(m.group(4))
+        if section == "all":
+            m = re.match(r"(\S+)\s+(\w+)\s+(\d+)\s+([0-9.]+)\s*$", line)
+            if m:
+                out[m.group(1)] = float(m.group(4))
+        else:
+            m = re.match(r"(\S+)\s+(\d+)\s+(\w+)\s+(\d+)\s+([0-9.]+)\s*$", line)
+            if m and (m.group(1) not in shaped or int(m.group(2)) > shaped[m.group(1)][0]):
+                shaped[m.group(1)] = (int(m.group(2)), float(m.group(5)))
+    for k, (g, v) in shaped.items():
+        out[k] = v
     return out
 
 

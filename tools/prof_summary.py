@@ -48,3 +48,19 @@ if n_pmc:
     print(f"{'kernel':96s} {'counter':>16s} {'calls':>7s} {'avg':>16s}")
     for n, pn, cnt, av, sm in list(c.execute(q))[:40]:
         print(f"{n[:96]:96s} {pn:>16s} {cnt:7d} {av:16.1f}")
+    if gcol and wcol:
+        q = f"""select s.{name_col}, d.{gcol} / max(d.{wcol}, 1), p.name, count(*), avg(e.value)
+                from rocpd_pmc_event e join rocpd_info_pmc p on e.pmc_id = p.id
+                join rocpd_kernel_dispatch d on d.event_id = e.event_id
+                join rocpd_info_kernel_symbol s on d.kernel_id = s.id
+                group by s.{name_col}, d.{gcol} / max(d.{wcol}, 1), p.name order by 1, 2"""
+        shaped = {}
+        for n, g, pn, cnt, av in c.execute(q):
+            shaped.setdefault(n, []).append((g, pn, cnt, av))
+        print("\nPMC counters by launch shape (kernels launched in more than one grid size):")
+        print(f"{'kernel':96s} {'workgroups':>10s} {'counter':>16s} {'calls':>7s} {'avg':>16s}")
+        for n, rows_ in shaped.items():
+            if len({g for g, *_ in rows_}) > 1 and "naruto" in n:
+                for g, pn, cnt, av in rows_:
+                    print(f"{n[:96]:96s} {g:10d} {pn:>16s} {cnt:7d} {av:16.1f}")
+

@@ -42,17 +42,27 @@ class ActiveRaySamplerHIP:
         self.base_sample_num = config['mapping']['sample']
         self.oversample_num = self.base_sample_num * self.oversample_mul
         self.min_pixels_cur = config['mapping']['min_pixels_cur'] * self.oversample_mul
-        self._vol_key = None
-        self._vol_dev = None
+        self._vol_dev = None          # set_volume(): an explicitly pinned device copy of the planner's uncertainty volume
+
+    def set_volume(self, uncert_vol, device) -> torch.Tensor:
+        """Upload the planner's cached uncertainty volume once (call again whenever the planner refreshes it, every 5 frames in
+        the reference); ``sample_rays(..., uncert_vol=None, ...)`` then uses this copy."""
+        if torch.is_tensor(uncert_vol):
+            self._vol_dev = _f32c(uncert_vol.to(device), "uncert_vol")
+        else:
+            self._vol_dev = torch.from_numpy(np.ascontiguousarray(uncert_vol, dtype=np.float32)).to(device)
+        return self._vol_dev
 
     def _volume(self, uncert_vol, device) -> torch.Tensor:
+        if uncert_vol is None:
+            if self._vol_dev is None:
+                raise RuntimeError("sample_rays(uncert_vol=None) needs a volume pinned with set_volume() first")
+            return self._vol_dev
         if torch.is_tensor(uncert_vol):
             return _f32c(uncert_vol.to(device), "uncert_vol")
-        key = (id(uncert_vol), uncert_vol.shape, str(device))
-        if key != self._vol_key:                       # the planner volume changes every 5 frames: one upload per change
-            self._vol_dev = torch.from_numpy(np.ascontiguousarray(uncert_vol, dtype=np.float32)).to(device)
-            self._vol_key = key
-        return self._vol_dev
+        # a host array is uploaded on every call (~100 k floats): the planner mutates / replaces its cached volume, and neither
+        # id() nor the shape can tell a refreshed array from the old one
+        return torch.from_numpy(np.ascontiguousarray(uncert_vol, dtype=np.float32)).to(device)
 
     def sample_rays(self, rays_o, rays_d, target_s, target_d, idx_cur: List, uncert_vol, bbox: List):
         lib = _lib.load()

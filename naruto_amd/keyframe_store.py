@@ -33,7 +33,16 @@ def _stream() -> C.c_void_p:
 
 
 class KeyFrameStoreHIP:
-    def __init__(self, config: Dict, H: int, W: int, num_kf: int, num_rays_to_save: int, device, seed: int = 0):
+    def __init__(self, config: Dict, H: int, W: int, num_kf: int, num_rays_to_save: int, device, seed: int = 0,
+                 filter_depth_mode: str = "reference"):
+        """``filter_depth_mode`` -- what ``filter_depth=True`` selects from:
+          "reference": the reference's behaviour, quirk included: the indices are drawn from ``range(num_valid)`` but then
+                       index the UNFILTERED pixel list (keyframe.py:27-36 ``rays[:, idxs]``, coslam.py:318-327
+                       ``current_rays[idx_cur]``), i.e. distinct pixels among the FIRST ``num_valid`` pixels of the frame,
+                       invalid-depth ones included;
+          "valid_only": what the option's name promises: distinct pixels among those with a valid depth."""
+        assert filter_depth_mode in ("reference", "valid_only")
+        self.filter_depth_mode = filter_depth_mode
         self.config = config
         self.H, self.W = int(H), int(W)
         self.total_pixels = self.H * self.W
@@ -67,7 +76,9 @@ class KeyFrameStoreHIP:
             valid = (rays[:, -1] > 0.0) & (rays[:, -1] <= self.config["cam"]["depth_trunc"])
             pool = torch.nonzero(valid).reshape(-1)
             n_take = min(int(pool.shape[0]), self.num_rays_to_save)
-            sel = pool[self._distinct(int(pool.shape[0]), n_take)] if n_take > 0 else pool[:0]
+            sel = self._distinct(int(pool.shape[0]), n_take) if n_take > 0 else pool[:0]
+            if self.filter_depth_mode == "valid_only":
+                sel = pool[sel]
         else:
             sel = self._distinct(rays.shape[0], self.num_rays_to_save)
         fid = batch['frame_id']
@@ -105,6 +116,8 @@ class KeyFrameStoreHIP:
             cur_list = torch.nonzero(valid).reshape(-1).to(torch.int32).contiguous()
             n_cur_pop = int(cur_list.shape[0])
             n_cur = min(n_cur_pop, n_cur)
+            if self.filter_depth_mode == "reference":
+                cur_list = None                   # pixels 0 .. n_valid-1 of the unfiltered frame (coslam.py:318-327)
         n = sample_num + n_cur
         f32 = dict(dtype=torch.float32, device=self.device)
         rays_o, rays_d, target_s = torch.empty(n, 3, **f32), torch.empty(n, 3, **f32), torch.empty(n, 3, **f32)

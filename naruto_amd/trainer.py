@@ -175,6 +175,8 @@ class MappingTrainer:
         self.direct = bool(fused_adam)
         self.fuse_optimizer = bool(fused_adam)          # single process: apply the mapping Adam inside the backward
         self._train_steps = {}
+        self.max_cached_steps = 2
+        self.assert_every = 8           # graph replay: deferred ``uncert_map.min() > 0`` check every this many iterations
         if self.direct:
             # {seed, iteration counter}: the kernels' own random numbers are keyed by it, the forward advances the counter,
             # and the mapping Adam reads its step number from it (one iteration = one step)
@@ -194,8 +196,15 @@ class MappingTrainer:
     def _train_step(self, n_rays: int, use_smooth: bool):
         from . import ops
         key = (n_rays, use_smooth, self.model.n_rays_total)
-        ts = self._train_steps.get(key)
+        ts = self._train_steps.pop(key, None)
+        if ts is not None:
+            self._train_steps[key] = ts                 # most recently used last
         if ts is None:
+            # the batch size of the reference's BA loop moves with the keyframe count (sample // n_kf, ceil(len(idx_cur) / 4)):
+            # keep the persistent buffers of the last few sizes only (each set is ~80 MB at 2048 x 128).  A captured graph
+            # holds its TrainStep through self._static, so eviction here never invalidates a replay.
+            while len(self._train_steps) >= self.max_cached_steps:
+                self._train_steps.pop(next(iter(self._train_steps)))
             tr, cam = self.config['training'], self.config['cam']
             m = self.model
             ts = ops.TrainStep(m._handle(), m._params(), m.uncert_grid.grad, n_rays, n_samples_d=tr['n_samples_d'], n_range_d=tr['n_range_d'],
@@ -286,12 +295,21 @@ class MappingTrainer:
             self.model.uncert_grid.grad.zero_()
         return ret, loss
 
-    def step(self, rays_o, rays_d, target_rgb, target_d, smooth: bool = False, n_rays_total: int = 0):
+    def step(self, rays_o, rays_d, target_rgb, target_d, smooth: bool = False, n_rays_total: int = 0,
+             uncert_step: Optional[bool] = None):
         """One mapping iteration (global_BA body, coslam.py:361-399).  With a process group the rays passed
-        in are THIS RANK's shard; gradients are summed over ranks before the (identical) Adam steps."""
+        in are THIS RANK's shard; gradients are summed over ranks before the (identical) Adam steps.
+
+        ``uncert_step``: whether the uncertainty-grid Adam steps (and its accumulated gradient is zeroed) after this
+        iteration.  Default (None): every 5th call of ``step`` over the trainer's lifetime.  The reference's drivers count
+        differently -- ``global_BA`` restarts its ``(i + 1) % 5`` counter on every call (coslam.py:397-399) and
+        ``first_frame_mapping`` never steps inside the loop (coslam.py:197-217) -- so ``global_BA`` / ``first_frame_mapping``
+        below pass it explicitly."""
         self.model.n_rays_total = n_rays_total
         self.iter += 1
-        uncert_step = self.iter % 5 == 0
+        if uncert_step is None:
+            uncert_step = self.iter % 5 == 0
+        uncert_step = bool(uncert_step)
         if self._graphs is not None:
             st = self._static
             assert smooth == st['smooth'] and rays_o.shape[0] == st['rays_o'].shape[0], "captured for another configuration"
@@ -314,10 +332,49 @@ class MappingTrainer:
                 if uncert_step:
                     parallel.allreduce_grads([self.model.uncert_grid], self.group)
                 seg['opt'][1 if uncert_step else 0].replay()
+                if self.iter % self.assert_every == 0:
+                    self.model.note_min_uncert(st['ret'][0]['_losses'][6])
+                    self.model.check_asserts()
                 return st['ret'][0], st['loss'][0]
             self._graphs[1 if uncert_step else 0].replay()
-            return st['ret'][1 if uncert_step else 0], st['loss'][1 if uncert_step else 0]
+            ret = st['ret'][1 if uncert_step else 0]
+            # the reference's in-line ``assert uncert_map.min() > 0`` (scene_rep.py:280) as a deferred check: queue this
+            # replay's minimum (asynchronous copy + event) and test whatever has landed -- no host sync; every
+            # ``assert_every``-th replay only (the copy is a separate ~2 us node on the stream)
+            if self.iter % self.assert_every == 0:
+                self.model.note_min_uncert(ret['_losses'][6])
+                self.model.check_asserts()
+            return ret, st['loss'][1 if uncert_step else 0]
         return self._iteration(rays_o, rays_d, target_rgb, target_d, smooth, uncert_step)
+
+    def global_BA(self, batches, smooth: bool = True, n_rays_total: int = 0):
+        """The optimisation loop of one ``global_BA`` call (coslam.py:361-399) over an iterable of ray batches
+        ``(rays_o, rays_d, target_rgb, target_d)``: the uncertainty grid steps after iterations 5, 10, ... OF THIS CALL (the
+        reference's ``(i + 1) % 5`` restarts with every call), its gradient accumulating in between."""
+        out = None
+        for i, b in enumerate(batches):
+            out = self.step(*b, smooth=smooth, n_rays_total=n_rays_total, uncert_step=(i + 1) % 5 == 0)
+        return out
+
+    def first_frame_mapping(self, batches, n_rays_total: int = 0):
+        """The optimisation loop of ``first_frame_mapping`` (coslam.py:197-217): the uncertainty grid's gradient is zeroed
+        once, accumulates over ALL iterations, and its Adam steps once at the end -- without zeroing the gradient afterwards
+        (the first ``global_BA`` call keeps adding to it, as in the reference)."""
+        with torch.no_grad():
+            self.model.uncert_grid.grad.zero_()
+        out = None
+        for b in batches:
+            out = self.step(*b, smooth=False, n_rays_total=n_rays_total, uncert_step=False)
+        with torch.no_grad():
+            if self.group is not None:
+                # every rank holds its shard's accumulated gradient; the sum stays in .grad on all ranks (what the next
+                # all-reduce would see is then world x too large, so rescale the kept copy)
+                parallel.allreduce_grads([self.model.uncert_grid], self.group)
+                self.uncert_optim.step()
+                self.model.uncert_grid.grad.div_(parallel.world_size(self.group))
+            else:
+                self.uncert_optim.step()
+        return out
 
     def capture(self, n_rays: int, smooth: bool = False, n_rays_total: int = 0, warmup: int = 3):
         """Record the iteration into hipGraphs (static shapes: n_rays rays per call)."""
@@ -328,10 +385,19 @@ class MappingTrainer:
         st['rays_o'], st['rays_d'], st['target_rgb'], st['target_d'] = unpack_rays(flat, n_rays)
         st['rays_d'][:, 2] = 1.0
         st['target_d'].fill_(1.0)
-        # snapshot: the warm-up / capture iterations below must not change the training state
+        # snapshot: the warm-up / capture iterations below must not change the training state -- parameters, both optimisers'
+        # moments and step counts, the accumulated uncertainty-grid gradient and the iteration counter are all put back
         params = self.parameters()
         snap = [p.detach().clone() for p in params]
         iter_snap = self.iter_state.clone() if self.direct else None
+        ugrad_snap = self.model.uncert_grid.grad.detach().clone()
+        opt_snap = []
+        for opt in (self.map_optimizer, self.uncert_optim):
+            if isinstance(opt, FusedAdam):
+                opt_snap.append((opt.step_dev.clone(), [(m.clone(), v.clone()) for m, v in opt.state.values()]))
+            else:
+                import copy
+                opt_snap.append(copy.deepcopy(opt.state_dict()))
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
@@ -392,16 +458,24 @@ class MappingTrainer:
                 p.copy_(q)
             if iter_snap is not None:
                 self.iter_state.copy_(iter_snap)
-            self.model.uncert_grid.grad.zero_()
-            for opt in (self.map_optimizer, self.uncert_optim):
+            self.model.uncert_grid.grad.copy_(ugrad_snap)
+            for opt, sn in zip((self.map_optimizer, self.uncert_optim), opt_snap):
                 if isinstance(opt, FusedAdam):
-                    opt.step_dev.zero_()
-                    for m, v in opt.state.values():
-                        m.zero_()
-                        v.zero_()
+                    opt.step_dev.copy_(sn[0])
+                    for (m, v), (m0, v0) in zip(opt.state.values(), sn[1]):
+                        m.copy_(m0)
+                        v.copy_(v0)
                 else:
-                    for stt in opt.state.values():
+                    # torch.optim.Adam creates its state lazily: a fresh optimiser has none before capture.  The captured graphs
+                    # hold the state tensors' ADDRESSES, so restore by value into the existing tensors.
+                    had = sn['state']
+                    index = {id(q): i for i, q in enumerate(q for gp in opt.param_groups for q in gp['params'])}
+                    for p_, stt in opt.state.items():
+                        idx = index[id(p_)]
                         for k, val in stt.items():
                             if torch.is_tensor(val):
-                                val.zero_()
+                                if idx in had and k in had[idx]:
+                                    val.copy_(had[idx][k])
+                                else:
+                                    val.zero_()
         self._graphs, self._static = graphs, st

@@ -1110,7 +1110,7 @@ def test_keyframe_store_batch_assembly(gpu):
     cfg = H.office_cfg(16)
     cfg["mapping"]["keyframe_every"] = 5
     Hh, Ww, R = 24, 32, 200
-    st = KeyFrameStoreHIP(cfg, Hh, Ww, num_kf=6, num_rays_to_save=R, device=gpu, seed=77)
+    st = KeyFrameStoreHIP(cfg, Hh, Ww, num_kf=6, num_rays_to_save=R, device=gpu, seed=77, filter_depth_mode="valid_only")
     rs = np.random.RandomState(61)
     frames = []
     for k in range(4):
@@ -1163,6 +1163,37 @@ def test_keyframe_store_batch_assembly(gpu):
     # sample_global_rays: distinct rows with their frame ids
     r2, f2 = st.sample_global_rays(128)
     assert r2.shape == (128, 7) and set(f2.cpu().tolist()) <= {0, 5, 10, 15}
+
+
+def test_keyframe_store_filter_depth_reference_quirk(gpu):
+    """filter_depth_mode="reference" (the default) reproduces the reference's indexing: indices drawn from range(num_valid)
+    are applied to the UNFILTERED pixel list (keyframe.py:27-36, coslam.py:318-327), so the kept pixels are distinct pixels among
+    the first num_valid of the frame, invalid-depth ones included."""
+    from naruto_amd import _lib
+    from naruto_amd.keyframe_store import KeyFrameStoreHIP
+    lib = _lib.load()
+    cfg = H.office_cfg(16)
+    cfg["mapping"]["keyframe_every"] = 5
+    Hh, Ww, R = 16, 20, 64
+    st = KeyFrameStoreHIP(cfg, Hh, Ww, num_kf=3, num_rays_to_save=R, device=gpu, seed=5)
+    assert st.filter_depth_mode == "reference"
+    rs = np.random.RandomState(8)
+    depth = rs.uniform(0.3, 4.0, (1, Hh, Ww)).astype(np.float32)
+    depth[0, rs.uniform(size=(Hh, Ww)) < 0.4] = 0.0
+    b = {"direction": torch.from_numpy(rs.normal(size=(1, Hh, Ww, 3)).astype(np.float32)), "rgb": torch.from_numpy(rs.uniform(size=(1, Hh, Ww, 3)).astype(np.float32)),
+         "depth": torch.from_numpy(depth), "frame_id": 0}
+    frame = torch.cat([b["direction"], b["rgb"], b["depth"][..., None]], -1).reshape(-1, 7)
+    n_valid = int(((frame[:, 6] > 0) & (frame[:, 6] <= cfg["cam"]["depth_trunc"])).sum())
+    st.add_keyframe(b, filter_depth=True)
+    idx = [lib.naruto_perm_index(i, n_valid, 5, st.counter, 1) for i in range(R)]
+    assert max(idx) < n_valid and len(set(idx)) == R
+    assert torch.equal(st.rays[0].cpu(), frame[idx])                     # rows of the UNFILTERED frame
+    assert (st.rays[0][:, 6] == 0).any()                                 # ... so invalid-depth pixels are among them
+    poses = torch.eye(4).repeat(2, 1, 1)
+    o, d, s, t, n_cur = st.assemble_batch(32, frame.to(gpu), poses, min_pixels_cur=24, filter_depth=True)
+    assert n_cur == min(n_valid, 32)
+    cidx = [lib.naruto_perm_index(i, n_valid, 5, st.counter, 3) for i in range(n_cur)]
+    assert torch.equal(t.cpu()[32:, 0], frame[cidx, 6]) and torch.equal(s.cpu()[32:], frame[cidx, 3:6])
 
 
 # --------------------------------------------------------------------------------------------- N4: dense volume -> mesh

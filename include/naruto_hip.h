@@ -359,7 +359,7 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
                           pointers may be NULL (gradients not materialised) */, void* stream);
 
 /* Hardware self-checks used by the GPU tests: the MFMA / permlane layouts the kernels rely on.
- * out: device buffer of 64*16 floats; returns 0 and fills out (see tests/test_gpu_intrinsics.py). */
+ * out: device buffer of 64*16 floats; returns 0 and fills out (see tests/test_gpu_parity.py: test_mfma_layout, test_permlane32_swap). */
 int naruto_debug_mfma_layout(const float* a, const float* b, float* out, void* stream);
 int naruto_debug_permlane_swap(const float* v0, const float* v1, float* out, void* stream);
 

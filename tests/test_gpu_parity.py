@@ -443,6 +443,58 @@ def test_fused_adam_matches_torch(gpu):
         H.assert_close(q, p, 2e-6, "fused adam", rel=1e-5)
 
 
+@pytest.mark.parametrize("n_samples_d,n_range_d", [(32, 0), (21, 11)])
+def test_reference_workload_config0_on_gpu(gpu, n_samples_d, n_range_d):
+    """BASELINE.json configs[0] through the HIP path: office_0, the 64 x 64 pinhole fan, 32 samples per ray (32 uniform +
+    no depth-guided ones -- SURVEY 8(d) row 1 -- and the 21 + 11 split), forward + losses + backward against the CPU oracle."""
+    cfg = H.office_cfg(16, n_samples_d=n_samples_d, n_range_d=n_range_d)
+    rays = syn.pinhole_rays(64, 64, 32.0, 32.0, cfg["mapping"]["bound"])
+    ora = H.make_oracle(cfg, 0.2, 3).train()
+    m = H.make_hip_from_oracle(cfg, ora, gpu).train()
+    t = {k: torch.from_numpy(v) for k, v in rays.items()}
+    ret_o = ora.forward(t["rays_o"], t["rays_d"], t["target_rgb"], t["target_d"])
+    S.total_loss(ret_o, cfg["training"]).backward()
+    ret_h = m.forward(*(t[k].to(gpu) for k in ("rays_o", "rays_d", "target_rgb", "target_d")))
+    assert ret_h["rgb"].shape == (4096, 3)
+    for k in ("rgb_loss", "depth_loss", "sdf_loss", "fs_loss", "uncert_loss"):
+        H.assert_close(ret_h[k].reshape(-1), ret_o[k].reshape(-1), 1e-6, f"config0.{k}", rel=1e-4)
+    H.assert_close(ret_h["rgb"], ret_o["rgb"], TOL_OUT, "config0.rgb")
+    H.assert_close(ret_h["depth"], ret_o["depth"], TOL_OUT, "config0.depth")
+    S.total_loss(ret_h, cfg["training"]).backward()
+    gh, go = H.hip_grads(m), H.ora_grads(ora)
+    for k in gh:
+        grad_close(gh[k], go[k], f"config0.grad.{k}")
+    m.eval()
+    with torch.no_grad():
+        rend = m.forward(*(t[k].to(gpu) for k in ("rays_o", "rays_d", "target_rgb", "target_d")))
+    ora.eval()
+    with torch.no_grad():
+        rend_o = ora.render_rays(t["rays_o"], t["rays_d"], target_d=t["target_d"])
+    for k in ("raw", "rgb", "depth", "depth_var", "uncert_map", "acc_map"):
+        H.assert_close(rend[k], rend_o[k], TOL_OUT, f"config0.render.{k}")
+
+
+def test_second_backward_over_a_retained_graph(gpu):
+    """The reference calls ``loss.backward(retain_graph=True)`` (coslam.py:368): the training node's saved tensors must survive
+    a backward and a second backward over the SAME graph must add the same gradients again."""
+    cfg = H.office_cfg(12)
+    ora = H.make_oracle(cfg, 0.25, 19)
+    m = H.make_hip_from_oracle(cfg, ora, gpu).train()
+    rays = syn.random_rays(130, cfg["mapping"]["bound"], seed=19, zero_depth_frac=0.1)
+    t = {k: torch.from_numpy(v) for k, v in rays.items()}
+    ora.train()
+    S.total_loss(ora.forward(t["rays_o"], t["rays_d"], t["target_rgb"], t["target_d"]), cfg["training"]).backward()
+    go = H.ora_grads(ora)
+    ret = m.forward(*(t[k].to(gpu) for k in ("rays_o", "rays_d", "target_rgb", "target_d")))
+    loss = S.total_loss(ret, cfg["training"])
+    loss.backward(retain_graph=True)
+    for k, g in H.hip_grads(m).items():
+        grad_close(g, go[k], f"retain.first.{k}")
+    loss.backward()                                    # same graph, saved tensors still there: gradients accumulate
+    for k, g in H.hip_grads(m).items():
+        grad_close(g, 2 * go[k], f"retain.second.{k}")
+
+
 def test_graph_replay_equals_eager(gpu):
     """The captured hipGraph iteration reproduces the eager iteration (same inputs, same jitter stream is not
     possible -- the graph owns its RNG offsets -- so perturb is off here)."""
@@ -462,6 +514,83 @@ def test_graph_replay_equals_eager(gpu):
         H.assert_close(lb.reshape(-1), la.reshape(-1), 1e-6, f"iter{it}.loss", rel=1e-5)
     for (n, p), (_, q) in zip(a.model.named_parameters(), b.model.named_parameters()):
         H.assert_close(q, p, 1e-6, f"param {n}", rel=1e-5)
+
+
+def test_capture_mid_training_keeps_the_trajectory(gpu):
+    """capture() after some training must not change the training state: parameters, both optimisers' moments and step
+    counts, the accumulated uncertainty-grid gradient and the iteration counter are restored after the warm-up / capture
+    iterations (a re-capture is needed whenever the ray count changes).  Twin trainers: one runs 8 eager iterations, the other
+    3 eager + capture + 5 replayed; an uncertainty-grid step (iteration 5) lies after the capture, fed by gradient
+    accumulated before it."""
+    from naruto_amd import trainer
+    cfg = H.office_cfg(12, perturb=1.0)
+    bound = torch.tensor(cfg["mapping"]["bound"])
+    torch.manual_seed(21)
+    a = trainer.MappingTrainer(cfg, bound, gpu, fused_adam=True)
+    b = trainer.MappingTrainer(cfg, bound, gpu, fused_adam=True)
+    b.model.load_state_dict(a.model.state_dict())
+    b.iter_state.copy_(a.iter_state)
+    for it in range(8):
+        if it == 3:
+            b.capture(176, smooth=True)
+            assert torch.equal(b.iter_state.cpu(), a.iter_state.cpu())
+            for (ma, va), (mb, vb) in zip(a.map_optimizer.state.values(), b.map_optimizer.state.values()):
+                assert torch.equal(ma, mb) and torch.equal(va, vb)
+            assert torch.equal(a.model.uncert_grid.grad, b.model.uncert_grid.grad) and float(b.model.uncert_grid.grad.abs().sum()) > 0
+        rays = syn.random_rays(176, cfg["mapping"]["bound"], seed=700 + it, zero_depth_frac=0.1)
+        t = [torch.from_numpy(rays[k]).to(gpu) for k in ("rays_o", "rays_d", "target_rgb", "target_d")]
+        ra, la = a.step(*t, smooth=True)
+        rb, lb = b.step(*t, smooth=True)
+        H.assert_close(lb.reshape(-1), la.reshape(-1), 1e-7, f"iter{it}.loss", rel=1e-6)
+    for (n, p), (_, q) in zip(a.model.named_parameters(), b.model.named_parameters()):
+        H.assert_close(q, p, 5e-6, f"param {n}", rel=1e-5)
+
+
+def test_reference_loop_shapes_for_the_uncert_grid(gpu):
+    """MappingTrainer.first_frame_mapping / global_BA reproduce when the reference steps the uncertainty grid
+    (coslam.py:197-217: once, after ALL first-frame iterations, gradient kept; coslam.py:397-399: after iterations 5, 10, ...
+    of EACH global_BA call) -- against the oracle driven by the reference's own loop shapes."""
+    from naruto_amd import trainer
+    cfg = H.office_cfg(12)
+    ora = H.make_oracle(cfg, 0.1, 77)
+    tr = trainer.MappingTrainer(cfg, torch.tensor(cfg["mapping"]["bound"]), gpu, fused_adam=True)
+    tr.model.load_state_dict(H.make_hip_from_oracle(cfg, ora, gpu).state_dict())
+    g1, g2 = ora.param_groups()
+    o_map = torch.optim.Adam(g1, betas=(0.9, 0.99))
+    o_unc = torch.optim.Adam(g2, lr=1)
+    ora.train()
+
+    def batch(seed):
+        rays = syn.random_rays(96, cfg["mapping"]["bound"], seed=seed)
+        return {k: torch.from_numpy(v) for k, v in rays.items()}
+
+    def ora_iter(t):
+        o_map.zero_grad()
+        ret = ora.forward(t["rays_o"], t["rays_d"], t["target_rgb"], t["target_d"])
+        S.total_loss(ret, cfg["training"]).backward()
+        o_map.step()
+
+    keys = ("rays_o", "rays_d", "target_rgb", "target_d")
+    first = [batch(900 + i) for i in range(3)]
+    o_unc.zero_grad()
+    for t in first:                                   # first_frame_mapping: no uncert step inside the loop
+        ora_iter(t)
+    o_unc.step()                                      # ... one at the end, gradient NOT zeroed
+    tr.first_frame_mapping([[t[k].to(gpu) for k in keys] for t in first])
+    H.assert_close(tr.model.uncert_grid.grad, ora.uncert_grid.grad, 1e-6 * float(ora.uncert_grid.grad.abs().max()), "uncert grad after first frame", rel=1e-3)
+    for call in range(2):                             # two global_BA calls of 7 iterations: the counter restarts per call
+        ba = [batch(950 + 10 * call + i) for i in range(7)]
+        for i, t in enumerate(ba):
+            ora_iter(t)
+            if (i + 1) % 5 == 0:
+                o_unc.step()
+                o_unc.zero_grad()
+        tr.global_BA([[t[k].to(gpu) for k in keys] for t in ba], smooth=False)
+    def frac_within(a, b, tol):
+        return ((a.detach().cpu() - b.detach()).abs() <= tol).float().mean().item()
+    assert frac_within(tr.model.uncert_grid, ora.uncert_grid, 2e-2) > 0.995
+    g_o = ora.uncert_grid.grad if ora.uncert_grid.grad is not None else torch.zeros_like(ora.uncert_grid)
+    H.assert_close(tr.model.uncert_grid.grad, g_o, 2e-3 * float(g_o.abs().max()) + 1e-12, "uncert grad carried between BA calls", rel=1e-2)
 
 
 def test_optimizer_in_backward_equals_separate_adam(gpu):
@@ -617,17 +746,32 @@ def test_train_step_full_size_against_oracle(gpu, workload):
     H.assert_close(losses[9].reshape(-1), total_o.detach().reshape(-1), 1e-5, "full.total", rel=1e-4)
     H.assert_close(ts.rgb, ret_o["rgb"], TOL_OUT, "full.rgb")
     H.assert_close(ts.depth, ret_o["depth"], TOL_OUT, "full.depth", rel=1e-4)
-    # Gradient entries are sums over up to 10^5 samples with heavy cancellation; at these sizes the fp32 reference itself
-    # moves by up to 4e-3 of max|grad| when it is evaluated in fp64 (table; 9e-4 on six entries of col_w0 -- measured on the
-    # oracle, 8192 x 43), so the small-batch bound of 1e-4 of max|grad| is below the reference's own arithmetic noise here.
-    # Measured HIP-vs-oracle: 2048 x 128 3e-6 of max|grad| everywhere; 8192 x 43 and MP3D 2048 x 256 <= 5e-4 on < 20 of the
-    # 1.7 M table entries and on the same six col_w0 entries (9.03e-4: the oracle's fp32 deviation from fp64, to the digit).
-    for k in ("table", "sdf_w0", "sdf_w1", "col_w0", "col_w1"):
-        grad_close(ts.grads[k].reshape(-1), go[k].reshape(-1), f"full.grad.{k}", frac=1e-3)
+    # Gradient entries are sums over up to 10^5 samples with heavy cancellation, so at these sizes the small-batch bound of 1e-4 of
+    # max|grad| can lie below the fp32 reference's OWN arithmetic noise.  That noise is measured here, not assumed: the same
+    # oracle is evaluated once more in fp64 (same inputs, same jitter draw), noise_k = max|grad32_k - grad64_k|, and the HIP
+    # gradient has to be as close to the fp64 result as max(1e-4 of the scale, the fp32 oracle's own deviation from it).
+    # (Measured, 8192 x 43: the fp32 oracle deviates from fp64 by 4.2e-3 of max|grad| on the table and 9.0e-4 on col_w0.)
+    import copy
+    o64 = copy.deepcopy(ora).double()
+    for p_ in o64.parameters():
+        p_.grad = None
+    ret64 = o64.forward(*(t[k].double() for k in ("rays_o", "rays_d", "target_rgb", "target_d")), rand=rand.double())
+    sm64 = S.smoothness(o64, tr["smooth_pts"], tr["smooth_vox"], tr["smooth_margin"], r6[:3].double(), r6[3:].double())
+    (S.total_loss(ret64, tr) + w_s * sm64).backward()
+    g64 = H.ora_grads(o64)
+    budget = {}
+    for k in ("table", "sdf_w0", "sdf_w1", "col_w0", "col_w1", "uncert_grid"):
+        scale = float(g64[k].abs().max())
+        noise = float((go[k].double() - g64[k]).abs().max())
+        budget[k] = max(1e-4 * scale, noise)
+        got = (ug if k == "uncert_grid" else ts.grads[k]).reshape(-1).double().cpu()
+        err64 = (got - g64[k].reshape(-1)).abs()
+        assert float(err64.max()) <= budget[k], (f"full.grad.{k}: {float(err64.max()):.3e} from the fp64 result; the fp32 oracle itself is "
+                                                 f"{noise:.3e} away (scale {scale:.3e})")
+        # and against the fp32 oracle: both sit within the budget of the fp64 result
+        H.assert_close(got, go[k].reshape(-1), 2.0 * budget[k], f"full.grad.{k} vs fp32 oracle", rel=1e-3)
         if k == "table":
-            err = (ts.grads[k].reshape(-1).double().cpu() - go[k].reshape(-1).double()).abs()
-            assert float((err > 1e-4 * go[k].abs().max().double()).float().mean()) < 1e-4, "full.grad.table: too many entries beyond 1e-4 of the scale"
-    grad_close(ug.reshape(-1), ora.uncert_grid.grad.reshape(-1), "full.grad.uncert_grid", frac=1e-3)
+            assert float((err64 > 1e-4 * scale).float().mean()) < 1e-4, "full.grad.table: too many entries beyond 1e-4 of the scale"
     if S_tot % 64 == 0 and S_tot > 64:
         n_stopped = int((ts.raw[:, 64:, :].reshape(N, -1).abs().sum(1) == 0).sum().item())
         assert 0 < n_stopped < N, f"early termination: {n_stopped} of {N} rays stopped after the first tile"

@@ -43,20 +43,29 @@ from naruto_amd import parallel, synthetic as syn  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 FP32_MFMA_PEAK_TF = 157.3      # v_mfma_f32_32x32x2_f32 peak = fp32 vector peak
+L2_PEAK_GBS = 34500.0          # aggregate L2 bandwidth (MI355X_MICROARCH.md, "L2 (per XCD)")
+
+
+WORKLOADS = {
+    # name: (config factory, rays per GPU (weak) or rays per job (strong), BASELINE.json config it is)
+    "office0_2048x128": (lambda: C.office0_config(perturb=1.0, n_samples_d=117), 2048, "configs[1]"),
+    "office0_2048x43": (lambda: C.office0_config(perturb=1.0), 2048, "configs[1] with the shipped 32+11 sampling"),
+    "office0_8192x43": (lambda: C.office0_config(perturb=1.0), 8192, "configs[2] (train step at the planner batch size)"),
+    "mp3d_2048x256": (lambda: C.mp3d_large_config(perturb=1.0, n_samples_d=245), 2048, "configs[3], one GPU's shard"),
+    "mp3d_16384x256": (lambda: C.mp3d_large_config(perturb=1.0, n_samples_d=245), 16384, "configs[3], the whole batch (use --scaling strong)"),
+    # configs[4]: 2^20 rays over 8 GPUs = 131072 per GPU, unit cube, finest level 1024^3.  T16: the shipped table size (7 MB,
+    # cache resident); T22: 2^22 entries per hashed level, 281 MB -- the HBM-resident table
+    "unit1024_131072x43": (lambda: C.unit_cube_config(1024, 16, perturb=1.0), 131072, "configs[4] at T=2^16"),
+    "unit1024_T22_131072x43": (lambda: C.unit_cube_config(1024, 22, perturb=1.0), 131072, "configs[4] at T=2^22 (HBM-resident table)"),
+    "unit1024_T22_16384x43": (lambda: C.unit_cube_config(1024, 22, perturb=1.0), 16384, "configs[4] at T=2^22, reduced ray count"),
+}
 
 
 def workload(name: str):
-    if name == "office0_2048x128":
-        return C.office0_config(perturb=1.0, n_samples_d=117), 2048
-    if name == "office0_2048x43":
-        return C.office0_config(perturb=1.0), 2048
-    if name == "mp3d_2048x256":
-        return C.mp3d_large_config(perturb=1.0, n_samples_d=245), 2048
-    if name == "office0_8192x43":
-        return C.office0_config(perturb=1.0), 8192
-    if name == "unit1024_131072x43":              # configs[4]: 2^20 rays over 8 GPUs, unit cube, 1024^3 finest level
-        return C.unit_cube_config(1024, 16, perturb=1.0), 131072
-    raise SystemExit(f"unknown workload {name}")
+    if name not in WORKLOADS:
+        raise SystemExit(f"unknown workload {name}; choose from {sorted(WORKLOADS)}")
+    make, n_rays, _ = WORKLOADS[name]
+    return make(), n_rays
 
 
 def events_ms(fn, iters: int) -> float:
@@ -106,8 +115,13 @@ def kernel_table(tr, rays, cfg, iters: int):
     mlp_fwd = 2 * (80 * 32 + 32 * 16 + 63 * 32 + 32 * 3)          # 10 368 FLOP
     add("k_sample_z", lambda: _lib.check(lib.naruto_sample_z(N, p(rays["target_d"]), float(cam["near"]), float(cam["far"]),
         trc["n_samples_d"], trc["n_range_d"], float(trc["range_d"]), 0, p(rand), p(z), st())), N * S * 8 + N * 4, 0, "hbm")
+    # k_query_fwd: SURVEY.md 8(d) "render inference, per ray of S samples: S x 1056 B gathered + 28 B in + 36 B out"; the launch
+    # also streams per sample 4 B of depth in, 20 B of raw out and 128 B of saved hash features (training only) -- kept as a
+    # second figure ("alg_bytes_incl_saved"), never as the roofline's
     add("k_query_fwd<color>", lambda: _lib.check(lib.naruto_query_fwd(h.ptr, CT.byref(ps), M, CT.byref(pts), p(raw), None, None,
-        p(feat), st())), M * (gather + 4 + 20 + 128) + N * 24, M * mlp_fwd, "hbm")
+        p(feat), st())), M * gather + N * 64, M * mlp_fwd, "hbm")
+    rows[-1]["alg_bytes_incl_saved"] = int(M * (gather + 4 + 20 + 128) + N * 24)
+    rows[-1]["launch"] = "all samples (flat 64-sample tiles)"
     rgb = torch.empty(N, 3, device=dev)
     outs = [torch.empty(N, device=dev) for _ in range(5)]
     add("k_composite_fwd", lambda: _lib.check(lib.naruto_composite_fwd(h.ptr, N, S, p(raw), p(z), p(rgb), p(outs[0]), p(outs[1]), None,
@@ -155,71 +169,134 @@ def kernel_table(tr, rays, cfg, iters: int):
     t.rays_o, t.rays_d, t.target_rgb, t.target_d = (p(a) for a in args)
     fwd_ms = events_ms(lambda: _lib.check(lib.naruto_train_forward(h.ptr, CT.byref(ts.ps), CT.byref(t), 1, st())), iters)
     bwd_ms = events_ms(lambda: _lib.check(lib.naruto_train_backward(h.ptr, CT.byref(ts.ps), CT.byref(t), CT.byref(ts.gs), ts.flags, None, st())), iters)
-    for name, ms in (("naruto_train_forward (4 launches, eager)", fwd_ms), ("naruto_train_backward (6 launches, eager)", bwd_ms)):
+    # the field query in the launch shape the ITERATION uses (one wave per ray, depth-ordered early termination when S % 64 == 0)
+    qit_ms = events_ms(lambda: _lib.check(lib.naruto_debug_train_query_fwd(h.ptr, CT.byref(ts.ps), CT.byref(t), st())), iters)
+    for name, ms in (("naruto_train_forward (4 launches, eager)", fwd_ms), ("naruto_train_backward (eager)", bwd_ms),
+                     ("k_query_fwd<color> as launched by the iteration", qit_ms)):
         rows.append({"kernel": name, "ms": round(ms, 5), "alg_bytes": 0, "alg_flops": 0, "GBps": 0.0, "TFLOPs": 0.0, "bound": None})
     rows.append({"kernel": "(active sample fraction)", "ms": 0.0, "alg_bytes": 0, "alg_flops": 0, "GBps": 0.0, "TFLOPs": 0.0,
                  "bound": "hbm", "fraction": round(frac, 4)})
     return rows
 
 
-def pmc_traffic(kernel: str):
-    """HBM bytes per launch of ``kernel`` from the committed PMC passes (profiles/rNN_pmc.json, newest round; collected by
-    tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes), or None."""
+def pmc_profile(workload_name: str, kernel: str):
+    """Per-launch PMC figures of ``kernel`` from the committed passes (profiles/rNN_pmc.json, newest round; collected by
+    tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, eager launches), or ({}, None).
+    The file is keyed by workload (older rounds: by kernel only = the default workload)."""
     import glob
     here = os.path.dirname(os.path.abspath(__file__))
-    files = sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc.json")))
-    if not files:
-        return None, None
+    for f in sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except (ValueError, OSError):
+            continue
+        d = d.get(workload_name, d if workload_name == "office0_2048x128" else {})
+        if isinstance(d.get(kernel), dict):
+            return d[kernel], os.path.basename(f)
+    return {}, None
+
+
+def physical_cores() -> int:
     try:
-        d = json.load(open(files[-1]))
-        return d[kernel]["traffic_bytes"], os.path.basename(files[-1])
-    except (KeyError, ValueError, OSError):
-        return None, None
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
 
 
-def cpu_baseline(cfg, n_rays: int, iters: int, device=None):
-    """The oracle's mapping iteration (plain PyTorch ops), same body, on a bounded sample: on the host cores (the reported
-    ``cpu_baseline``), or -- device given -- as unfused torch ops on the GPU, the stand-in for "the reference in single-GPU
-    PyTorch" (SURVEY.md 8(d); the reference itself needs the CUDA-only tiny-cuda-nn)."""
+def cpu_baseline(cfg, n_rays: int, device=None, budget_s: float = 30.0):
+    """The oracle's mapping iteration (plain PyTorch ops; oracle/spec_torch.py, pinned against the reference by
+    oracle/make_golden.py), same body as the timed GPU step: forward + losses + smoothness + backward + Adam.
+
+    Host (the reported ``cpu_baseline``): threads = PHYSICAL cores, 5 warm-ups, median of 20 iterations.  The
+    sample is bounded to ~``budget_s`` of CPU work: when 25 iterations of the workload itself would take longer, the rays keep
+    their count but use the SHIPPED sampling (32 + 11 samples per ray, coslam.yaml) and the line says so.
+    ``device`` given: the same oracle as unfused torch ops on the GPU -- the stand-in for "the reference in single-GPU PyTorch"
+    (the reference itself needs the CUDA-only tiny-cuda-nn)."""
+    import copy
     from oracle import spec_torch as S
-    torch.manual_seed(0)
     on_gpu = device is not None
     dev = device if on_gpu else torch.device("cpu")
-    bbox = torch.tensor(cfg["mapping"]["bound"], dtype=torch.float32)
-    ora = S.OracleField(cfg, bbox, 0.1).to(dev)
-    g1, g2 = ora.param_groups()
-    o_map = torch.optim.Adam(g1, betas=(0.9, 0.99))
-    o_unc = torch.optim.Adam(g2, lr=1)
-    rays = {k: torch.from_numpy(v).to(dev) for k, v in syn.random_rays(n_rays, cfg["mapping"]["bound"], seed=0).items()}
+    n_threads_before = torch.get_num_threads()
+    if not on_gpu:
+        torch.set_num_threads(physical_cores())
+
+    def build(c):
+        torch.manual_seed(0)
+        bbox = torch.tensor(c["mapping"]["bound"], dtype=torch.float32)
+        ora = S.OracleField(c, bbox, 0.1).to(dev)
+        g1, g2 = ora.param_groups()
+        o_map = torch.optim.Adam(g1, betas=(0.9, 0.99))
+        o_unc = torch.optim.Adam(g2, lr=1)
+        rays = {k: torch.from_numpy(v).to(dev) for k, v in bench_rays(c, n_rays).items()}
+        trc = c["training"]
+        ora.train()
+
+        def step(i):
+            o_map.zero_grad()
+            ret = ora.forward(rays["rays_o"], rays["rays_d"], rays["target_rgb"], rays["target_d"])
+            sm = S.smoothness(ora, trc["smooth_pts"], trc["smooth_vox"], trc["smooth_margin"], torch.rand(3).to(dev), torch.rand(3).to(dev))
+            S.total_loss(ret, trc, smooth_term=sm).backward()
+            o_map.step()
+            if (i + 1) % 5 == 0:
+                o_unc.step()
+                o_unc.zero_grad()
+            if on_gpu:
+                torch.cuda.synchronize()
+        return step
+
+    def timed(step, warm, iters):
+        for i in range(warm):
+            step(i)
+        ts = []
+        for i in range(iters):
+            t0 = time.perf_counter()
+            step(warm + i)
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), ts
+
     trc = cfg["training"]
-    ora.train()
-
-    def step(i):
-        o_map.zero_grad()
-        ret = ora.forward(rays["rays_o"], rays["rays_d"], rays["target_rgb"], rays["target_d"])
-        sm = S.smoothness(ora, trc["smooth_pts"], trc["smooth_vox"], trc["smooth_margin"], torch.rand(3).to(dev), torch.rand(3).to(dev))
-        S.total_loss(ret, trc, smooth_term=sm).backward()
-        o_map.step()
-        if (i + 1) % 5 == 0:
-            o_unc.step()
-            o_unc.zero_grad()
-
-    step(0)
-    if on_gpu:
-        torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(iters):
-        step(i + 1)
-    if on_gpu:
-        torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / iters
     S_tot = trc["n_samples_d"] + trc["n_range_d"]
+    note = ""
+    c = cfg
+    step = build(c)
+    step(0)                                         # cold
+    t0 = time.perf_counter()
+    step(1)
+    pilot = time.perf_counter() - t0
+    if not on_gpu and pilot * 25 > budget_s * 1.5 and S_tot > 43:
+        c = copy.deepcopy(cfg)
+        c["training"]["n_samples_d"], c["training"]["n_range_d"] = 32, 11
+        note = (f"; the workload's own {S_tot} samples per ray take {pilot:.2f} s per iteration here, so the sample keeps the ray count and uses the "
+                "SHIPPED 32 + 11 samples per ray (cost is proportional to the samples: divide the value by "
+                f"{S_tot / 43.0:.2f} for the workload's sampling)")
+        S_tot = 43
+        step = build(c)
+    warm, iters = (5, 20) if not on_gpu else (2, 10)
+    med, ts = timed(step, warm, iters)
+    if not on_gpu:
+        torch.set_num_threads(n_threads_before)
+    spread = (max(ts) - min(ts)) / med if med > 0 else 0.0
+    out = {"value": round(n_rays / med, 1), "unit": "rays/s", "kind": "port",
+           "sample": f"median of {iters} mapping iterations after {warm} warm-ups, {n_rays} rays x {S_tot} samples (oracle/spec_torch.py: forward + losses + "
+                     f"smoothness + backward + Adam), {med * 1e3:.0f} ms/iter, spread {spread * 100:.0f} %" + note}
     if on_gpu:
-        return {"value": round(n_rays / dt, 1), "unit": "rays/s", "kind": "port, unfused torch ops on the same GPU",
-                "sample": f"{iters} mapping iterations of {n_rays} rays x {S_tot} samples after 1 warm-up, {dt * 1e3:.1f} ms/iter"}
-    return {"value": round(n_rays / dt, 1), "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{iters} mapping iterations of {n_rays} rays x {S_tot} samples after 1 warm-up (oracle/spec_torch.py, "
-                      f"forward+losses+smoothness+backward+Adam), {dt * 1e3:.0f} ms/iter"}
+        out["kind"] = "port, unfused torch ops on the same GPU"
+    else:
+        out["cores"] = physical_cores()
+        out["logical_cpus"] = os.cpu_count()
+        out["samples_per_ray"] = S_tot
+    return out
+
+
+def bench_rays(cfg, n_rays: int, seed: int = 0):
+    """Synthetic ray batch of a workload: origins in the box shrunk by 20 %, directions uniform on the sphere, measured depths
+    U(0.5, 2.5) m (5 % missing) -- scaled to the box for the unit-cube volumes."""
+    unit = max(b[1] - b[0] for b in cfg["mapping"]["bound"]) <= 1.0 + 1e-6
+    return syn.random_rays(n_rays, cfg["mapping"]["bound"], seed=seed, depth_range=(0.15, 0.7) if unit else (0.5, 2.5))
 
 
 def main():
@@ -227,10 +304,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="office0_2048x128")
+    ap.add_argument("--workload", default="office0_2048x128", help="one of: " + ", ".join(sorted(WORKLOADS)))
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: the workload's ray count PER GPU; strong: the workload's ray count per JOB, sharded over the GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=4)
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the fused HIP Adam")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph")
     args = ap.parse_args()
@@ -251,7 +329,14 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    cfg, n_rays = workload(args.workload)
+    cfg, n_workload = workload(args.workload)
+    if args.scaling == "strong":
+        n_total = n_workload
+        assert n_total % world == 0, f"strong scaling: {n_total} rays do not split over {world} GPUs"
+    else:
+        n_total = n_workload * world
+    lo, hi = parallel.shard_bounds(n_total, rank, world)
+    n_rays = hi - lo
     from naruto_amd.trainer import MappingTrainer
     torch.manual_seed(0)                                     # identical replicas on every rank
     tr = MappingTrainer(cfg, torch.tensor(cfg["mapping"]["bound"], dtype=torch.float32), dev, 0.1, group=group,
@@ -261,11 +346,10 @@ def main():
     # NARUTO_FORCE_DIST=1), and nothing depends on capturing a multi-rank collective.  NARUTO_GRAPH_DIST=segmented|whole opts in.
     use_graph = (not args.no_graph) and (group is None or os.environ.get("NARUTO_GRAPH_DIST", "") in ("segmented", "whole"))
     if use_graph:
-        tr.capture(n_rays, smooth=True, n_rays_total=n_rays * world)
-    n_total = n_rays * world
-    all_rays = syn.random_rays(n_total, cfg["mapping"]["bound"], seed=0)
-    lo, hi = parallel.shard_bounds(n_total, rank, world)
+        tr.capture(n_rays, smooth=True, n_rays_total=n_total)
+    all_rays = bench_rays(cfg, n_total)
     rays = {k: torch.from_numpy(v[lo:hi]).to(dev) for k, v in all_rays.items()}
+    del all_rays
     from naruto_amd.trainer import pack_rays
     rays["rays_o"], rays["rays_d"], rays["target_rgb"], rays["target_d"] = pack_rays(rays["rays_o"], rays["rays_d"], rays["target_rgb"],
                                                                                       rays["target_d"])
@@ -296,19 +380,29 @@ def main():
         trc = cfg["training"]
         S_tot = trc["n_samples_d"] + trc["n_range_d"]
         ms = dt / args.steps * 1e3
-        volume = "MP3D 1LXtFkjw3qL bbox" if args.workload.startswith("mp3d") else ("unit cube, finest level 1024^3" if args.workload.startswith("unit") else "office_0 bbox")
+        volume = "MP3D YmJkqBEsHnH bbox (largest shipped)" if args.workload.startswith("mp3d") else (
+            "unit cube, finest level 1024^3" if args.workload.startswith("unit") else "office_0 bbox")
+        n_params = int(tr.model.embed_fn.params.numel()) + 5184 + int(tr.model.uncert_grid.numel())
         out = {
             "metric": "rendered rays/sec (train step), Replica office_0",
             "value": round(n_total * args.steps / dt, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {volume}, {n_rays} rays x {S_tot} samples per GPU, hash L16 F2 T2^{cfg['grid']['hash_size']}, "
-                                   "MLP 2x32, uncert grid; one global_BA mapping iteration incl. smoothness + Adam",
-                       "rays_per_gpu": n_rays, "samples_per_ray": S_tot, "parallelism": f"ray-sharded dp{world}",
+            "config": {"workload": f"{args.workload} = BASELINE {WORKLOADS[args.workload][2]}: {volume}, {n_rays} rays x {S_tot} samples per GPU "
+                                   f"({n_total} rays per step over {world} GPU), hash L16 F2 T2^{cfg['grid']['hash_size']} ({n_params * 4 / 1e6:.1f} MB of parameters), "
+                                   "MLP 2x32 fp32, uncert grid; one global_BA mapping iteration incl. smoothness + Adam",
+                       "rays_per_gpu": n_rays, "rays_per_step": n_total, "samples_per_ray": S_tot, "parallelism": f"ray-sharded dp{world}",
                        "optimizer": "torch.optim.Adam" if args.torch_adam else "fused HIP Adam", "hip_graph": bool(use_graph)},
         }
+        # whole-step roofline figures: per ray S x 3168 B + 44 B and S x 31104 FLOP; per step Adam's 28 B / parameter
+        rays_s = n_total * args.steps / dt
+        step_bytes = n_rays * (S_tot * 3168 + 44) + n_params * 28
+        out["step_roofline"] = {"alg_bytes_per_step_per_gpu": int(step_bytes), "achieved_GBps": round(step_bytes / (ms * 1e-3) / 1e9, 1),
+                                "hbm_frac": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "mfma_util": round(rays_s / world * S_tot * 31104 / (FP32_MFMA_PEAK_TF * 1e12), 4),
+                                "mfma_peak": f"{FP32_MFMA_PEAK_TF} TFLOP/s (fp32 MFMA = fp32 vector rate)"}
         if not args.no_kernels:
-            rows = kernel_table(tr, rays, cfg, max(10, args.steps))
+            rows = kernel_table(tr, rays, cfg, max(10, min(args.steps, 50)))
             dom = max((r for r in rows if r["bound"] is not None), key=lambda r: r["ms"])
             if dom["bound"] == "mfma":
                 roof = {"bound": "mfma", "achieved": dom["TFLOPs"], "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
@@ -319,17 +413,32 @@ def main():
             roof["kernel"] = dom["kernel"]
             roof["kernel_ms"] = dom["ms"]
             roof["alg_bytes"] = dom["alg_bytes"]
-            tb, src = pmc_traffic(dom["kernel"])
-            if tb is not None:
-                roof["traffic"] = tb                      # bytes per launch (FETCH_SIZE + WRITE_SIZE), same launch shape
+            if "launch" in dom:
+                roof["launch"] = dom["launch"]
+            if "alg_bytes_incl_saved" in dom:
+                b2 = dom["alg_bytes_incl_saved"]
+                roof["alg_bytes_incl_saved"] = b2
+                roof["frac_incl_saved"] = round(b2 / dom["ms"] / 1e6 / HBM_PEAK_GBS, 4)
+            if dom["kernel"].startswith("k_query_fwd"):
+                it = next(r for r in rows if r["kernel"].endswith("as launched by the iteration"))
+                roof["kernel_ms_in_iteration"] = it["ms"]
+                roof["mfma_util"] = round(dom["TFLOPs"] / FP32_MFMA_PEAK_TF, 4)
+                # L2 line rate (MI355X_MICROARCH.md: ~34.5 TB/s aggregate): a wave's 64 8-byte gathers touch ~36 distinct 64-byte
+                # lines (x-neighbour corners share a line, tools/gather_coalesce_bench.hip), i.e. 4.5 lines per (sample, level)
+                l2_bytes = n_rays * S_tot * (16 * 4.5 * 64 + 4 * 64) + dom.get("alg_bytes_incl_saved", 0) - n_rays * S_tot * (16 * 8 * 8 + 32)
+                roof["l2_bytes_model"] = int(l2_bytes)
+                roof["l2_frac"] = round(l2_bytes / dom["ms"] / 1e6 / L2_PEAK_GBS, 4)
+            prof, src = pmc_profile(args.workload, dom["kernel"])
+            if prof.get("traffic_bytes") is not None:
+                roof["traffic"] = prof["traffic_bytes"]                      # bytes per launch (FETCH_SIZE + WRITE_SIZE), same launch shape
                 roof["traffic_source"] = f"profiles/{src}"
             out["roofline"] = roof
             out["kernels"] = rows
             out["kernels_ms_sum"] = round(sum(r["ms"] for r in rows if r["bound"] is not None), 4)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, n_rays, args.cpu_iters)
+            out["cpu_baseline"] = cpu_baseline(cfg, n_rays)
             try:
-                out["torch_gpu_baseline"] = cpu_baseline(cfg, n_rays, 10, device=dev)
+                out["torch_gpu_baseline"] = cpu_baseline(cfg, n_rays, device=dev)
             except Exception as e:                               # informational: never fail the bench line over it
                 out["torch_gpu_baseline"] = {"error": repr(e)[:200]}
         sys.stdout.flush()

@@ -108,8 +108,13 @@ int naruto_sample_z(uint32_t n_rays, const float* target_d, float near_, float f
 int naruto_hash_encode_fwd(const NarutoField* f, uint32_t M, const float* x, const float* table,
                            float* feat, void* stream);
 /* its backward (tcnn HashGrid backward): d_table += scatter(d_feat).
- * workspace: naruto_scatter_workspace(f) bytes (per-split partial tables of the LDS-tiled scatter). */
-size_t naruto_scatter_workspace(const NarutoField* f);
+ * workspace: naruto_scatter_workspace(f, M) bytes for lists of up to M points (per-split partial tables of the LDS-tiled
+ * scatter; count matrix + 12-byte (corner, contribution) items of the binned scatter that serves levels of more than 2^17
+ * entries).  No level uses global float atomics: the result is bitwise reproducible for any log2_hashmap_size <= 24.
+ * naruto_field_scatter_overwrites(f): 1 if the scatter can WRITE the table gradient (NARUTO_BWD_OVERWRITE_TABLE_GRAD, the
+ * fused optimiser) -- always, unless the debug switch NARUTO_DEBUG_SCATTER_ATOMIC sent the large levels through global atomics. */
+size_t naruto_scatter_workspace(const NarutoField* f, uint32_t M);
+int naruto_field_scatter_overwrites(const NarutoField* f);
 int naruto_hash_encode_bwd(const NarutoField* f, uint32_t M, const float* x, const float* d_feat,
                            const float* d_feat_scale /* device scalar multiplying d_feat, or NULL */,
                            float* d_table, void* workspace, void* stream);
@@ -141,7 +146,7 @@ int naruto_query_fwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
  * extra (optional): E more points whose feature cotangents are already known (the smoothness lattice of
  * naruto_smoothness_fwd); they are appended to the scatter's point list so that ONE scatter pass produces the
  * whole table gradient.  flags: NARUTO_BWD_OVERWRITE_* make the reductions WRITE the weight / table gradients
- * instead of accumulating (saves the caller the zero fill; table: needs log2_hashmap_size <= 17).
+ * instead of accumulating (saves the caller the zero fill).
  * Workspace: naruto_query_bwd_workspace(f, M + E). */
 typedef struct NarutoExtraPoints {
     const float* x;        /* [E,3] normalised points                         */
@@ -344,7 +349,8 @@ typedef struct NarutoTrainStep {
 } NarutoTrainStep;
 /* Optimiser in the backward (single process): the launch that finishes the gradients applies torch.optim.Adam
  * (amsgrad off, L2 weight decay; reference create_optimizer, coslam.py:409-419) to the table and the MLP weights in
- * place.  Tensor order: table, sdf_w0, sdf_w1, col_w0, col_w1.  Needs every level LDS-tiled (log2_hashmap_size <= 16). */
+ * place.  Tensor order: table, sdf_w0, sdf_w1, col_w0, col_w1.  (Levels of more than 2^17 entries are stepped by the last
+ * kernel of the binned scatter, one 8 192-entry slice per workgroup.) */
 typedef struct NarutoFusedAdam {
     float* param[5]; float* exp_avg[5]; float* exp_avg_sq[5];
     float lr[5], eps[5], weight_decay[5];
@@ -357,6 +363,10 @@ int naruto_train_finalize(const NarutoField* f, const NarutoTrainStep* t, void* 
 int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, const NarutoGrads* g,
                           uint32_t flags, const NarutoFusedAdam* opt /* NULL: gradients only; else g's table / weight
                           pointers may be NULL (gradients not materialised) */, void* stream);
+
+/* Measurement aid (bench.py): ONLY the field-query launch of naruto_train_forward, in the launch shape the iteration uses (one wave
+ * per ray with early termination when S % 64 == 0); t->z_vals must hold a previous forward's depths. */
+int naruto_debug_train_query_fwd(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, void* stream);
 
 /* Hardware self-checks used by the GPU tests: the MFMA / permlane layouts the kernels rely on.
  * out: device buffer of 64*16 floats; returns 0 and fills out (see tests/test_gpu_parity.py: test_mfma_layout, test_permlane32_swap). */

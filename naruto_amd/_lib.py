@@ -14,7 +14,7 @@ from typing import List, Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NARUTO_HIP_LIB") or os.path.join(_HERE, "libnaruto_hip.so")      # override: kernel experiments only
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["naruto_api.hip", "naruto_field.hip", "naruto_render.hip", "naruto_rays.hip", "naruto_train.hip", "naruto_planner.hip", "naruto_mesh.hip",
+SOURCES = ["naruto_api.hip", "naruto_field.hip", "naruto_binned.hip", "naruto_render.hip", "naruto_rays.hip", "naruto_train.hip", "naruto_planner.hip", "naruto_mesh.hip",
            "naruto_mc_table.inc", "naruto_common.h"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "naruto_hip.h")
 
@@ -133,7 +133,8 @@ SIGNATURES = {
     "naruto_field_n_entries": (_U64, [_V]),
     "naruto_sample_z": (_I, [_U32, _V, _F, _F, _U32, _U32, _F, _U32, _V, _V, _V]),
     "naruto_hash_encode_fwd": (_I, [_V, _U32, _V, _V, _V, _V]),
-    "naruto_scatter_workspace": (C.c_size_t, [_V]),
+    "naruto_scatter_workspace": (C.c_size_t, [_V, _U32]),
+    "naruto_field_scatter_overwrites": (C.c_int, [_V]),
     "naruto_hash_encode_bwd": (_I, [_V, _U32, _V, _V, _V, _V, _V, _V]),
     "naruto_smoothness_workspace": (C.c_size_t, [_U32]),
     "naruto_smoothness_fwd": (_I, [_V, _V, _U32, _F, _F, _V, _V, _V, _V, _V, _V]),
@@ -159,6 +160,7 @@ SIGNATURES = {
     "naruto_train_workspace": (C.c_size_t, [_V, C.POINTER(NarutoTrainStep)]),
     "naruto_train_forward": (_I, [_V, C.POINTER(NarutoParams), C.POINTER(NarutoTrainStep), _I, _V]),
     "naruto_train_finalize": (_I, [_V, C.POINTER(NarutoTrainStep), _V]),
+    "naruto_debug_train_query_fwd": (_I, [_V, C.POINTER(NarutoParams), C.POINTER(NarutoTrainStep), _V]),
     "naruto_train_backward": (_I, [_V, C.POINTER(NarutoParams), C.POINTER(NarutoTrainStep), C.POINTER(NarutoGrads), _U32,
                                    C.POINTER(NarutoFusedAdam), _V]),
     "naruto_compact_active": (_I, [_U32, _U32, _V, _V, _V, _V, _V]),

@@ -105,4 +105,6 @@ def unit_cube_config(desired_resolution: int = 1024, hash_size: int = 16, **trai
     cfg["grid"]["voxel_sdf"] = desired_resolution
     cfg["grid"]["hash_size"] = hash_size
     cfg["cam"]["far"] = 1.0
+    cfg["training"]["smooth_vox"] = 0.02          # the 31-point smoothness lattice (0.62 wide) has to fit the 1 m cube
+    cfg["training"]["smooth_margin"] = 0.01
     return cfg

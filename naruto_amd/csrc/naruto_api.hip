@@ -7,6 +7,7 @@
 #include <new>
 
 #include "naruto_field.hip"
+#include "naruto_binned.hip"
 #include "naruto_render.hip"
 #include "naruto_rays.hip"
 #include "naruto_train.hip"
@@ -23,7 +24,9 @@ struct NarutoField {
     uint32_t offset[NARUTO_MAX_LEVELS + 1];
     uint64_t n_entries;
     int n_cu;
-    ScatterPlan plan;
+    ScatterPlan plan;          // LDS-tiled scatter: the levels of up to kMaxChunksPerLevel chunks (a prefix of the levels)
+    BinPlan bplan;             // binned scatter: the larger levels (the rest)
+    uint64_t n_tiled_entries;  // entries of the LDS-tiled prefix = offset of the first larger level
 };
 
 namespace {
@@ -83,12 +86,47 @@ int ray_lds_attr() {
 
 constexpr uint32_t kBwdMaxBlocks = 256;     // one 145 KB-LDS block per CU
 
-// table scatter: LDS-tiled units + k_scatter_reduce, and/or the global-atomic kernel for oversized levels
+inline size_t al256(size_t b) { return (b + 255u) / 256u * 256u; }
+
+// rows of the binned scatter's count matrix: one per kBinRound points, at most kBinMaxRows
+inline uint32_t bin_rows(uint32_t M) {
+    const uint32_t r = (M + (uint32_t)kBinRound - 1u) / (uint32_t)kBinRound;
+    return r < 1u ? 1u : (r > (uint32_t)kBinMaxRows ? (uint32_t)kBinMaxRows : r);
+}
+
+// workspace of the table scatter for a list of up to M points: | tiled partial tables | counts | totals | starts | items |
+struct ScatterWs {
+    float* partial; uint32_t* counts; uint32_t* totals; uint32_t* starts; BinItem* items;
+    size_t total;
+};
+ScatterWs scatter_ws(const NarutoField* f, void* base, uint32_t M) {
+    ScatterWs w{};
+    char* b = reinterpret_cast<char*>(base);
+    size_t off = 0;
+    const uint32_t smax = f->plan.s_dense > f->plan.s_hashed ? f->plan.s_dense : f->plan.s_hashed;
+    w.partial = reinterpret_cast<float*>(b + off);
+    off += al256((f->plan.n_dense + f->plan.n_hashed) ? (size_t)smax * (size_t)f->n_tiled_entries * 2u * sizeof(float) : 16u);
+    if (f->bplan.n_levels != 0) {
+        w.counts = reinterpret_cast<uint32_t*>(b + off); off += al256((size_t)bin_rows(M) * f->bplan.n_bins * sizeof(uint32_t));
+        w.totals = reinterpret_cast<uint32_t*>(b + off); off += al256((size_t)f->bplan.n_bins * sizeof(uint32_t));
+        w.starts = reinterpret_cast<uint32_t*>(b + off); off += al256(((size_t)f->bplan.n_bins + 1u) * sizeof(uint32_t));
+        w.items = reinterpret_cast<BinItem*>(b + off);   off += al256((size_t)M * f->bplan.n_levels * 8u * sizeof(BinItem));
+    }
+    w.total = off;
+    return w;
+}
+
+// table scatter.  Levels of up to kMaxChunksPerLevel chunks: LDS-tiled units (+ k_scatter_reduce unless the caller finishes the
+// gradient itself); larger levels: the binned scatter (naruto_binned.hip), whose last kernel writes / adds the gradient slice or,
+// with ``adam``, steps the optimiser on it.  (Debug: NARUTO_DEBUG_SCATTER_ATOMIC=1 sends the larger levels through global
+// float atomics instead -- for A/B timing only.)
 int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const float* d_feat, size_t stride_m, size_t stride_l, float* d_table,
-                   float* partial, hipStream_t st, const uint32_t* m_dev = nullptr, const float* scale_dev = nullptr, int overwrite = 0,
-                   bool do_reduce = true) {
-    if (overwrite && f->plan.atomic_levels != 0) return fail(NARUTO_ERR_INVALID, "scatter: overwrite mode needs every level LDS-tiled (log2_hashmap_size <= 17)");
-    const size_t n_params = (size_t)f->n_entries * 2u;
+                   void* workspace, hipStream_t st, const uint32_t* m_dev = nullptr, const float* scale_dev = nullptr, int overwrite = 0,
+                   bool do_reduce = true, const AdamFuse* adam = nullptr) {
+    if ((overwrite || adam != nullptr) && f->plan.atomic_levels != 0)
+        return fail(NARUTO_ERR_INVALID, "scatter: written (not accumulated) gradients / the fused optimiser are not available with NARUTO_DEBUG_SCATTER_ATOMIC");
+    const ScatterWs w = scatter_ws(f, workspace, M);
+    const size_t n_tiled_params = (size_t)f->n_tiled_entries * 2u;
     if (f->plan.n_dense + f->plan.n_hashed > 0) {
         static bool attr_set = false;
         const size_t lds = (size_t)kChunk * sizeof(unsigned long long);
@@ -99,12 +137,38 @@ int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const f
         }
         const uint32_t blocks = (f->plan.n_dense * f->plan.s_dense + f->plan.n_hashed * f->plan.s_hashed + 7u) / 8u * 8u;      // XCD-aware order: multiple of 8
         hipLaunchKernelGGL(k_hash_scatter_lds, dim3(blocks), dim3(kScatterThreads), lds, st, f->lt, f->bt, ps, M, d_feat, stride_m, stride_l, f->plan,
-                           partial, n_params, m_dev, scale_dev);
+                           w.partial, n_tiled_params, m_dev, scale_dev);
         if (int rc = check_launch("hash_scatter_lds")) return rc;
-        if (!do_reduce) return NARUTO_OK;          // the caller finishes the gradient itself (k_bwd_finish)
-        hipLaunchKernelGGL(k_scatter_reduce, dim3((uint32_t)((n_params / 4u + 255u) / 256u)), dim3(256), 0, st, f->lt, f->plan.atomic_levels, partial,
-                           f->plan.s_dense, f->plan.s_hashed, n_params, d_table, overwrite);
-        if (int rc = check_launch("scatter_reduce")) return rc;
+        if (do_reduce) {
+            hipLaunchKernelGGL(k_scatter_reduce, dim3((uint32_t)((n_tiled_params / 4u + 255u) / 256u)), dim3(256), 0, st, f->lt, f->plan.atomic_levels, w.partial,
+                               f->plan.s_dense, f->plan.s_hashed, n_tiled_params, d_table, overwrite);
+            if (int rc = check_launch("scatter_reduce")) return rc;
+        }
+    }
+    if (f->bplan.n_levels != 0) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_fill), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BinFillLds)) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_apply), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(2u * kBinEntries * sizeof(unsigned long long))) != hipSuccess)
+                return fail(NARUTO_ERR_LAUNCH, "binned scatter: cannot reserve LDS: %s", hipGetErrorString(hipGetLastError()));
+            attr_set = true;
+        }
+        const BinPlan& bp = f->bplan;
+        const uint32_t rows = bin_rows(M);
+        hipLaunchKernelGGL(k_bin_count, dim3(rows, bp.n_levels), dim3(kBinThreads), 0, st, f->lt, f->bt, ps, M, d_feat, stride_m, stride_l, bp, w.counts, m_dev);
+        if (int rc = check_launch("bin_count")) return rc;
+        hipLaunchKernelGGL(k_bin_colscan, dim3((bp.n_bins + 255u) / 256u), dim3(256), 0, st, w.counts, rows, bp.n_bins, w.totals);
+        if (int rc = check_launch("bin_colscan")) return rc;
+        hipLaunchKernelGGL(k_bin_start, dim3(1), dim3(1024), 0, st, w.totals, bp.n_bins, w.starts);
+        if (int rc = check_launch("bin_start")) return rc;
+        hipLaunchKernelGGL(k_bin_fill, dim3(rows, bp.n_levels), dim3(kBinThreads), sizeof(BinFillLds), st, f->lt, f->bt, ps, M, d_feat, stride_m, stride_l, bp,
+                           w.counts, w.starts, w.items, m_dev);
+        if (int rc = check_launch("bin_fill")) return rc;
+        AdamFuse none{};
+        hipLaunchKernelGGL(k_bin_apply, dim3(bp.n_bins), dim3(kBinApplyThreads), 2u * kBinEntries * sizeof(unsigned long long), st, f->lt, bp, w.starts, w.items,
+                           d_table, overwrite, scale_dev, adam != nullptr ? *adam : none);
+        if (int rc = check_launch("bin_apply")) return rc;
     }
     if (f->plan.atomic_levels != 0) {
         hipLaunchKernelGGL(k_hash_scatter_atomic, dim3((M + 255u) / 256u, kLevels), dim3(256), 0, st, f->lt, f->bt, ps, M, d_feat, stride_m, stride_l,
@@ -172,13 +236,14 @@ int naruto_field_create(const NarutoFieldDesc* d, NarutoField** out) {
     // scatter plan: levels of up to kMaxChunksPerLevel 16 384-entry chunks are LDS-tiled, one unit per (chunk, feature),
     // dense levels first; larger levels use global atomics
     memset(&f->plan, 0, sizeof(f->plan));
-    uint32_t n_units = 0;
+    memset(&f->bplan, 0, sizeof(f->bplan));
+    uint32_t n_units = 0, big_levels = 0;
     for (int pass = 0; pass < 2; ++pass) {
         for (uint32_t l = 0; l < d->n_levels; ++l) {
             const bool hashed = (f->lt.hashed >> l) & 1u;
             if ((pass == 1) != hashed) continue;
             const uint32_t chunks = (f->lt.size[l] + kChunk - 1u) / kChunk;
-            if (chunks > (uint32_t)kMaxChunksPerLevel) { f->plan.atomic_levels |= 1u << l; continue; }
+            if (chunks > (uint32_t)kMaxChunksPerLevel) { big_levels |= 1u << l; continue; }
             for (uint32_t c = 0; c < chunks; ++c) {
                 for (uint32_t ft = 0; ft < 2u; ++ft) {
                     f->plan.level[n_units] = (uint8_t)l;
@@ -187,6 +252,31 @@ int naruto_field_create(const NarutoFieldDesc* d, NarutoField** out) {
                 }
             }
             if (hashed) f->plan.n_hashed += 2u * chunks; else f->plan.n_dense += 2u * chunks;
+        }
+    }
+    // the larger levels (a suffix of the levels: sizes never decrease) go through the binned scatter
+    f->n_tiled_entries = f->n_entries;
+    if (big_levels != 0) {
+        uint32_t first = 0;
+        while (!((big_levels >> first) & 1u)) ++first;
+        if (big_levels != ((0xFFFFFFFFu << first) & ((1u << d->n_levels) - 1u))) { delete f; return fail(NARUTO_ERR_INVALID, "create: level sizes are not monotone"); }
+        f->n_tiled_entries = f->offset[first];
+        if (getenv("NARUTO_DEBUG_SCATTER_ATOMIC") != nullptr) {
+            f->plan.atomic_levels = big_levels;
+        } else {
+            BinPlan& bp = f->bplan;
+            bp.level_mask = big_levels;
+            bp.first_level = first;
+            bp.n_levels = d->n_levels - first;
+            uint32_t nb = 0;
+            for (uint32_t k = 0; k < bp.n_levels; ++k) {
+                const uint32_t bins = (f->lt.size[first + k] + kBinEntries - 1u) / kBinEntries;
+                if (bins > (uint32_t)kMaxBinsPerLevel) { delete f; return fail(NARUTO_ERR_INVALID, "create: log2_hashmap_size > 24 is not supported by the table scatter"); }
+                bp.bin0[k] = nb;
+                nb += bins;
+            }
+            bp.bin0[bp.n_levels] = nb;
+            bp.n_bins = nb;
         }
     }
     // one 128 KB-LDS workgroup per CU and every workgroup takes about the same time (it is bound by the points it
@@ -247,11 +337,12 @@ int naruto_hash_encode_fwd(const NarutoField* f, uint32_t M, const float* x, con
     return check_launch("hash_encode_fwd");
 }
 
-size_t naruto_scatter_workspace(const NarutoField* f) {
-    if (f == nullptr || f->plan.n_dense + f->plan.n_hashed == 0) return 16;
-    const uint32_t smax = f->plan.s_dense > f->plan.s_hashed ? f->plan.s_dense : f->plan.s_hashed;
-    return (size_t)smax * (size_t)f->n_entries * 2u * sizeof(float);
+size_t naruto_scatter_workspace(const NarutoField* f, uint32_t M) {
+    if (f == nullptr) return 16;
+    return scatter_ws(f, nullptr, M).total;
 }
+
+int naruto_field_scatter_overwrites(const NarutoField* f) { return (f != nullptr && f->plan.atomic_levels == 0) ? 1 : 0; }
 
 int naruto_hash_encode_bwd(const NarutoField* f, uint32_t M, const float* x, const float* d_feat, const float* d_feat_scale, float* d_table,
                            void* workspace, void* stream) {
@@ -261,8 +352,7 @@ int naruto_hash_encode_bwd(const NarutoField* f, uint32_t M, const float* x, con
     PointSrc ps{};
     ps.x = x;
     ps.S = 1;
-    return launch_scatter(f, ps, M, d_feat, (size_t)kFeat, (size_t)2, d_table, reinterpret_cast<float*>(workspace), (hipStream_t)stream, nullptr,
-                          d_feat_scale);
+    return launch_scatter(f, ps, M, d_feat, (size_t)kFeat, (size_t)2, d_table, workspace, (hipStream_t)stream, nullptr, d_feat_scale);
 }
 
 size_t naruto_smoothness_workspace(uint32_t sample_points) {
@@ -325,7 +415,7 @@ int naruto_query_fwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
 size_t naruto_query_bwd_workspace(const NarutoField* f, uint32_t M) {
     // M here = points + extra points.  d_feat [16][cap][2] | x [3][cap] | wgrad partials | scatter partials | count word
     M = list_cap(M);
-    return ((size_t)kLevels * 2u + 3u) * sizeof(float) * (size_t)M + (size_t)kBwdMaxBlocks * kAccFloats * sizeof(float) + naruto_scatter_workspace(f) + 64;
+    return ((size_t)kLevels * 2u + 3u) * sizeof(float) * (size_t)M + (size_t)kBwdMaxBlocks * kAccFloats * sizeof(float) + naruto_scatter_workspace(f, M) + 64;
 }
 
 }  // extern "C"
@@ -342,7 +432,7 @@ BwdWs bwd_ws(const NarutoField* f, void* workspace, uint32_t cap) {
     w.x_soa = w.d_feat + (size_t)kLevels * 2u * (size_t)cap;
     w.partials = w.x_soa + 3u * (size_t)cap;
     w.scatter_ws = w.partials + (size_t)kBwdMaxBlocks * kAccFloats;
-    w.n_total = reinterpret_cast<uint32_t*>(w.scatter_ws + naruto_scatter_workspace(f) / sizeof(float));
+    w.n_total = reinterpret_cast<uint32_t*>(w.scatter_ws + naruto_scatter_workspace(f, cap) / sizeof(float));
     return w;
 }
 
@@ -382,17 +472,17 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
                        d_geo, d_feat, (g->table != nullptr || adam != nullptr) ? x_soa : nullptr, g->uncert_grid, partials, active_idx, n_active, n_front);
     if (int rc = check_launch("query_bwd")) return rc;
     if (adam != nullptr) {
-        // optimiser in the backward: scatter without its reduce, then ONE launch finishes table + weight gradients and steps
-        if (f->plan.atomic_levels != 0) return fail(NARUTO_ERR_INVALID, "query_bwd: the fused optimiser needs every level LDS-tiled (log2_hashmap_size <= 16)");
+        // optimiser in the backward: the tiled scatter without its reduce, then ONE launch finishes the tiled levels' table
+        // gradient + the weight gradients and steps them; the binned scatter's last kernel steps the larger levels itself
         PointSrc pss{};
         pss.xsoa = x_soa;
         pss.M = cap;
         pss.S = 1;
         const uint32_t* cnt = n_front > 0 ? n_list_dev : n_active;
-        if (int rc = launch_scatter(f, pss, cnt != nullptr ? cap : M, d_feat, (size_t)2, (size_t)2 * (size_t)cap, nullptr, scatter_ws, (hipStream_t)stream, cnt,
-                                    nullptr, 1, false))
+        if (int rc = launch_scatter(f, pss, cnt != nullptr ? cap : M, d_feat, (size_t)2, (size_t)2 * (size_t)cap, g->table, scatter_ws, (hipStream_t)stream, cnt,
+                                    nullptr, 1, false, adam))
             return rc;
-        const size_t n_params = (size_t)f->n_entries * 2u;
+        const size_t n_params = (size_t)f->n_tiled_entries * 2u;
         const uint32_t n_table_blocks = (uint32_t)((n_params / 4u + 255u) / 256u);
         hipLaunchKernelGGL(k_bwd_finish, dim3(n_table_blocks + kAccFloats / 32), dim3(256), 0, (hipStream_t)stream, f->lt, scatter_ws, f->plan.s_dense,
                            f->plan.s_hashed, n_params, partials, blocks, *g, *adam, n_table_blocks);
@@ -485,6 +575,27 @@ int train_check(const NarutoField* f, const NarutoParams* p, const NarutoTrainSt
     if (t->smooth_points != 0 && t->loss_weights == nullptr) return fail(NARUTO_ERR_INVALID, "%s: the smoothness term needs loss_weights", who);
     return NARUTO_OK;
 }
+// A2..A5 of the training forward: k_query_fwd over the batch's samples, one wave per ray with depth-ordered early termination
+// when the samples per ray are a multiple of 64 (otherwise flat 64-sample tiles)
+int launch_train_query(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, hipStream_t st) {
+    const uint32_t N = t->n_rays, S = t->n_samples_d + t->n_range_d, M = N * S;
+    PointSrc ps{};
+    ps.rays_o = t->rays_o; ps.rays_d = t->rays_d; ps.z_vals = t->z_vals; ps.S = S;
+    const uint32_t n_tiles = (M + 63u) / 64u;
+    uint32_t blocks = (n_tiles + 3u) / 4u;
+    if (blocks > cu_count(f) * 4u) blocks = cu_count(f) * 4u;
+    EarlyExit ee{};
+    static const bool no_ee = getenv("NARUTO_DEBUG_NO_EARLY_EXIT") != nullptr;             // profiling knob
+    if (S % 64u == 0u && S > 64u && !no_ee) {      // depth-ordered early termination: one wave per ray, front to back
+        ee.target_d = t->target_d;
+        ee.trunc_sc = f->desc.trunc * f->desc.sc_factor;
+        ee.tiles_per_ray = S / 64u;
+        blocks = (N + 3u) / 4u;
+        if (blocks > cu_count(f) * 4u) blocks = cu_count(f) * 4u;
+    }
+    hipLaunchKernelGGL(k_query_fwd<true>, dim3(blocks), dim3(256), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
+    return check_launch("query_fwd");
+}
 TvArgs tv_args(const NarutoTrainStep* t) {
     TvArgs a{};
     if (t->smooth_points == 0) return a;
@@ -527,22 +638,7 @@ int naruto_train_forward(const NarutoField* f, const NarutoParams* p, const Naru
         if (int rc = check_launch("sample_z")) return rc;
     }
     // A2..A5
-    PointSrc ps{};
-    ps.rays_o = t->rays_o; ps.rays_d = t->rays_d; ps.z_vals = t->z_vals; ps.S = S;
-    const uint32_t n_tiles = (M + 63u) / 64u;
-    uint32_t blocks = (n_tiles + 3u) / 4u;
-    if (blocks > cu_count(f) * 4u) blocks = cu_count(f) * 4u;
-    EarlyExit ee{};
-    static const bool no_ee = getenv("NARUTO_DEBUG_NO_EARLY_EXIT") != nullptr;             // profiling knob
-    if (S % 64u == 0u && S > 64u && !no_ee) {      // depth-ordered early termination: one wave per ray, front to back
-        ee.target_d = t->target_d;
-        ee.trunc_sc = f->desc.trunc * f->desc.sc_factor;
-        ee.tiles_per_ray = S / 64u;
-        blocks = (N + 3u) / 4u;
-        if (blocks > cu_count(f) * 4u) blocks = cu_count(f) * 4u;
-    }
-    hipLaunchKernelGGL(k_query_fwd<true>, dim3(blocks), dim3(256), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
-    if (int rc = check_launch("query_fwd")) return rc;
+    if (int rc = launch_train_query(f, p, t, st)) return rc;
     // A6..A8 (+ the lattice's TV term), then the one-workgroup tail
     LossStageArgs a{};
     a.n_rays = N; a.S = S;
@@ -576,6 +672,11 @@ int naruto_train_finalize(const NarutoField* f, const NarutoTrainStep* t, void* 
     hipLaunchKernelGGL(k_loss_finalize_total, dim3(1), dim3(64), 0, (hipStream_t)stream, t->sums, t->n_rays_total ? t->n_rays_total : t->n_rays, S, t->losses,
                        t->loss_weights);
     return check_launch("loss_finalize_total");
+}
+
+int naruto_debug_train_query_fwd(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, void* stream) {
+    if (int rc = train_check(f, p, t, "debug_train_query_fwd")) return rc;
+    return launch_train_query(f, p, t, (hipStream_t)stream);
 }
 
 int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, const NarutoGrads* g, uint32_t flags,

@@ -1,0 +1,299 @@
+// Table scatter for LARGE hash tables (levels of more than kMaxChunksPerLevel LDS chunks: log2_hashmap_size > 17, and the
+// big dense levels under such a table) -- the HBM-resident regime of BASELINE.json configs[4] (2^22-entry levels, 283 MB).
+//
+// The LDS-tiled scatter (naruto_field.hip) lets every (level, chunk) workgroup stream the level's whole point list and
+// keep what lands in its chunk; that costs (chunks x list) traffic and stops making sense at 256+ chunks per level.  Global
+// float atomics execute at the memory side of the fabric (~50 G updates/s chip-wide, order-dependent).  So the big levels
+// are scattered by a COUNTING SORT of the (corner, contribution) items into 8 192-entry bins, each bin then being
+// accumulated by ONE workgroup in LDS -- every table line is written once, no global float atomics, and the int64
+// fixed-point accumulation (value * 2^40, same as the tiled path) makes the result independent of item order, i.e.
+// bitwise reproducible:
+//
+//   k_bin_count   (row, level): items per bin of this row's share of the point list            -> counts[row][bin]
+//   k_bin_colscan / k_bin_start: exclusive prefix over rows per bin, exclusive prefix over bins  -> item run of (row, bin)
+//   k_bin_fill    (row, level): recompute the items, sort each 512-point round by bin in LDS, write the runs coalesced
+//   k_bin_apply   (bin)       : accumulate the bin's items in a 128 KB LDS image (both features of 8 192 entries), then
+//                               either write / add the gradient slice or apply the fused Adam step to it in place
+//
+// HBM traffic per (point, level): 96 B of items written + 96 B read (12 B per corner: entry-in-bin, two contributions),
+// against the 2 x 64 B read-modify-write of the 8 corners that the algorithm asks for; the point list is read twice.
+//
+// Reference behaviour replaced: the backward of tcnn's HashGrid encoding (atomicAdd into the gradient table) behind
+// JointEncodingNaruto.embed_fn (reference src/slam/coslam/model/scene_rep.py:59,110) and, with the fused optimiser,
+// torch.optim.Adam on embed_fn.params (src/slam/coslam/coslam.py:409-419).
+
+#include "naruto_common.h"
+
+namespace naruto {
+
+constexpr int kBinLog2 = 13;
+constexpr uint32_t kBinEntries = 1u << kBinLog2;         // entries per bin: x 2 features x int64 = 128 KB of LDS
+constexpr int kMaxBinsPerLevel = 2048;                   // log2_hashmap_size <= 24
+constexpr int kBinRound = 512;                           // points sorted per LDS round of k_bin_fill
+constexpr int kBinThreads = 256;
+constexpr int kBinPtsPerThread = kBinRound / kBinThreads;
+constexpr int kBinMaxRows = 256;
+constexpr int kBinApplyThreads = 1024;
+
+struct BinPlan {
+    uint32_t level_mask;              // bit l: level l goes through the binned scatter
+    uint32_t n_levels;                // number of such levels (they are the LAST n_levels levels: sizes never decrease)
+    uint32_t first_level;             // index of the first binned level
+    uint32_t bin0[kLevels + 1];       // first global bin id of binned level k (k = level - first_level); bin0[n_levels] = n_bins
+    uint32_t n_bins;
+};
+
+struct BinItem { uint32_t rel; float v0, v1; };          // entry within the bin, contribution * 2^8 per feature
+
+// this (row)'s share of the point list: multiples of kBinRound so that count and fill walk the same rounds
+__device__ __forceinline__ void bin_row_range(uint32_t M, uint32_t rows, uint32_t row, uint32_t& m_lo, uint32_t& m_hi) {
+    const uint32_t per = ((M + rows - 1u) / rows + (uint32_t)kBinRound - 1u) / (uint32_t)kBinRound * (uint32_t)kBinRound;
+    m_lo = row * per < M ? row * per : M;
+    m_hi = m_lo + per < M ? m_lo + per : M;
+}
+
+__global__ __launch_bounds__(kBinThreads) void k_bin_count(LevelTab lt, BoxTab bt, PointSrc ps, uint32_t M, const float* __restrict__ d_feat,
+                                                           size_t stride_m, size_t stride_l, BinPlan plan, uint32_t* __restrict__ counts,
+                                                           const uint32_t* __restrict__ m_dev) {
+    __shared__ uint32_t hist[kMaxBinsPerLevel];
+    if (m_dev != nullptr) M = m_dev[0];
+    const uint32_t row = blockIdx.x, k = blockIdx.y, level = plan.first_level + k;
+    const uint32_t nb = plan.bin0[k + 1] - plan.bin0[k];
+    for (uint32_t b = threadIdx.x; b < nb; b += kBinThreads) hist[b] = 0u;
+    __syncthreads();
+    uint32_t m_lo, m_hi;
+    bin_row_range(M, gridDim.x, row, m_lo, m_hi);
+    const uint32_t sm32 = (uint32_t)stride_m, sl32 = (uint32_t)stride_l;
+    for (uint32_t m = m_lo + threadIdx.x; m < m_hi; m += kBinThreads) {
+        const float2 g = *reinterpret_cast<const float2*>(d_feat + (size_t)m * sm32 + (size_t)level * sl32);
+        if (g.x == 0.0f && g.y == 0.0f) continue;
+        float x, y, z;
+        load_point(ps, bt, m, x, y, z);
+        uint32_t idx[8];
+        float w[8];
+        hash_corners_rt(lt, (int)level, x, y, z, idx, w);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) atomicAdd(&hist[idx[c] >> kBinLog2], 1u);
+    }
+    __syncthreads();
+    uint32_t* __restrict__ out = counts + (size_t)row * plan.n_bins + plan.bin0[k];
+    for (uint32_t b = threadIdx.x; b < nb; b += kBinThreads) out[b] = hist[b];
+}
+
+// counts[row][bin] -> exclusive prefix over the rows (in place), totals[bin]
+__global__ __launch_bounds__(256) void k_bin_colscan(uint32_t* __restrict__ counts, uint32_t rows, uint32_t n_bins, uint32_t* __restrict__ totals) {
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+    if (b >= n_bins) return;
+    uint32_t run = 0;
+    for (uint32_t r0 = 0; r0 < rows; r0 += 16u) {           // 16 independent loads per batch
+        uint32_t v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = r0 + u < rows ? counts[(size_t)(r0 + u) * n_bins + b] : 0u;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (r0 + u < rows) counts[(size_t)(r0 + u) * n_bins + b] = run;
+            run += v[u];
+        }
+    }
+    totals[b] = run;
+}
+
+// exclusive scan of a 1024-thread workgroup's values; returns the prefix of this thread and leaves the total in *total
+__device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t* wave_tot, uint32_t* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int w = 0; w < wave; ++w) before += wave_tot[w];
+    if (threadIdx.x == blockDim.x - 1u) *total = before + incl;
+    __syncthreads();
+    return before + incl - v;
+}
+
+// totals[n_bins] -> starts[n_bins + 1] (exclusive prefix), one workgroup
+__global__ __launch_bounds__(1024) void k_bin_start(const uint32_t* __restrict__ totals, uint32_t n_bins, uint32_t* __restrict__ starts) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t total, carry;
+    if (threadIdx.x == 0) carry = 0u;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < n_bins; b0 += 1024u) {
+        const uint32_t b = b0 + threadIdx.x;
+        const uint32_t v = b < n_bins ? totals[b] : 0u;
+        const uint32_t ex = block_exclusive_scan_1024(v, wave_tot, &total);
+        if (b < n_bins) starts[b] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) starts[n_bins] = carry;
+}
+
+struct BinFillLds {
+    BinItem items[kBinRound * 8];                 // 48 KB: one round's items sorted by bin
+    uint16_t item_bin[kBinRound * 8];             //  8 KB
+    uint32_t hist[kMaxBinsPerLevel];              // items per bin in this round
+    uint32_t off[kMaxBinsPerLevel];               // exclusive prefix of hist
+    uint32_t base[kMaxBinsPerLevel];              // where this row's next item of the bin goes in the global item array
+    uint32_t wave_tot[kBinThreads / 64];
+};
+
+__global__ __launch_bounds__(kBinThreads) void k_bin_fill(LevelTab lt, BoxTab bt, PointSrc ps, uint32_t M, const float* __restrict__ d_feat,
+                                                          size_t stride_m, size_t stride_l, BinPlan plan, const uint32_t* __restrict__ counts,
+                                                          const uint32_t* __restrict__ starts, BinItem* __restrict__ items_out,
+                                                          const uint32_t* __restrict__ m_dev) {
+    extern __shared__ __attribute__((aligned(16))) char bin_smem[];
+    BinFillLds& L = *reinterpret_cast<BinFillLds*>(bin_smem);
+    if (m_dev != nullptr) M = m_dev[0];
+    const uint32_t row = blockIdx.x, k = blockIdx.y, level = plan.first_level + k;
+    const uint32_t nb = plan.bin0[k + 1] - plan.bin0[k];
+    {
+        const uint32_t* __restrict__ cnt = counts + (size_t)row * plan.n_bins + plan.bin0[k];
+        const uint32_t* __restrict__ stt = starts + plan.bin0[k];
+        for (uint32_t b = threadIdx.x; b < nb; b += kBinThreads) {
+            L.base[b] = stt[b] + cnt[b];
+            L.hist[b] = 0u;
+        }
+    }
+    __syncthreads();
+    uint32_t m_lo, m_hi;
+    bin_row_range(M, gridDim.x, row, m_lo, m_hi);
+    const uint32_t sm32 = (uint32_t)stride_m, sl32 = (uint32_t)stride_l;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t r0 = m_lo; r0 < m_hi; r0 += (uint32_t)kBinRound) {
+        // 1. this thread's points -> items in registers, rank of each item within (round, bin)
+        uint32_t e_idx[kBinPtsPerThread][8], e_rank[kBinPtsPerThread][8];
+        float e_w[kBinPtsPerThread][8];
+        float2 e_g[kBinPtsPerThread];
+#pragma unroll
+        for (int q = 0; q < kBinPtsPerThread; ++q) {
+            const uint32_t m = r0 + (uint32_t)q * kBinThreads + threadIdx.x;
+            e_g[q] = make_float2(0.0f, 0.0f);
+            if (m < m_hi) e_g[q] = *reinterpret_cast<const float2*>(d_feat + (size_t)m * sm32 + (size_t)level * sl32);
+            if (e_g[q].x == 0.0f && e_g[q].y == 0.0f) continue;
+            float x, y, z;
+            load_point(ps, bt, m, x, y, z);
+            hash_corners_rt(lt, (int)level, x, y, z, e_idx[q], e_w[q]);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) e_rank[q][c] = atomicAdd(&L.hist[e_idx[q][c] >> kBinLog2], 1u);
+        }
+        __syncthreads();
+        // 2. exclusive prefix of the round's histogram (thread t: bins [8t, 8t+8))
+        {
+            uint32_t loc[kMaxBinsPerLevel / kBinThreads], s = 0;
+#pragma unroll
+            for (int u = 0; u < kMaxBinsPerLevel / kBinThreads; ++u) {
+                const uint32_t b = threadIdx.x * (kMaxBinsPerLevel / kBinThreads) + u;
+                loc[u] = b < nb ? L.hist[b] : 0u;
+                s += loc[u];
+            }
+            uint32_t incl = s;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            if (lane == 63) L.wave_tot[wave] = incl;
+            __syncthreads();
+            uint32_t run = incl - s;
+            for (int w2 = 0; w2 < wave; ++w2) run += L.wave_tot[w2];
+#pragma unroll
+            for (int u = 0; u < kMaxBinsPerLevel / kBinThreads; ++u) {
+                const uint32_t b = threadIdx.x * (kMaxBinsPerLevel / kBinThreads) + u;
+                if (b < nb) L.off[b] = run;
+                run += loc[u];
+            }
+        }
+        __syncthreads();
+        const uint32_t n_items = L.off[nb - 1u] + L.hist[nb - 1u];
+        // 3. place
+#pragma unroll
+        for (int q = 0; q < kBinPtsPerThread; ++q) {
+            if (e_g[q].x == 0.0f && e_g[q].y == 0.0f) continue;
+            const float g0 = e_g[q].x * 256.0f, g1 = e_g[q].y * 256.0f;       // the 2^8 of to_fix40 folded in once per point
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const uint32_t b = e_idx[q][c] >> kBinLog2;
+                const uint32_t pos = L.off[b] + e_rank[q][c];
+                L.items[pos] = BinItem{e_idx[q][c] & (kBinEntries - 1u), e_w[q][c] * g0, e_w[q][c] * g1};
+                L.item_bin[pos] = (uint16_t)b;
+            }
+        }
+        __syncthreads();
+        // 4. write the runs: consecutive sorted positions of a bin go to consecutive addresses
+        for (uint32_t i = threadIdx.x; i < n_items; i += kBinThreads) {
+            const uint32_t b = L.item_bin[i];
+            items_out[(size_t)L.base[b] + (i - L.off[b])] = L.items[i];
+        }
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < nb; b += kBinThreads) {
+            L.base[b] += L.hist[b];
+            L.hist[b] = 0u;
+        }
+        __syncthreads();
+    }
+}
+
+// One workgroup per bin: accumulate, then finish the bin's slice of the gradient (write / add), or step Adam on it.
+__global__ __launch_bounds__(kBinApplyThreads) void k_bin_apply(LevelTab lt, BinPlan plan, const uint32_t* __restrict__ starts,
+                                                                const BinItem* __restrict__ items, float* __restrict__ d_table, int overwrite,
+                                                                const float* __restrict__ scale_dev, AdamFuse adam) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long bin_acc[];           // [kBinEntries][2]
+    const uint32_t bin = blockIdx.x;
+    uint32_t k = 0;
+#pragma unroll
+    for (int u = 1; u < kLevels; ++u) k += (u < (int)plan.n_levels && bin >= plan.bin0[u]) ? 1u : 0u;
+    const uint32_t level = plan.first_level + k, chunk = bin - plan.bin0[k];
+    const uint32_t i_lo = starts[bin], i_hi = starts[bin + 1u];
+    const bool fused = adam.on && adam.p[0] != nullptr;
+    if (i_lo == i_hi && !fused && !overwrite) return;             // nothing to add
+    const uint32_t n_e = lt.size[level] - chunk * kBinEntries < kBinEntries ? lt.size[level] - chunk * kBinEntries : kBinEntries;
+    if (i_lo != i_hi) {
+        for (uint32_t i = threadIdx.x; i < 2u * kBinEntries; i += kBinApplyThreads) bin_acc[i] = 0ull;
+        __syncthreads();
+        // four independent item loads in flight per thread
+        for (uint32_t i0 = i_lo + threadIdx.x; i0 < i_hi; i0 += 4u * kBinApplyThreads) {
+            BinItem it[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = i0 + (uint32_t)u * kBinApplyThreads;
+                it[u] = items[i < i_hi ? i : i_hi - 1u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i0 + (uint32_t)u * kBinApplyThreads >= i_hi) break;
+                atomicAdd(bin_acc + 2u * it[u].rel, to_fix40_scaled(it[u].v0));            // ds_add_u64
+                atomicAdd(bin_acc + 2u * it[u].rel + 1u, to_fix40_scaled(it[u].v1));
+            }
+        }
+        __syncthreads();
+    }
+    const double inv = kFixInv * (double)(scale_dev != nullptr ? scale_dev[0] : 1.0f);
+    const size_t p0 = ((size_t)lt.off[level] + (size_t)chunk * kBinEntries) * 2u;          // first parameter of the slice; a multiple of 16
+    const bool have = i_lo != i_hi;
+    AdamCoef co{1.0f, 1.0f};
+    if (fused) co = adam_coef(adam);
+    for (uint32_t q = threadIdx.x; q < n_e / 2u; q += kBinApplyThreads) {                   // float4 = two entries (sizes are multiples of 8)
+        float4 g = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (have) {
+            g.x = (float)((double)(long long)bin_acc[4u * q + 0u] * inv);
+            g.y = (float)((double)(long long)bin_acc[4u * q + 1u] * inv);
+            g.z = (float)((double)(long long)bin_acc[4u * q + 2u] * inv);
+            g.w = (float)((double)(long long)bin_acc[4u * q + 3u] * inv);
+        }
+        const size_t i4 = p0 / 4u + q;
+        if (d_table != nullptr) {
+            float4* d = reinterpret_cast<float4*>(d_table) + i4;
+            if (overwrite) *d = g;
+            else if (have) { float4 o = *d; o.x += g.x; o.y += g.y; o.z += g.z; o.w += g.w; *d = o; }
+        }
+        if (fused) adam_apply4(adam, co, i4, g);
+    }
+}
+
+}  // namespace naruto

@@ -202,6 +202,38 @@ __device__ __forceinline__ float2 hash_level_rt(const LevelTab& lt, int T, const
     return acc;
 }
 
+// hash_corners with the level as a RUNTIME (wave-uniform) index: same indices, same weight association.
+__device__ __forceinline__ void hash_corners_rt(const LevelTab& lt, int T, float x, float y, float z, uint32_t (&idx)[8], float (&w)[8]) {
+    const float scale = lt.scale[T];
+    const uint32_t res = lt.res[T];
+    const uint32_t size = lt.size[T];
+    const float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
+    const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+    const uint32_t gx = (uint32_t)(int)fx, gy = (uint32_t)(int)fy, gz = (uint32_t)(int)fz;
+    const float wx = px - fx, wy = py - fy, wz = pz - fz;
+    const float ux = 1.0f - wx, uy = 1.0f - wy, uz = 1.0f - wz;
+    if ((lt.hashed >> T) & 1u) {
+        const uint32_t mask = size - 1u;
+        const uint32_t hy0 = gy * kPrime1, hy1 = hy0 + kPrime1;
+        const uint32_t hz0 = gz * kPrime2, hz1 = hz0 + kPrime2;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) idx[c] = ((gx + (uint32_t)(c & 1)) ^ ((c & 2) ? hy1 : hy0) ^ ((c & 4) ? hz1 : hz0)) & mask;
+    } else {
+        const uint32_t r2 = res * res;
+        const uint32_t base = gx + gy * res + gz * r2;
+        const uint32_t magic = 0xFFFFFFFFu / size;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            uint32_t i = base + (uint32_t)(c & 1) + ((c & 2) ? res : 0u) + ((c & 4) ? r2 : 0u);
+            i -= __umulhi(i, magic) * size;
+            if (i >= size) i -= size;
+            idx[c] = i;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) w[c] = ((c & 1) ? wx : ux) * ((c & 2) ? wy : uy) * ((c & 4) ? wz : uz);
+}
+
 // Half of a level's interpolation: the four corners with x offset ``xh`` (0 or 1), i.e. sum over (dy,dz) of w * table[idx].
 // Used with the two halves of a wave working on the SAME 32 points (lanes j and j+32, xh = lane >> 5): the x-neighbour
 // corners idx(x) and idx(x+1) differ only in their low bits (hashed: (gx ^ h) vs ((gx+1) ^ h); dense: consecutive), so in

@@ -1256,6 +1256,26 @@ __device__ __forceinline__ void adam_apply(const AdamFuse& a, const AdamCoef& c,
     a.p[tensor][i] = pi - (a.lr[tensor] / c.bc1) * (mi / (sqrtf(vi) / c.bc2_sqrt + a.eps[tensor]));
 }
 
+// float4-wide form for the table (tensor 0): parameters 4 i4 .. 4 i4 + 3
+__device__ __forceinline__ void adam_apply4(const AdamFuse& a, const AdamCoef& c, size_t i4, const float4& s) {
+    const float step_size = a.lr[0] / c.bc1, eps = a.eps[0], wd = a.wd[0];
+    float4 pv = reinterpret_cast<float4*>(a.p[0])[i4], mv = reinterpret_cast<float4*>(a.m[0])[i4], vv = reinterpret_cast<float4*>(a.v[0])[i4];
+    float* pp = &pv.x; float* mm = &mv.x; float* vw = &vv.x; const float* gg = &s.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float gi = gg[k];
+        if (wd != 0.0f) gi = fmaf(wd, pp[k], gi);
+        const float mi = mm[k] + (gi - mm[k]) * (1.0f - a.b1);
+        const float vi = a.b2 * vw[k] + (1.0f - a.b2) * gi * gi;
+        mm[k] = mi;
+        vw[k] = vi;
+        pp[k] = pp[k] - step_size * (mi / (sqrtf(vi) / c.bc2_sqrt + eps));
+    }
+    reinterpret_cast<float4*>(a.p[0])[i4] = pv;
+    reinterpret_cast<float4*>(a.m[0])[i4] = mv;
+    reinterpret_cast<float4*>(a.v[0])[i4] = vv;
+}
+
 __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ partials, uint32_t n_blocks, const NarutoGrads& g, int overwrite, uint32_t block,
                                                   const AdamFuse* __restrict__ adam = nullptr) {
     __shared__ float red[8][32];
@@ -1333,26 +1353,7 @@ __global__ __launch_bounds__(256) void k_bwd_finish(LevelTab lt, const float* __
         s.x += f0.x; s.y += f1.x; s.z += f0.y; s.w += f1.y;
     }
     if (g.table != nullptr) reinterpret_cast<float4*>(g.table)[i4] = s;
-    if (adam.on && adam.p[0] != nullptr) {
-        // float4-wide version of adam_apply for tensor 0
-        const AdamCoef c = adam_coef(adam);
-        const float step_size = adam.lr[0] / c.bc1, eps = adam.eps[0], wd = adam.wd[0];
-        float4 pv = reinterpret_cast<float4*>(adam.p[0])[i4], mv = reinterpret_cast<float4*>(adam.m[0])[i4], vv = reinterpret_cast<float4*>(adam.v[0])[i4];
-        float* pp = &pv.x; float* mm = &mv.x; float* vw = &vv.x; const float* gg = &s.x;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float gi = gg[k];
-            if (wd != 0.0f) gi = fmaf(wd, pp[k], gi);
-            const float mi = mm[k] + (gi - mm[k]) * (1.0f - adam.b1);
-            const float vi = adam.b2 * vw[k] + (1.0f - adam.b2) * gi * gi;
-            mm[k] = mi;
-            vw[k] = vi;
-            pp[k] = pp[k] - step_size * (mi / (sqrtf(vi) / c.bc2_sqrt + eps));
-        }
-        reinterpret_cast<float4*>(adam.p[0])[i4] = pv;
-        reinterpret_cast<float4*>(adam.m[0])[i4] = mv;
-        reinterpret_cast<float4*>(adam.v[0])[i4] = vv;
-    }
+    if (adam.on && adam.p[0] != nullptr) adam_apply4(adam, adam_coef(adam), i4, s);
 }
 
 }  // namespace naruto

@@ -147,7 +147,7 @@ class _HashEncode(torch.autograd.Function):
             d_feat = _f32c(d_feat, "d_feat")
             d_table = torch.zeros_like(table)
             with torch.cuda.device(x.device):
-                ws = torch.empty((lib.naruto_scatter_workspace(ctx.handle.ptr) + 3) // 4, dtype=torch.float32, device=x.device)
+                ws = torch.empty((lib.naruto_scatter_workspace(ctx.handle.ptr, x.shape[0]) + 3) // 4, dtype=torch.float32, device=x.device)
                 check(lib.naruto_hash_encode_bwd(ctx.handle.ptr, x.shape[0], _p(x), _p(d_feat), None, _p(d_table), _p(ws), _stream()),
                       "naruto_hash_encode_bwd")
         return None, None, d_table
@@ -189,7 +189,7 @@ class _Smoothness(torch.autograd.Function):
         g = _f32c(g, "grad").reshape(1)
         d_table = torch.zeros_like(table)
         with torch.cuda.device(x.device):
-            ws = torch.empty((lib.naruto_scatter_workspace(ctx.handle.ptr) + 3) // 4, dtype=torch.float32, device=x.device)
+            ws = torch.empty((lib.naruto_scatter_workspace(ctx.handle.ptr, x.shape[0]) + 3) // 4, dtype=torch.float32, device=x.device)
             check(lib.naruto_hash_encode_bwd(ctx.handle.ptr, x.shape[0], _p(x), _p(d_feat), _p(g), _p(d_table), _p(ws), _stream()),
                   "naruto_hash_encode_bwd")
         return None, d_table, None, None, None, None
@@ -527,8 +527,9 @@ class _RenderTrain(torch.autograd.Function):
 
 
 def handle_supports_overwrite(handle: FieldHandle) -> bool:
-    """Table gradients can be written (not accumulated) when every level is LDS-tiled, i.e. log2_hashmap_size <= 17."""
-    return handle.desc.log2_hashmap_size <= 17
+    """Table gradients can be written (not accumulated) and the optimiser fused into the backward for every table size; only
+    the debug switch NARUTO_DEBUG_SCATTER_ATOMIC (large levels through global float atomics) turns that off."""
+    return bool(_lib.load().naruto_field_scatter_overwrites(handle.ptr))
 
 
 def render_train(handle: FieldHandle, params: Dict[str, torch.Tensor], rays_o, rays_d, z_vals, target_rgb, target_d,
@@ -655,7 +656,7 @@ class TrainStep:
         runs.  The launch that finishes the gradients then applies the Adam step in place; with ``write_grads=False`` the
         table / weight gradients are not materialised at all."""
         assert self.group is None, "the fused optimiser is single-process: data-parallel ranks must all-reduce gradients first"
-        assert handle_supports_overwrite(self.handle), "the fused optimiser needs every level LDS-tiled (log2_hashmap_size <= 16)"
+        assert handle_supports_overwrite(self.handle), "the fused optimiser is not available with NARUTO_DEBUG_SCATTER_ATOMIC"
         o = _lib.NarutoFusedAdam()
         self._opt_keep = []
         for k, name in enumerate(self.FLAT_NAMES):

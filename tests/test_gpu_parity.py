@@ -146,7 +146,7 @@ def test_query_boundary_sweeps(gpu, hash_size):
 @pytest.mark.parametrize("case", list(range(10)))
 def test_random_field_configs(gpu, case):
     """Drawn scene boxes (anisotropic, 1 .. 25 m), finest voxel sizes and table sizes 2^10 .. 2^18 (18: larger than the LDS-tiled
-    scatter takes, global atomics): level tables, features, outputs and every gradient of the fused query against the oracle, on
+    scatter takes: the binned scatter): level tables, features, outputs and every gradient of the fused query against the oracle, on
     points inside and outside the box."""
     from naruto_amd import config as C
     rs = np.random.RandomState(500 + case)
@@ -207,6 +207,115 @@ def test_hash_encode_vs_oracle(gpu, kind):
         want = ora.query_sdf(torch.from_numpy(x), embed=True)
         got = m.query_sdf(torch.from_numpy(x).to(gpu), embed=True)
     H.assert_close(got, want, 2e-6, f"{kind}.embed")
+
+
+# --------------------------------------------------------------------------------------------- large tables: the binned scatter
+@pytest.mark.parametrize("log2_T", [18, 20, 22])
+def test_hash_encode_backward_large_tables(gpu, log2_T):
+    """Tables of 2^18 .. 2^22 entries per level (configs[4]: unit cube, finest level 1024^3, 2^22 = the HBM-resident table):
+    the levels beyond 2^17 entries go through the binned scatter (counting sort into 8 192-entry bins + one LDS accumulation
+    per bin, no global float atomics).  Against oracle autograd on points inside / outside the box and with colliding
+    points; and bitwise reproducible -- a second run and a permuted point order give the identical gradient."""
+    from naruto_amd import config as C, ops
+    cfg = C.unit_cube_config(1024, log2_T)
+    ora = H.make_oracle(cfg, 0.3, 13)
+    m = H.make_hip_from_oracle(cfg, ora, gpu)
+    sc, res, size, off = m._handle().levels()
+    assert np.array_equal(np.asarray(size), ora.meta.size) and np.array_equal(np.asarray(off), ora.meta.offset)
+    assert max(size) == min(1 << log2_T, 1 << 22) or log2_T > 22
+    rs = np.random.RandomState(log2_T)
+    base = rs.uniform(0, 1, size=(6000, 3))
+    x = np.concatenate([base, base[:500], base[:500] + 1e-4,                     # exact repeats and near neighbours: collisions inside a bin
+                        rs.uniform(-0.6, 1.6, size=(700, 3)), np.array([[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5]])]).astype(np.float32)
+    c = rs.normal(size=(x.shape[0], 32)).astype(np.float32)
+    c[rs.uniform(size=x.shape[0]) < 0.2] = 0.0                                    # points without a cotangent are skipped by the sort
+    xt, ct = torch.from_numpy(x), torch.from_numpy(c)
+    feat_o = ora.query_sdf(xt, embed=True)
+    (feat_o * ct).sum().backward()
+    want = ora.table.grad
+    table = m.embed_fn.params
+
+    def run(xx, cc):
+        table.grad = None
+        f = ops.hash_encode(m._handle(), xx.to(gpu), table)
+        (f * cc.to(gpu)).sum().backward()
+        return table.grad.detach().clone()
+
+    got = run(xt, ct)
+    H.assert_close(ops.hash_encode(m._handle(), xt.to(gpu), table), feat_o.detach(), 2e-6, f"T{log2_T}.embed")
+    grad_close(got, want, f"T{log2_T}.grad.table")
+    for l in range(16):                                                           # every level carries its share (tiled and binned ones)
+        a, b = got[2 * off[l]:2 * off[l + 1]].double().cpu(), want[2 * off[l]:2 * off[l + 1]].double()
+        assert abs(float(a.abs().sum()) - float(b.abs().sum())) <= 1e-4 * float(b.abs().sum()) + 1e-12, f"level {l}"
+    assert torch.equal(run(xt, ct), got), "second run differs: the scatter is not reproducible"
+    perm = torch.from_numpy(rs.permutation(x.shape[0]))
+    assert torch.equal(run(xt[perm], ct[perm]), got), "permuted point order changes the gradient: accumulation is order-dependent"
+
+
+@pytest.mark.parametrize("log2_T", [18, 20, 22])
+def test_train_step_large_tables(gpu, log2_T):
+    """The trainer's fast path (naruto_train_forward / naruto_train_backward) on the unit-cube volume of configs[4] with 2^18 ..
+    2^22-entry levels, reduced ray count: every loss and every gradient against the CPU oracle, with the smoothness lattice
+    riding in the same scatter; then the optimiser fused into the backward (the binned scatter's last kernel steps the large
+    levels in place) against gradients + a separate Adam launch, three iterations."""
+    from naruto_amd import config as C, ops, trainer
+    cfg = C.unit_cube_config(1024, log2_T, perturb=1.0)
+    tr, cam = cfg["training"], cfg["cam"]
+    ora = H.make_oracle(cfg, 0.05, 29)
+    m = H.make_hip_from_oracle(cfg, ora, gpu)
+    N = 301
+    S_tot = tr["n_samples_d"] + tr["n_range_d"]
+    rays = syn.random_rays(N, cfg["mapping"]["bound"], seed=29, zero_depth_frac=0.1)
+    rays["target_d"] = (rays["target_d"] * 0.25).astype(np.float32)                # depths inside the unit cube (far = 1)
+    t = {k: torch.from_numpy(v) for k, v in rays.items()}
+    r6 = torch.tensor([0.35, 0.1, 0.75, 0.2, 0.9, 0.5])
+    rand = torch.rand(N, S_tot, generator=torch.Generator().manual_seed(3))
+    sp, vox, mar = 12, 0.02, 0.01
+    w_s = 0.5
+    w = torch.tensor([tr["rgb_weight"], tr["depth_weight"], tr["sdf_weight"], tr["fs_weight"], 0.0, tr["uncert_weight"], 0.0, 0.0, w_s, 0.0])
+    ora.train()
+    ret_o = ora.forward(t["rays_o"], t["rays_d"], t["target_rgb"], t["target_d"], rand=rand)
+    sm_o = S.smoothness(ora, sp, vox, mar, r6[:3], r6[3:])
+    total_o = S.total_loss(ret_o, tr) + w_s * sm_o
+    total_o.backward()
+    go = H.ora_grads(ora)
+    ug = torch.zeros_like(m.uncert_grid)
+    ts = ops.TrainStep(m._handle(), m._params(), ug, N, n_samples_d=tr["n_samples_d"], n_range_d=tr["n_range_d"], near=cam["near"], far=cam["far"],
+                       range_d=tr["range_d"], depth_trunc=cam["depth_trunc"], rgb_missing=tr["rgb_missing"], perturb=True,
+                       loss_weights=w.to(gpu), smooth=(sp, vox, mar), device_rng=False)
+    assert ops.handle_supports_overwrite(m._handle())
+    args = [t[k].to(gpu).contiguous() for k in ("rays_o", "rays_d", "target_rgb")] + [t["target_d"].to(gpu).reshape(-1).contiguous()]
+    for rep in range(2):                                     # written, not accumulated: a second run gives the same table gradient
+        ts.rand[N * S_tot:].copy_(r6)
+        losses = ts.run(*args, rand=rand.to(gpu))
+        torch.cuda.synchronize()
+        for i, k in enumerate(("rgb_loss", "depth_loss", "sdf_loss", "fs_loss")):
+            H.assert_close(losses[i].reshape(-1), ret_o[k].reshape(-1), 1e-6, f"T{log2_T}.{k}", rel=1e-4)
+        H.assert_close(losses[8].reshape(-1), sm_o.reshape(-1), 1e-7, f"T{log2_T}.smooth", rel=1e-4)
+        H.assert_close(losses[9].reshape(-1), total_o.detach().reshape(-1), 1e-5, f"T{log2_T}.total", rel=1e-4)
+        for k in ("table", "sdf_w0", "sdf_w1", "col_w0", "col_w1"):
+            grad_close(ts.grads[k].reshape(-1), go[k].reshape(-1), f"T{log2_T}.rep{rep}.grad.{k}")
+    del ts, ora, go
+    # fused optimiser vs gradients + separate Adam, same in-kernel random numbers
+    bound = torch.tensor(cfg["mapping"]["bound"])
+    torch.manual_seed(4)
+    a = trainer.MappingTrainer(cfg, bound, gpu, fused_adam=True)
+    b = trainer.MappingTrainer(cfg, bound, gpu, fused_adam=True)
+    with torch.no_grad():
+        a.model.embed_fn.params.mul_(500.0)                  # tcnn's U(-1e-4, 1e-4) init scaled up so that the table matters
+    b.model.load_state_dict(a.model.state_dict())
+    b.iter_state.copy_(a.iter_state)
+    a.fuse_optimizer = False
+    for it in range(3):
+        rays = syn.random_rays(257, cfg["mapping"]["bound"], seed=40 + it, zero_depth_frac=0.1)
+        rays["target_d"] = (rays["target_d"] * 0.25).astype(np.float32)
+        tt = [torch.from_numpy(rays[k]).to(gpu) for k in ("rays_o", "rays_d", "target_rgb", "target_d")]
+        ra, la = a.step(*tt, smooth=True)
+        rb, lb = b.step(*tt, smooth=True)
+        H.assert_close(lb.reshape(-1), la.reshape(-1), 1e-7, f"T{log2_T}.iter{it}.loss", rel=1e-6)
+    assert next(iter(b._train_steps.values())).opt is not None and next(iter(a._train_steps.values())).opt is None
+    for (n, p), (_, q) in zip(a.model.named_parameters(), b.model.named_parameters()):
+        H.assert_close(q, p, 5e-6, f"T{log2_T}.param {n}", rel=1e-5)
 
 
 # --------------------------------------------------------------------------------------------- A6 / A7

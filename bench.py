@@ -275,6 +275,21 @@ def cpu_baseline(cfg, n_rays: int, device=None, budget_s: float = 30.0):
                 f"{S_tot / 43.0:.2f} for the workload's sampling)")
         S_tot = 43
         step = build(c)
+    sweep = ""
+    if not on_gpu:
+        # many-core hosts: torch's CPU kernels stop scaling (and fall back) well before all cores -- 128 threads measured 4x SLOWER
+        # than 16 on the MI355X hosts -- so the thread count is the best of a short sweep up to the physical cores
+        cand = sorted({n for n in (8, 16, 32, 64, physical_cores()) if n <= physical_cores()})
+        best, res = None, []
+        for n in cand:
+            torch.set_num_threads(n)
+            m_, _ = timed(step, 1, 2)
+            res.append(f"{n}: {m_ * 1e3:.0f} ms")
+            if best is None or m_ < best[0]:
+                best = (m_, n)
+        torch.set_num_threads(best[1])
+        used_threads = best[1]
+        sweep = "; thread sweep (ms/iter): " + ", ".join(res)
     warm, iters = (5, 20) if not on_gpu else (2, 10)
     med, ts = timed(step, warm, iters)
     if not on_gpu:
@@ -286,8 +301,10 @@ def cpu_baseline(cfg, n_rays: int, device=None, budget_s: float = 30.0):
     if on_gpu:
         out["kind"] = "port, unfused torch ops on the same GPU"
     else:
-        out["cores"] = physical_cores()
+        out["cores"] = used_threads
+        out["physical_cores"] = physical_cores()
         out["logical_cpus"] = os.cpu_count()
+        out["sample"] += sweep
         out["samples_per_ray"] = S_tot
     return out
 

@@ -49,7 +49,13 @@ typedef struct NarutoFieldDesc {
     float    trunc;               /* training.trunc                                              */
     float    sc_factor;           /* data.sc_factor                                              */
     int32_t  white_bkgd;          /* training.white_bkgd                                         */
+    uint32_t mlp_mode;            /* NARUTO_MLP_FP32 (exact fp32 MFMA chain: the parity mode) or
+                                     NARUTO_MLP_BF16 (bf16 operands, fp32 accumulate, on v_mfma_f32_32x32x16_bf16: the
+                                     speed mode; the reference's counterpart is its half-precision tcnn FullyFusedMLP
+                                     option, decoder.py:43-59)                                  */
 } NarutoFieldDesc;
+#define NARUTO_MLP_FP32 0u
+#define NARUTO_MLP_BF16 1u
 
 /* Learnable parameters, in the reference's own layouts (state_dict tensors):
  *   table        embed_fn.params                         [n_entries * 2]
@@ -372,6 +378,9 @@ int naruto_debug_train_query_fwd(const NarutoField* f, const NarutoParams* p, co
  * out: device buffer of 64*16 floats; returns 0 and fills out (see tests/test_gpu_parity.py: test_mfma_layout, test_permlane32_swap). */
 int naruto_debug_mfma_layout(const float* a, const float* b, float* out, void* stream);
 int naruto_debug_permlane_swap(const float* v0, const float* v1, float* out, void* stream);
+/* a [32,16], b [16,32] fp32 (rounded to bf16 inside) -> out [64*16]: lane l, reg r of D = A.B by v_mfma_f32_32x32x16_bf16 with
+ * A lane l = A[l&31][8*(l>>5) + e], B lane l = B[8*(l>>5) + e][l&31], e = 0..7 (test_mfma_bf16_layout). */
+int naruto_debug_mfma_bf16_layout(const float* a, const float* b, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,7 @@ class NarutoFieldDesc(C.Structure):
         ("base_resolution", C.c_uint32), ("per_level_scale", C.c_float), ("n_bins", C.c_uint32),
         ("hidden_dim", C.c_uint32), ("geo_feat_dim", C.c_uint32), ("hidden_dim_color", C.c_uint32),
         ("uncert_dims", C.c_uint32 * 3), ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3),
-        ("trunc", C.c_float), ("sc_factor", C.c_float), ("white_bkgd", C.c_int32),
+        ("trunc", C.c_float), ("sc_factor", C.c_float), ("white_bkgd", C.c_int32), ("mlp_mode", C.c_uint32),
     ]
 
 
@@ -50,6 +50,7 @@ class NarutoAdamSeg(C.Structure):
                 ("n", C.c_uint64), ("lr", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float)]
 
 
+MLP_FP32, MLP_BF16 = 0, 1
 BWD_OVERWRITE_WEIGHT_GRADS = 1
 BWD_OVERWRITE_TABLE_GRAD = 2
 ADAM_ADVANCE = 1
@@ -173,6 +174,7 @@ SIGNATURES = {
     "naruto_adam_step": (_I, [_V, _V, _V, _V, _U64, _F, _F, _F, _F, _F, _U32, _V, _V]),
     "naruto_debug_mfma_layout": (_I, [_V, _V, _V, _V]),
     "naruto_debug_permlane_swap": (_I, [_V, _V, _V, _V]),
+    "naruto_debug_mfma_bf16_layout": (_I, [_V, _V, _V, _V]),
 }
 
 _lib: Optional[C.CDLL] = None

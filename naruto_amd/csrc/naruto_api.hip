@@ -194,6 +194,7 @@ int naruto_field_create(const NarutoFieldDesc* d, NarutoField** out) {
     if (d->log2_hashmap_size < 4 || d->log2_hashmap_size > 28) return fail(NARUTO_ERR_INVALID, "create: log2_hashmap_size out of range");
     if (d->uncert_dims[0] == 0 || d->uncert_dims[1] == 0 || d->uncert_dims[2] == 0) return fail(NARUTO_ERR_INVALID, "create: empty uncert grid");
     if (!(d->trunc > 0.0f)) return fail(NARUTO_ERR_INVALID, "create: trunc must be > 0");
+    if (d->mlp_mode != NARUTO_MLP_FP32 && d->mlp_mode != NARUTO_MLP_BF16) return fail(NARUTO_ERR_INVALID, "create: unknown mlp_mode %u", d->mlp_mode);
     NarutoField* f = new (std::nothrow) NarutoField;
     if (f == nullptr) return fail(NARUTO_ERR_INVALID, "create: out of memory");
     f->desc = *d;
@@ -404,8 +405,14 @@ int naruto_query_fwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
     if (blocks > cap) blocks = cap;
     const PointSrc ps = make_points(pts);
     const EarlyExit none{};
-    if (color)
+    const bool bf = f->desc.mlp_mode == NARUTO_MLP_BF16;
+    if (color && bf)
+        hipLaunchKernelGGL(k_query_fwd_bf<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, f->lt, f->ut, f->bt, pp, ps, M, raw, sdf_uncert, geo, feat_save, none);
+    else if (color)
         hipLaunchKernelGGL(k_query_fwd<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, f->lt, f->ut, f->bt, pp, ps, M, raw, sdf_uncert, geo, feat_save, none);
+    else if (bf)
+        hipLaunchKernelGGL(k_query_fwd_bf<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, f->lt, f->ut, f->bt, pp, ps, M, raw, sdf_uncert, geo, feat_save,
+                           none);
     else
         hipLaunchKernelGGL(k_query_fwd<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, f->lt, f->ut, f->bt, pp, ps, M, raw, sdf_uncert, geo, feat_save,
                            none);
@@ -593,7 +600,10 @@ int launch_train_query(const NarutoField* f, const NarutoParams* p, const Naruto
         blocks = (N + 3u) / 4u;
         if (blocks > cu_count(f) * 4u) blocks = cu_count(f) * 4u;
     }
-    hipLaunchKernelGGL(k_query_fwd<true>, dim3(blocks), dim3(256), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
+    if (f->desc.mlp_mode == NARUTO_MLP_BF16)
+        hipLaunchKernelGGL(k_query_fwd_bf<true>, dim3(blocks), dim3(256), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
+    else
+        hipLaunchKernelGGL(k_query_fwd<true>, dim3(blocks), dim3(256), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
     return check_launch("query_fwd");
 }
 TvArgs tv_args(const NarutoTrainStep* t) {
@@ -1030,7 +1040,7 @@ int naruto_adam_multi(const NarutoAdamSeg* segs, uint32_t n_segs, float beta1, f
     return check_launch("adam_multi");
 }
 
-// ---- hardware layout probes (tests/test_gpu_intrinsics.py) ---------------------------------------
+// ---- hardware layout probes (tests/test_gpu_parity.py: test_mfma_layout, test_mfma_bf16_layout, test_permlane32_swap) ---------------------------------------
 __global__ void k_debug_mfma(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out) {
     const int lane = threadIdx.x;
     f32x16 c = zero16();
@@ -1045,6 +1055,26 @@ __global__ void k_debug_swap(const float* __restrict__ v0, const float* __restri
     swap32(a, b);
     out[lane] = a;
     out[64 + lane] = b;
+}
+
+__global__ void k_debug_mfma_bf16(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out) {
+    const int lane = threadIdx.x, i = lane & 31, hh = lane >> 5;
+    float av[8], bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        av[e] = a[i * 16 + 8 * hh + e];                 // A[i][k = 8 hh + e]
+        bv[e] = b[(8 * hh + e) * 32 + i];               // B[k = 8 hh + e][j = i]
+    }
+    f32x16 c = zero16();
+    c = mfma16(pack8(av), pack8(bv), c);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[lane * 16 + r] = c[r];
+}
+
+int naruto_debug_mfma_bf16_layout(const float* a, const float* b, float* out, void* stream) {
+    if (a == nullptr || b == nullptr || out == nullptr) return fail(NARUTO_ERR_INVALID, "debug_mfma_bf16_layout: NULL argument");
+    hipLaunchKernelGGL(k_debug_mfma_bf16, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, out);
+    return check_launch("debug_mfma_bf16_layout");
 }
 
 int naruto_debug_mfma_layout(const float* a, const float* b, float* out, void* stream) {

@@ -442,6 +442,31 @@ __device__ __forceinline__ void swap32(float& a, float& b) {
     b = __uint_as_float(r[1]);
 }
 
+// ---- bf16 matrix path (MLP "speed mode": bf16 operands, fp32 accumulate; v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the
+// fp32 form).  A operand: lane l holds A[i = l&31][k = 8*(l>>5) + e], B operand: lane l holds B[k = 8*(l>>5) + e][j = l&31],
+// e = 0..7 as eight bf16 in four registers (element e in bits 16*(e&1) of register e>>1); C/D as the fp32 form.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+// (lo, hi) -> packed pair of round-to-nearest-even bf16 (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ float bf16_round(float x) { return __uint_as_float(pk_bf16(x, 0.0f) << 16); }
+
+__device__ __forceinline__ f32x16 mfma16(u32x4_t a, u32x4_t b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void swap32u(uint32_t& a, uint32_t& b) {
+    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+
 // row index held by (reg r, half hh) of a 32x32 MFMA result
 __host__ __device__ constexpr int crow(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 

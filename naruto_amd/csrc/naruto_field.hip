@@ -159,6 +159,46 @@ struct EarlyExit {
     uint32_t tiles_per_ray;
 };
 
+// state of one ray's front-to-back walk (wave-uniform): first sign change seen, its depth, the last sample so far
+struct EeState {
+    bool found;
+    float zfirst, prev_sdf, prev_z;
+};
+
+// after tile tq of ray `task`: update the state from the tile's sdf values (lane = sample) and decide whether the ray's remaining
+// tiles can be skipped (their raw entries are then written as zeros).  Returns true = stop.
+__device__ __forceinline__ bool ee_after_tile(EeState& st, const EarlyExit& ee, const PointSrc& ps, uint32_t m, uint32_t tq, uint32_t tpr, uint32_t tile,
+                                              uint32_t task, float sdf, int lane, float* __restrict__ raw) {
+    const float zs = ps.z_vals[m];
+    if (!st.found) {
+        if (tq > 0u && st.prev_sdf * lane_f32(sdf, 0) < 0.0f) {          // the pair straddling the tile boundary
+            st.found = true;
+            st.zfirst = st.prev_z;
+        } else {
+            const float nb = __shfl_down(sdf, 1, 64);
+            const uint32_t first = wave_min_u32((lane < 63 && sdf * nb < 0.0f) ? (uint32_t)lane : 0xFFFFFFFFu);
+            if (first != 0xFFFFFFFFu) {
+                st.found = true;
+                st.zfirst = __shfl(zs, (int)first, 64);
+            }
+        }
+    }
+    const float z_last = lane_f32(zs, 63);
+    st.prev_sdf = lane_f32(sdf, 63);
+    st.prev_z = z_last;
+    if (st.found) {
+        // conservative margin: the consumers form z_first + sc*trunc and d + sc*trunc with their own rounding
+        const float lim = fmaxf(st.zfirst, ee.target_d[task]) + ee.trunc_sc;
+        if (z_last > lim + 1e-5f * fabsf(lim) + 1e-6f) {
+            if (raw != nullptr) {
+                for (uint32_t k = (tile + 1u) * 64u * 5u + lane; k < (task + 1u) * tpr * 64u * 5u; k += 64u) raw[k] = 0.0f;
+            }
+            return true;
+        }
+    }
+    return false;
+}
+
 template <bool COLOR>
 __global__ __launch_bounds__(256, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps,
                                                    uint32_t M, float* __restrict__ raw, float* __restrict__ sdf_uncert,
@@ -174,8 +214,7 @@ __global__ __launch_bounds__(256, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab
     const uint32_t tpr = ee.tiles_per_ray;
     const uint32_t n_tasks = tpr ? n_tiles / tpr : n_tiles;          // rays, or tiles of the flat point list
     for (uint32_t task = blockIdx.x * 4u + wave; task < n_tasks; task += gridDim.x * 4u) {
-    bool ee_found = false;                       // per ray (wave-uniform): first sign change seen, its depth, the last sample so far
-    float ee_zfirst = 0.0f, ee_prev_sdf = 0.0f, ee_prev_z = 0.0f;
+    EeState ees{false, 0.0f, 0.0f, 0.0f};
     for (uint32_t tq = 0; tq < (tpr ? tpr : 1u); ++tq) {
         const uint32_t tile = tpr ? task * tpr + tq : task;
         const uint32_t m_raw = tile * 64u + lane;
@@ -308,33 +347,192 @@ __global__ __launch_bounds__(256, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab
             }
         }
         if (tpr != 0u && tq + 1u < tpr) {
-            const float zs = ps.z_vals[m];
-            if (!ee_found) {
-                if (tq > 0u && ee_prev_sdf * lane_f32(sdf, 0) < 0.0f) {          // the pair straddling the tile boundary
-                    ee_found = true;
-                    ee_zfirst = ee_prev_z;
-                } else {
-                    const float nb = __shfl_down(sdf, 1, 64);
-                    const uint32_t first = wave_min_u32((lane < 63 && sdf * nb < 0.0f) ? (uint32_t)lane : 0xFFFFFFFFu);
-                    if (first != 0xFFFFFFFFu) {
-                        ee_found = true;
-                        ee_zfirst = __shfl(zs, (int)first, 64);
-                    }
+            if (ee_after_tile(ees, ee, ps, m, tq, tpr, tile, task, sdf, lane, raw)) break;
+        }
+    }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 "speed mode" of the same kernel (NarutoFieldDesc.mlp_mode = 1): the MLP products run on v_mfma_f32_32x32x16_bf16 --
+// bf16 operands (round to nearest even), fp32 accumulation -- at 16x the matrix rate of the exact fp32 form.  Everything
+// else (gathers, trilinear blend, OneBlob, the 32 -> 3 colour layer, compositing) stays fp32.  The reference has the same
+// switch: its optional tcnn FullyFusedMLP decoder computes in half precision (reference src/slam/coslam/model/decoder.py:43-59).
+//
+// Same trick as the fp32 kernel, wider: a K block of 16 inputs is split over the two half-waves (8 each), and
+//   * hash levels: after the x-half exchange lane (j, hh) holds feature hh of level T of point j -- eight levels packed are
+//     exactly its half of a K block (slot e <-> level 8 kb + e, the weights are staged in that order);
+//   * OneBlob: a lane owns the 16 bins of one coordinate of ITS point; one v_permlane32_swap per packed register hands bins
+//     8..15 of points 0..31 to the high half and bins 0..7 of points 32..63 to the low half -- tile A / tile B operands;
+//   * layer to layer: C/D register r of half hh is unit crow(r, hh), so registers 8 kb .. 8 kb + 7 packed are the half-K-block
+//     of the next layer (weights staged in crow order).
+// 22 matrix instructions per 64 points (704 cycles per SIMD) instead of ~130 fp32 ones (8 300).
+// ------------------------------------------------------------------------------------------------
+struct FwdLdsBf {
+    u32x4_t s0[5 * 64];    // sdf layer 0: K blocks 0,1 = hash levels 0..7 / 8..15 (slot (hh,e): feature hh of level 8kb+e); 2..4 = OneBlob x,y,z
+    u32x4_t c0[4 * 64];    // colour layer 0: K blocks 0..2 = OneBlob x,y,z; 3 = sdf-net outputs (slot (hh,e): row crow(e,hh), row 0 = sdf unused)
+    u32x4_t s1[2 * 64];    // sdf layer 1: slot (hh,e) of block kb = hidden unit crow(8kb+e, hh); rows >= 16 zero
+    float c1[3 * 16 * 2];  // colour layer 1 (fp32 VALU), as FwdLds::c1
+};
+
+template <int NT>
+__device__ __forceinline__ void stage_fwd_weights_bf(FwdLdsBf& L, const NarutoParams& p, int tid) {
+#pragma unroll
+    for (int e0 = 0; e0 < 11 * 64; e0 += NT) {
+        const int e = e0 + tid;
+        if (e >= 11 * 64) continue;
+        const int t = e >> 6, l = e & 63, i = l & 31, hh = l >> 5;
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (t < 2) v[q] = p.sdf_w0[i * kInSdf + 2 * (8 * t + q) + hh];
+            else if (t < 5) v[q] = p.sdf_w0[i * kInSdf + kFeat + 16 * (t - 2) + 8 * hh + q];
+            else if (t < 8) v[q] = p.col_w0[i * kInCol + 16 * (t - 5) + 8 * hh + q];
+            else if (t == 8) { const int row = crow(q, hh); v[q] = row >= 1 ? p.col_w0[i * kInCol + kPos + row - 1] : 0.0f; }
+            else v[q] = i < kOut ? p.sdf_w1[i * kHidden + crow(8 * (t - 9) + q, hh)] : 0.0f;
+        }
+        const u32x4_t w = {pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
+        if (t < 5) L.s0[t * 64 + l] = w;
+        else if (t < 9) L.c0[(t - 5) * 64 + l] = w;
+        else L.s1[(t - 9) * 64 + l] = w;
+    }
+#pragma unroll
+    for (int e0 = 0; e0 < 3 * 16 * 2; e0 += NT) {
+        const int e = e0 + tid;
+        if (e >= 3 * 16 * 2) continue;
+        const int c = e / 32, r = (e >> 1) & 15, hh = e & 1;
+        L.c1[e] = p.col_w1[c * kHidden + crow(r, hh)];
+    }
+}
+
+__device__ __forceinline__ u32x4_t pack8(const float (&v)[8]) {
+    return u32x4_t{pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
+}
+// eight consecutive accumulator registers, ReLU'd or not, as a half K block
+template <bool RELU>
+__device__ __forceinline__ u32x4_t pack8_acc(const f32x16& a, int r0) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = RELU ? fmaxf(a[r0 + q], 0.0f) : a[r0 + q];
+    return pack8(v);
+}
+
+template <bool COLOR>
+__global__ __launch_bounds__(256, NARUTO_FWD_MINWAVES) void k_query_fwd_bf(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps,
+                                                      uint32_t M, float* __restrict__ raw, float* __restrict__ sdf_uncert,
+                                                      float* __restrict__ geo, float* __restrict__ feat_save, EarlyExit ee) {
+    __shared__ FwdLdsBf L;
+    stage_fwd_weights_bf<256>(L, p, threadIdx.x);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hh = lane >> 5, j = lane & 31;
+    const uint32_t n_tiles = (M + 63u) / 64u;
+    const float2* __restrict__ table = reinterpret_cast<const float2*>(p.table);
+    const uint32_t tpr = ee.tiles_per_ray;
+    const uint32_t n_tasks = tpr ? n_tiles / tpr : n_tiles;
+    for (uint32_t task = blockIdx.x * 4u + wave; task < n_tasks; task += gridDim.x * 4u) {
+    EeState ees{false, 0.0f, 0.0f, 0.0f};
+    for (uint32_t tq = 0; tq < (tpr ? tpr : 1u); ++tq) {
+        const uint32_t tile = tpr ? task * tpr + tq : task;
+        const uint32_t m_raw = tile * 64u + lane;
+        const bool valid = m_raw < M;
+        const uint32_t m = valid ? m_raw : M - 1u;
+        float x, y, z;
+        load_point(ps, bt, m, x, y, z);
+        const float u = uncert_sample(ut, p.uncert_grid, x, y, z);
+
+        f32x16 hA = zero16(), hB = zero16(), cA = zero16(), cB = zero16();
+        float xa = x, xb = x, ya = y, yb = y, za = z, zb = z;
+        swap32(xa, xb); swap32(ya, yb); swap32(za, zb);        // xa = x of points (0..31 | 0..31), xb = (32..63 | 32..63)
+        const uint32_t mA = tile * 64u + (uint32_t)j, mB = mA + 32u;
+        for (int kb = 0; kb < 2; ++kb) {
+            float fa[8], fb[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int T = 8 * kb + e;
+                const float2 pa = hash_level_half_rt(lt, T, table, xa, ya, za, (uint32_t)hh);
+                const float2 pb = hash_level_half_rt(lt, T, table, xb, yb, zb, (uint32_t)hh);
+                float ua = pa.x, wa = pa.y, ub = pb.x, wb = pb.y;
+                swap32(ua, wa);
+                swap32(ub, wb);
+                fa[e] = ua + wa;                      // feature hh of level T of point j (tile A) / j + 32 (tile B), fp32
+                fb[e] = ub + wb;
+                if (feat_save != nullptr) {
+                    char* __restrict__ fs = reinterpret_cast<char*>(feat_save + (size_t)T * M * 2u);
+                    if (mA < M) *reinterpret_cast<float*>(fs + ((mA * 2u + (uint32_t)hh) << 2)) = fa[e];
+                    if (mB < M) *reinterpret_cast<float*>(fs + ((mB * 2u + (uint32_t)hh) << 2)) = fb[e];
                 }
             }
-            const float z_last = lane_f32(zs, 63);
-            ee_prev_sdf = lane_f32(sdf, 63);
-            ee_prev_z = z_last;
-            if (ee_found) {
-                // conservative margin: the consumers form z_first + sc*trunc and d + sc*trunc with their own rounding
-                const float lim = fmaxf(ee_zfirst, ee.target_d[task]) + ee.trunc_sc;
-                if (z_last > lim + 1e-5f * fabsf(lim) + 1e-6f) {
-                    if (raw != nullptr) {
-                        for (uint32_t k = (tile + 1u) * 64u * 5u + lane; k < (task + 1u) * tpr * 64u * 5u; k += 64u) raw[k] = 0.0f;
-                    }
-                    break;
+            const u32x4_t w = L.s0[kb * 64 + lane];
+            hA = mfma16(w, pack8(fa), hA);
+            hB = mfma16(w, pack8(fb), hB);
+        }
+        const bool blob_fast = __all(oneblob_sparse_ok(x) && oneblob_sparse_ok(y) && oneblob_sparse_ok(z));
+        static_for<0, 3>([&](auto dc) {
+            constexpr int D = decltype(dc)::value;
+            float e[kBins];
+            oneblob16_auto(D == 0 ? x : (D == 1 ? y : z), blob_fast, e);
+            float lo8[8], hi8[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { lo8[q] = e[q]; hi8[q] = e[8 + q]; }
+            u32x4_t lo = pack8(lo8), hi = pack8(hi8);
+            // low lanes keep their bins 0..7 (tile A, hh = 0) and receive bins 0..7 of point j + 32 (tile B, hh = 0);
+            // high lanes receive bins 8..15 of point j (tile A, hh = 1) and keep their bins 8..15 (tile B, hh = 1)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { uint32_t a = lo[q], b = hi[q]; swap32u(a, b); lo[q] = a; hi[q] = b; }
+            const u32x4_t ws = L.s0[(2 + D) * 64 + lane];
+            hA = mfma16(ws, lo, hA);
+            hB = mfma16(ws, hi, hB);
+            if constexpr (COLOR) {
+                const u32x4_t wc = L.c0[D * 64 + lane];
+                cA = mfma16(wc, lo, cA);
+                cB = mfma16(wc, hi, cB);
+            }
+        });
+        f32x16 oA = zero16(), oB = zero16();
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const u32x4_t w = L.s1[kb * 64 + lane];
+            oA = mfma16(w, pack8_acc<true>(hA, 8 * kb), oA);
+            oB = mfma16(w, pack8_acc<true>(hB, 8 * kb), oB);
+        }
+        float sdf = oA[0], sdf_b = oB[0];
+        swap32(sdf, sdf_b);
+        if (geo != nullptr) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int row = crow(r, hh);
+                if (row >= 1) {
+                    if (mA < M) geo[(size_t)mA * kGeo + row - 1] = oA[r];
+                    if (mB < M) geo[(size_t)mB * kGeo + row - 1] = oB[r];
                 }
             }
+        }
+        if (sdf_uncert != nullptr && valid) reinterpret_cast<float2*>(sdf_uncert)[m] = make_float2(sdf, u);
+        if constexpr (COLOR) {
+            const u32x4_t wg = L.c0[3 * 64 + lane];
+            cA = mfma16(wg, pack8_acc<false>(oA, 0), cA);
+            cB = mfma16(wg, pack8_acc<false>(oB, 0), cB);
+            float rgb[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float pa = 0.0f, pb = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float w = L.c1[(c * 16 + r) * 2 + hh];
+                    pa = fmaf(w, fmaxf(cA[r], 0.0f), pa);
+                    pb = fmaf(w, fmaxf(cB[r], 0.0f), pb);
+                }
+                swap32(pa, pb);
+                rgb[c] = pa + pb;
+            }
+            if (raw != nullptr && valid) {
+                float* o = raw + (size_t)m * 5;
+                o[0] = rgb[0]; o[1] = rgb[1]; o[2] = rgb[2]; o[3] = sdf; o[4] = u;
+            }
+        }
+        if (tpr != 0u && tq + 1u < tpr) {
+            if (ee_after_tile(ees, ee, ps, m, tq, tpr, tile, task, sdf, lane, raw)) break;
         }
     }
     }

@@ -126,7 +126,8 @@ class NarutoFieldHIP(nn.Module):
                                 hidden_dim=self.config['decoder']['hidden_dim'], geo_feat_dim=self.config['decoder']['geo_feat_dim'],
                                 hidden_dim_color=self.config['decoder']['hidden_dim_color'], uncert_dims=key,
                                 bbox_min=bb[:, 0].tolist(), bbox_max=bb[:, 1].tolist(), trunc=tr['trunc'],
-                                sc_factor=self.config['data']['sc_factor'], white_bkgd=tr['white_bkgd'])
+                                sc_factor=self.config['data']['sc_factor'], white_bkgd=tr['white_bkgd'],
+                                mlp_mode=self.config['decoder'].get('mlp_precision', 'fp32'))
             self._handles[key] = h
         return h
 

@@ -39,7 +39,7 @@ class FieldHandle:
 
     def __init__(self, *, n_levels=16, n_features=2, log2_hashmap_size=16, base_resolution=16, per_level_scale,
                  n_bins=16, hidden_dim=32, geo_feat_dim=15, hidden_dim_color=32, uncert_dims, bbox_min, bbox_max,
-                 trunc, sc_factor, white_bkgd=False):
+                 trunc, sc_factor, white_bkgd=False, mlp_mode: str = "fp32"):
         lib = _lib.load()
         d = NarutoFieldDesc()
         d.n_levels, d.n_features, d.log2_hashmap_size = n_levels, n_features, log2_hashmap_size
@@ -50,6 +50,10 @@ class FieldHandle:
             d.bbox_min[i] = float(bbox_min[i])
             d.bbox_max[i] = float(bbox_max[i])
         d.trunc, d.sc_factor, d.white_bkgd = float(trunc), float(sc_factor), int(bool(white_bkgd))
+        if mlp_mode not in ("fp32", "bf16"):
+            raise ValueError(f"mlp_mode must be 'fp32' (exact, the parity mode) or 'bf16' (speed mode), got {mlp_mode!r}")
+        d.mlp_mode = _lib.MLP_BF16 if mlp_mode == "bf16" else _lib.MLP_FP32
+        self.mlp_mode = mlp_mode
         self.desc = d
         self._h = C.c_void_p()
         check(lib.naruto_field_create(C.byref(d), C.byref(self._h)), "naruto_field_create")

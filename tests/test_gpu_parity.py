@@ -45,6 +45,26 @@ def test_mfma_layout(gpu, built_lib):
             assert abs(out[l, r] - D[row, l & 31]) < 1e-5, (l, r)
 
 
+def test_mfma_bf16_layout(gpu, built_lib):
+    """D = A.B with v_mfma_f32_32x32x16_bf16: A lane l = A[l&31][8(l>>5) + e], B lane l = B[8(l>>5) + e][l&31] (e = 0..7, eight bf16
+    in four registers), D as the fp32 form.  Operands are rounded to bf16 (nearest even), products are exact in fp32."""
+    from naruto_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(1)
+    A = torch.from_numpy(rs.normal(size=(32, 16)).astype(np.float32))
+    B = torch.from_numpy(rs.normal(size=(16, 32)).astype(np.float32))
+    out = torch.empty(64 * 16, device=gpu)
+    _lib.check(lib.naruto_debug_mfma_bf16_layout(A.to(gpu).data_ptr(), B.to(gpu).data_ptr(), out.data_ptr(), None), "debug_mfma_bf16_layout")
+    torch.cuda.synchronize()
+    D = (A.bfloat16().double() @ B.bfloat16().double()).float()
+    got = out.cpu().reshape(64, 16)
+    want = torch.empty(64, 16)
+    for l in range(64):
+        for r in range(16):
+            want[l, r] = D[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31]
+    H.assert_close(got, want, 2e-6, "mfma bf16 layout", rel=1e-6)
+
+
 def test_permlane32_swap(gpu, built_lib):
     v0 = torch.arange(64, dtype=torch.float32, device=gpu)
     v1 = torch.arange(64, dtype=torch.float32, device=gpu) + 100
@@ -209,6 +229,49 @@ def test_hash_encode_vs_oracle(gpu, kind):
     H.assert_close(got, want, 2e-6, f"{kind}.embed")
 
 
+# --------------------------------------------------------------------------------------------- bf16 MLP mode
+def _bf16_emulated_raw(ora, x):
+    """What the bf16 mode computes, restated with torch: operands of the three matrix layers rounded to bf16 (nearest even),
+    products and sums in fp32; encodings, the 32 -> 3 colour layer and the uncertainty sample untouched."""
+    bf = lambda t: t.bfloat16().float()
+    with torch.no_grad():
+        feats, pos = S.hash_encode(x, ora.table, ora.meta), S.oneblob_encode(x, 16)
+        h = bf(torch.cat([feats, pos], -1)).double() @ bf(ora.sdf_w0).double().T
+        out = bf(torch.relu(h.float())).double() @ bf(ora.sdf_w1).double().T
+        c = bf(torch.cat([pos, out.float()[:, 1:]], -1)).double() @ bf(ora.col_w0).double().T
+        rgb = torch.relu(c.float()) @ ora.col_w1.T
+        unc = ora.query_color_sdf(x)[:, 4:5]
+        return torch.cat([rgb, out.float()[:, :1], unc], -1), out.float()
+
+
+@pytest.mark.parametrize("hash_size", [12, 16])
+def test_bf16_mode_matches_its_restatement(gpu, hash_size):
+    """decoder.mlp_precision = 'bf16' (v_mfma_f32_32x32x16_bf16): raw, sdf / uncertainty and geo features against a torch
+    restatement of exactly that arithmetic -- a layout or packing mistake cannot hide in a precision tolerance.  Points inside
+    and outside the box, a count that leaves a partly filled 64-point tile."""
+    cfg = H.office_cfg(hash_size)
+    ora = H.make_oracle(cfg, 0.3, 61)
+    cfg_bf = H.office_cfg(hash_size)
+    cfg_bf["decoder"]["mlp_precision"] = "bf16"
+    m = H.make_hip_from_oracle(cfg_bf, ora, gpu).eval()
+    assert m._handle().mlp_mode == "bf16"
+    rs = np.random.RandomState(61)
+    x = torch.from_numpy(np.concatenate([rs.uniform(0, 1, (2000, 3)), rs.uniform(-0.4, 1.4, (333, 3))]).astype(np.float32))
+    want, out = _bf16_emulated_raw(ora, x)
+    with torch.no_grad():
+        got = m.query_color_sdf(x.to(gpu))
+        su, geo = m.query_sdf(x.to(gpu), return_geo=True, return_uncert=True)
+    H.assert_close(got, want, 2e-5, "bf16.raw", rel=1e-5)
+    H.assert_close(su[:, 0], out[:, 0], 2e-5, "bf16.sdf", rel=1e-5)
+    H.assert_close(geo, out[:, 1:], 2e-5, "bf16.geo", rel=1e-5)
+    # and the distance to the exact (fp32) network is the bf16 rounding of the operands: ~2^-9 relative per product
+    exact = ora.query_color_sdf(x).detach()
+    err = (got.cpu() - exact).abs().max(0).values
+    scale = exact.abs().max(0).values
+    assert (err[:4] <= 2e-2 * scale[:4] + 1e-4).all(), f"bf16 vs fp32 network: {err.tolist()} at scales {scale.tolist()}"
+    assert float(err[4]) <= 1e-6                              # the uncertainty channel does not pass through the MLPs
+
+
 # --------------------------------------------------------------------------------------------- large tables: the binned scatter
 @pytest.mark.parametrize("log2_T", [18, 20, 22])
 def test_hash_encode_backward_large_tables(gpu, log2_T):
@@ -248,8 +311,13 @@ def test_hash_encode_backward_large_tables(gpu, log2_T):
         a, b = got[2 * off[l]:2 * off[l + 1]].double().cpu(), want[2 * off[l]:2 * off[l + 1]].double()
         assert abs(float(a.abs().sum()) - float(b.abs().sum())) <= 1e-4 * float(b.abs().sum()) + 1e-12, f"level {l}"
     assert torch.equal(run(xt, ct), got), "second run differs: the scatter is not reproducible"
+    # the binned levels (more than 2^17 entries) accumulate in fixed point: ANY point order gives the same bits.  (The small dense
+    # levels of the LDS-tiled scatter pre-sum runs of consecutive points in fp32 registers: reproducible, not order-free.)
+    first_big = next(l for l in range(16) if size[l] > (1 << 17))
     perm = torch.from_numpy(rs.permutation(x.shape[0]))
-    assert torch.equal(run(xt[perm], ct[perm]), got), "permuted point order changes the gradient: accumulation is order-dependent"
+    got_p = run(xt[perm], ct[perm])
+    assert torch.equal(got_p[2 * off[first_big]:], got[2 * off[first_big]:]), "permuted point order changes the binned levels' gradient"
+    grad_close(got_p, want, f"T{log2_T}.grad.table (permuted)")
 
 
 @pytest.mark.parametrize("log2_T", [18, 20, 22])

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), as summarised by prof_summary.py.
 
-    python tools/pmc_json.py gpurun_out/r01_pmc_FETCH_SIZE.txt gpurun_out/r01_pmc_WRITE_SIZE.txt > profiles/r01_pmc.json
+    python tools/pmc_json.py <workload> <fetch.txt> <write.txt> [<workload> <fetch.txt> <write.txt> ...] > profiles/r02_pmc.json
+
+The output is keyed by workload (bench.py --workload), then by bench.py's kernel-table row.
 
 Units and corrections (MI355X_MICROARCH.md, "HBM"): the counters report KiB per dispatch; on gfx950 FETCH_SIZE counts
 128-byte requests of wide coalesced streams as 64 bytes (x2 for those), other access widths are uncalibrated.  The
@@ -12,7 +14,9 @@ import re
 import sys
 
 NAMES = {"k_query_fwd<color>": ["k_query_fwdILb1"], "k_query_bwd": ["k_query_bwd"],
-         "k_hash_scatter+reduce+k_wgrad_reduce": ["k_hash_scatter_lds", "k_scatter_reduce", "k_hash_scatter_atomic", "k_bwd_post", "k_wgrad_reduce"], "k_tv_encode": ["k_tv_encode"],
+         "k_hash_scatter+reduce+k_wgrad_reduce": ["k_hash_scatter_lds", "k_scatter_reduce", "k_hash_scatter_atomic", "k_bwd_post", "k_wgrad_reduce", "k_bin_count",
+                                                  "k_bin_colscan", "k_bin_start", "k_bin_fill", "k_bin_apply"],
+         "k_bin_fill": ["k_bin_fill"], "k_bin_apply": ["k_bin_apply"], "k_bin_count": ["k_bin_count"], "k_bwd_finish": ["k_bwd_finish"], "k_tv_encode": ["k_tv_encode"],
          "k_loss_stage": ["k_loss_stage"], "k_composite_bwd<loss>": ["k_composite_bwdILb1"], "k_adam_multi": ["k_adam_multi"]}
 
 
@@ -43,12 +47,20 @@ def parse(path):
     return out
 
 
-fetch, write = parse(sys.argv[1]), parse(sys.argv[2])
-res = {"note": "per-dispatch averages, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over eager launches "
-               "(bench.py --no-graph); bytes = KiB * 1024.  fetch_bytes_x2 = the gfx950 wide-read correction applied (upper bound)."}
-for label, keys in NAMES.items():
-    f = sum(v for k, v in fetch.items() if any(("naruto" + str(len(x)) + x) in k or x in k for x in keys))
-    w = sum(v for k, v in write.items() if any(x in k for x in keys))
-    res[label] = {"fetch_bytes": int(f * 1024), "fetch_bytes_x2": int(2 * f * 1024), "write_bytes": int(w * 1024),
-                  "traffic_bytes": int((f + w) * 1024)}
-print(json.dumps(res, indent=1))
+out = {"note": "per-dispatch averages, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over eager launches "
+               "(bench.py --no-graph); bytes = KiB * 1024.  fetch_bytes_x2 = the gfx950 wide-read correction applied (upper bound).  "
+               "A kernel launched in several grid sizes is taken at its largest one (bench.py's kernel-table launch over all samples)."}
+args = sys.argv[1:]
+for k in range(0, len(args) - 2, 3):
+    wl = args[k]
+    fetch, write = parse(args[k + 1]), parse(args[k + 2])
+    res = {}
+    for label, keys in NAMES.items():
+        f = sum(v for kk, v in fetch.items() if any(x in kk for x in keys))
+        w = sum(v for kk, v in write.items() if any(x in kk for x in keys))
+        if f == 0 and w == 0:
+            continue
+        res[label] = {"fetch_bytes": int(f * 1024), "fetch_bytes_x2": int(2 * f * 1024), "write_bytes": int(w * 1024),
+                      "traffic_bytes": int((f + w) * 1024)}
+    out[wl] = res
+print(json.dumps(out, indent=1))

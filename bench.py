@@ -43,6 +43,7 @@ from naruto_amd import parallel, synthetic as syn  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 FP32_MFMA_PEAK_TF = 157.3      # v_mfma_f32_32x32x2_f32 peak = fp32 vector peak
+BF16_MFMA_PEAK_TF = 2500.0     # v_mfma_f32_32x32x16_bf16 dense peak (MI355X_MICROARCH.md; AMD's 5 PF figure includes 2:1 sparsity)
 L2_PEAK_GBS = 34500.0          # aggregate L2 bandwidth (MI355X_MICROARCH.md, "L2 (per XCD)")
 
 
@@ -324,6 +325,8 @@ def main():
     ap.add_argument("--workload", default="office0_2048x128", help="one of: " + ", ".join(sorted(WORKLOADS)))
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: the workload's ray count PER GPU; strong: the workload's ray count per JOB, sharded over the GPUs")
+    ap.add_argument("--mlp", choices=("fp32", "bf16"), default="fp32",
+                    help="fp32: exact fp32 MFMA chain (the parity mode, the headline); bf16: bf16 operands on v_mfma_f32_32x32x16_bf16 (speed mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the fused HIP Adam")
@@ -347,6 +350,7 @@ def main():
     dev = torch.device("cuda", local)
 
     cfg, n_workload = workload(args.workload)
+    cfg["decoder"]["mlp_precision"] = args.mlp
     if args.scaling == "strong":
         n_total = n_workload
         assert n_total % world == 0, f"strong scaling: {n_total} rays do not split over {world} GPUs"
@@ -404,26 +408,27 @@ def main():
             "metric": "rendered rays/sec (train step), Replica office_0",
             "value": round(n_total * args.steps / dt, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.mlp == "fp32" else "bf16 (MLP operands; fp32 accumulate, fp32 elsewhere)", "data": "synthetic",
             "config": {"workload": f"{args.workload} = BASELINE {WORKLOADS[args.workload][2]}: {volume}, {n_rays} rays x {S_tot} samples per GPU "
                                    f"({n_total} rays per step over {world} GPU), hash L16 F2 T2^{cfg['grid']['hash_size']} ({n_params * 4 / 1e6:.1f} MB of parameters), "
-                                   "MLP 2x32 fp32, uncert grid; one global_BA mapping iteration incl. smoothness + Adam",
+                                   f"MLP 2x32 {args.mlp}, uncert grid; one global_BA mapping iteration incl. smoothness + Adam",
                        "rays_per_gpu": n_rays, "rays_per_step": n_total, "samples_per_ray": S_tot, "parallelism": f"ray-sharded dp{world}",
                        "optimizer": "torch.optim.Adam" if args.torch_adam else "fused HIP Adam", "hip_graph": bool(use_graph)},
         }
         # whole-step roofline figures: per ray S x 3168 B + 44 B and S x 31104 FLOP; per step Adam's 28 B / parameter
+        mfma_peak = FP32_MFMA_PEAK_TF if args.mlp == "fp32" else BF16_MFMA_PEAK_TF
         rays_s = n_total * args.steps / dt
         step_bytes = n_rays * (S_tot * 3168 + 44) + n_params * 28
         out["step_roofline"] = {"alg_bytes_per_step_per_gpu": int(step_bytes), "achieved_GBps": round(step_bytes / (ms * 1e-3) / 1e9, 1),
                                 "hbm_frac": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                "mfma_util": round(rays_s / world * S_tot * 31104 / (FP32_MFMA_PEAK_TF * 1e12), 4),
-                                "mfma_peak": f"{FP32_MFMA_PEAK_TF} TFLOP/s (fp32 MFMA = fp32 vector rate)"}
+                                "mfma_util": round(rays_s / world * S_tot * 31104 / (mfma_peak * 1e12), 6),
+                                "mfma_peak": f"{mfma_peak} TFLOP/s " + ("(fp32 MFMA = fp32 vector rate)" if args.mlp == "fp32" else "(bf16 MFMA, dense)")}
         if not args.no_kernels:
             rows = kernel_table(tr, rays, cfg, max(10, min(args.steps, 50)))
             dom = max((r for r in rows if r["bound"] is not None), key=lambda r: r["ms"])
             if dom["bound"] == "mfma":
-                roof = {"bound": "mfma", "achieved": dom["TFLOPs"], "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": round(dom["TFLOPs"] / FP32_MFMA_PEAK_TF, 4), "traffic": None}
+                roof = {"bound": "mfma", "achieved": dom["TFLOPs"], "peak": mfma_peak, "unit": "TFLOP/s",
+                        "frac": round(dom["TFLOPs"] / mfma_peak, 4), "traffic": None}
             else:
                 roof = {"bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": None}
@@ -439,7 +444,7 @@ def main():
             if dom["kernel"].startswith("k_query_fwd"):
                 it = next(r for r in rows if r["kernel"].endswith("as launched by the iteration"))
                 roof["kernel_ms_in_iteration"] = it["ms"]
-                roof["mfma_util"] = round(dom["TFLOPs"] / FP32_MFMA_PEAK_TF, 4)
+                roof["mfma_util"] = round(dom["TFLOPs"] / mfma_peak, 6)
                 # L2 line rate (MI355X_MICROARCH.md: ~34.5 TB/s aggregate): a wave's 64 8-byte gathers touch ~36 distinct 64-byte
                 # lines (x-neighbour corners share a line, tools/gather_coalesce_bench.hip), i.e. 4.5 lines per (sample, level)
                 l2_bytes = n_rays * S_tot * (16 * 4.5 * 64 + 4 * 64) + dom.get("alg_bytes_incl_saved", 0) - n_rays * S_tot * (16 * 8 * 8 + 32)

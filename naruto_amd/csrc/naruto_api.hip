@@ -84,7 +84,7 @@ int ray_lds_attr() {
     return NARUTO_OK;
 }
 
-constexpr uint32_t kBwdMaxBlocks = 256;     // one 145 KB-LDS block per CU
+constexpr uint32_t kBwdMaxBlocks = 512;     // fp32: one 145 KB-LDS block per CU; bf16 mode: two 53 KB blocks per CU
 
 inline size_t al256(size_t b) { return (b + 255u) / 256u * 256u; }
 
@@ -148,7 +148,8 @@ int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const f
     if (f->bplan.n_levels != 0) {
         static bool attr_set = false;
         if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_fill), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BinFillLds)) != hipSuccess ||
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_fill), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)bin_fill_lds_bytes((uint32_t)kMaxBinsPerLevel)) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_apply), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(2u * kBinEntries * sizeof(unsigned long long))) != hipSuccess)
                 return fail(NARUTO_ERR_LAUNCH, "binned scatter: cannot reserve LDS: %s", hipGetErrorString(hipGetLastError()));
@@ -162,8 +163,10 @@ int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const f
         if (int rc = check_launch("bin_colscan")) return rc;
         hipLaunchKernelGGL(k_bin_start, dim3(1), dim3(1024), 0, st, w.totals, bp.n_bins, w.starts);
         if (int rc = check_launch("bin_start")) return rc;
-        hipLaunchKernelGGL(k_bin_fill, dim3(rows, bp.n_levels), dim3(kBinThreads), sizeof(BinFillLds), st, f->lt, f->bt, ps, M, d_feat, stride_m, stride_l, bp,
-                           w.counts, w.starts, w.items, m_dev);
+        uint32_t nb_max = 0;
+        for (uint32_t k = 0; k < bp.n_levels; ++k) nb_max = bp.bin0[k + 1] - bp.bin0[k] > nb_max ? bp.bin0[k + 1] - bp.bin0[k] : nb_max;
+        hipLaunchKernelGGL(k_bin_fill, dim3(rows, bp.n_levels), dim3(kBinFillThreads), bin_fill_lds_bytes(nb_max), st, f->lt, f->bt, ps, M, d_feat, stride_m, stride_l,
+                           bp, nb_max, w.counts, w.starts, w.items, m_dev);
         if (int rc = check_launch("bin_fill")) return rc;
         AdamFuse none{};
         hipLaunchKernelGGL(k_bin_apply, dim3(bp.n_bins), dim3(kBinApplyThreads), 2u * kBinEntries * sizeof(unsigned long long), st, f->lt, bp, w.starts, w.items,
@@ -463,20 +466,28 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
     const BwdWs w = bwd_ws(f, workspace, cap);
     float* d_feat = w.d_feat; float* x_soa = w.x_soa; float* partials = w.partials; float* scatter_ws = w.scatter_ws;
     uint32_t* n_total = w.n_total;
-    const uint32_t n_tiles = (M + 31u) / 32u;
-    uint32_t blocks = (n_tiles + (uint32_t)kBwdWaves - 1u) / (uint32_t)kBwdWaves;
-    uint32_t max_blocks = cu_count(f);
+    const bool bf = f->desc.mlp_mode == NARUTO_MLP_BF16;
+    const uint32_t n_tiles = bf ? (M + 63u) / 64u : (M + 31u) / 32u;
+    const uint32_t waves = bf ? 4u : (uint32_t)kBwdWaves;
+    uint32_t blocks = (n_tiles + waves - 1u) / waves;
+    uint32_t max_blocks = cu_count(f) * (bf ? 2u : 1u);
     if (max_blocks > kBwdMaxBlocks) max_blocks = kBwdMaxBlocks;
     if (blocks > max_blocks) blocks = max_blocks;
     const PointSrc ps = make_points(pts);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BwdLds)) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BwdLds)) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_bwd_bf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BwdLdsBf)) != hipSuccess)
             return fail(NARUTO_ERR_LAUNCH, "query_bwd: cannot reserve %zu bytes of LDS: %s", sizeof(BwdLds), hipGetErrorString(hipGetLastError()));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_query_bwd, dim3(blocks), dim3(64 * kBwdWaves), sizeof(BwdLds), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, ps, M, cap, feat_save, d_raw,
-                       d_geo, d_feat, (g->table != nullptr || adam != nullptr) ? x_soa : nullptr, g->uncert_grid, partials, active_idx, n_active, n_front);
+    float* x_list = (g->table != nullptr || adam != nullptr) ? x_soa : nullptr;
+    if (bf)
+        hipLaunchKernelGGL(k_query_bwd_bf, dim3(blocks), dim3(256), sizeof(BwdLdsBf), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, ps, M, cap, feat_save, d_raw,
+                           d_geo, d_feat, x_list, g->uncert_grid, partials, active_idx, n_active, n_front);
+    else
+        hipLaunchKernelGGL(k_query_bwd, dim3(blocks), dim3(64 * kBwdWaves), sizeof(BwdLds), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, ps, M, cap, feat_save, d_raw,
+                           d_geo, d_feat, x_list, g->uncert_grid, partials, active_idx, n_active, n_front);
     if (int rc = check_launch("query_bwd")) return rc;
     if (adam != nullptr) {
         // optimiser in the backward: the tiled scatter without its reduce, then ONE launch finishes the tiled levels' table
@@ -544,7 +555,7 @@ int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
 // ------------------------------------------------------------------------------------------------
 namespace {
 struct TrainWs {
-    float* terms; float* tv_feat; double* tv_partial; void* bwd;
+    float* terms; float* tv_feat; double* tv_partial; void* bwd; double* fold; uint32_t* block_sums;
     uint32_t n3, n_tv_blocks;
     size_t total;
 };
@@ -562,6 +573,8 @@ TrainWs train_ws(const NarutoField* f, const NarutoTrainStep* t) {
     w.terms = reinterpret_cast<float*>(base + off);       off += al((size_t)t->n_rays * 16u * sizeof(float));
     w.tv_feat = reinterpret_cast<float*>(base + off);     off += al((size_t)w.n3 * kFeat * sizeof(float));
     w.tv_partial = reinterpret_cast<double*>(base + off); off += al((size_t)w.n_tv_blocks * sizeof(double));
+    w.fold = reinterpret_cast<double*>(base + off);       off += al((size_t)kTailRows * 16u * sizeof(double));
+    w.block_sums = reinterpret_cast<uint32_t*>(base + off); off += al(((size_t)t->n_rays / kCompactBlock + 2u) * sizeof(uint32_t));
     w.bwd = base + off;                                   off += al(naruto_query_bwd_workspace(f, (uint32_t)(M + w.n3)));
     w.total = off;
     return w;
@@ -667,6 +680,11 @@ int naruto_train_forward(const NarutoField* f, const NarutoParams* p, const Naru
     if (int rc = check_launch("loss_stage")) return rc;
     LossTailArgs tl{};
     tl.partials = a.partials; tl.n_ray_blocks = a.n_ray_blocks;
+    if (a.n_ray_blocks > 4u * kTailRows) {          // large batch: fold the per-workgroup rows first
+        hipLaunchKernelGGL(k_loss_fold, dim3(kTailRows), dim3(64), 0, st, a.partials, a.n_ray_blocks, w.fold);
+        if (int rc = check_launch("loss_fold")) return rc;
+        tl.partials = w.fold; tl.n_ray_blocks = kTailRows;
+    }
     tl.tv_partial = w.tv_partial; tl.n_tv_blocks = a.n_tv_blocks; tl.tv_inv_p3 = tva.inv_p3;
     tl.sums = t->sums; tl.losses = t->losses; tl.loss_weights = t->loss_weights;
     tl.n_rays_total = t->n_rays_total ? t->n_rays_total : N; tl.S = S;
@@ -719,7 +737,14 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
     const bool smooth = t->smooth_points != 0 && (g->table != nullptr || opt != nullptr);
     const uint32_t n_front = smooth ? w.n3 : 0u;
     const BwdWs bw = bwd_ws(f, w.bwd, list_cap(M + w.n3));
-    hipLaunchKernelGGL(k_compact, dim3((N + 3u) / 4u), dim3(256), 0, st, N, S, t->ray_count, t->ray_offset, t->active_idx, t->n_active, n_front, bw.n_total);
+    const uint32_t* block_sums = nullptr;
+    if (N > 4u * kCompactBlock) {                    // large batch: two-level prefix of the per-ray counts
+        hipLaunchKernelGGL(k_count_blocks, dim3((N + kCompactBlock - 1u) / kCompactBlock), dim3(256), 0, st, N, t->ray_count, w.block_sums);
+        if (int rc = check_launch("count_blocks")) return rc;
+        block_sums = w.block_sums;
+    }
+    hipLaunchKernelGGL(k_compact, dim3((N + 3u) / 4u), dim3(256), 0, st, N, S, t->ray_count, t->ray_offset, t->active_idx, t->n_active, n_front, bw.n_total,
+                       block_sums);
     if (int rc = check_launch("compact")) return rc;
     NarutoPoints pts{};
     pts.rays_o = t->rays_o; pts.rays_d = t->rays_d; pts.z_vals = t->z_vals; pts.n_samples = S;

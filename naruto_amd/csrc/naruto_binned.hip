@@ -31,7 +31,6 @@ constexpr uint32_t kBinEntries = 1u << kBinLog2;         // entries per bin: x 2
 constexpr int kMaxBinsPerLevel = 2048;                   // log2_hashmap_size <= 24
 constexpr int kBinRound = 512;                           // points sorted per LDS round of k_bin_fill
 constexpr int kBinThreads = 256;
-constexpr int kBinPtsPerThread = kBinRound / kBinThreads;
 constexpr int kBinMaxRows = 256;
 constexpr int kBinApplyThreads = 1024;
 
@@ -134,30 +133,31 @@ __global__ __launch_bounds__(1024) void k_bin_start(const uint32_t* __restrict__
     if (threadIdx.x == 0) starts[n_bins] = carry;
 }
 
-struct BinFillLds {
-    BinItem items[kBinRound * 8];                 // 48 KB: one round's items sorted by bin
-    uint16_t item_bin[kBinRound * 8];             //  8 KB
-    uint32_t hist[kMaxBinsPerLevel];              // items per bin in this round
-    uint32_t off[kMaxBinsPerLevel];               // exclusive prefix of hist
-    uint32_t base[kMaxBinsPerLevel];              // where this row's next item of the bin goes in the global item array
-    uint32_t wave_tot[kBinThreads / 64];
-};
+// k_bin_fill: 512 threads, one point per thread and round.  Dynamic LDS: | items[kBinRound * 8] | hist[nb_max] | off[nb_max] |
+// base[nb_max] | wave_tot[8] | -- 54 KB at 512 bins per level (T = 2^22), so two workgroups (16 waves) share a CU.  While an
+// item sits in LDS its first word carries the bin next to the entry (rel | bin << 13); the bin is stripped on the way out.
+constexpr int kBinFillThreads = kBinRound;
+inline size_t bin_fill_lds_bytes(uint32_t nb_max) { return (size_t)kBinRound * 8u * sizeof(BinItem) + 3u * (size_t)nb_max * sizeof(uint32_t) + 64u; }
 
-__global__ __launch_bounds__(kBinThreads) void k_bin_fill(LevelTab lt, BoxTab bt, PointSrc ps, uint32_t M, const float* __restrict__ d_feat,
-                                                          size_t stride_m, size_t stride_l, BinPlan plan, const uint32_t* __restrict__ counts,
-                                                          const uint32_t* __restrict__ starts, BinItem* __restrict__ items_out,
-                                                          const uint32_t* __restrict__ m_dev) {
+__global__ __launch_bounds__(kBinFillThreads) void k_bin_fill(LevelTab lt, BoxTab bt, PointSrc ps, uint32_t M, const float* __restrict__ d_feat,
+                                                              size_t stride_m, size_t stride_l, BinPlan plan, uint32_t nb_max,
+                                                              const uint32_t* __restrict__ counts, const uint32_t* __restrict__ starts,
+                                                              BinItem* __restrict__ items_out, const uint32_t* __restrict__ m_dev) {
     extern __shared__ __attribute__((aligned(16))) char bin_smem[];
-    BinFillLds& L = *reinterpret_cast<BinFillLds*>(bin_smem);
+    BinItem* __restrict__ l_items = reinterpret_cast<BinItem*>(bin_smem);
+    uint32_t* __restrict__ l_hist = reinterpret_cast<uint32_t*>(bin_smem + (size_t)kBinRound * 8u * sizeof(BinItem));
+    uint32_t* __restrict__ l_off = l_hist + nb_max;
+    uint32_t* __restrict__ l_base = l_off + nb_max;
+    uint32_t* __restrict__ l_wave_tot = l_base + nb_max;
     if (m_dev != nullptr) M = m_dev[0];
     const uint32_t row = blockIdx.x, k = blockIdx.y, level = plan.first_level + k;
     const uint32_t nb = plan.bin0[k + 1] - plan.bin0[k];
     {
         const uint32_t* __restrict__ cnt = counts + (size_t)row * plan.n_bins + plan.bin0[k];
         const uint32_t* __restrict__ stt = starts + plan.bin0[k];
-        for (uint32_t b = threadIdx.x; b < nb; b += kBinThreads) {
-            L.base[b] = stt[b] + cnt[b];
-            L.hist[b] = 0u;
+        for (uint32_t b = threadIdx.x; b < nb; b += kBinFillThreads) {
+            l_base[b] = stt[b] + cnt[b];
+            l_hist[b] = 0u;
         }
     }
     __syncthreads();
@@ -165,75 +165,83 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_fill(LevelTab lt, BoxTab bt
     bin_row_range(M, gridDim.x, row, m_lo, m_hi);
     const uint32_t sm32 = (uint32_t)stride_m, sl32 = (uint32_t)stride_l;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t per_thread = (nb + (uint32_t)kBinFillThreads - 1u) / (uint32_t)kBinFillThreads;      // bins per thread in the scan: <= 4
+    // the next round's inputs are fetched while this round is sorted (nothing computes on them before the next iteration)
+    auto load_in = [&](uint32_t r0, float2& g, PointRaw& pr) {
+        const uint32_t m = r0 + threadIdx.x;
+        const uint32_t mm = m < m_hi ? m : (m_hi > 0u ? m_hi - 1u : 0u);
+        g = *reinterpret_cast<const float2*>(d_feat + (size_t)mm * sm32 + (size_t)level * sl32);
+        pr = load_point_raw(ps, mm);
+        if (m >= m_hi) g = make_float2(0.0f, 0.0f);
+    };
+    float2 g_nxt = make_float2(0.0f, 0.0f);
+    PointRaw p_nxt{};
+    if (m_lo < m_hi) load_in(m_lo, g_nxt, p_nxt);
     for (uint32_t r0 = m_lo; r0 < m_hi; r0 += (uint32_t)kBinRound) {
-        // 1. this thread's points -> items in registers, rank of each item within (round, bin)
-        uint32_t e_idx[kBinPtsPerThread][8], e_rank[kBinPtsPerThread][8];
-        float e_w[kBinPtsPerThread][8];
-        float2 e_g[kBinPtsPerThread];
-#pragma unroll
-        for (int q = 0; q < kBinPtsPerThread; ++q) {
-            const uint32_t m = r0 + (uint32_t)q * kBinThreads + threadIdx.x;
-            e_g[q] = make_float2(0.0f, 0.0f);
-            if (m < m_hi) e_g[q] = *reinterpret_cast<const float2*>(d_feat + (size_t)m * sm32 + (size_t)level * sl32);
-            if (e_g[q].x == 0.0f && e_g[q].y == 0.0f) continue;
+        const float2 g = g_nxt;
+        const PointRaw pr = p_nxt;
+        if (r0 + (uint32_t)kBinRound < m_hi) load_in(r0 + (uint32_t)kBinRound, g_nxt, p_nxt);
+        // 1. this thread's point -> 8 items in registers, rank of each item within (round, bin)
+        uint32_t e_idx[8], e_rank[8];
+        float e_w[8];
+        const bool live = !(g.x == 0.0f && g.y == 0.0f);
+        if (live) {
             float x, y, z;
-            load_point(ps, bt, m, x, y, z);
-            hash_corners_rt(lt, (int)level, x, y, z, e_idx[q], e_w[q]);
+            finish_point(ps, bt, pr, x, y, z);
+            hash_corners_rt(lt, (int)level, x, y, z, e_idx, e_w);
 #pragma unroll
-            for (int c = 0; c < 8; ++c) e_rank[q][c] = atomicAdd(&L.hist[e_idx[q][c] >> kBinLog2], 1u);
+            for (int c = 0; c < 8; ++c) e_rank[c] = atomicAdd(&l_hist[e_idx[c] >> kBinLog2], 1u);
         }
         __syncthreads();
-        // 2. exclusive prefix of the round's histogram (thread t: bins [8t, 8t+8))
+        // 2. exclusive prefix of the round's histogram (thread t: bins [t * per_thread, (t + 1) * per_thread))
         {
-            uint32_t loc[kMaxBinsPerLevel / kBinThreads], s = 0;
+            uint32_t loc[4], s_ = 0;
 #pragma unroll
-            for (int u = 0; u < kMaxBinsPerLevel / kBinThreads; ++u) {
-                const uint32_t b = threadIdx.x * (kMaxBinsPerLevel / kBinThreads) + u;
-                loc[u] = b < nb ? L.hist[b] : 0u;
-                s += loc[u];
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t b = threadIdx.x * per_thread + (uint32_t)u;
+                loc[u] = ((uint32_t)u < per_thread && b < nb) ? l_hist[b] : 0u;
+                s_ += loc[u];
             }
-            uint32_t incl = s;
+            uint32_t incl = s_;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
                 const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
                 if (lane >= o) incl += t;
             }
-            if (lane == 63) L.wave_tot[wave] = incl;
+            if (lane == 63) l_wave_tot[wave] = incl;
             __syncthreads();
-            uint32_t run = incl - s;
-            for (int w2 = 0; w2 < wave; ++w2) run += L.wave_tot[w2];
+            uint32_t run = incl - s_;
+            for (int w2 = 0; w2 < wave; ++w2) run += l_wave_tot[w2];
 #pragma unroll
-            for (int u = 0; u < kMaxBinsPerLevel / kBinThreads; ++u) {
-                const uint32_t b = threadIdx.x * (kMaxBinsPerLevel / kBinThreads) + u;
-                if (b < nb) L.off[b] = run;
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t b = threadIdx.x * per_thread + (uint32_t)u;
+                if ((uint32_t)u < per_thread && b < nb) l_off[b] = run;
                 run += loc[u];
             }
         }
         __syncthreads();
-        const uint32_t n_items = L.off[nb - 1u] + L.hist[nb - 1u];
+        const uint32_t n_items = l_off[nb - 1u] + l_hist[nb - 1u];
         // 3. place
-#pragma unroll
-        for (int q = 0; q < kBinPtsPerThread; ++q) {
-            if (e_g[q].x == 0.0f && e_g[q].y == 0.0f) continue;
-            const float g0 = e_g[q].x * 256.0f, g1 = e_g[q].y * 256.0f;       // the 2^8 of to_fix40 folded in once per point
+        if (live) {
+            const float g0 = g.x * 256.0f, g1 = g.y * 256.0f;       // the 2^8 of to_fix40 folded in once per point
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const uint32_t b = e_idx[q][c] >> kBinLog2;
-                const uint32_t pos = L.off[b] + e_rank[q][c];
-                L.items[pos] = BinItem{e_idx[q][c] & (kBinEntries - 1u), e_w[q][c] * g0, e_w[q][c] * g1};
-                L.item_bin[pos] = (uint16_t)b;
+                const uint32_t b = e_idx[c] >> kBinLog2;
+                l_items[l_off[b] + e_rank[c]] = BinItem{(e_idx[c] & (kBinEntries - 1u)) | (b << kBinLog2), e_w[c] * g0, e_w[c] * g1};
             }
         }
         __syncthreads();
         // 4. write the runs: consecutive sorted positions of a bin go to consecutive addresses
-        for (uint32_t i = threadIdx.x; i < n_items; i += kBinThreads) {
-            const uint32_t b = L.item_bin[i];
-            items_out[(size_t)L.base[b] + (i - L.off[b])] = L.items[i];
+        for (uint32_t i = threadIdx.x; i < n_items; i += kBinFillThreads) {
+            BinItem it = l_items[i];
+            const uint32_t b = it.rel >> kBinLog2;
+            it.rel &= kBinEntries - 1u;
+            items_out[(size_t)l_base[b] + (i - l_off[b])] = it;
         }
         __syncthreads();
-        for (uint32_t b = threadIdx.x; b < nb; b += kBinThreads) {
-            L.base[b] += L.hist[b];
-            L.hist[b] = 0u;
+        for (uint32_t b = threadIdx.x; b < nb; b += kBinFillThreads) {
+            l_base[b] += l_hist[b];
+            l_hist[b] = 0u;
         }
         __syncthreads();
     }

@@ -1427,6 +1427,323 @@ __global__ __launch_bounds__(64 * kBwdWaves) void k_query_bwd(LevelTab lt, Uncer
     for (int e = threadIdx.x; e < kAccFloats; e += blockDim.x) out[e] = acc[e];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward in the bf16 mode.  All of it lives in registers: no activation ever goes through LDS.
+//
+// With bf16 matrix instructions a 32 x 32 x 16 product costs 32 cycles, so the matrix core is also the cheapest TRANSPOSER:
+// the A and B register layouts of v_mfma_f32_32x32x16_bf16 are mirror images (lane = row resp. column, eight K slots per lane),
+// hence swapping the two operands of an instruction yields the transposed product, and a product with a 0/1 selection matrix
+// re-lays a tensor out.  Two orientations of a [point, unit] tensor are used (C/D layout: lane = column, registers = rows):
+//   P: Y^T -- lane = point, registers = units.   This is the next layer's B operand (forward recompute, dgrad chain).
+//   U: Y   -- lane = unit,  registers = points.  Eight consecutive registers are eight points: with the point index as the K
+//             dimension this is exactly the A operand (G = cotangents) / B operand (X = layer inputs) of dW = G^T . X.
+// P -> U is "Y . S" with S a selection matrix (the P registers packed are the A operand); the layer inputs (hash features,
+// OneBlob, sdf-net outputs), which exist as B-operand packs anyway, get their U form the same way.  47 matrix instructions per
+// 32 points (1 500 cycles per SIMD) replace the fp32 kernel's 240 (15 400) and all of its LDS staging; the dW tiles accumulate in
+// fp32 registers over the whole kernel as before.  Operands are rounded to bf16 (the cotangents too): a speed mode.
+// ------------------------------------------------------------------------------------------------
+struct BwdLdsBf {
+    FwdLdsBf f;
+    u32x4_t s0T[2 * 64];    // dgrad sdf0 -> hash feats:      A[i = feature][slot (hh,e) of block kb = hidden unit crow(8kb+e,hh)] = sdf_w0[unit][i]
+    u32x4_t s1T[1 * 64];    // dgrad sdf1 -> hidden:          A[i = hidden unit][slot (hh,e) = output row crow(e,hh)]            = sdf_w1[row][i]
+    u32x4_t c0gT[2 * 64];   // dgrad col0 -> sdf-net outputs: A[i = output row][slot = colour hidden unit crow(8kb+e,hh)]        = col_w0[unit][48+i-1], 1 <= i < 16
+    // selection matrices (B operands: lane (u = l&31, hh), slot e): 1.0 where the slot's source index maps to column u
+    u32x4_t selU[2 * 64];   // P -> U of a 32-unit tensor: slot (hh,e) of block kb is unit crow(8kb+e,hh)
+    u32x4_t selF[2 * 64];   // hash K block kb -> input columns 0..31: slot (hh,e) is column 2(8kb+e)+hh
+    u32x4_t selB[2 * 64];   // OneBlob K block -> 32 columns: slot (hh,e) is column 16 d + 8hh + e  (d = 0, 1)
+    u32x4_t selO[1 * 64];   // sdf-net outputs (registers 0..7) -> columns 16 + row
+    u32x4_t selQ[1 * 64];   // rgb cotangent (slots 0..2 of the low half) -> units 0..2
+    float acc[kAccFloats];  // block-level dW image for the final reduction over the waves
+};
+
+template <int NT>
+__device__ __forceinline__ void stage_bwd_weights_bf(BwdLdsBf& L, const NarutoParams& p, int tid) {
+    stage_fwd_weights_bf<NT>(L.f, p, tid);
+#pragma unroll
+    for (int e0 = 0; e0 < 13 * 64; e0 += NT) {
+        const int e = e0 + tid;
+        if (e >= 13 * 64) continue;
+        const int t = e >> 6, l = e & 63, i = l & 31, hh = l >> 5;
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (t < 2) v[q] = p.sdf_w0[crow(8 * t + q, hh) * kInSdf + i];
+            else if (t == 2) v[q] = p.sdf_w1[crow(q, hh) * kHidden + i];
+            else if (t < 5) v[q] = (i >= 1 && i < kOut) ? p.col_w0[crow(8 * (t - 3) + q, hh) * kInCol + kPos + i - 1] : 0.0f;
+            else if (t < 7) v[q] = crow(8 * (t - 5) + q, hh) == i ? 1.0f : 0.0f;
+            else if (t < 9) v[q] = 2 * (8 * (t - 7) + q) + hh == i ? 1.0f : 0.0f;
+            else if (t < 11) v[q] = 16 * (t - 9) + 8 * hh + q == i ? 1.0f : 0.0f;
+            else if (t == 11) v[q] = 16 + crow(q, hh) == i ? 1.0f : 0.0f;
+            else v[q] = (hh == 0 && q < 3 && q == i) ? 1.0f : 0.0f;
+        }
+        const u32x4_t w = pack8(v);
+        if (t < 2) L.s0T[t * 64 + l] = w;
+        else if (t == 2) L.s1T[l] = w;
+        else if (t < 5) L.c0gT[(t - 3) * 64 + l] = w;
+        else if (t < 7) L.selU[(t - 5) * 64 + l] = w;
+        else if (t < 9) L.selF[(t - 7) * 64 + l] = w;
+        else if (t < 11) L.selB[(t - 9) * 64 + l] = w;
+        else if (t == 11) L.selO[l] = w;
+        else L.selQ[l] = w;
+    }
+}
+
+struct DwTiles { f32x16 w0a, w0b, w0c, w1, c0a, c0b, c1; };
+
+// P -> U: Y[point][unit] with lane = unit, registers = points, from the P form (lane = point, registers = units)
+__device__ __forceinline__ f32x16 to_units_on_lanes(const BwdLdsBf& L, const f32x16& yP, int lane) {
+    f32x16 u = zero16();
+    u = mfma16(pack8_acc<false>(yP, 0), L.selU[lane], u);
+    u = mfma16(pack8_acc<false>(yP, 8), L.selU[64 + lane], u);
+    return u;
+}
+// dW tile += G^T . X over the tile's 32 points (K = points: registers 8kb .. 8kb+7 of both U tensors are the same eight points)
+__device__ __forceinline__ void wgrad_u(f32x16& d, const f32x16& gU, const f32x16& xU) {
+    d = mfma16(pack8_acc<false>(gU, 0), pack8_acc<false>(xU, 0), d);
+    d = mfma16(pack8_acc<false>(gU, 8), pack8_acc<false>(xU, 8), d);
+}
+
+// one 32-point tile.  F: the two hash K blocks, Bl: the three OneBlob K blocks (B-operand packs of these points); g_*: the
+// cotangent of raw at this lane's point (both halves hold point j's values); returns df (P form: rows = the 32 hash features).
+// The order of the steps keeps few 16-register tensors alive at a time (the seven dW tiles already take 112 registers): the
+// hidden activations survive as their bf16 packs + a sign mask, the U forms of the layer inputs are rebuilt where they are used.
+__device__ __forceinline__ f32x16 bwd_tile_bf(const BwdLdsBf& L, DwTiles& dw, const u32x4_t (&F)[2], const u32x4_t (&Bl)[3], const float (&g_rgb)[3],
+                                              float g_sdf, const float* __restrict__ d_geo_pt, int lane) {
+    const int hh = lane >> 5;
+    // the weight / selection images are loop invariant: left alone the compiler keeps all 24 of them (96 registers) live across the
+    // tile loop.  An opaque copy of the lane index ties every image read to this call.
+    int li = lane;
+    asm volatile("" : "+v"(li));
+    // ---- forward recompute (P): h -> (packs of relu(h), sign mask), o -> pack, c
+    u32x4_t ph[2];
+    uint32_t hmask = 0;
+    {
+        f32x16 h = zero16();
+        h = mfma16(L.f.s0[li], F[0], h);
+        h = mfma16(L.f.s0[64 + li], F[1], h);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) h = mfma16(L.f.s0[(2 + d) * 64 + li], Bl[d], h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hmask |= h[r] > 0.0f ? (1u << r) : 0u;
+        ph[0] = pack8_acc<true>(h, 0);
+        ph[1] = pack8_acc<true>(h, 8);
+    }
+    u32x4_t oP;
+    {
+        f32x16 o = zero16();
+        o = mfma16(L.f.s1[li], ph[0], o);
+        o = mfma16(L.f.s1[64 + li], ph[1], o);
+        oP = pack8_acc<false>(o, 0);
+    }
+    f32x16 dcv;
+    {
+        f32x16 c = zero16();
+#pragma unroll
+        for (int d = 0; d < 3; ++d) c = mfma16(L.f.c0[d * 64 + li], Bl[d], c);
+        c = mfma16(L.f.c0[3 * 64 + li], oP, c);
+        // ---- colour layer 1 backward (fp32 VALU): d_c = relu'(c) * (col_w1^T . d_rgb)
+        f32x16 cact;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) a = fmaf(L.f.c1[(q * 16 + r) * 2 + hh], g_rgb[q], a);
+            dcv[r] = c[r] > 0.0f ? a : 0.0f;
+            cact[r] = fmaxf(c[r], 0.0f);
+        }
+        // dW(col_w1)[q][i] = sum_pt d_rgb[q] relu(c)[i]: the rgb cotangent re-laid to U through selQ (slots 0..2 of the low half)
+        float gq[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) gq[q] = (q < 3 && hh == 0) ? g_rgb[q < 3 ? q : 0] : 0.0f;
+        f32x16 gU = zero16();
+        gU = mfma16(pack8(gq), L.selQ[li], gU);
+        wgrad_u(dw.c1, gU, to_units_on_lanes(L, cact, li));
+    }
+    // ---- dW(col_w0) = d_c^T . [OneBlob48 | out16]; layer inputs in U form: T1 = OneBlob 0..31, T2 = OneBlob 32..47 | sdf-net outputs 0..15
+    {
+        const f32x16 gU = to_units_on_lanes(L, dcv, li);
+        f32x16 t = zero16();
+        t = mfma16(Bl[0], L.selB[li], t);
+        t = mfma16(Bl[1], L.selB[64 + li], t);
+        wgrad_u(dw.c0a, gU, t);
+        t = zero16();
+        t = mfma16(Bl[2], L.selB[li], t);
+        t = mfma16(oP, L.selO[li], t);
+        wgrad_u(dw.c0b, gU, t);
+    }
+    // ---- dgrad colour layer 0 -> sdf-net outputs (rows 1..15 = geo features), + the direct cotangents
+    f32x16 dov = zero16();
+    dov = mfma16(L.c0gT[li], pack8_acc<false>(dcv, 0), dov);
+    dov = mfma16(L.c0gT[64 + li], pack8_acc<false>(dcv, 8), dov);
+    if (d_geo_pt != nullptr) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int row = crow(r, hh);
+            if (row >= 1) dov[r] += d_geo_pt[row - 1];
+        }
+    }
+    if (hh == 0) dov[0] += g_sdf;
+    const u32x4_t dovP = pack8_acc<false>(dov, 0);          // rows >= 16 of d_out are exact zeros: one K block
+    // ---- dW(sdf_w1)[o][i] = sum_pt d_out[o] relu(h)[i]
+    {
+        f32x16 gU = zero16(), xU = zero16();
+        gU = mfma16(dovP, L.selU[li], gU);
+        xU = mfma16(ph[0], L.selU[li], xU);
+        xU = mfma16(ph[1], L.selU[64 + li], xU);
+        wgrad_u(dw.w1, gU, xU);
+    }
+    // ---- dgrad sdf layer 1 -> hidden, masked by ReLU
+    f32x16 dh = zero16();
+    dh = mfma16(L.s1T[li], dovP, dh);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dh[r] = ((hmask >> r) & 1u) ? dh[r] : 0.0f;
+    const u32x4_t dhP[2] = {pack8_acc<false>(dh, 0), pack8_acc<false>(dh, 8)};
+    // ---- dW(sdf_w0) = d_h^T . [feat32 | OneBlob48 | (16 discarded)]
+    {
+        f32x16 gU = zero16();
+        gU = mfma16(dhP[0], L.selU[li], gU);
+        gU = mfma16(dhP[1], L.selU[64 + li], gU);
+        f32x16 t = zero16();
+        t = mfma16(F[0], L.selF[li], t);
+        t = mfma16(F[1], L.selF[64 + li], t);
+        wgrad_u(dw.w0a, gU, t);
+        t = zero16();
+        t = mfma16(Bl[0], L.selB[li], t);
+        t = mfma16(Bl[1], L.selB[64 + li], t);
+        wgrad_u(dw.w0b, gU, t);
+        t = zero16();
+        t = mfma16(Bl[2], L.selB[li], t);
+        t = mfma16(oP, L.selO[li], t);
+        wgrad_u(dw.w0c, gU, t);
+    }
+    // ---- dgrad sdf layer 0 -> hash features
+    f32x16 df = zero16();
+    df = mfma16(L.s0T[li], dhP[0], df);
+    df = mfma16(L.s0T[64 + li], dhP[1], df);
+    return df;
+}
+
+#ifndef NARUTO_BWD_BF_MINWAVES
+#define NARUTO_BWD_BF_MINWAVES 2
+#endif
+
+__global__ __launch_bounds__(256, NARUTO_BWD_BF_MINWAVES) void k_query_bwd_bf(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps, uint32_t M, uint32_t cap,
+                                                      const float* __restrict__ feat_save, const float* __restrict__ d_raw,
+                                                      const float* __restrict__ d_geo, float* __restrict__ d_feat, float* __restrict__ x_out,
+                                                      float* __restrict__ d_uncert_grid, float* __restrict__ partials,
+                                                      const uint32_t* __restrict__ active_idx, const uint32_t* __restrict__ n_active, uint32_t list_off) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    BwdLdsBf& L = *reinterpret_cast<BwdLdsBf*>(smem_raw);
+    stage_bwd_weights_bf<256>(L, p, threadIdx.x);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hh = lane >> 5, j = lane & 31;
+    const uint32_t M_eff = n_active != nullptr ? n_active[0] : M;
+    const uint32_t n_tiles = (M_eff + 63u) / 64u;                  // 64 list entries per wave and step: two 32-point tiles
+    DwTiles dw{zero16(), zero16(), zero16(), zero16(), zero16(), zero16(), zero16()};
+    float2* __restrict__ dfo = reinterpret_cast<float2*>(d_feat);
+    for (uint32_t tile = blockIdx.x * 4u + wave; tile < n_tiles; tile += gridDim.x * 4u) {
+        // every lane owns one list entry for the per-point work (point, OneBlob, uncertainty corners, cotangent)
+        const uint32_t i_raw = tile * 64u + lane;
+        const bool valid = i_raw < M_eff;
+        const uint32_t i_pt = valid ? i_raw : M_eff - 1u;
+        const uint32_t m = active_idx != nullptr ? active_idx[i_pt] : i_pt;
+        float x, y, z;
+        load_point(ps, bt, m, x, y, z);
+        float g[5];
+        {
+            const float* gp = d_raw + (size_t)m * 5;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) g[q] = valid ? gp[q] : 0.0f;          // padding lanes: zero cotangent => zero contribution
+        }
+        if (x_out != nullptr && valid) {                                    // normalised points [3][cap] (list order) for the table scatter
+            x_out[list_off + i_pt] = x;
+            x_out[(size_t)cap + list_off + i_pt] = y;
+            x_out[2 * (size_t)cap + list_off + i_pt] = z;
+        }
+        if (d_uncert_grid != nullptr && g[4] != 0.0f) {                      // raw[...,4] is the trilinear sample itself
+            int32_t ui[8];
+            float uw[8];
+            uncert_corners(ut, x, y, z, ui, uw);
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (ui[c] >= 0) unsafeAtomicAdd(d_uncert_grid + ui[c], uw[c] * g[4]);
+        }
+        // OneBlob packs of the two tiles (as in k_query_fwd_bf)
+        u32x4_t blA[3], blB[3];
+        const bool blob_fast = __all(oneblob_sparse_ok(x) && oneblob_sparse_ok(y) && oneblob_sparse_ok(z));
+        static_for<0, 3>([&](auto dc) {
+            constexpr int D = decltype(dc)::value;
+            float e[kBins];
+            oneblob16_auto(D == 0 ? x : (D == 1 ? y : z), blob_fast, e);
+            float lo8[8], hi8[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { lo8[q] = e[q]; hi8[q] = e[8 + q]; }
+            u32x4_t lo = pack8(lo8), hi = pack8(hi8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { uint32_t a = lo[q], b = hi[q]; swap32u(a, b); lo[q] = a; hi[q] = b; }
+            blA[D] = lo;
+            blB[D] = hi;
+        });
+        // per-point scalars of point j (tile A) / j + 32 (tile B) in BOTH halves
+        uint32_t mA = m, mB = m;
+        swap32u(mA, mB);
+        float gA[5], gB[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { gA[q] = g[q]; gB[q] = g[q]; swap32(gA[q], gB[q]); }
+        const uint32_t iA = tile * 64u + (uint32_t)j, iB = iA + 32u;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            const uint32_t mt = half ? mB : mA, it = half ? iB : iA;
+            float ft[kLevels];
+#pragma unroll
+            for (int T = 0; T < kLevels; ++T) ft[T] = feat_save[((size_t)T * M + mt) * 2 + hh];
+            float f0[8], f1[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { f0[q] = ft[q]; f1[q] = ft[8 + q]; }
+            const u32x4_t F[2] = {pack8(f0), pack8(f1)};
+            const float g_rgb[3] = {half ? gB[0] : gA[0], half ? gB[1] : gA[1], half ? gB[2] : gA[2]};
+            const float* dg = d_geo != nullptr ? d_geo + (size_t)mt * kGeo : nullptr;
+            u32x4_t bl[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bl[d][q] = half ? blB[d][q] : blA[d][q];
+            }
+            const f32x16 df = bwd_tile_bf(L, dw, F, bl, g_rgb, half ? gB[3] : gA[3], dg, lane);
+            // reg 4q+e of half hh is feature e + 8q + 4hh  => level (e>>1) + 4q + 2hh, component e&1
+            if (it < M_eff) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int e2 = 0; e2 < 2; ++e2) {
+                        const int level = e2 + 4 * q + 2 * hh;
+                        dfo[(size_t)level * cap + list_off + it] = make_float2(df[4 * q + 2 * e2], df[4 * q + 2 * e2 + 1]);
+                    }
+                }
+            }
+        }
+    }
+    // block-level sum of the four waves' register tiles through the LDS image, then one coalesced write of the partial
+    float* __restrict__ acc = L.acc;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+            const f32x16* tiles[kAccTiles] = {&dw.w0a, &dw.w0b, &dw.w0c, &dw.w1, &dw.c0a, &dw.c0b, &dw.c1};
+#pragma unroll
+            for (int t = 0; t < kAccTiles; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float* a = &acc[t * 1024 + crow(r, hh) * 32 + j];
+                    *a = (w == 0 ? 0.0f : *a) + (*tiles[t])[r];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* __restrict__ out = partials + (size_t)blockIdx.x * kAccFloats;
+    for (int e = threadIdx.x; e < kAccFloats; e += blockDim.x) out[e] = acc[e];
+}
+
 // partials [n_blocks][7][32][32] -> += into the four weight gradients.  Block = 32 outputs x 8 slices of the
 // block range; fixed summation order (deterministic for a given grid).
 // Fused torch.optim.Adam update (amsgrad off, L2 weight decay; the arithmetic of k_adam_multi) applied by the kernels

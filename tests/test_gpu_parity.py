@@ -54,7 +54,8 @@ def test_mfma_bf16_layout(gpu, built_lib):
     A = torch.from_numpy(rs.normal(size=(32, 16)).astype(np.float32))
     B = torch.from_numpy(rs.normal(size=(16, 32)).astype(np.float32))
     out = torch.empty(64 * 16, device=gpu)
-    _lib.check(lib.naruto_debug_mfma_bf16_layout(A.to(gpu).data_ptr(), B.to(gpu).data_ptr(), out.data_ptr(), None), "debug_mfma_bf16_layout")
+    Ag, Bg = A.to(gpu), B.to(gpu)                       # keep them alive: a temporary's block is recycled by the next allocation
+    _lib.check(lib.naruto_debug_mfma_bf16_layout(Ag.data_ptr(), Bg.data_ptr(), out.data_ptr(), None), "debug_mfma_bf16_layout")
     torch.cuda.synchronize()
     D = (A.bfloat16().double() @ B.bfloat16().double()).float()
     got = out.cpu().reshape(64, 16)
@@ -261,15 +262,79 @@ def test_bf16_mode_matches_its_restatement(gpu, hash_size):
     with torch.no_grad():
         got = m.query_color_sdf(x.to(gpu))
         su, geo = m.query_sdf(x.to(gpu), return_geo=True, return_uncert=True)
-    H.assert_close(got, want, 2e-5, "bf16.raw", rel=1e-5)
-    H.assert_close(su[:, 0], out[:, 0], 2e-5, "bf16.sdf", rel=1e-5)
-    H.assert_close(geo, out[:, 1:], 2e-5, "bf16.geo", rel=1e-5)
+    # Both sides round intermediate activations to bf16; where an fp32 sum lands within its accumulation-order noise of a bf16
+    # rounding boundary the two can round it to neighbouring bf16 values (a 2^-8 relative step on ONE operand).  So: nearly every
+    # element agrees to fp32 accuracy, a handful may differ by such a step -- and nothing by more.
+    def close_up_to_bf16_flips(a, b, what):
+        a, b = a.detach().float().cpu(), b.detach().float().cpu()
+        err = (a - b).abs()
+        tight = err <= 2e-5 + 1e-5 * b.abs()
+        assert float(tight.float().mean()) > 0.998, f"{what}: only {float(tight.float().mean()):.4f} of the elements agree to fp32 accuracy"
+        assert float(err.max()) <= 2e-3 * float(b.abs().max()), f"{what}: max err {float(err.max()):.3e} at scale {float(b.abs().max()):.3e}"
+    close_up_to_bf16_flips(got, want, "bf16.raw")
+    close_up_to_bf16_flips(su[:, 0], out[:, 0], "bf16.sdf")
+    close_up_to_bf16_flips(geo, out[:, 1:], "bf16.geo")
     # and the distance to the exact (fp32) network is the bf16 rounding of the operands: ~2^-9 relative per product
     exact = ora.query_color_sdf(x).detach()
     err = (got.cpu() - exact).abs().max(0).values
     scale = exact.abs().max(0).values
     assert (err[:4] <= 2e-2 * scale[:4] + 1e-4).all(), f"bf16 vs fp32 network: {err.tolist()} at scales {scale.tolist()}"
     assert float(err[4]) <= 1e-6                              # the uncertainty channel does not pass through the MLPs
+
+
+class _BfLinear(torch.autograd.Function):
+    """y = bf16(x) . bf16(W)^T with fp32 accumulation; backward the way k_query_bwd_bf computes it: dx = bf16(g) . bf16(W),
+    dW = bf16(g)^T . bf16(x).  ``exact_dx``: the 32 -> 3 colour layer, whose forward and input gradient are fp32 VALU code."""
+
+    @staticmethod
+    def forward(ctx, x, W, exact):
+        bf = lambda t: t.bfloat16().float()
+        ctx.save_for_backward(x, W)
+        ctx.exact = exact
+        return (x.double() @ W.double().T).float() if exact else (bf(x).double() @ bf(W).double().T).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        bf = lambda t: t.bfloat16().float()
+        x, W = ctx.saved_tensors
+        dx = (g.double() @ W.double()).float() if ctx.exact else (bf(g).double() @ bf(W).double()).float()
+        dW = (bf(g).double().T @ bf(x).double()).float()
+        return dx, dW, None
+
+
+def test_bf16_mode_backward_matches_its_restatement(gpu):
+    """k_query_bwd_bf (everything in registers, transposes on the matrix core) against a torch restatement of its arithmetic:
+    every matrix product with bf16-rounded operands and fp32 accumulation, ReLU masks from the bf16 forward.  All six gradients,
+    incl. the table gradient through the scatter; a point count that leaves partly filled tiles in both 32-point halves."""
+    cfg = H.office_cfg(12)
+    ora = H.make_oracle(cfg, 0.3, 67)
+    cfg_bf = H.office_cfg(12)
+    cfg_bf["decoder"]["mlp_precision"] = "bf16"
+    m = H.make_hip_from_oracle(cfg_bf, ora, gpu)
+    rs = np.random.RandomState(67)
+    n = 2049 + 40
+    x = torch.from_numpy(np.concatenate([rs.uniform(0, 1, (2049, 3)), rs.uniform(-0.3, 1.3, (40, 3))]).astype(np.float32))
+    cot = torch.from_numpy(rs.normal(size=(n, 5)).astype(np.float32))
+    cot[rs.uniform(size=n) < 0.1] = 0.0
+    feats, pos = S.hash_encode(x, ora.table, ora.meta), S.oneblob_encode(x, 16)
+    h = _BfLinear.apply(torch.cat([feats, pos], -1), ora.sdf_w0, False)
+    out = _BfLinear.apply(torch.relu(h), ora.sdf_w1, False)
+    c = _BfLinear.apply(torch.cat([pos, out[:, 1:]], -1), ora.col_w0, False)
+    rgb = _BfLinear.apply(torch.relu(c), ora.col_w1, True)
+    unc = ora.query_color_sdf(x)[:, 4:5]
+    raw_o = torch.cat([rgb, out[:, :1], unc], -1)
+    (raw_o * cot).sum().backward()
+    raw_h = m.query_color_sdf(x.to(gpu))
+    (raw_h * cot.to(gpu)).sum().backward()
+    gh, go = H.hip_grads(m), H.ora_grads(ora)
+    for k in gh:
+        got, want = gh[k].reshape(-1).double().cpu(), go[k].reshape(-1).double()
+        scale = float(want.abs().max())
+        err = (got - want).abs()
+        # bf16 rounding flips of single operands (see test_bf16_mode_matches_its_restatement) move an entry by <= ~2^-8 of ONE of its
+        # ~2000 terms: far below 1e-3 of the scale; everything else agrees to accumulation-order accuracy
+        assert float((err <= 2e-5 * scale).float().mean()) > 0.99, f"bf16 backward, {k}: {float((err <= 2e-5 * scale).float().mean()):.4f} within 2e-5 of the scale"
+        assert float(err.max()) <= 1e-3 * scale, f"bf16 backward, {k}: max err {float(err.max()):.3e}, scale {scale:.3e}"
 
 
 # --------------------------------------------------------------------------------------------- large tables: the binned scatter
@@ -713,7 +778,10 @@ def test_capture_mid_training_keeps_the_trajectory(gpu):
             assert torch.equal(b.iter_state.cpu(), a.iter_state.cpu())
             for (ma, va), (mb, vb) in zip(a.map_optimizer.state.values(), b.map_optimizer.state.values()):
                 assert torch.equal(ma, mb) and torch.equal(va, vb)
-            assert torch.equal(a.model.uncert_grid.grad, b.model.uncert_grid.grad) and float(b.model.uncert_grid.grad.abs().sum()) > 0
+            # (the uncertainty grid's gradient is accumulated with float atomics: equal up to summation order)
+            gsc = float(a.model.uncert_grid.grad.abs().max())
+            assert gsc > 0
+            H.assert_close(b.model.uncert_grid.grad, a.model.uncert_grid.grad, 1e-5 * gsc, "uncert-grid gradient carried over the capture", rel=1e-4)
         rays = syn.random_rays(176, cfg["mapping"]["bound"], seed=700 + it, zero_depth_frac=0.1)
         t = [torch.from_numpy(rays[k]).to(gpu) for k in ("rays_o", "rays_d", "target_rgb", "target_d")]
         ra, la = a.step(*t, smooth=True)
@@ -948,7 +1016,10 @@ def test_train_step_full_size_against_oracle(gpu, workload):
         # and against the fp32 oracle: both sit within the budget of the fp64 result
         H.assert_close(got, go[k].reshape(-1), 2.0 * budget[k], f"full.grad.{k} vs fp32 oracle", rel=1e-3)
         if k == "table":
-            assert float((err64 > 1e-4 * scale).float().mean()) < 1e-4, "full.grad.table: too many entries beyond 1e-4 of the scale"
+            # how many entries lie beyond 1e-4 of the scale: no more than for the fp32 oracle itself (x 1.5), or 1e-4 of the table
+            frac_h = float((err64 > 1e-4 * scale).float().mean())
+            frac_o = float(((go[k].reshape(-1).double() - g64[k].reshape(-1)).abs() > 1e-4 * scale).float().mean())
+            assert frac_h <= max(1e-4, 1.5 * frac_o), f"full.grad.table: {frac_h:.2e} of the entries beyond 1e-4 of the scale (fp32 oracle: {frac_o:.2e})"
     if S_tot % 64 == 0 and S_tot > 64:
         n_stopped = int((ts.raw[:, 64:, :].reshape(N, -1).abs().sum(1) == 0).sum().item())
         assert 0 < n_stopped < N, f"early termination: {n_stopped} of {N} rays stopped after the first tile"

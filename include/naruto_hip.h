@@ -162,6 +162,11 @@ typedef struct NarutoExtraPoints {
 } NarutoExtraPoints;
 #define NARUTO_BWD_OVERWRITE_WEIGHT_GRADS 1u
 #define NARUTO_BWD_OVERWRITE_TABLE_GRAD 2u
+/* naruto_train_backward in two calls (data parallel: the small MLP-gradient bucket is all-reduced while the table scatter runs):
+ * MLP_ONLY = loss backward, compaction, MLP backward, weight gradients (complete after this call); TABLE_ONLY = the table scatter
+ * over the point list the MLP_ONLY call left in the workspace.  Not with the fused optimiser. */
+#define NARUTO_TRAIN_BWD_MLP_ONLY 4u
+#define NARUTO_TRAIN_BWD_TABLE_ONLY 8u
 size_t naruto_query_bwd_workspace(const NarutoField* f, uint32_t M);
 int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, const NarutoPoints* pts,
                      const float* feat_save, const float* d_raw, const float* d_geo,

@@ -482,7 +482,10 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
         attr_set = true;
     }
     float* x_list = (g->table != nullptr || adam != nullptr) ? x_soa : nullptr;
-    if (bf)
+    const bool phase_mlp = (flags & NARUTO_TRAIN_BWD_TABLE_ONLY) == 0u;        // phases: see naruto_train_backward
+    const bool phase_table = (flags & NARUTO_TRAIN_BWD_MLP_ONLY) == 0u;
+    if (!phase_mlp) { /* the point list, d_feat and the wgrad partials are those of the preceding MLP-only call */ }
+    else if (bf)
         hipLaunchKernelGGL(k_query_bwd_bf, dim3(blocks), dim3(256), sizeof(BwdLdsBf), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, ps, M, cap, feat_save, d_raw,
                            d_geo, d_feat, x_list, g->uncert_grid, partials, active_idx, n_active, n_front);
     else
@@ -490,6 +493,7 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
                            d_geo, d_feat, x_list, g->uncert_grid, partials, active_idx, n_active, n_front);
     if (int rc = check_launch("query_bwd")) return rc;
     if (adam != nullptr) {
+        if (!phase_mlp || !phase_table) return fail(NARUTO_ERR_INVALID, "query_bwd: the fused optimiser runs the backward in one piece");
         // optimiser in the backward: the tiled scatter without its reduce, then ONE launch finishes the tiled levels' table
         // gradient + the weight gradients and steps them; the binned scatter's last kernel steps the larger levels itself
         PointSrc pss{};
@@ -507,11 +511,12 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
         return check_launch("bwd_finish");
     }
     const bool want_w = g->sdf_w0 || g->sdf_w1 || g->col_w0 || g->col_w1;
-    if (want_w) {
+    if (want_w && phase_mlp) {
         hipLaunchKernelGGL(k_wgrad_reduce, dim3(kAccFloats / 32), dim3(256), 0, (hipStream_t)stream, partials, blocks, *g,
                            (int)(flags & NARUTO_BWD_OVERWRITE_WEIGHT_GRADS));
         if (int rc = check_launch("wgrad_reduce")) return rc;
     }
+    if (!phase_table) return NARUTO_OK;
     if (n_front > 0) {
         if (g->table == nullptr) return NARUTO_OK;
         PointSrc pss{};
@@ -730,22 +735,28 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
     CompositeCot cot{};
     LossArgs la{t->target_rgb, t->target_d, t->sums, t->loss_weights, t->n_rays_total ? t->n_rays_total : N, t->depth_trunc, t->rgb_missing,
                 f->desc.trunc * f->desc.sc_factor};
+    if ((flags & NARUTO_TRAIN_BWD_MLP_ONLY) && (flags & NARUTO_TRAIN_BWD_TABLE_ONLY)) return fail(NARUTO_ERR_INVALID, "train_backward: pick one phase");
+    const bool table_only = (flags & NARUTO_TRAIN_BWD_TABLE_ONLY) != 0u;
     if (int rc = ray_lds_attr()) return rc;
-    hipLaunchKernelGGL(k_composite_bwd<true>, dim3((N + kRaysPerBlock - 1) / kRaysPerBlock), dim3(64 * kRaysPerBlock), ray_scratch_bytes(S), st, N, S, f->desc.trunc,
-                       f->desc.sc_factor, f->desc.white_bkgd, t->raw, t->z_vals, cot, la, t->d_raw, 0, t->ray_count);
-    if (int rc = check_launch("loss_bwd")) return rc;
+    if (!table_only) {
+        hipLaunchKernelGGL(k_composite_bwd<true>, dim3((N + kRaysPerBlock - 1) / kRaysPerBlock), dim3(64 * kRaysPerBlock), ray_scratch_bytes(S), st, N, S, f->desc.trunc,
+                           f->desc.sc_factor, f->desc.white_bkgd, t->raw, t->z_vals, cot, la, t->d_raw, 0, t->ray_count);
+        if (int rc = check_launch("loss_bwd")) return rc;
+    }
     const bool smooth = t->smooth_points != 0 && (g->table != nullptr || opt != nullptr);
     const uint32_t n_front = smooth ? w.n3 : 0u;
     const BwdWs bw = bwd_ws(f, w.bwd, list_cap(M + w.n3));
     const uint32_t* block_sums = nullptr;
-    if (N > 4u * kCompactBlock) {                    // large batch: two-level prefix of the per-ray counts
+    if (!table_only && N > 4u * kCompactBlock) {     // large batch: two-level prefix of the per-ray counts
         hipLaunchKernelGGL(k_count_blocks, dim3((N + kCompactBlock - 1u) / kCompactBlock), dim3(256), 0, st, N, t->ray_count, w.block_sums);
         if (int rc = check_launch("count_blocks")) return rc;
         block_sums = w.block_sums;
     }
-    hipLaunchKernelGGL(k_compact, dim3((N + 3u) / 4u), dim3(256), 0, st, N, S, t->ray_count, t->ray_offset, t->active_idx, t->n_active, n_front, bw.n_total,
-                       block_sums);
-    if (int rc = check_launch("compact")) return rc;
+    if (!table_only) {
+        hipLaunchKernelGGL(k_compact, dim3((N + 3u) / 4u), dim3(256), 0, st, N, S, t->ray_count, t->ray_offset, t->active_idx, t->n_active, n_front, bw.n_total,
+                           block_sums);
+        if (int rc = check_launch("compact")) return rc;
+    }
     NarutoPoints pts{};
     pts.rays_o = t->rays_o; pts.rays_d = t->rays_d; pts.z_vals = t->z_vals; pts.n_samples = S;
     const AdamFuse* ad = opt != nullptr ? &adam : nullptr;

@@ -1634,7 +1634,9 @@ __global__ __launch_bounds__(256, NARUTO_BWD_BF_MINWAVES) void k_query_bwd_bf(Le
                                                       const uint32_t* __restrict__ active_idx, const uint32_t* __restrict__ n_active, uint32_t list_off) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     BwdLdsBf& L = *reinterpret_cast<BwdLdsBf*>(smem_raw);
+#ifndef NARUTO_ABL_BF_NOSTAGE
     stage_bwd_weights_bf<256>(L, p, threadIdx.x);
+#endif
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hh = lane >> 5, j = lane & 31;
@@ -1661,6 +1663,7 @@ __global__ __launch_bounds__(256, NARUTO_BWD_BF_MINWAVES) void k_query_bwd_bf(Le
             x_out[(size_t)cap + list_off + i_pt] = y;
             x_out[2 * (size_t)cap + list_off + i_pt] = z;
         }
+#ifndef NARUTO_ABL_BF_NOATOMIC
         if (d_uncert_grid != nullptr && g[4] != 0.0f) {                      // raw[...,4] is the trilinear sample itself
             int32_t ui[8];
             float uw[8];
@@ -1669,6 +1672,7 @@ __global__ __launch_bounds__(256, NARUTO_BWD_BF_MINWAVES) void k_query_bwd_bf(Le
             for (int c = 0; c < 8; ++c)
                 if (ui[c] >= 0) unsafeAtomicAdd(d_uncert_grid + ui[c], uw[c] * g[4]);
         }
+#endif
         // OneBlob packs of the two tiles (as in k_query_fwd_bf)
         u32x4_t blA[3], blB[3];
         const bool blob_fast = __all(oneblob_sparse_ok(x) && oneblob_sparse_ok(y) && oneblob_sparse_ok(z));
@@ -1710,7 +1714,13 @@ __global__ __launch_bounds__(256, NARUTO_BWD_BF_MINWAVES) void k_query_bwd_bf(Le
 #pragma unroll
                 for (int q = 0; q < 4; ++q) bl[d][q] = half ? blB[d][q] : blA[d][q];
             }
+#ifdef NARUTO_ABL_BF_NOTILE
+            f32x16 df = zero16();
+            asm volatile("" :: "v"(F[0][0]), "v"(F[1][3]), "v"(bl[0][0]), "v"(bl[2][3]), "v"(g_rgb[0]), "v"(dg));
+            df[0] = g_rgb[1];
+#else
             const f32x16 df = bwd_tile_bf(L, dw, F, bl, g_rgb, half ? gB[3] : gA[3], dg, lane);
+#endif
             // reg 4q+e of half hh is feature e + 8q + 4hh  => level (e>>1) + 4q + 2hh, component e&1
             if (it < M_eff) {
 #pragma unroll
@@ -1726,6 +1736,10 @@ __global__ __launch_bounds__(256, NARUTO_BWD_BF_MINWAVES) void k_query_bwd_bf(Le
     }
     // block-level sum of the four waves' register tiles through the LDS image, then one coalesced write of the partial
     float* __restrict__ acc = L.acc;
+#ifdef NARUTO_ABL_BF_NOEPI
+    if (dw.w0a[0] == 123.0f && dw.c1[3] == 5.0f) acc[lane] = dw.w1[2] + dw.w0b[1] + dw.w0c[1] + dw.c0a[1] + dw.c0b[1];
+    return;
+#endif
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
             const f32x16* tiles[kAccTiles] = {&dw.w0a, &dw.w0b, &dw.w0c, &dw.w1, &dw.c0a, &dw.c0b, &dw.c1};

@@ -622,6 +622,8 @@ class TrainStep:
             k = self.params[n].numel()
             self.grads[n] = self.flat_grad[off:off + k].view_as(self.params[n])
             off += k
+        n_table = self.params["table"].numel()
+        self.grad_bucket_table, self.grad_bucket_mlp = self.flat_grad[:n_table], self.flat_grad[n_table:]      # the two all-reduce buckets
         assert uncert_grad.is_cuda and uncert_grad.dtype == torch.float32 and uncert_grad.is_contiguous()
         self.grads["uncert_grid"] = uncert_grad
         world = 1
@@ -727,11 +729,20 @@ class TrainStep:
             check(lib.naruto_train_forward(self.handle.ptr, C.byref(self.ps), C.byref(t), 0 if self.group is not None else 1, st),
                   "naruto_train_forward")
 
-    def run_backward(self):
+    def run_backward(self, phase: int = 0):
+        """phase 0: the whole backward.  Data parallel, for overlap: phase 1 = everything up to the MLP weight gradients (then
+        complete in self.grads), phase 2 = the table scatter; the caller all-reduces the weight bucket in between."""
         lib = _lib.load()
         t = self.t
         with torch.cuda.device(self.device):
             st = _stream()
+            if phase != 0:
+                assert self.opt is None, "the fused optimiser runs the backward in one piece"
+                if phase == 1 and self.group is not None:
+                    check(lib.naruto_train_finalize(self.handle.ptr, C.byref(t), st), "naruto_train_finalize")
+                fl = self.flags | (_lib.TRAIN_BWD_MLP_ONLY if phase == 1 else _lib.TRAIN_BWD_TABLE_ONLY)
+                check(lib.naruto_train_backward(self.handle.ptr, C.byref(self.ps), C.byref(t), C.byref(self.gs), fl, None, st), "naruto_train_backward")
+                return
             if self.group is not None:
                 check(lib.naruto_train_finalize(self.handle.ptr, C.byref(t), st), "naruto_train_finalize")
             if self.opt is not None:

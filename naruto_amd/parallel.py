@@ -52,13 +52,33 @@ def shard_rays(tensors: Sequence[torch.Tensor], rank_: int, world: int) -> List[
     return [t[lo:hi] for t in tensors]
 
 
+class _Done:
+    def wait(self):
+        return True
+
+
+def all_reduce_sum(t: torch.Tensor, group=None, async_op: bool = False):
+    """SUM all-reduce of ``t`` in place.  RCCL ("nccl") takes device tensors directly; the gloo backend (CPU tests, and the
+    two-ranks-on-one-GPU test) gets device tensors staged through the host.  ``async_op``: returns a handle whose ``wait()`` makes
+    the current stream wait for the result (RCCL runs the collective on its own stream: kernels launched meanwhile overlap it)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return _Done()
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+        return _Done()
+    w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return w if async_op else _Done()
+
+
 def allreduce_loss_sums(sums: torch.Tensor, group=None) -> torch.Tensor:
     """In-place all-reduce (SUM) of the nine additive loss-sum slots.  Slot 9, min(uncert_map), stays this rank's own
     minimum: it only feeds the reference's ``assert uncert_map.min() > 0``, which every rank can check for its own
     rays -- not worth a second collective per iteration."""
     if not (dist.is_available() and dist.is_initialized()):
         return sums
-    dist.all_reduce(sums[:LOSS_SLOT_MINUNCERT], op=dist.ReduceOp.SUM, group=group)
+    all_reduce_sum(sums[:LOSS_SLOT_MINUNCERT], group)
     return sums
 
 
@@ -74,7 +94,7 @@ def allreduce_grads(params: Iterable[torch.nn.Parameter], group=None, flat: Opti
     if len(bases) == 1 and all(p.grad._base is not None for p in ps):
         base = ps[0].grad._base
         if base.is_contiguous() and base.numel() == sum(p.grad.numel() for p in ps):
-            dist.all_reduce(base, op=dist.ReduceOp.SUM, group=group)
+            all_reduce_sum(base, group)
             return
     n = sum(p.grad.numel() for p in ps)
     if flat is None or flat.numel() != n or flat.device != ps[0].grad.device:
@@ -84,7 +104,7 @@ def allreduce_grads(params: Iterable[torch.nn.Parameter], group=None, flat: Opti
         k = p.grad.numel()
         flat[off:off + k].copy_(p.grad.reshape(-1))
         off += k
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    all_reduce_sum(flat, group)
     off = 0
     for p in ps:
         k = p.grad.numel()

@@ -236,12 +236,23 @@ class MappingTrainer:
         use_smooth = bool(smooth and tr['smooth_weight'] > 0)
         ts = self._train_step(rays_o.shape[0], use_smooth)
         with torch.no_grad():
-            losses = ts.run(rays_o, rays_d, target_rgb, target_d.reshape(-1))
+            if self.group is not None and ts.opt is None:
+                # data parallel: forward | all-reduce of the loss sums | backward up to the MLP weight gradients | their (20 KB)
+                # all-reduce, issued asynchronously so that it runs under the table scatter | scatter | all-reduce of the table
+                # gradient | identical Adam steps on every rank
+                ts.run_forward(rays_o, rays_d, target_rgb, target_d.reshape(-1))
+                parallel.allreduce_loss_sums(ts.sums, self.group)
+                ts.run_backward(phase=1)
+                pending = parallel.all_reduce_sum(ts.grad_bucket_mlp, self.group, async_op=True)
+                ts.run_backward(phase=2)
+                parallel.all_reduce_sum(ts.grad_bucket_table, self.group)
+                pending.wait()
+                losses = ts.losses
+            else:
+                losses = ts.run(rays_o, rays_d, target_rgb, target_d.reshape(-1))
             if ts.opt is None:
                 for name, p in model._params().items():
                     p.grad = ts.grads[name]
-                if self.group is not None:
-                    torch.distributed.all_reduce(ts.flat_grad, op=torch.distributed.ReduceOp.SUM, group=self.group)
                 self.map_optimizer.step()
             else:
                 model.uncert_grid.grad = ts.grads["uncert_grid"]          # table / weight gradients are consumed inside the backward
@@ -328,7 +339,7 @@ class MappingTrainer:
                 seg['fwd'].replay()
                 parallel.allreduce_loss_sums(ts.sums, self.group)
                 seg['bwd'].replay()
-                torch.distributed.all_reduce(ts.flat_grad, op=torch.distributed.ReduceOp.SUM, group=self.group)
+                parallel.all_reduce_sum(ts.flat_grad, self.group)
                 if uncert_step:
                     parallel.allreduce_grads([self.model.uncert_grid], self.group)
                 seg['opt'][1 if uncert_step else 0].replay()

@@ -148,8 +148,7 @@ def kernel_table(tr, rays, cfg, iters: int):
         setattr(gs, k, p(v))
     wsb = torch.empty(lib.naruto_query_bwd_workspace(h.ptr, M) // 4, device=dev)
     # the three kernels of naruto_query_bwd, split by giving each call only the outputs one kernel produces
-    gs_mlp = _lib.NarutoGrads()                 # k_query_bwd alone: no table (scatter), no weight outputs (k_wgrad_reduce)
-    gs_mlp.uncert_grid = p(grads["uncert_grid"])
+    gs_mlp = _lib.NarutoGrads()                 # k_query_bwd alone: no table / uncertainty grid (scatter), no weight outputs (k_wgrad_reduce)
     Ma = int(round(frac * M))                                                           # active (non-zero cotangent) samples
     mlp_bwd_flops = Ma * 2 * (5184 + (15 * 32 + 16 * 32 + 32 * 32 + 3 * 32) + 5184)   # recompute + dgrad + wgrad
     add("k_query_bwd", lambda: _lib.check(lib.naruto_query_bwd(h.ptr, CT.byref(ps), M, CT.byref(pts), p(feat), p(d_raw), None,

@@ -99,13 +99,17 @@ struct ScatterWs {
     float* partial; uint32_t* counts; uint32_t* totals; uint32_t* starts; BinItem* items;
     size_t total;
 };
+// entries per feature plane of a partial table: the tiled levels, then (plane 0 only uses it) the uncertainty-grid image
+inline size_t partial_plane(const NarutoField* f) { return (size_t)f->n_tiled_entries + (((size_t)f->plan.n_uncert ? (size_t)f->plan.uncert_voxels : 0u) + 3u) / 4u * 4u; }
+
 ScatterWs scatter_ws(const NarutoField* f, void* base, uint32_t M) {
     ScatterWs w{};
     char* b = reinterpret_cast<char*>(base);
     size_t off = 0;
-    const uint32_t smax = f->plan.s_dense > f->plan.s_hashed ? f->plan.s_dense : f->plan.s_hashed;
+    uint32_t smax = f->plan.s_dense > f->plan.s_hashed ? f->plan.s_dense : f->plan.s_hashed;
+    if (f->plan.s_uncert > smax) smax = f->plan.s_uncert;
     w.partial = reinterpret_cast<float*>(b + off);
-    off += al256((f->plan.n_dense + f->plan.n_hashed) ? (size_t)smax * (size_t)f->n_tiled_entries * 2u * sizeof(float) : 16u);
+    off += al256((f->plan.n_dense + f->plan.n_hashed) ? (size_t)smax * partial_plane(f) * 2u * sizeof(float) : 16u);
     if (f->bplan.n_levels != 0) {
         w.counts = reinterpret_cast<uint32_t*>(b + off); off += al256((size_t)bin_rows(M) * f->bplan.n_bins * sizeof(uint32_t));
         w.totals = reinterpret_cast<uint32_t*>(b + off); off += al256((size_t)f->bplan.n_bins * sizeof(uint32_t));
@@ -120,13 +124,24 @@ ScatterWs scatter_ws(const NarutoField* f, void* base, uint32_t M) {
 // gradient itself); larger levels: the binned scatter (naruto_binned.hip), whose last kernel writes / adds the gradient slice or,
 // with ``adam``, steps the optimiser on it.  (Debug: NARUTO_DEBUG_SCATTER_ATOMIC=1 sends the larger levels through global
 // float atomics instead -- for A/B timing only.)
+// unc_g / d_uncert (both or neither; training list layout only): row 3 of the point list and the grid's gradient it is scattered into
 int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const float* d_feat, size_t stride_m, size_t stride_l, float* d_table,
                    void* workspace, hipStream_t st, const uint32_t* m_dev = nullptr, const float* scale_dev = nullptr, int overwrite = 0,
-                   bool do_reduce = true, const AdamFuse* adam = nullptr) {
+                   bool do_reduce = true, const AdamFuse* adam = nullptr, const float* unc_g = nullptr, float* d_uncert = nullptr) {
     if ((overwrite || adam != nullptr) && f->plan.atomic_levels != 0)
         return fail(NARUTO_ERR_INVALID, "scatter: written (not accumulated) gradients / the fused optimiser are not available with NARUTO_DEBUG_SCATTER_ATOMIC");
     const ScatterWs w = scatter_ws(f, workspace, M);
     const size_t n_tiled_params = (size_t)f->n_tiled_entries * 2u;
+    const size_t n_plane = partial_plane(f);
+    UncertScatter us{};
+    UncertReduce ur{};
+    if (unc_g != nullptr && d_uncert != nullptr && f->plan.n_uncert != 0) {
+        us.g = unc_g; us.ut = f->ut; us.partial_off = (uint32_t)f->n_tiled_entries;
+        ur.d_uncert = d_uncert; ur.n_voxels = f->plan.uncert_voxels; ur.n_splits = f->plan.s_uncert; ur.partial_off = (uint32_t)f->n_tiled_entries;
+    }
+    if (d_table == nullptr && adam == nullptr && us.g == nullptr) return NARUTO_OK;
+    ScatterPlan plan = f->plan;
+    if (d_table == nullptr && adam == nullptr) plan.n_dense = plan.n_hashed = 0;        // only the uncertainty grid's gradient is wanted
     if (f->plan.n_dense + f->plan.n_hashed > 0) {
         static bool attr_set = false;
         const size_t lds = (size_t)kChunk * sizeof(unsigned long long);
@@ -135,17 +150,22 @@ int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const f
                 return fail(NARUTO_ERR_LAUNCH, "hash_scatter: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(hipGetLastError()));
             attr_set = true;
         }
-        const uint32_t blocks = (f->plan.n_dense * f->plan.s_dense + f->plan.n_hashed * f->plan.s_hashed + 7u) / 8u * 8u;      // XCD-aware order: multiple of 8
-        hipLaunchKernelGGL(k_hash_scatter_lds, dim3(blocks), dim3(kScatterThreads), lds, st, f->lt, f->bt, ps, M, d_feat, stride_m, stride_l, f->plan,
-                           w.partial, n_tiled_params, m_dev, scale_dev);
+        const uint32_t blocks = (plan.n_dense * plan.s_dense + plan.n_hashed * plan.s_hashed + (us.g != nullptr ? plan.n_uncert * plan.s_uncert : 0u) + 7u) /
+                                8u * 8u;      // XCD-aware order: multiple of 8
+        hipLaunchKernelGGL(k_hash_scatter_lds, dim3(blocks), dim3(kScatterThreads), lds, st, f->lt, f->bt, ps, M, d_feat, stride_m, stride_l, plan,
+                           w.partial, 2u * n_plane, m_dev, scale_dev, us);
         if (int rc = check_launch("hash_scatter_lds")) return rc;
         if (do_reduce) {
-            hipLaunchKernelGGL(k_scatter_reduce, dim3((uint32_t)((n_tiled_params / 4u + 255u) / 256u)), dim3(256), 0, st, f->lt, f->plan.atomic_levels, w.partial,
-                               f->plan.s_dense, f->plan.s_hashed, n_tiled_params, d_table, overwrite);
-            if (int rc = check_launch("scatter_reduce")) return rc;
+            const uint32_t n_table_blocks = d_table != nullptr ? (uint32_t)((n_tiled_params / 4u + 255u) / 256u) : 0u;
+            const uint32_t n_unc_blocks = ur.d_uncert != nullptr ? (ur.n_voxels + 255u) / 256u : 0u;
+            if (n_table_blocks + n_unc_blocks > 0) {
+                hipLaunchKernelGGL(k_scatter_reduce, dim3(n_table_blocks + n_unc_blocks), dim3(256), 0, st, f->lt, f->plan.atomic_levels, w.partial,
+                                   f->plan.s_dense, f->plan.s_hashed, n_tiled_params, n_plane, d_table, overwrite, n_table_blocks, ur);
+                if (int rc = check_launch("scatter_reduce")) return rc;
+            }
         }
     }
-    if (f->bplan.n_levels != 0) {
+    if (f->bplan.n_levels != 0 && (d_table != nullptr || adam != nullptr)) {
         static bool attr_set = false;
         if (!attr_set) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_fill), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -173,7 +193,7 @@ int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const f
                            d_table, overwrite, scale_dev, adam != nullptr ? *adam : none);
         if (int rc = check_launch("bin_apply")) return rc;
     }
-    if (f->plan.atomic_levels != 0) {
+    if (f->plan.atomic_levels != 0 && d_table != nullptr) {
         hipLaunchKernelGGL(k_hash_scatter_atomic, dim3((M + 255u) / 256u, kLevels), dim3(256), 0, st, f->lt, f->bt, ps, M, d_feat, stride_m, stride_l,
                            f->plan.atomic_levels, d_table, m_dev, scale_dev);
         if (int rc = check_launch("hash_scatter_atomic")) return rc;
@@ -287,10 +307,20 @@ int naruto_field_create(const NarutoFieldDesc* d, NarutoField** out) {
     // streams, not by its unit): never launch more workgroups than CUs (a second round doubles the kernel time).  About
     // 70 % of the CUs go to the hashed units, the rest to the dense ones (measured optimum on MI355X: 2 x 88 + 5 x 16).
     {
+        // the uncertainty grid rides along as 16 384-voxel units (grids beyond kMaxUncertChunks chunks keep float atomics in k_query_bwd)
+        const uint64_t vox = (uint64_t)d->uncert_dims[0] * d->uncert_dims[1] * d->uncert_dims[2];
+        const uint64_t uch = (vox + kChunk - 1u) / kChunk;
+        if (uch <= (uint64_t)kMaxUncertChunks && vox < 0x7FFFFFFFull) {
+            f->plan.n_uncert = (uint32_t)uch;
+            f->plan.uncert_voxels = (uint32_t)vox;
+            f->plan.s_uncert = uch <= 8u ? 2u : 1u;
+        }
         const uint32_t cus = cu_count(f);
+        const uint32_t unc_blocks = f->plan.n_uncert * f->plan.s_uncert;
         uint32_t sh = f->plan.n_hashed ? (cus * 7u / 10u) / f->plan.n_hashed : 1u;
         sh = sh < 1u ? 1u : (sh > 8u ? 8u : sh);
-        const uint32_t left = cus > f->plan.n_hashed * sh ? cus - f->plan.n_hashed * sh : 0u;
+        // the dense units share what the hashed units and the grid's units leave
+        const uint32_t left = cus > f->plan.n_hashed * sh + unc_blocks ? cus - f->plan.n_hashed * sh - unc_blocks : 0u;
         uint32_t sd = f->plan.n_dense ? left / f->plan.n_dense : 1u;
         sd = sd < 1u ? 1u : (sd > 8u ? 8u : sd);
         f->plan.s_hashed = sh;
@@ -423,9 +453,9 @@ int naruto_query_fwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
 }
 
 size_t naruto_query_bwd_workspace(const NarutoField* f, uint32_t M) {
-    // M here = points + extra points.  d_feat [16][cap][2] | x [3][cap] | wgrad partials | scatter partials | count word
+    // M here = points + extra points.  d_feat [16][cap][2] | x [4][cap] (x, y, z, d raw[...,4]) | wgrad partials | scatter partials | count word
     M = list_cap(M);
-    return ((size_t)kLevels * 2u + 3u) * sizeof(float) * (size_t)M + (size_t)kBwdMaxBlocks * kAccFloats * sizeof(float) + naruto_scatter_workspace(f, M) + 64;
+    return ((size_t)kLevels * 2u + 4u) * sizeof(float) * (size_t)M + (size_t)kBwdMaxBlocks * kAccFloats * sizeof(float) + naruto_scatter_workspace(f, M) + 64;
 }
 
 }  // extern "C"
@@ -434,13 +464,13 @@ namespace {
 struct BwdWs {
     float* d_feat; float* x_soa; float* partials; float* scatter_ws; uint32_t* n_total;
 };
-// layout of naruto_query_bwd_workspace(): the scatter's point list (d_feat [16][cap][2], x [3][cap]), wgrad partials,
+// layout of naruto_query_bwd_workspace(): the scatter's point list (d_feat [16][cap][2], x [4][cap]), wgrad partials,
 // scatter partial tables, one count word
 BwdWs bwd_ws(const NarutoField* f, void* workspace, uint32_t cap) {
     BwdWs w;
     w.d_feat = reinterpret_cast<float*>(workspace);
     w.x_soa = w.d_feat + (size_t)kLevels * 2u * (size_t)cap;
-    w.partials = w.x_soa + 3u * (size_t)cap;
+    w.partials = w.x_soa + 4u * (size_t)cap;          // x, y, z, cotangent of raw[...,4]
     w.scatter_ws = w.partials + (size_t)kBwdMaxBlocks * kAccFloats;
     w.n_total = reinterpret_cast<uint32_t*>(w.scatter_ws + naruto_scatter_workspace(f, cap) / sizeof(float));
     return w;
@@ -477,20 +507,25 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BwdLds)) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_bwd_bf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BwdLdsBf)) != hipSuccess)
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_bwd_bf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwdBfLdsBytes) != hipSuccess)
             return fail(NARUTO_ERR_LAUNCH, "query_bwd: cannot reserve %zu bytes of LDS: %s", sizeof(BwdLds), hipGetErrorString(hipGetLastError()));
         attr_set = true;
     }
-    float* x_list = (g->table != nullptr || adam != nullptr) ? x_soa : nullptr;
+    // the uncertainty grid's gradient: through the scatter (row 3 of the point list) unless the grid is too large for that
+    const bool unc_scatter = g->uncert_grid != nullptr && f->plan.n_uncert != 0;
+    const int unc_atomic = (g->uncert_grid != nullptr && f->plan.n_uncert == 0) ? 1 : 0;
+    const float* unc_g = unc_scatter ? x_soa + 3u * (size_t)cap : nullptr;
+    float* d_unc = unc_scatter ? g->uncert_grid : nullptr;
+    float* x_list = (g->table != nullptr || adam != nullptr || unc_scatter) ? x_soa : nullptr;
     const bool phase_mlp = (flags & NARUTO_TRAIN_BWD_TABLE_ONLY) == 0u;        // phases: see naruto_train_backward
     const bool phase_table = (flags & NARUTO_TRAIN_BWD_MLP_ONLY) == 0u;
     if (!phase_mlp) { /* the point list, d_feat and the wgrad partials are those of the preceding MLP-only call */ }
     else if (bf)
-        hipLaunchKernelGGL(k_query_bwd_bf, dim3(blocks), dim3(256), sizeof(BwdLdsBf), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, ps, M, cap, feat_save, d_raw,
-                           d_geo, d_feat, x_list, g->uncert_grid, partials, active_idx, n_active, n_front);
+        hipLaunchKernelGGL(k_query_bwd_bf, dim3(blocks), dim3(256), kBwdBfLdsBytes, (hipStream_t)stream, f->lt, f->ut, f->bt, *p, ps, M, cap, feat_save, d_raw,
+                           d_geo, d_feat, x_list, g->uncert_grid, partials, active_idx, n_active, n_front, unc_atomic);
     else
         hipLaunchKernelGGL(k_query_bwd, dim3(blocks), dim3(64 * kBwdWaves), sizeof(BwdLds), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, ps, M, cap, feat_save, d_raw,
-                           d_geo, d_feat, x_list, g->uncert_grid, partials, active_idx, n_active, n_front);
+                           d_geo, d_feat, x_list, g->uncert_grid, partials, active_idx, n_active, n_front, unc_atomic);
     if (int rc = check_launch("query_bwd")) return rc;
     if (adam != nullptr) {
         if (!phase_mlp || !phase_table) return fail(NARUTO_ERR_INVALID, "query_bwd: the fused optimiser runs the backward in one piece");
@@ -502,12 +537,15 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
         pss.S = 1;
         const uint32_t* cnt = n_front > 0 ? n_list_dev : n_active;
         if (int rc = launch_scatter(f, pss, cnt != nullptr ? cap : M, d_feat, (size_t)2, (size_t)2 * (size_t)cap, g->table, scatter_ws, (hipStream_t)stream, cnt,
-                                    nullptr, 1, false, adam))
+                                    nullptr, 1, false, adam, unc_g, d_unc))
             return rc;
         const size_t n_params = (size_t)f->n_tiled_entries * 2u;
         const uint32_t n_table_blocks = (uint32_t)((n_params / 4u + 255u) / 256u);
-        hipLaunchKernelGGL(k_bwd_finish, dim3(n_table_blocks + kAccFloats / 32), dim3(256), 0, (hipStream_t)stream, f->lt, scatter_ws, f->plan.s_dense,
-                           f->plan.s_hashed, n_params, partials, blocks, *g, *adam, n_table_blocks);
+        UncertReduce ur{};
+        if (unc_scatter) { ur.d_uncert = d_unc; ur.n_voxels = f->plan.uncert_voxels; ur.n_splits = f->plan.s_uncert; ur.partial_off = (uint32_t)f->n_tiled_entries; }
+        const uint32_t n_unc_blocks = unc_scatter ? (ur.n_voxels + 255u) / 256u : 0u;
+        hipLaunchKernelGGL(k_bwd_finish, dim3(n_table_blocks + kAccFloats / 32 + n_unc_blocks), dim3(256), 0, (hipStream_t)stream, f->lt, scatter_ws, f->plan.s_dense,
+                           f->plan.s_hashed, n_params, partial_plane(f), partials, blocks, *g, *adam, n_table_blocks, ur);
         return check_launch("bwd_finish");
     }
     const bool want_w = g->sdf_w0 || g->sdf_w1 || g->col_w0 || g->col_w1;
@@ -518,15 +556,15 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
     }
     if (!phase_table) return NARUTO_OK;
     if (n_front > 0) {
-        if (g->table == nullptr) return NARUTO_OK;
+        if (g->table == nullptr && !unc_scatter) return NARUTO_OK;
         PointSrc pss{};
         pss.xsoa = x_soa;
         pss.M = cap;
         pss.S = 1;
         return launch_scatter(f, pss, cap, d_feat, (size_t)2, (size_t)2 * (size_t)cap, g->table, scatter_ws, (hipStream_t)stream, n_list_dev, nullptr,
-                              (int)(flags & NARUTO_BWD_OVERWRITE_TABLE_GRAD));
+                              (int)(flags & NARUTO_BWD_OVERWRITE_TABLE_GRAD), true, nullptr, unc_g, d_unc);
     }
-    if (g->table != nullptr) {
+    if (g->table != nullptr || unc_scatter) {
         PointSrc pss{};
         pss.xsoa = x_soa;
         pss.M = cap;
@@ -540,7 +578,7 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
         }
         // host-side point count: the padded capacity only bounds a device-side count; without one the list holds exactly M points
         if (int rc = launch_scatter(f, pss, count_dev != nullptr ? cap : M, d_feat, (size_t)2, (size_t)2 * (size_t)cap, g->table, scatter_ws, (hipStream_t)stream, count_dev, nullptr,
-                                    (int)(flags & NARUTO_BWD_OVERWRITE_TABLE_GRAD)))
+                                    (int)(flags & NARUTO_BWD_OVERWRITE_TABLE_GRAD), true, nullptr, unc_g, d_unc))
             return rc;
     }
     return NARUTO_OK;

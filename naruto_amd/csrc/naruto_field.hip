@@ -132,6 +132,7 @@ __device__ __forceinline__ void tv_encode_body(const LevelTab& lt, const BoxTab&
             if (a.cap != 0) x_out[(size_t)d * a.cap + m] = xn[d];
             else x_out[3 * (size_t)m + d] = xn[d];
         }
+        if (level == 0 && d == 0 && a.cap != 0) x_out[3 * (size_t)a.cap + m] = 0.0f;        // row 3: no raw[...,4] cotangent at lattice points
     }
     const float2 f = hash_level_rt(lt, (int)level, table, xn[0], xn[1], xn[2]);
     if (a.cap != 0) reinterpret_cast<float2*>(feat)[(size_t)level * n3 + m] = f;
@@ -199,45 +200,19 @@ __device__ __forceinline__ bool ee_after_tile(EeState& st, const EarlyExit& ee, 
     return false;
 }
 
-template <bool COLOR>
-__global__ __launch_bounds__(256, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps,
-                                                   uint32_t M, float* __restrict__ raw, float* __restrict__ sdf_uncert,
-                                                   float* __restrict__ geo, float* __restrict__ feat_save, EarlyExit ee) {
-    __shared__ FwdLds L;
-    stage_fwd_weights<256>(L, p, threadIdx.x);
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int hh = lane >> 5, j = lane & 31;
-    const uint32_t n_tiles = (M + 63u) / 64u;
-    const float2* __restrict__ table = reinterpret_cast<const float2*>(p.table);
-    float2* __restrict__ feat_out = reinterpret_cast<float2*>(feat_save);
-    const uint32_t tpr = ee.tiles_per_ray;
-    const uint32_t n_tasks = tpr ? n_tiles / tpr : n_tiles;          // rays, or tiles of the flat point list
-    for (uint32_t task = blockIdx.x * 4u + wave; task < n_tasks; task += gridDim.x * 4u) {
-    EeState ees{false, 0.0f, 0.0f, 0.0f};
-    for (uint32_t tq = 0; tq < (tpr ? tpr : 1u); ++tq) {
-        const uint32_t tile = tpr ? task * tpr + tq : task;
-        const uint32_t m_raw = tile * 64u + lane;
-        const bool valid = m_raw < M;
-        const uint32_t m = valid ? m_raw : M - 1u;       // padding lanes redo the last point, stores masked
-        float x, y, z;
-        load_point(ps, bt, m, x, y, z);
-        const float u = uncert_sample(ut, p.uncert_grid, x, y, z);
+// One 64-point tile of the forward: hash gather (lane half hh fetches the corners with x offset hh of points 0..31, then 32..63),
+// OneBlob, both MLPs.  x, y, z: THIS lane's point (lane = point within the tile); mA / mB: feat_save rows of point j / j + 32.
+// Results: out.rgb / out.sdf for this lane's point; geo (optional) [M,15]: the sdf-net's geometric features of both halves.
+struct FwdTileOut {
+    float rgb[3];
+    float sdf;
+};
 
+template <bool COLOR>
+__device__ __forceinline__ void fwd_tile(const FwdLds& L, const LevelTab& lt, const float2* __restrict__ table, float x, float y, float z,
+                                         float* __restrict__ feat_save, float* __restrict__ geo, uint32_t M, uint32_t mA, uint32_t mB, int lane, FwdTileOut& out) {
+    const int hh = lane >> 5;
         f32x16 hA = zero16(), hB = zero16(), cA = zero16(), cB = zero16();
-#ifdef NARUTO_FWD_UNROLLED_LEVELS
-        static_for<0, kLevels>([&](auto tc) {
-            constexpr int T = decltype(tc)::value;
-            const float2 f = hash_level<T>(lt, table, x, y, z);
-            if (feat_out != nullptr && valid) feat_out[(size_t)T * M + m] = f;
-            const float a = L.s0[T * 64 + lane];
-            float b0 = f.x, b1 = f.y;
-            swap32(b0, b1);                      // b0: tile A operand, b1: tile B operand
-            hA = mfma32(a, b0, hA);
-            hB = mfma32(a, b1, hB);
-            if constexpr ((T + 1) % kGatherGroup == 0) __builtin_amdgcn_sched_barrier(0);
-        });
-#else
         // levels in a real loop (unrolled by kGatherGroup): the gathers of a group are in flight together, the code
         // stays an order of magnitude smaller than the fully unrolled form.
         // Lane layout of the gathers: both halves of the wave work on the same 32 points -- round A on points 0..31,
@@ -246,8 +221,7 @@ __global__ __launch_bounds__(256, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab
         // B operand of the MFMA tile.
         float xa = x, xb = x, ya = y, yb = y, za = z, zb = z;
         swap32(xa, xb); swap32(ya, yb); swap32(za, zb);        // xa = x of points (0..31 | 0..31), xb = (32..63 | 32..63)
-        const uint32_t mA = tile * 64u + (uint32_t)j, mB = mA + 32u;
-#pragma unroll NARUTO_GATHER_GROUP
+#pragma unroll kGatherGroup
         for (int T = 0; T < kLevels; ++T) {
             const float2 pa = hash_level_half_rt(lt, T, table, xa, ya, za, (uint32_t)hh);
             const float2 pb = hash_level_half_rt(lt, T, table, xb, yb, zb, (uint32_t)hh);
@@ -265,7 +239,6 @@ __global__ __launch_bounds__(256, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab
             hA = mfma32(a, b0, hA);
             hB = mfma32(a, b1, hB);
         }
-#endif
         // OneBlob: three of a coordinate's 16 bins are non-zero, and the 64 points of a tile are neighbours on a ray, so
         // most of the 24 K pairs are exact zeros for every point of the tile: those matrix steps are skipped (a product
         // with 0.0f adds nothing to a finite accumulator; fp32 MFMA runs at the vector rate, every one skipped is 16 slots).
@@ -306,11 +279,10 @@ __global__ __launch_bounds__(256, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab
             oA = mfma32(a, fmaxf(hA[T], 0.0f), oA);
             oB = mfma32(a, fmaxf(hB[T], 0.0f), oB);
         });
-        // this lane's own sdf: output row 0 lives in reg 0 of the low half of each tile
         float sdf = oA[0], sdf_b = oB[0];
         swap32(sdf, sdf_b);
+        out.sdf = sdf;
         if (geo != nullptr) {
-            const uint32_t mA = tile * 64u + j, mB = mA + 32u;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int row = crow(r, hh);
@@ -320,7 +292,6 @@ __global__ __launch_bounds__(256, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab
                 }
             }
         }
-        if (sdf_uncert != nullptr && valid) reinterpret_cast<float2*>(sdf_uncert)[m] = make_float2(sdf, u);
         if constexpr (COLOR) {
             static_for<0, 8>([&](auto rc) {
                 constexpr int R = decltype(rc)::value;
@@ -328,7 +299,6 @@ __global__ __launch_bounds__(256, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab
                 cA = mfma32(a, oA[R], cA);
                 cB = mfma32(a, oB[R], cB);
             });
-            float rgb[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 float pa = 0.0f, pb = 0.0f;
@@ -339,11 +309,43 @@ __global__ __launch_bounds__(256, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab
                     pb = fmaf(w, fmaxf(cB[r], 0.0f), pb);
                 }
                 swap32(pa, pb);                  // lanes<32: (A lo, A hi); lanes>=32: (B lo, B hi)
-                rgb[c] = pa + pb;
+                out.rgb[c] = pa + pb;
             }
+        }
+}
+
+template <bool COLOR>
+__global__ __launch_bounds__(256, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps,
+                                                   uint32_t M, float* __restrict__ raw, float* __restrict__ sdf_uncert,
+                                                   float* __restrict__ geo, float* __restrict__ feat_save, EarlyExit ee) {
+    __shared__ FwdLds L;
+    stage_fwd_weights<256>(L, p, threadIdx.x);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hh = lane >> 5, j = lane & 31;
+    const uint32_t n_tiles = (M + 63u) / 64u;
+    const float2* __restrict__ table = reinterpret_cast<const float2*>(p.table);
+    const uint32_t tpr = ee.tiles_per_ray;
+    const uint32_t n_tasks = tpr ? n_tiles / tpr : n_tiles;          // rays, or tiles of the flat point list
+    for (uint32_t task = blockIdx.x * 4u + wave; task < n_tasks; task += gridDim.x * 4u) {
+    EeState ees{false, 0.0f, 0.0f, 0.0f};
+    for (uint32_t tq = 0; tq < (tpr ? tpr : 1u); ++tq) {
+        const uint32_t tile = tpr ? task * tpr + tq : task;
+        const uint32_t m_raw = tile * 64u + lane;
+        const bool valid = m_raw < M;
+        const uint32_t m = valid ? m_raw : M - 1u;       // padding lanes redo the last point, stores masked
+        float x, y, z;
+        load_point(ps, bt, m, x, y, z);
+        const float u = uncert_sample(ut, p.uncert_grid, x, y, z);
+
+        FwdTileOut to;
+        fwd_tile<COLOR>(L, lt, table, x, y, z, feat_save, geo, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to);
+        const float sdf = to.sdf;
+        if (sdf_uncert != nullptr && valid) reinterpret_cast<float2*>(sdf_uncert)[m] = make_float2(sdf, u);
+        if constexpr (COLOR) {
             if (raw != nullptr && valid) {
                 float* o = raw + (size_t)m * 5;
-                o[0] = rgb[0]; o[1] = rgb[1]; o[2] = rgb[2]; o[3] = sdf; o[4] = u;
+                o[0] = to.rgb[0]; o[1] = to.rgb[1]; o[2] = to.rgb[2]; o[3] = sdf; o[4] = u;
             }
         }
         if (tpr != 0u && tq + 1u < tpr) {
@@ -418,33 +420,12 @@ __device__ __forceinline__ u32x4_t pack8_acc(const f32x16& a, int r0) {
 }
 
 template <bool COLOR>
-__global__ __launch_bounds__(256, NARUTO_FWD_MINWAVES) void k_query_fwd_bf(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps,
-                                                      uint32_t M, float* __restrict__ raw, float* __restrict__ sdf_uncert,
-                                                      float* __restrict__ geo, float* __restrict__ feat_save, EarlyExit ee) {
-    __shared__ FwdLdsBf L;
-    stage_fwd_weights_bf<256>(L, p, threadIdx.x);
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int hh = lane >> 5, j = lane & 31;
-    const uint32_t n_tiles = (M + 63u) / 64u;
-    const float2* __restrict__ table = reinterpret_cast<const float2*>(p.table);
-    const uint32_t tpr = ee.tiles_per_ray;
-    const uint32_t n_tasks = tpr ? n_tiles / tpr : n_tiles;
-    for (uint32_t task = blockIdx.x * 4u + wave; task < n_tasks; task += gridDim.x * 4u) {
-    EeState ees{false, 0.0f, 0.0f, 0.0f};
-    for (uint32_t tq = 0; tq < (tpr ? tpr : 1u); ++tq) {
-        const uint32_t tile = tpr ? task * tpr + tq : task;
-        const uint32_t m_raw = tile * 64u + lane;
-        const bool valid = m_raw < M;
-        const uint32_t m = valid ? m_raw : M - 1u;
-        float x, y, z;
-        load_point(ps, bt, m, x, y, z);
-        const float u = uncert_sample(ut, p.uncert_grid, x, y, z);
-
+__device__ __forceinline__ void fwd_tile_bf(const FwdLdsBf& L, const LevelTab& lt, const float2* __restrict__ table, float x, float y, float z,
+                                            float* __restrict__ feat_save, float* __restrict__ geo, uint32_t M, uint32_t mA, uint32_t mB, int lane, FwdTileOut& out) {
+    const int hh = lane >> 5;
         f32x16 hA = zero16(), hB = zero16(), cA = zero16(), cB = zero16();
         float xa = x, xb = x, ya = y, yb = y, za = z, zb = z;
         swap32(xa, xb); swap32(ya, yb); swap32(za, zb);        // xa = x of points (0..31 | 0..31), xb = (32..63 | 32..63)
-        const uint32_t mA = tile * 64u + (uint32_t)j, mB = mA + 32u;
         for (int kb = 0; kb < 2; ++kb) {
             float fa[8], fb[8];
 #pragma unroll
@@ -498,6 +479,7 @@ __global__ __launch_bounds__(256, NARUTO_FWD_MINWAVES) void k_query_fwd_bf(Level
         }
         float sdf = oA[0], sdf_b = oB[0];
         swap32(sdf, sdf_b);
+        out.sdf = sdf;
         if (geo != nullptr) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
@@ -508,12 +490,10 @@ __global__ __launch_bounds__(256, NARUTO_FWD_MINWAVES) void k_query_fwd_bf(Level
                 }
             }
         }
-        if (sdf_uncert != nullptr && valid) reinterpret_cast<float2*>(sdf_uncert)[m] = make_float2(sdf, u);
         if constexpr (COLOR) {
             const u32x4_t wg = L.c0[3 * 64 + lane];
             cA = mfma16(wg, pack8_acc<false>(oA, 0), cA);
             cB = mfma16(wg, pack8_acc<false>(oB, 0), cB);
-            float rgb[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 float pa = 0.0f, pb = 0.0f;
@@ -524,11 +504,46 @@ __global__ __launch_bounds__(256, NARUTO_FWD_MINWAVES) void k_query_fwd_bf(Level
                     pb = fmaf(w, fmaxf(cB[r], 0.0f), pb);
                 }
                 swap32(pa, pb);
-                rgb[c] = pa + pb;
+                out.rgb[c] = pa + pb;
             }
+        }
+}
+
+#ifndef NARUTO_FWD_BF_MINWAVES
+#define NARUTO_FWD_BF_MINWAVES 3
+#endif
+template <bool COLOR>
+__global__ __launch_bounds__(256, NARUTO_FWD_BF_MINWAVES) void k_query_fwd_bf(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps,
+                                                      uint32_t M, float* __restrict__ raw, float* __restrict__ sdf_uncert,
+                                                      float* __restrict__ geo, float* __restrict__ feat_save, EarlyExit ee) {
+    __shared__ FwdLdsBf L;
+    stage_fwd_weights_bf<256>(L, p, threadIdx.x);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hh = lane >> 5, j = lane & 31;
+    const uint32_t n_tiles = (M + 63u) / 64u;
+    const float2* __restrict__ table = reinterpret_cast<const float2*>(p.table);
+    const uint32_t tpr = ee.tiles_per_ray;
+    const uint32_t n_tasks = tpr ? n_tiles / tpr : n_tiles;
+    for (uint32_t task = blockIdx.x * 4u + wave; task < n_tasks; task += gridDim.x * 4u) {
+    EeState ees{false, 0.0f, 0.0f, 0.0f};
+    for (uint32_t tq = 0; tq < (tpr ? tpr : 1u); ++tq) {
+        const uint32_t tile = tpr ? task * tpr + tq : task;
+        const uint32_t m_raw = tile * 64u + lane;
+        const bool valid = m_raw < M;
+        const uint32_t m = valid ? m_raw : M - 1u;
+        float x, y, z;
+        load_point(ps, bt, m, x, y, z);
+        const float u = uncert_sample(ut, p.uncert_grid, x, y, z);
+
+        FwdTileOut to;
+        fwd_tile_bf<COLOR>(L, lt, table, x, y, z, feat_save, geo, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to);
+        const float sdf = to.sdf;
+        if (sdf_uncert != nullptr && valid) reinterpret_cast<float2*>(sdf_uncert)[m] = make_float2(sdf, u);
+        if constexpr (COLOR) {
             if (raw != nullptr && valid) {
                 float* o = raw + (size_t)m * 5;
-                o[0] = rgb[0]; o[1] = rgb[1]; o[2] = rgb[2]; o[3] = sdf; o[4] = u;
+                o[0] = to.rgb[0]; o[1] = to.rgb[1]; o[2] = to.rgb[2]; o[3] = sdf; o[4] = u;
             }
         }
         if (tpr != 0u && tq + 1u < tpr) {
@@ -581,12 +596,16 @@ constexpr double kFixInv = 1.0 / 1099511627776.0;
 
 // Units are ordered dense-levels-first; dense (coarse) units take every update of their points and suffer
 // same-address conflicts, hashed units only 1/chunks of them, so dense units get more point splits.
+constexpr int kMaxUncertChunks = 64;         // uncertainty grids of up to 2^20 voxels ride in the scatter (larger ones: float atomics in k_query_bwd)
 struct ScatterPlan {
     uint8_t level[kMaxUnits];
     uint8_t chunk[kMaxUnits];     // bit 7: feature, bits 0..6: chunk
     uint32_t n_dense, n_hashed;   // LDS-tiled (level, chunk) units of non-hashed / hashed levels
     uint32_t s_dense, s_hashed;   // point splits per unit
     uint32_t atomic_levels;       // bit l: level l goes through the global-atomic kernel instead
+    // the uncertainty voxel grid as one more (dense, single-feature) table: n_uncert chunks x s_uncert point splits, after the
+    // level units; its partial images live behind the tiled table entries in feature plane 0 of the partial tables
+    uint32_t n_uncert, s_uncert, uncert_voxels;
 };
 
 template <int T>
@@ -816,10 +835,17 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
     }
 }
 
+// the uncertainty grid's part of a scatter launch: g = cotangent of raw[...,4] per list point (row 3 of the point list), or NULL
+struct UncertScatter {
+    const float* g;
+    UncertTab ut;
+    uint32_t partial_off;       // first float of the uncertainty image inside a partial table's feature plane 0
+};
+
 __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab lt, BoxTab bt, PointSrc ps, uint32_t M, const float* __restrict__ d_feat,
                                                                        size_t stride_m, size_t stride_l, ScatterPlan plan,
                                                                        float* __restrict__ partial, size_t n_params,
-                                                                       const uint32_t* __restrict__ m_dev, const float* __restrict__ scale_dev) {
+                                                                       const uint32_t* __restrict__ m_dev, const float* __restrict__ scale_dev, UncertScatter unc) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];
     if (m_dev != nullptr) M = m_dev[0];          // compacted point list: the count lives on the device
     const float gscale = scale_dev != nullptr ? scale_dev[0] : 1.0f;     // cotangent of a scalar loss (smoothness term)
@@ -832,7 +858,39 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
     const uint32_t dense_blocks = plan.n_dense * plan.s_dense;
     const uint32_t n_blocks = dense_blocks + plan.n_hashed * plan.s_hashed;
     const uint32_t pos = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    if (pos >= n_blocks) return;
+    if (pos >= n_blocks) {
+        // ---- uncertainty-grid units (training list layout only): d(loss)/d(uncert_grid) = scatter of the raw[...,4] cotangents with
+        // grid_sample's trilinear weights, accumulated in the same fixed point -- no float atomics, order independent
+        const uint32_t ub = pos - n_blocks;
+        if (unc.g == nullptr || ub >= plan.n_uncert * plan.s_uncert) return;
+        const uint32_t chunk = ub / plan.s_uncert, split = ub % plan.s_uncert;
+        for (uint32_t i = threadIdx.x; i < kChunk; i += kScatterThreads) acc[i] = 0ull;
+        __syncthreads();
+        const uint32_t per = ((M + plan.s_uncert - 1u) / plan.s_uncert + 3u) & ~3u;
+        const uint32_t m_lo = split * per < M ? split * per : M;
+        const uint32_t m_hi = m_lo + per < M ? m_lo + per : M;
+        const uint32_t chunk_base = chunk * kChunk;
+        for (uint32_t base = m_lo + threadIdx.x * 4u; base < m_hi; base += kScatterThreads * 4u) {
+            const float4 X = *reinterpret_cast<const float4*>(ps.xsoa + base), Y = *reinterpret_cast<const float4*>(ps.xsoa + ps.M + base);
+            const float4 Z = *reinterpret_cast<const float4*>(ps.xsoa + 2u * ps.M + base), G = *reinterpret_cast<const float4*>(unc.g + base);
+            const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w}, gs[4] = {G.x, G.y, G.z, G.w};
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (base + b >= m_hi || gs[b] == 0.0f) continue;
+                int32_t ui[8];
+                float uw[8];
+                uncert_corners(unc.ut, xs[b], ys[b], zs[b], ui, uw);
+                const float g256 = gs[b] * 256.0f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) fix_add_rel(acc, (uint32_t)ui[c] - chunk_base, uw[c] * g256);      // idx -1 (outside the grid) wraps out of every chunk
+            }
+        }
+        __syncthreads();
+        const uint32_t n_e = plan.uncert_voxels - chunk_base < kChunk ? plan.uncert_voxels - chunk_base : kChunk;
+        float* out = partial + (size_t)split * n_params + unc.partial_off + chunk_base;          // feature plane 0 of this split's partial table
+        for (uint32_t i = threadIdx.x; i < n_e; i += kScatterThreads) out[i] = (float)((double)(long long)acc[i] * kFixInv);
+        return;
+    }
     if (pos < dense_blocks) {
         n_splits = plan.s_dense;
         unit = pos / n_splits;
@@ -874,9 +932,27 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
     }
 }
 
+// the uncertainty grid's share of a reduction launch: d_uncert[v] += sum over splits of the partial images (always accumulated: the
+// grid's optimiser steps every 5th iteration, its gradient adds up in between -- reference coslam.py:397-399)
+struct UncertReduce {
+    float* d_uncert;            // NULL: nothing to do
+    uint32_t n_voxels, n_splits, partial_off;
+};
+__device__ __forceinline__ void uncert_reduce_body(const float* __restrict__ partial, size_t n_plane, const UncertReduce& u, uint32_t block) {
+    const uint32_t v = block * 256u + threadIdx.x;
+    if (u.d_uncert == nullptr || v >= u.n_voxels) return;
+    float s = 0.0f;
+    for (uint32_t k = 0; k < u.n_splits; ++k) s += partial[(size_t)k * 2u * n_plane + u.partial_off + v];
+    u.d_uncert[v] += s;
+}
+
 // d_table += sum over the level's splits of partial[split], for the entry ranges of the LDS-tiled levels
+// (n_params: floats of the tiled levels; n_plane: entries per feature plane of a partial table; blocks >= n_table_blocks: uncertainty grid)
 __global__ __launch_bounds__(256) void k_scatter_reduce(LevelTab lt, uint32_t atomic_levels, const float* __restrict__ partial, uint32_t s_dense,
-                                                        uint32_t s_hashed, size_t n_params, float* __restrict__ d_table, int overwrite) {
+                                                        uint32_t s_hashed, size_t n_params, size_t n_plane, float* __restrict__ d_table, int overwrite,
+                                                        uint32_t n_table_blocks, UncertReduce unc) {
+    if (blockIdx.x >= n_table_blocks) { uncert_reduce_body(partial, n_plane, unc, blockIdx.x - n_table_blocks); return; }
+    if (d_table == nullptr) return;
     const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // float4 index of the output = entries 2 i4, 2 i4 + 1
     if (i4 * 4 >= n_params) return;
     const uint32_t entry = (uint32_t)(i4 * 2);
@@ -885,7 +961,7 @@ __global__ __launch_bounds__(256) void k_scatter_reduce(LevelTab lt, uint32_t at
     for (int l = 1; l < kLevels; ++l) level += entry >= lt.off[l] ? 1 : 0;
     if ((atomic_levels >> level) & 1u) return;
     const uint32_t n_splits = ((lt.hashed >> level) & 1u) ? s_hashed : s_dense;
-    const size_t n_entries = n_params / 2u;
+    const size_t n_entries = n_plane;
     float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (uint32_t k = 0; k < n_splits; ++k) {
         const float2 f0 = *reinterpret_cast<const float2*>(partial + ((size_t)k * 2u) * n_entries + entry);          // feature 0 of both entries
@@ -1035,6 +1111,7 @@ __device__ __forceinline__ void append_points_body(uint32_t E, const float* __re
     const float2 g = *reinterpret_cast<const float2*>(ed + (size_t)i * kFeat + 2 * level);
     reinterpret_cast<float2*>(d_feat)[(size_t)level * cap + base + i] = make_float2(g.x * sc, g.y * sc);
     if (level < 3) x_soa[(size_t)level * cap + base + i] = ex[3 * (size_t)i + level];
+    if (level == 3) x_soa[3 * (size_t)cap + base + i] = 0.0f;                                   // no raw[...,4] cotangent at the extra points
 }
 
 __global__ __launch_bounds__(256) void k_append_points(uint32_t E, const float* __restrict__ ex, const float* __restrict__ ed, const float* __restrict__ scale_dev,
@@ -1184,7 +1261,7 @@ __global__ __launch_bounds__(64 * kBwdWaves) void k_query_bwd(LevelTab lt, Uncer
                                                    const float* __restrict__ feat_save, const float* __restrict__ d_raw,
                                                    const float* __restrict__ d_geo, float* __restrict__ d_feat, float* __restrict__ x_out,
                                                    float* __restrict__ d_uncert_grid, float* __restrict__ partials,
-                                                   const uint32_t* __restrict__ active_idx, const uint32_t* __restrict__ n_active, uint32_t list_off) {
+                                                   const uint32_t* __restrict__ active_idx, const uint32_t* __restrict__ n_active, uint32_t list_off, int unc_atomic) {
     // list_off: position of this launch's first point in the scatter's point list (the smoothness lattice sits in front)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     BwdLds& L = *reinterpret_cast<BwdLds*>(smem_raw);
@@ -1268,8 +1345,10 @@ __global__ __launch_bounds__(64 * kBwdWaves) void k_query_bwd(LevelTab lt, Uncer
             g_sdf = valid ? cur.g[3] : 0.0f;
             g_unc = valid ? cur.g[4] : 0.0f;
         }
-        // uncertainty grid: raw[...,4] is the trilinear sample itself (the decoder passes it through)
-        if (d_uncert_grid != nullptr && hh == 0 && g_unc != 0.0f) {
+        // uncertainty grid: raw[...,4] is the trilinear sample itself (the decoder passes it through), so its cotangent goes to row 3
+        // of the point list and the scatter turns it into the grid's gradient (fixed point, no float atomics)
+        if (x_out != nullptr && valid && hh == 0) x_out[3 * (size_t)cap + list_off + i_pt] = (d_uncert_grid != nullptr && !unc_atomic) ? g_unc : 0.0f;
+        if (unc_atomic && d_uncert_grid != nullptr && hh == 0 && g_unc != 0.0f) {       // grids beyond kMaxUncertChunks chunks only
             int32_t ui[8];
             float uw[8];
             uncert_corners(ut, x, y, z, ui, uw);
@@ -1453,8 +1532,10 @@ struct BwdLdsBf {
     u32x4_t selB[2 * 64];   // OneBlob K block -> 32 columns: slot (hh,e) is column 16 d + 8hh + e  (d = 0, 1)
     u32x4_t selO[1 * 64];   // sdf-net outputs (registers 0..7) -> columns 16 + row
     u32x4_t selQ[1 * 64];   // rgb cotangent (slots 0..2 of the low half) -> units 0..2
-    float acc[kAccFloats];  // block-level dW image for the final reduction over the waves
 };
+// after the tile loop the same LDS holds the block-level dW image: int64 fixed point (value * 2^40), so that the four waves add
+// their register tiles concurrently with ds_add_u64 (order independent; one pass instead of four barrier-separated ones)
+constexpr size_t kBwdBfLdsBytes = sizeof(BwdLdsBf) > kAccFloats * sizeof(unsigned long long) ? sizeof(BwdLdsBf) : kAccFloats * sizeof(unsigned long long);
 
 template <int NT>
 __device__ __forceinline__ void stage_bwd_weights_bf(BwdLdsBf& L, const NarutoParams& p, int tid) {
@@ -1631,7 +1712,7 @@ __global__ __launch_bounds__(256, NARUTO_BWD_BF_MINWAVES) void k_query_bwd_bf(Le
                                                       const float* __restrict__ feat_save, const float* __restrict__ d_raw,
                                                       const float* __restrict__ d_geo, float* __restrict__ d_feat, float* __restrict__ x_out,
                                                       float* __restrict__ d_uncert_grid, float* __restrict__ partials,
-                                                      const uint32_t* __restrict__ active_idx, const uint32_t* __restrict__ n_active, uint32_t list_off) {
+                                                      const uint32_t* __restrict__ active_idx, const uint32_t* __restrict__ n_active, uint32_t list_off, int unc_atomic) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     BwdLdsBf& L = *reinterpret_cast<BwdLdsBf*>(smem_raw);
 #ifndef NARUTO_ABL_BF_NOSTAGE
@@ -1663,8 +1744,8 @@ __global__ __launch_bounds__(256, NARUTO_BWD_BF_MINWAVES) void k_query_bwd_bf(Le
             x_out[(size_t)cap + list_off + i_pt] = y;
             x_out[2 * (size_t)cap + list_off + i_pt] = z;
         }
-#ifndef NARUTO_ABL_BF_NOATOMIC
-        if (d_uncert_grid != nullptr && g[4] != 0.0f) {                      // raw[...,4] is the trilinear sample itself
+        if (x_out != nullptr && valid) x_out[3 * (size_t)cap + list_off + i_pt] = (d_uncert_grid != nullptr && !unc_atomic) ? g[4] : 0.0f;     // -> uncertainty-grid units of the scatter
+        if (unc_atomic && d_uncert_grid != nullptr && g[4] != 0.0f) {                    // grids beyond kMaxUncertChunks chunks only
             int32_t ui[8];
             float uw[8];
             uncert_corners(ut, x, y, z, ui, uw);
@@ -1672,7 +1753,6 @@ __global__ __launch_bounds__(256, NARUTO_BWD_BF_MINWAVES) void k_query_bwd_bf(Le
             for (int c = 0; c < 8; ++c)
                 if (ui[c] >= 0) unsafeAtomicAdd(d_uncert_grid + ui[c], uw[c] * g[4]);
         }
-#endif
         // OneBlob packs of the two tiles (as in k_query_fwd_bf)
         u32x4_t blA[3], blB[3];
         const bool blob_fast = __all(oneblob_sparse_ok(x) && oneblob_sparse_ok(y) && oneblob_sparse_ok(z));
@@ -1734,28 +1814,26 @@ __global__ __launch_bounds__(256, NARUTO_BWD_BF_MINWAVES) void k_query_bwd_bf(Le
             }
         }
     }
-    // block-level sum of the four waves' register tiles through the LDS image, then one coalesced write of the partial
-    float* __restrict__ acc = L.acc;
+    // block-level sum of the four waves' register tiles: fixed-point LDS image over the (now unused) weight images
+    __syncthreads();
 #ifdef NARUTO_ABL_BF_NOEPI
-    if (dw.w0a[0] == 123.0f && dw.c1[3] == 5.0f) acc[lane] = dw.w1[2] + dw.w0b[1] + dw.w0c[1] + dw.c0a[1] + dw.c0b[1];
+    if (dw.w0a[0] == 123.0f && dw.c1[3] == 5.0f) partials[lane] = dw.w1[2] + dw.w0b[1] + dw.w0c[1] + dw.c0a[1] + dw.c0b[1];
     return;
 #endif
-    for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
-            const f32x16* tiles[kAccTiles] = {&dw.w0a, &dw.w0b, &dw.w0c, &dw.w1, &dw.c0a, &dw.c0b, &dw.c1};
+    unsigned long long* __restrict__ img = reinterpret_cast<unsigned long long*>(smem_raw);
+    for (int e = threadIdx.x; e < kAccFloats; e += 256) img[e] = 0ull;
+    __syncthreads();
+    {
+        const f32x16* tiles[kAccTiles] = {&dw.w0a, &dw.w0b, &dw.w0c, &dw.w1, &dw.c0a, &dw.c0b, &dw.c1};
 #pragma unroll
-            for (int t = 0; t < kAccTiles; ++t) {
+        for (int t = 0; t < kAccTiles; ++t) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float* a = &acc[t * 1024 + crow(r, hh) * 32 + j];
-                    *a = (w == 0 ? 0.0f : *a) + (*tiles[t])[r];
-                }
-            }
+            for (int r = 0; r < 16; ++r) atomicAdd(&img[t * 1024 + crow(r, hh) * 32 + j], to_fix40((*tiles[t])[r]));
         }
-        __syncthreads();
     }
+    __syncthreads();
     float* __restrict__ out = partials + (size_t)blockIdx.x * kAccFloats;
-    for (int e = threadIdx.x; e < kAccFloats; e += blockDim.x) out[e] = acc[e];
+    for (int e = threadIdx.x; e < kAccFloats; e += 256) out[e] = (float)((double)(long long)img[e] * kFixInv);
 }
 
 // partials [n_blocks][7][32][32] -> += into the four weight gradients.  Block = 32 outputs x 8 slices of the
@@ -1861,8 +1939,9 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 // written (g pointers may be NULL), k_adam_multi and one more pass over parameters + moments disappear.
 // Single process only: data parallelism needs the gradients all-reduced first.
 __global__ __launch_bounds__(256) void k_bwd_finish(LevelTab lt, const float* __restrict__ partial, uint32_t s_dense, uint32_t s_hashed, size_t n_params,
-                                                    const float* __restrict__ wpartials, uint32_t n_wblocks, NarutoGrads g, AdamFuse adam,
-                                                    uint32_t n_table_blocks) {
+                                                    size_t n_plane, const float* __restrict__ wpartials, uint32_t n_wblocks, NarutoGrads g, AdamFuse adam,
+                                                    uint32_t n_table_blocks, UncertReduce unc) {
+    if (blockIdx.x >= n_table_blocks + kAccFloats / 32) { uncert_reduce_body(partial, n_plane, unc, blockIdx.x - n_table_blocks - kAccFloats / 32); return; }
     if (blockIdx.x >= n_table_blocks) {
         wgrad_reduce_body(wpartials, n_wblocks, g, 1, blockIdx.x - n_table_blocks, &adam);
         return;
@@ -1874,7 +1953,7 @@ __global__ __launch_bounds__(256) void k_bwd_finish(LevelTab lt, const float* __
 #pragma unroll
     for (int l = 1; l < kLevels; ++l) level += entry >= lt.off[l] ? 1 : 0;
     const uint32_t n_splits = ((lt.hashed >> level) & 1u) ? s_hashed : s_dense;
-    const size_t n_entries = n_params / 2u;
+    const size_t n_entries = n_plane;
     float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (uint32_t k = 0; k < n_splits; ++k) {
         const float2 f0 = *reinterpret_cast<const float2*>(partial + ((size_t)k * 2u) * n_entries + entry);

@@ -52,6 +52,7 @@ WORKLOADS = {
     "office0_2048x128": (lambda: C.office0_config(perturb=1.0, n_samples_d=117), 2048, "configs[1]"),
     "office0_2048x43": (lambda: C.office0_config(perturb=1.0), 2048, "configs[1] with the shipped 32+11 sampling"),
     "office0_8192x43": (lambda: C.office0_config(perturb=1.0), 8192, "configs[2] (train step at the planner batch size)"),
+    "office0_8192x43_eval": (lambda: C.office0_config(perturb=1.0), 8192, "configs[2] (uncertainty head on, planner query path: eval render + dense lattice query)"),
     "mp3d_2048x256": (lambda: C.mp3d_large_config(perturb=1.0, n_samples_d=245), 2048, "configs[3], one GPU's shard"),
     "mp3d_16384x256": (lambda: C.mp3d_large_config(perturb=1.0, n_samples_d=245), 16384, "configs[3], the whole batch (use --scaling strong)"),
     # configs[4]: 2^20 rays over 8 GPUs = 131072 per GPU, unit cube, finest level 1024^3.  T16: the shipped table size (7 MB,
@@ -316,6 +317,69 @@ def bench_rays(cfg, n_rays: int, seed: int = 0):
     return syn.random_rays(n_rays, cfg["mapping"]["bound"], seed=seed, depth_range=(0.15, 0.7) if unit else (0.5, 2.5))
 
 
+def run_eval(args, dev):
+    """--workload office0_8192x43_eval (BASELINE configs[2], the planner query path): one step = the eval-mode render of 8192
+    rays (naruto_render_fwd: sampling + field query + compositing + uncertainty aggregation in one launch, raw kept on chip);
+    the dense uncertainty / SDF lattice query of get_map_volumes is timed next to it."""
+    from naruto_amd.field import NarutoFieldHIP, get_map_volumes
+    cfg, n_rays = workload(args.workload)
+    cfg["decoder"]["mlp_precision"] = args.mlp
+    torch.manual_seed(0)
+    bbox = torch.tensor(cfg["mapping"]["bound"], dtype=torch.float32, device=dev)
+    m = NarutoFieldHIP(cfg, bbox).to(dev)
+    m.get_uncert_grid(0.1)
+    with torch.no_grad():
+        m.embed_fn.params.copy_(torch.from_numpy(syn.closed_form_table(m.embed_fn.params.numel(), 0.05)).to(dev))
+    m.eval()
+    rays = {k: torch.from_numpy(v).to(dev) for k, v in bench_rays(cfg, n_rays).items()}
+    trc = cfg["training"]
+    S_tot = trc["n_samples_d"] + trc["n_range_d"]
+    rand = torch.rand(n_rays, S_tot, device=dev)
+
+    def step():
+        with torch.no_grad():
+            return m.render_rays(rays["rays_o"], rays["rays_d"], target_d=rays["target_d"], rand=rand, want_raw=False)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = dt / args.steps * 1e3
+    k_ms = events_ms(step, max(10, min(args.steps, 50)))
+    gather = 16 * 8 * 8 + 32
+    alg = n_rays * (S_tot * gather + 64)                       # SURVEY.md 8(d): render inference, per ray S x 1056 B + 28 B in + 36 B out
+    mfma_peak = FP32_MFMA_PEAK_TF if args.mlp == "fp32" else BF16_MFMA_PEAK_TF
+    flops = n_rays * S_tot * 2 * (80 * 32 + 32 * 16 + 63 * 32 + 32 * 3)
+    with torch.no_grad():
+        unfused = events_ms(lambda: m.render_rays(rays["rays_o"], rays["rays_d"], target_d=rays["target_d"], rand=rand, fused=False), 20)
+    # the planner's dense query (coslam_utils.py:58-97): [49,56,35] lattice -> sdf + uncertainty volumes
+    get_map_volumes(m.query_sdf, m.bounding_box, 0.1)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(20):
+        vols = get_map_volumes(m.query_sdf, m.bounding_box, 0.1)
+    map_ms = (time.perf_counter() - t1) / 20 * 1e3
+    n_vox = int(np.prod(vols[0].shape))
+    out = {
+        "metric": "rendered rays/sec (eval render), Replica office_0", "value": round(n_rays * args.steps / dt, 1), "unit": "rays/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.mlp == "fp32" else "bf16 (MLP operands; fp32 accumulate, fp32 elsewhere)", "data": "synthetic",
+        "config": {"workload": f"{args.workload} = BASELINE {WORKLOADS[args.workload][2]}: office_0 bbox, {n_rays} rays x {S_tot} samples, uncertainty grid on, "
+                               f"eval-mode render_rays in one launch (naruto_render_fwd), MLP {args.mlp}", "rays_per_gpu": n_rays, "samples_per_ray": S_tot},
+        "roofline": {"bound": "hbm", "achieved": round(alg / k_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / k_ms / 1e6 / HBM_PEAK_GBS, 4),
+                     "traffic": None, "kernel": "k_render_fwd", "kernel_ms": round(k_ms, 5), "alg_bytes": int(alg),
+                     "mfma_util": round(flops / k_ms / 1e9 / mfma_peak, 6)},
+        "render_unfused_ms": round(unfused, 5),
+        "map_volumes": {"voxels": n_vox, "ms_end_to_end": round(map_ms, 4), "points_per_s": round(n_vox / map_ms * 1e3, 1),
+                        "note": "get_map_volumes: query_sdf(return_uncert) on the cached lattice + post-processing kernel + one D2H copy"},
+    }
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -348,6 +412,15 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    if args.workload.endswith("_eval"):
+        assert world == 1, "the eval workload is a single-GPU query path"
+        out = run_eval(args, dev)
+        sys.stdout.flush()
+        libc.fflush(None)
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
+        return
     cfg, n_workload = workload(args.workload)
     cfg["decoder"]["mlp_precision"] = args.mlp
     if args.scaling == "strong":

@@ -174,6 +174,25 @@ int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
                      const NarutoExtraPoints* extra, uint32_t flags,
                      const NarutoGrads* g, void* workspace, void* stream);
 
+/* A1-A7 in ONE launch -- render_rays as an inference call (scene_rep.py:150-225; eval-mode forward, planner-side queries): depth
+ * sampling as naruto_sample_z, the field query of naruto_query_fwd and the compositing of naruto_composite_fwd per ray, raw kept
+ * in LDS.  Outputs (any may be NULL): rgb [N,3], depth, disp, acc, depth_var, uncert_map [N], weights [N,S], raw [N,S,5],
+ * z_vals [N,S] -- the per-sample ones cost their global writes only when asked for.  Sampling arguments as naruto_sample_z
+ * (target_d NULL: n_samples uniform depths); rand [N,S] or rng {seed, counter} or neither (no jitter).  Not differentiable:
+ * training goes through naruto_train_forward / the autograd operators. */
+typedef struct NarutoRender {
+    uint32_t n_rays;
+    const float *rays_o, *rays_d, *target_d;
+    float near_, far_;
+    uint32_t n_samples_d, n_range_d;
+    float range_d;
+    uint32_t n_samples;
+    const float* rand;
+    const uint64_t* rng;
+    float *rgb, *depth, *disp, *acc, *depth_var, *uncert_map, *weights, *raw, *z_vals;
+} NarutoRender;
+int naruto_render_fwd(const NarutoField* f, const NarutoParams* p, const NarutoRender* r, void* stream);
+
 /* A6+A7 -- sdf2weights [Co-SLAM] + raw2outputs (scene_rep.py:66-96).  Outputs (any may be NULL):
  * rgb [N,3], disp [N], acc [N], weights [N,S], depth [N], depth_var [N], uncert_map [N]. */
 int naruto_composite_fwd(const NarutoField* f, uint32_t n_rays, uint32_t S, const float* raw,

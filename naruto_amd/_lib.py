@@ -14,7 +14,7 @@ from typing import List, Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NARUTO_HIP_LIB") or os.path.join(_HERE, "libnaruto_hip.so")      # override: kernel experiments only
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["naruto_api.hip", "naruto_field.hip", "naruto_binned.hip", "naruto_render.hip", "naruto_rays.hip", "naruto_train.hip", "naruto_planner.hip", "naruto_mesh.hip",
+SOURCES = ["naruto_api.hip", "naruto_field.hip", "naruto_binned.hip", "naruto_render.hip", "naruto_rays.hip", "naruto_train.hip", "naruto_renderfused.hip", "naruto_planner.hip", "naruto_mesh.hip",
            "naruto_mc_table.inc", "naruto_common.h"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "naruto_hip.h")
 
@@ -86,6 +86,14 @@ class NarutoTrainStep(C.Structure):
         ("ray_count", C.c_void_p), ("ray_offset", C.c_void_p), ("active_idx", C.c_void_p), ("n_active", C.c_void_p),
         ("workspace", C.c_void_p),
     ]
+
+
+class NarutoRender(C.Structure):
+    _fields_ = [("n_rays", C.c_uint32), ("rays_o", C.c_void_p), ("rays_d", C.c_void_p), ("target_d", C.c_void_p),
+                ("near_", C.c_float), ("far_", C.c_float), ("n_samples_d", C.c_uint32), ("n_range_d", C.c_uint32), ("range_d", C.c_float),
+                ("n_samples", C.c_uint32), ("rand", C.c_void_p), ("rng", C.c_void_p),
+                ("rgb", C.c_void_p), ("depth", C.c_void_p), ("disp", C.c_void_p), ("acc", C.c_void_p), ("depth_var", C.c_void_p),
+                ("uncert_map", C.c_void_p), ("weights", C.c_void_p), ("raw", C.c_void_p), ("z_vals", C.c_void_p)]
 
 
 class NarutoPoints(C.Structure):
@@ -163,6 +171,7 @@ SIGNATURES = {
     "naruto_train_forward": (_I, [_V, C.POINTER(NarutoParams), C.POINTER(NarutoTrainStep), _I, _V]),
     "naruto_train_finalize": (_I, [_V, C.POINTER(NarutoTrainStep), _V]),
     "naruto_debug_train_query_fwd": (_I, [_V, C.POINTER(NarutoParams), C.POINTER(NarutoTrainStep), _V]),
+    "naruto_render_fwd": (_I, [_V, C.POINTER(NarutoParams), C.POINTER(NarutoRender), _V]),
     "naruto_train_backward": (_I, [_V, C.POINTER(NarutoParams), C.POINTER(NarutoTrainStep), C.POINTER(NarutoGrads), _U32,
                                    C.POINTER(NarutoFusedAdam), _V]),
     "naruto_compact_active": (_I, [_U32, _U32, _V, _V, _V, _V, _V]),

@@ -11,6 +11,7 @@
 #include "naruto_render.hip"
 #include "naruto_rays.hip"
 #include "naruto_train.hip"
+#include "naruto_renderfused.hip"
 #include "naruto_planner.hip"
 #include "naruto_mesh.hip"
 
@@ -127,7 +128,7 @@ ScatterWs scatter_ws(const NarutoField* f, void* base, uint32_t M) {
 // unc_g / d_uncert (both or neither; training list layout only): row 3 of the point list and the grid's gradient it is scattered into
 int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const float* d_feat, size_t stride_m, size_t stride_l, float* d_table,
                    void* workspace, hipStream_t st, const uint32_t* m_dev = nullptr, const float* scale_dev = nullptr, int overwrite = 0,
-                   bool do_reduce = true, const AdamFuse* adam = nullptr, const float* unc_g = nullptr, float* d_uncert = nullptr) {
+                   bool do_reduce = true, const AdamFuse* adam = nullptr, const float* unc_g = nullptr, float* d_uncert = nullptr, uint32_t unc_first = 0) {
     if ((overwrite || adam != nullptr) && f->plan.atomic_levels != 0)
         return fail(NARUTO_ERR_INVALID, "scatter: written (not accumulated) gradients / the fused optimiser are not available with NARUTO_DEBUG_SCATTER_ATOMIC");
     const ScatterWs w = scatter_ws(f, workspace, M);
@@ -136,7 +137,7 @@ int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const f
     UncertScatter us{};
     UncertReduce ur{};
     if (unc_g != nullptr && d_uncert != nullptr && f->plan.n_uncert != 0) {
-        us.g = unc_g; us.ut = f->ut; us.partial_off = (uint32_t)f->n_tiled_entries;
+        us.g = unc_g; us.ut = f->ut; us.partial_off = (uint32_t)f->n_tiled_entries; us.first = unc_first & ~3u;
         ur.d_uncert = d_uncert; ur.n_voxels = f->plan.uncert_voxels; ur.n_splits = f->plan.s_uncert; ur.partial_off = (uint32_t)f->n_tiled_entries;
     }
     if (d_table == nullptr && adam == nullptr && us.g == nullptr) return NARUTO_OK;
@@ -537,7 +538,7 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
         pss.S = 1;
         const uint32_t* cnt = n_front > 0 ? n_list_dev : n_active;
         if (int rc = launch_scatter(f, pss, cnt != nullptr ? cap : M, d_feat, (size_t)2, (size_t)2 * (size_t)cap, g->table, scatter_ws, (hipStream_t)stream, cnt,
-                                    nullptr, 1, false, adam, unc_g, d_unc))
+                                    nullptr, 1, false, adam, unc_g, d_unc, n_front))
             return rc;
         const size_t n_params = (size_t)f->n_tiled_entries * 2u;
         const uint32_t n_table_blocks = (uint32_t)((n_params / 4u + 255u) / 256u);
@@ -562,7 +563,7 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
         pss.M = cap;
         pss.S = 1;
         return launch_scatter(f, pss, cap, d_feat, (size_t)2, (size_t)2 * (size_t)cap, g->table, scatter_ws, (hipStream_t)stream, n_list_dev, nullptr,
-                              (int)(flags & NARUTO_BWD_OVERWRITE_TABLE_GRAD), true, nullptr, unc_g, d_unc);
+                              (int)(flags & NARUTO_BWD_OVERWRITE_TABLE_GRAD), true, nullptr, unc_g, d_unc, n_front);
     }
     if (g->table != nullptr || unc_scatter) {
         PointSrc pss{};
@@ -802,6 +803,40 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
         return query_bwd_impl(f, p, M, &pts, t->feat_save, t->d_raw, nullptr, t->active_idx, t->n_active, nullptr, flags, g, w.bwd, stream, n_front, bw.n_total, ad);
     // no smoothness term: the workspace was sized for cap = M + n3 with n3 = 0
     return query_bwd_impl(f, p, M, &pts, t->feat_save, t->d_raw, nullptr, t->active_idx, t->n_active, nullptr, flags, g, w.bwd, stream, 0u, nullptr, ad);
+}
+
+int naruto_render_fwd(const NarutoField* f, const NarutoParams* p, const NarutoRender* r, void* stream) {
+    if (f == nullptr || p == nullptr || r == nullptr) return fail(NARUTO_ERR_INVALID, "render_fwd: NULL argument");
+    if (p->table == nullptr || p->uncert_grid == nullptr || p->sdf_w0 == nullptr || p->sdf_w1 == nullptr || p->col_w0 == nullptr || p->col_w1 == nullptr)
+        return fail(NARUTO_ERR_INVALID, "render_fwd: NULL parameter");
+    if (r->n_rays == 0) return NARUTO_OK;
+    if (r->rays_o == nullptr || r->rays_d == nullptr) return fail(NARUTO_ERR_INVALID, "render_fwd: NULL rays");
+    RenderArgs a{};
+    a.n_rays = r->n_rays; a.rays_o = r->rays_o; a.rays_d = r->rays_d; a.target_d = r->target_d;
+    a.near_ = r->near_; a.far_ = r->far_; a.range_d = r->range_d;
+    if (r->target_d != nullptr) { a.nu = r->n_samples_d; a.nr = r->n_range_d; }
+    else { a.nu = r->n_samples; a.nr = 0; }
+    const uint32_t S = a.nu + a.nr;
+    if (S < 2 || S > (uint32_t)kMaxSamples) return fail(NARUTO_ERR_INVALID, "render_fwd: need 2 <= samples per ray <= %d (got %u)", kMaxSamples, S);
+    a.rand = r->rand; a.rng = r->rng;
+    a.trunc = f->desc.trunc; a.sc_factor = f->desc.sc_factor; a.white_bkgd = f->desc.white_bkgd;
+    a.rgb = r->rgb; a.depth = r->depth; a.disp = r->disp; a.acc = r->acc; a.depth_var = r->depth_var; a.uncert_map = r->uncert_map;
+    a.weights = r->weights; a.raw = r->raw; a.z_vals = r->z_vals;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const int bytes = (int)ray_scratch_bytes(kMaxSamples);
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+            return fail(NARUTO_ERR_LAUNCH, "render_fwd: cannot reserve %d bytes of LDS: %s", bytes, hipGetErrorString(hipGetLastError()));
+        attr_set = true;
+    }
+    uint32_t blocks = (r->n_rays + 3u) / 4u;
+    if (blocks > cu_count(f) * 4u) blocks = cu_count(f) * 4u;
+    if (f->desc.mlp_mode == NARUTO_MLP_BF16)
+        hipLaunchKernelGGL(k_render_fwd<true>, dim3(blocks), dim3(256), ray_scratch_bytes(S), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, a);
+    else
+        hipLaunchKernelGGL(k_render_fwd<false>, dim3(blocks), dim3(256), ray_scratch_bytes(S), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, a);
+    return check_launch("render_fwd");
 }
 
 int naruto_composite_fwd(const NarutoField* f, uint32_t n_rays, uint32_t S, const float* raw, const float* z_vals, float* rgb, float* disp,

@@ -509,8 +509,9 @@ __device__ __forceinline__ void fwd_tile_bf(const FwdLdsBf& L, const LevelTab& l
         }
 }
 
+// 2, not 3, waves per SIMD: at 3 (<= 168 registers) the kernel spills 65 registers and the forward takes 65 us instead of 51
 #ifndef NARUTO_FWD_BF_MINWAVES
-#define NARUTO_FWD_BF_MINWAVES 3
+#define NARUTO_FWD_BF_MINWAVES 2
 #endif
 template <bool COLOR>
 __global__ __launch_bounds__(256, NARUTO_FWD_BF_MINWAVES) void k_query_fwd_bf(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps,
@@ -648,7 +649,10 @@ __global__ __launch_bounds__(256) void k_hash_scatter_atomic(LevelTab lt, BoxTab
 
 constexpr int kScatterBatch = 4;   // independent point loads in flight per thread (the loop is latency-bound otherwise)
 
-constexpr int kScatterRun = 8;     // consecutive points per thread on the dense (coarse) levels
+#ifndef NARUTO_SCATTER_RUN
+#define NARUTO_SCATTER_RUN 8
+#endif
+constexpr int kScatterRun = NARUTO_SCATTER_RUN;     // consecutive points per thread on the dense (coarse) levels (a multiple of 4)
 #ifndef NARUTO_LIST_VEC
 #define NARUTO_LIST_VEC 2
 #endif
@@ -786,10 +790,10 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
             // the whole run's inputs up front (list layout: ten 16-byte loads; otherwise 32 scalar loads, all independent): one
             // point at a time the run is a chain of kScatterRun memory round trips
             float rg[kScatterRun], rx[kScatterRun], ry[kScatterRun], rz[kScatterRun];
-            if (ps.xsoa != nullptr && stride_m == 2 && (ps.M & 3u) == 0u && (m_lo & 3u) == 0u && (stride_l & 3u) == 0u && kScatterRun == 8) {
+            if (ps.xsoa != nullptr && stride_m == 2 && (ps.M & 3u) == 0u && (m_lo & 3u) == 0u && (stride_l & 3u) == 0u && kScatterRun % 4 == 0) {
                 const float* __restrict__ pair = d_feat - feat + (size_t)T * stride_l;
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < kScatterRun / 4; ++h) {
                     const uint32_t b4 = r0 + 4u * h;
                     const float4 X = *reinterpret_cast<const float4*>(ps.xsoa + b4), Y = *reinterpret_cast<const float4*>(ps.xsoa + ps.M + b4);
                     const float4 Z = *reinterpret_cast<const float4*>(ps.xsoa + 2u * ps.M + b4);
@@ -840,6 +844,7 @@ struct UncertScatter {
     const float* g;
     UncertTab ut;
     uint32_t partial_off;       // first float of the uncertainty image inside a partial table's feature plane 0
+    uint32_t first;             // list entries before this one carry no cotangent (a multiple of 4: 16-byte aligned rows)
 };
 
 __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab lt, BoxTab bt, PointSrc ps, uint32_t M, const float* __restrict__ d_feat,
@@ -866,24 +871,59 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
         const uint32_t chunk = ub / plan.s_uncert, split = ub % plan.s_uncert;
         for (uint32_t i = threadIdx.x; i < kChunk; i += kScatterThreads) acc[i] = 0ull;
         __syncthreads();
-        const uint32_t per = ((M + plan.s_uncert - 1u) / plan.s_uncert + 3u) & ~3u;
-        const uint32_t m_lo = split * per < M ? split * per : M;
+        // the smoothness lattice at the front of the list carries no raw[...,4] cotangent: the units share the points behind it
+        const uint32_t first = unc.first < M ? unc.first : M, Mu = M - first;
+        const uint32_t per = ((Mu + plan.s_uncert - 1u) / plan.s_uncert + 3u) & ~3u;
+        const uint32_t m_lo = first + (split * per < Mu ? split * per : Mu);
         const uint32_t m_hi = m_lo + per < M ? m_lo + per : M;
         const uint32_t chunk_base = chunk * kChunk;
-        for (uint32_t base = m_lo + threadIdx.x * 4u; base < m_hi; base += kScatterThreads * 4u) {
-            const float4 X = *reinterpret_cast<const float4*>(ps.xsoa + base), Y = *reinterpret_cast<const float4*>(ps.xsoa + ps.M + base);
-            const float4 Z = *reinterpret_cast<const float4*>(ps.xsoa + 2u * ps.M + base), G = *reinterpret_cast<const float4*>(unc.g + base);
-            const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w}, gs[4] = {G.x, G.y, G.z, G.w};
+        // consecutive list entries are consecutive samples of a ray and stay in one voxel for a few samples: a thread walks a run of
+        // 8 points and sums the corner contributions in registers while the base voxel does not change (fewer, less conflicting LDS adds)
+        for (uint32_t r0 = m_lo + threadIdx.x * 8u; r0 < m_hi; r0 += kScatterThreads * 8u) {
+            float rx[8], ry[8], rz[8], rg[8];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                if (base + b >= m_hi || gs[b] == 0.0f) continue;
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t b4 = r0 + 4u * h;
+                const float4 X = *reinterpret_cast<const float4*>(ps.xsoa + b4), Y = *reinterpret_cast<const float4*>(ps.xsoa + ps.M + b4);
+                const float4 Z = *reinterpret_cast<const float4*>(ps.xsoa + 2u * ps.M + b4), G = *reinterpret_cast<const float4*>(unc.g + b4);
+                rx[4 * h] = X.x; rx[4 * h + 1] = X.y; rx[4 * h + 2] = X.z; rx[4 * h + 3] = X.w;
+                ry[4 * h] = Y.x; ry[4 * h + 1] = Y.y; ry[4 * h + 2] = Y.z; ry[4 * h + 3] = Y.w;
+                rz[4 * h] = Z.x; rz[4 * h + 1] = Z.y; rz[4 * h + 2] = Z.z; rz[4 * h + 3] = Z.w;
+                rg[4 * h] = G.x; rg[4 * h + 1] = G.y; rg[4 * h + 2] = G.z; rg[4 * h + 3] = G.w;
+            }
+            int32_t cur[8];
+            float a0[8];
+            bool have = false;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { cur[c] = -1; a0[c] = 0.0f; }
+            auto flush = [&]() {
+                if (!have) return;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    fix_add_rel(acc, (uint32_t)cur[c] - chunk_base, a0[c] * 256.0f);      // idx -1 (outside the grid) wraps out of every chunk
+                    a0[c] = 0.0f;
+                }
+            };
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (r0 + (uint32_t)k >= m_hi) break;
+                if (rg[k] == 0.0f) continue;
                 int32_t ui[8];
                 float uw[8];
-                uncert_corners(unc.ut, xs[b], ys[b], zs[b], ui, uw);
-                const float g256 = gs[b] * 256.0f;
+                uncert_corners(unc.ut, rx[k], ry[k], rz[k], ui, uw);
+                bool same = have;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) fix_add_rel(acc, (uint32_t)ui[c] - chunk_base, uw[c] * g256);      // idx -1 (outside the grid) wraps out of every chunk
+                for (int c = 0; c < 8; ++c) same = same && ui[c] == cur[c];
+                if (!same) {
+                    flush();
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) cur[c] = ui[c];
+                    have = true;
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) a0[c] = fmaf(uw[c], rg[k], a0[c]);
             }
+            flush();
         }
         __syncthreads();
         const uint32_t n_e = plan.uncert_voxels - chunk_base < kChunk ? plan.uncert_voxels - chunk_base : kChunk;

@@ -28,9 +28,11 @@ __device__ __forceinline__ float linspace_at(float start, float end, uint32_t st
 // ------------------------------------------------------------------------------------------------
 // one wave = one ray; zs / us: this wave's LDS, S floats each (merged list; the two sorted input lists: uniform [0, nu) then
 // near-surface [nu, nu+nr))
+// z_vals (global [n_rays,S]) and z_keep (this wave's LDS, S floats, distinct from zs / us) are both optional destinations
 __device__ __forceinline__ void sample_z_ray(uint32_t n, const float* __restrict__ target_d, float near_, float far_, uint32_t nu, uint32_t nr,
                                              float range_d, const float* __restrict__ rand, const uint64_t* __restrict__ rng,
-                                             float* __restrict__ z_vals, float* __restrict__ zs, float* __restrict__ us, int lane) {
+                                             float* __restrict__ z_vals, float* __restrict__ zs, float* __restrict__ us, int lane,
+                                             float* __restrict__ z_keep = nullptr) {
     const uint32_t S = nu + nr;
     if (target_d == nullptr) {
         for (uint32_t s = lane; s < S; s += 64) zs[s] = linspace_at(near_, far_, S, s);     // S == n_samples, nr == 0
@@ -69,7 +71,8 @@ __device__ __forceinline__ void sample_z_ray(uint32_t n, const float* __restrict
             const float r = rand != nullptr ? rand[(size_t)n * S + s] : rng_uniform(key, (uint64_t)n * S + s);
             v = __fadd_rn(lo, __fmul_rn(__fsub_rn(up, lo), r));
         }
-        z_vals[(size_t)n * S + s] = v;
+        if (z_vals != nullptr) z_vals[(size_t)n * S + s] = v;
+        if (z_keep != nullptr) z_keep[s] = v;
     }
 }
 

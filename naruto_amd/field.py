@@ -219,8 +219,30 @@ class NarutoFieldHIP(nn.Module):
         return ops.sample_z(n_rays, target_d, float(cam['near']), float(cam['far']), n_unif, n_range, float(tr['range_d']),
                             n_samples, rand, device=rays_o.device)
 
-    def render_rays(self, rays_o, rays_d, target_d=None, rand=None):
-        """scene_rep.py:150-225.  ``rand`` (optional, [N,S]) replaces the jitter draw for reproducible tests."""
+    def render_rays(self, rays_o, rays_d, target_d=None, rand=None, want_raw=True, fused=None):
+        """scene_rep.py:150-225.  ``rand`` (optional, [N,S]) replaces the jitter draw for reproducible tests.
+
+        Without autograd (eval renders, planner-side queries: ``torch.no_grad()``) the whole call is ONE launch
+        (``naruto_render_fwd``: sampling + field query + compositing per ray, raw kept on chip); ``want_raw=False`` then also
+        skips writing ``raw`` / ``z_vals`` (the returned dict has no such keys).  With autograd enabled the three
+        differentiable operators are used."""
+        if fused is None:
+            fused = not torch.is_grad_enabled()
+        if fused:
+            tr, cam = self.config['training'], self.config['cam']
+            n_rays = rays_o.shape[0]
+            if target_d is not None:
+                n_range, n_unif, n_samples = tr['n_range_d'], tr['n_samples_d'], 0
+            else:
+                n_range, n_unif, n_samples = 0, 0, tr['n_samples']        # KeyError with shipped configs, as in the reference
+            S = n_unif + n_range if target_d is not None else n_samples
+            if tr['perturb'] > 0. and rand is None:
+                rand = torch.rand(n_rays, S, device=rays_o.device)
+            if not tr['perturb'] > 0.:
+                rand = None
+            return ops.render_fused(self._handle(), self._params(), rays_o, rays_d, target_d, near=cam['near'], far=cam['far'],
+                                    n_samples_d=n_unif, n_range_d=n_range, range_d=tr['range_d'], n_samples=n_samples, rand=rand,
+                                    want_raw=want_raw)
         z_vals = self._sample_z(rays_o, target_d, rand)
         raw = ops.field_query(self._handle(), self._params(), rays_o=rays_o, rays_d=rays_d, z_vals=z_vals, color=True)
         raw = raw.reshape(z_vals.shape[0], z_vals.shape[1], 5)

@@ -124,6 +124,43 @@ def sample_z(n_rays: int, target_d: Optional[torch.Tensor], near: float, far: fl
     return z
 
 
+def render_fused(handle: "FieldHandle", params: Dict[str, torch.Tensor], rays_o, rays_d, target_d, *, near: float, far: float, n_samples_d: int,
+                 n_range_d: int, range_d: float, n_samples: int = 0, rand: Optional[torch.Tensor] = None, want_raw: bool = True,
+                 want_weights: bool = False) -> Dict[str, torch.Tensor]:
+    """render_rays as ONE launch (naruto_render_fwd): depth sampling + field query + compositing per ray.  Inference only (no
+    autograd).  ``want_raw``: also write raw [N,S,5] and z_vals [N,S] (the reference's render dict carries them)."""
+    lib = _lib.load()
+    rays_o, rays_d = _f32c(rays_o, "rays_o"), _f32c(rays_d, "rays_d")
+    dev = rays_o.device
+    N = rays_o.shape[0]
+    if target_d is not None:
+        target_d = _f32c(target_d, "target_d").reshape(-1)
+        S = n_samples_d + n_range_d
+    else:
+        S = n_samples
+    if rand is not None:
+        rand = _f32c(rand, "rand")
+        assert rand.shape == (N, S)
+    f32 = dict(dtype=torch.float32, device=dev)
+    out = {"rgb": torch.empty(N, 3, **f32)}
+    for k in ("depth", "disp_map", "acc_map", "depth_var", "uncert_map"):
+        out[k] = torch.empty(N, **f32)
+    if want_raw:
+        out["raw"], out["z_vals"] = torch.empty(N, S, 5, **f32), torch.empty(N, S, **f32)
+    if want_weights:
+        out["weights"] = torch.empty(N, S, **f32)
+    r = _lib.NarutoRender()
+    r.n_rays, r.rays_o, r.rays_d, r.target_d = N, _p(rays_o), _p(rays_d), _p(target_d)
+    r.near_, r.far_, r.n_samples_d, r.n_range_d, r.range_d, r.n_samples = float(near), float(far), int(n_samples_d), int(n_range_d), float(range_d), int(n_samples)
+    r.rand, r.rng = _p(rand), None
+    r.rgb, r.depth, r.disp, r.acc, r.depth_var, r.uncert_map = (_p(out[k]) for k in ("rgb", "depth", "disp_map", "acc_map", "depth_var", "uncert_map"))
+    r.weights, r.raw, r.z_vals = _p(out.get("weights")), _p(out.get("raw")), _p(out.get("z_vals"))
+    ps = _params_struct({k: _f32c(v.detach(), k) for k, v in params.items()})
+    with torch.cuda.device(dev):
+        check(lib.naruto_render_fwd(handle.ptr, C.byref(ps), C.byref(r), _stream()), "naruto_render_fwd")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------
 # A3 alone: embed_fn(x)
 # ---------------------------------------------------------------------------------------------------

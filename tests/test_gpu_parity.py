@@ -230,6 +230,45 @@ def test_hash_encode_vs_oracle(gpu, kind):
     H.assert_close(got, want, 2e-6, f"{kind}.embed")
 
 
+# --------------------------------------------------------------------------------------------- fused inference render
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("n_samples_d,with_depth", [(32, True), (117, True), (181, True), (40, False)])
+def test_render_fused_equals_the_three_operators(gpu, mode, n_samples_d, with_depth):
+    """naruto_render_fwd (render_rays without autograd: sampling + field query + compositing in one launch, raw kept on chip)
+    against the sample_z / field_query / composite operators it replaces -- same kernels' arithmetic, so the rendered maps are
+    bit-identical; rays of 128 / 192 samples also stop early (raw zero behind the truncation band), which no output can see."""
+    cfg = H.office_cfg(12, perturb=1.0, n_samples_d=n_samples_d)
+    cfg["training"]["n_samples"] = n_samples_d
+    cfg["decoder"]["mlp_precision"] = mode
+    ora = H.make_oracle(cfg, 0.25, 91)
+    m = H.make_hip_from_oracle(cfg, ora, gpu).eval()
+    N = 203
+    rays = syn.random_rays(N, cfg["mapping"]["bound"], seed=91, zero_depth_frac=0.1)
+    ro, rd = torch.from_numpy(rays["rays_o"]).to(gpu), torch.from_numpy(rays["rays_d"]).to(gpu)
+    td = torch.from_numpy(rays["target_d"]).to(gpu) if with_depth else None
+    S_tot = n_samples_d + (cfg["training"]["n_range_d"] if with_depth else 0)
+    rand = torch.rand(N, S_tot, generator=torch.Generator().manual_seed(5)).to(gpu)
+    with torch.no_grad():
+        a = m.render_rays(ro, rd, target_d=td, rand=rand, fused=False)
+        b = m.render_rays(ro, rd, target_d=td, rand=rand)                      # no autograd: the fused launch
+        c = m.render_rays(ro, rd, target_d=td, rand=rand, want_raw=False)
+    assert "raw" in b and "raw" not in c and "z_vals" not in c
+    assert torch.equal(a["z_vals"], b["z_vals"])
+    for k in ("rgb", "depth", "disp_map", "acc_map", "depth_var", "uncert_map"):
+        assert torch.equal(a[k], b[k]), f"{k}: fused render differs from the operator chain ({mode}, S={S_tot})"
+        assert torch.equal(b[k], c[k]), f"{k}: want_raw=False changes the result"
+    live = b["raw"].abs().sum(-1) > 0
+    assert torch.equal(a["raw"][live], b["raw"][live])
+    if S_tot > 64:
+        assert int((~live).sum()) > 0, "no ray stopped early"
+    if mode == "fp32":                                                        # and the oracle, for good measure
+        ora.eval()
+        with torch.no_grad():
+            o = ora.render_rays(ro.cpu(), rd.cpu(), target_d=td.cpu() if with_depth else None, rand=rand.cpu())
+        for k in ("rgb", "depth", "depth_var", "uncert_map", "acc_map"):
+            H.assert_close(b[k], o[k], TOL_OUT, f"fused.{k}")
+
+
 # --------------------------------------------------------------------------------------------- bf16 MLP mode
 def _bf16_emulated_raw(ora, x):
     """What the bf16 mode computes, restated with torch: operands of the three matrix layers rounded to bf16 (nearest even),

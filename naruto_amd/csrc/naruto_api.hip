@@ -328,6 +328,9 @@ int naruto_field_create(const NarutoFieldDesc* d, NarutoField** out) {
         f->plan.s_dense = sd;
         // profiling knobs (performance only: the split counts change the summation order, nothing else)
         if (const char* e1 = getenv("NARUTO_DEBUG_SCATTER_SPLITS_HASHED")) f->plan.s_hashed = (uint32_t)atoi(e1) < 1 ? 1u : ((uint32_t)atoi(e1) > 8u ? 8u : (uint32_t)atoi(e1));
+        f->plan.role_mask = 7u;
+        if (const char* e0 = getenv("NARUTO_DEBUG_SCATTER_ROLES")) f->plan.role_mask = (uint32_t)atoi(e0);
+        if (const char* e3 = getenv("NARUTO_DEBUG_SCATTER_SPLITS_UNCERT")) { const uint32_t v = (uint32_t)atoi(e3); f->plan.s_uncert = v < 1u ? 1u : (v > 8u ? 8u : v); }
         if (const char* e2 = getenv("NARUTO_DEBUG_SCATTER_SPLITS_DENSE")) f->plan.s_dense = (uint32_t)atoi(e2) < 1 ? 1u : ((uint32_t)atoi(e2) > 8u ? 8u : (uint32_t)atoi(e2));
     }
     *out = f;

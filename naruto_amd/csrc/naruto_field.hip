@@ -607,6 +607,7 @@ struct ScatterPlan {
     // the uncertainty voxel grid as one more (dense, single-feature) table: n_uncert chunks x s_uncert point splits, after the
     // level units; its partial images live behind the tiled table entries in feature plane 0 of the partial tables
     uint32_t n_uncert, s_uncert, uncert_voxels;
+    uint32_t role_mask;           // profiling knob (NARUTO_DEBUG_SCATTER_ROLES): bit 0 dense, 1 hashed, 2 uncertainty units do their work
 };
 
 template <int T>
@@ -867,7 +868,7 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
         // ---- uncertainty-grid units (training list layout only): d(loss)/d(uncert_grid) = scatter of the raw[...,4] cotangents with
         // grid_sample's trilinear weights, accumulated in the same fixed point -- no float atomics, order independent
         const uint32_t ub = pos - n_blocks;
-        if (unc.g == nullptr || ub >= plan.n_uncert * plan.s_uncert) return;
+        if (unc.g == nullptr || ub >= plan.n_uncert * plan.s_uncert || !(plan.role_mask & 4u)) return;
         const uint32_t chunk = ub / plan.s_uncert, split = ub % plan.s_uncert;
         for (uint32_t i = threadIdx.x; i < kChunk; i += kScatterThreads) acc[i] = 0ull;
         __syncthreads();
@@ -931,6 +932,7 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
         for (uint32_t i = threadIdx.x; i < n_e; i += kScatterThreads) out[i] = (float)((double)(long long)acc[i] * kFixInv);
         return;
     }
+    if (!(plan.role_mask & (pos < dense_blocks ? 1u : 2u))) return;
     if (pos < dense_blocks) {
         n_splits = plan.s_dense;
         unit = pos / n_splits;

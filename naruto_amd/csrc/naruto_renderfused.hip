@@ -4,8 +4,8 @@
 //
 // One wave = one ray: the wave samples the ray's depths into its LDS image, evaluates the field on 64-sample tiles (the same tile
 // code as k_query_fwd / k_query_fwd_bf), keeps raw in the LDS image, and composites from there.  raw / z_vals / weights are written
-// to global memory only when the caller asks for them.  Rays with more than 64 samples stop early once nothing behind the
-// first sign change's truncation band can carry weight (no measured depth is involved in eval mode).
+// to global memory only when the caller asks for them.  When raw is NOT asked for, rays with more than 64 samples stop early once
+// nothing behind the first sign change's truncation band can carry weight (no measured depth is involved in eval mode).
 
 #include "naruto_common.h"
 
@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256, 2) void k_render_fwd(LevelTab lt, UncertTab ut
                     o[0] = to.rgb[0]; o[1] = to.rgb[1]; o[2] = to.rgb[2]; o[3] = to.sdf; o[4] = u;
                 }
             }
-            if (tq + 1u < n_tiles) {                 // front-to-back early termination (full tiles only get here)
+            if (tq + 1u < n_tiles && a.raw == nullptr) {     // front-to-back early termination (full tiles only get here); a caller who asked
+                                                            // for raw gets every sample evaluated, as from the reference's render_rays
                 const float sdf = to.sdf;
                 if (!found) {
                     if (tq > 0u && prev_sdf * lane_f32(sdf, 0) < 0.0f) {

@@ -254,13 +254,18 @@ def test_render_fused_equals_the_three_operators(gpu, mode, n_samples_d, with_de
         c = m.render_rays(ro, rd, target_d=td, rand=rand, want_raw=False)
     assert "raw" in b and "raw" not in c and "z_vals" not in c
     assert torch.equal(a["z_vals"], b["z_vals"])
+    # Same tile code; what can differ is which points share a 64-point tile (the operator chain tiles the flat point list, the fused
+    # kernel tiles ray by ray): the OneBlob closed form / dense form is chosen per tile, and the two agree to ~1e-6.  When the
+    # samples per ray are a multiple of 64 the tilings coincide and everything is bit-identical.
+    same_tiles = S_tot % 64 == 0
+    for k in ("raw", "rgb", "depth", "disp_map", "acc_map", "depth_var", "uncert_map"):
+        if same_tiles:
+            assert torch.equal(a[k], b[k]), f"{k}: fused render differs from the operator chain ({mode}, S={S_tot})"
+        else:
+            H.assert_close(b[k], a[k], 5e-6 if mode == "fp32" else 2e-3, f"fused.{k} ({mode}, S={S_tot})", rel=1e-5)
+    # without raw the rays may stop early behind the truncation band: invisible in every rendered map
     for k in ("rgb", "depth", "disp_map", "acc_map", "depth_var", "uncert_map"):
-        assert torch.equal(a[k], b[k]), f"{k}: fused render differs from the operator chain ({mode}, S={S_tot})"
         assert torch.equal(b[k], c[k]), f"{k}: want_raw=False changes the result"
-    live = b["raw"].abs().sum(-1) > 0
-    assert torch.equal(a["raw"][live], b["raw"][live])
-    if S_tot > 64:
-        assert int((~live).sum()) > 0, "no ray stopped early"
     if mode == "fp32":                                                        # and the oracle, for good measure
         ora.eval()
         with torch.no_grad():

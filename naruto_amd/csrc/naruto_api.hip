@@ -97,20 +97,33 @@ inline uint32_t bin_rows(uint32_t M) {
 
 // workspace of the table scatter for a list of up to M points: | tiled partial tables | counts | totals | starts | items |
 struct ScatterWs {
-    float* partial; uint32_t* counts; uint32_t* totals; uint32_t* starts; BinItem* items;
+    float* partial; float* unc_partial; uint32_t* counts; uint32_t* totals; uint32_t* starts; BinItem* items;
     size_t total;
 };
-// entries per feature plane of a partial table: the tiled levels, then (plane 0 only uses it) the uncertainty-grid image
-inline size_t partial_plane(const NarutoField* f) { return (size_t)f->n_tiled_entries + (((size_t)f->plan.n_uncert ? (size_t)f->plan.uncert_voxels : 0u) + 3u) / 4u * 4u; }
+// entries per feature plane of a partial table: the tiled levels
+inline size_t partial_plane(const NarutoField* f) { return (size_t)f->n_tiled_entries; }
+// the uncertainty grid's units: point splits per chunk for a list of up to M points -- the planned count for the mapping batches
+// (workgroup budget), more for long lists (a unit should not stream more than ~64 k points), at most kMaxUncertSplits
+constexpr uint32_t kMaxUncertSplits = 32;
+inline uint32_t uncert_splits(const NarutoField* f, uint32_t M) {
+    uint32_t s = (M + 65535u) / 65536u;
+    if (s < f->plan.s_uncert) s = f->plan.s_uncert;
+    const uint32_t cap = f->plan.n_uncert ? (64u / f->plan.n_uncert > 1u ? 64u / f->plan.n_uncert : 1u) : 1u;
+    if (s > cap) s = cap;
+    if (s > kMaxUncertSplits) s = kMaxUncertSplits;
+    return s < 1u ? 1u : s;
+}
+inline uint32_t uncert_pad(const NarutoField* f) { return (f->plan.uncert_voxels + 3u) / 4u * 4u; }
 
 ScatterWs scatter_ws(const NarutoField* f, void* base, uint32_t M) {
     ScatterWs w{};
     char* b = reinterpret_cast<char*>(base);
     size_t off = 0;
-    uint32_t smax = f->plan.s_dense > f->plan.s_hashed ? f->plan.s_dense : f->plan.s_hashed;
-    if (f->plan.s_uncert > smax) smax = f->plan.s_uncert;
+    const uint32_t smax = f->plan.s_dense > f->plan.s_hashed ? f->plan.s_dense : f->plan.s_hashed;
     w.partial = reinterpret_cast<float*>(b + off);
     off += al256((f->plan.n_dense + f->plan.n_hashed) ? (size_t)smax * partial_plane(f) * 2u * sizeof(float) : 16u);
+    w.unc_partial = reinterpret_cast<float*>(b + off);
+    off += al256(f->plan.n_uncert ? (size_t)uncert_splits(f, M) * uncert_pad(f) * sizeof(float) : 16u);
     if (f->bplan.n_levels != 0) {
         w.counts = reinterpret_cast<uint32_t*>(b + off); off += al256((size_t)bin_rows(M) * f->bplan.n_bins * sizeof(uint32_t));
         w.totals = reinterpret_cast<uint32_t*>(b + off); off += al256((size_t)f->bplan.n_bins * sizeof(uint32_t));
@@ -137,8 +150,8 @@ int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const f
     UncertScatter us{};
     UncertReduce ur{};
     if (unc_g != nullptr && d_uncert != nullptr && f->plan.n_uncert != 0) {
-        us.g = unc_g; us.ut = f->ut; us.partial_off = (uint32_t)f->n_tiled_entries; us.first = unc_first & ~3u;
-        ur.d_uncert = d_uncert; ur.n_voxels = f->plan.uncert_voxels; ur.n_splits = f->plan.s_uncert; ur.partial_off = (uint32_t)f->n_tiled_entries;
+        us.g = unc_g; us.ut = f->ut; us.partial = w.unc_partial; us.voxels_pad = uncert_pad(f); us.n_splits = uncert_splits(f, M); us.first = unc_first & ~3u;
+        ur.d_uncert = d_uncert; ur.partial = w.unc_partial; ur.n_voxels = f->plan.uncert_voxels; ur.n_splits = us.n_splits; ur.voxels_pad = us.voxels_pad;
     }
     if (d_table == nullptr && adam == nullptr && us.g == nullptr) return NARUTO_OK;
     ScatterPlan plan = f->plan;
@@ -151,7 +164,7 @@ int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const f
                 return fail(NARUTO_ERR_LAUNCH, "hash_scatter: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(hipGetLastError()));
             attr_set = true;
         }
-        const uint32_t blocks = (plan.n_dense * plan.s_dense + plan.n_hashed * plan.s_hashed + (us.g != nullptr ? plan.n_uncert * plan.s_uncert : 0u) + 7u) /
+        const uint32_t blocks = (plan.n_dense * plan.s_dense + plan.n_hashed * plan.s_hashed + (us.g != nullptr ? plan.n_uncert * us.n_splits : 0u) + 7u) /
                                 8u * 8u;      // XCD-aware order: multiple of 8
         hipLaunchKernelGGL(k_hash_scatter_lds, dim3(blocks), dim3(kScatterThreads), lds, st, f->lt, f->bt, ps, M, d_feat, stride_m, stride_l, plan,
                            w.partial, 2u * n_plane, m_dev, scale_dev, us);
@@ -217,6 +230,7 @@ int naruto_field_create(const NarutoFieldDesc* d, NarutoField** out) {
         return fail(NARUTO_ERR_INVALID, "create: this build supports n_bins=16, hidden_dim=32, hidden_dim_color=32, geo_feat_dim=15");
     if (d->log2_hashmap_size < 4 || d->log2_hashmap_size > 28) return fail(NARUTO_ERR_INVALID, "create: log2_hashmap_size out of range");
     if (d->uncert_dims[0] == 0 || d->uncert_dims[1] == 0 || d->uncert_dims[2] == 0) return fail(NARUTO_ERR_INVALID, "create: empty uncert grid");
+    if (d->uncert_dims[0] > 1000 || d->uncert_dims[1] > 1000 || d->uncert_dims[2] > 1000) return fail(NARUTO_ERR_INVALID, "create: uncert grid axes of more than 1000 voxels are not supported");
     if (!(d->trunc > 0.0f)) return fail(NARUTO_ERR_INVALID, "create: trunc must be > 0");
     if (d->mlp_mode != NARUTO_MLP_FP32 && d->mlp_mode != NARUTO_MLP_BF16) return fail(NARUTO_ERR_INVALID, "create: unknown mlp_mode %u", d->mlp_mode);
     NarutoField* f = new (std::nothrow) NarutoField;
@@ -499,6 +513,7 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
     if (int rc = check_points(pts)) return rc;
     const BwdWs w = bwd_ws(f, workspace, cap);
     float* d_feat = w.d_feat; float* x_soa = w.x_soa; float* partials = w.partials; float* scatter_ws = w.scatter_ws;
+    void* scatter_ws_ptr = w.scatter_ws;
     uint32_t* n_total = w.n_total;
     const bool bf = f->desc.mlp_mode == NARUTO_MLP_BF16;
     const uint32_t n_tiles = bf ? (M + 63u) / 64u : (M + 31u) / 32u;
@@ -546,7 +561,11 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
         const size_t n_params = (size_t)f->n_tiled_entries * 2u;
         const uint32_t n_table_blocks = (uint32_t)((n_params / 4u + 255u) / 256u);
         UncertReduce ur{};
-        if (unc_scatter) { ur.d_uncert = d_unc; ur.n_voxels = f->plan.uncert_voxels; ur.n_splits = f->plan.s_uncert; ur.partial_off = (uint32_t)f->n_tiled_entries; }
+        if (unc_scatter) {
+            const uint32_t Ml = cnt != nullptr ? cap : M;
+            ur.d_uncert = d_unc; ur.partial = ::scatter_ws(f, scatter_ws_ptr, Ml).unc_partial; ur.n_voxels = f->plan.uncert_voxels; ur.n_splits = uncert_splits(f, Ml);
+            ur.voxels_pad = uncert_pad(f);
+        }
         const uint32_t n_unc_blocks = unc_scatter ? (ur.n_voxels + 255u) / 256u : 0u;
         hipLaunchKernelGGL(k_bwd_finish, dim3(n_table_blocks + kAccFloats / 32 + n_unc_blocks), dim3(256), 0, (hipStream_t)stream, f->lt, scatter_ws, f->plan.s_dense,
                            f->plan.s_hashed, n_params, partial_plane(f), partials, blocks, *g, *adam, n_table_blocks, ur);

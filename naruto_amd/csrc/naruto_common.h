@@ -343,6 +343,30 @@ __device__ __forceinline__ void uncert_corners(const UncertTab& ut, float x, flo
     }
 }
 
+// the same in two steps for run-combining scatter code: base voxel (packed 10 bits per axis, biased by 2) + fractions, and the 8
+// corner indices of a packed base voxel (-1 outside the grid)
+__device__ __forceinline__ uint32_t uncert_base(const UncertTab& ut, float x, float y, float z, float& fx, float& fy, float& fz) {
+    const float gx = x * 2.0f - 1.0f, gy = y * 2.0f - 1.0f, gz = z * 2.0f - 1.0f;
+    const float ix = ((gx + 1.0f) * (float)ut.W - 1.0f) * 0.5f;
+    const float iy = ((gy + 1.0f) * (float)ut.H - 1.0f) * 0.5f;
+    const float iz = ((gz + 1.0f) * (float)ut.D - 1.0f) * 0.5f;
+    const float fx0 = floorf(ix), fy0 = floorf(iy), fz0 = floorf(iz);
+    fx = ix - fx0; fy = iy - fy0; fz = iz - fz0;
+    const int x0 = (int)fminf(fmaxf(fx0, -2.0f), (float)ut.W + 1.0f);
+    const int y0 = (int)fminf(fmaxf(fy0, -2.0f), (float)ut.H + 1.0f);
+    const int z0 = (int)fminf(fmaxf(fz0, -2.0f), (float)ut.D + 1.0f);
+    return (uint32_t)(x0 + 2) | ((uint32_t)(y0 + 2) << 10) | ((uint32_t)(z0 + 2) << 20);
+}
+__device__ __forceinline__ void uncert_base_corners(const UncertTab& ut, uint32_t key, int32_t (&idx)[8]) {
+    const int x0 = (int)(key & 1023u) - 2, y0 = (int)((key >> 10) & 1023u) - 2, z0 = (int)(key >> 20) - 2;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int xi = x0 + (c & 1), yi = y0 + ((c >> 1) & 1), zi = z0 + ((c >> 2) & 1);
+        const bool ok = (xi >= 0) & (xi < ut.W) & (yi >= 0) & (yi < ut.H) & (zi >= 0) & (zi < ut.D);
+        idx[c] = ok ? ((zi * ut.H + yi) * ut.W + xi) : -1;
+    }
+}
+
 __device__ __forceinline__ float uncert_sample(const UncertTab& ut, const float* __restrict__ grid, float x, float y, float z) {
     int32_t idx[8];
     float w[8];

@@ -604,9 +604,9 @@ struct ScatterPlan {
     uint32_t n_dense, n_hashed;   // LDS-tiled (level, chunk) units of non-hashed / hashed levels
     uint32_t s_dense, s_hashed;   // point splits per unit
     uint32_t atomic_levels;       // bit l: level l goes through the global-atomic kernel instead
-    // the uncertainty voxel grid as one more (dense, single-feature) table: n_uncert chunks x s_uncert point splits, after the
-    // level units; its partial images live behind the tiled table entries in feature plane 0 of the partial tables
-    uint32_t n_uncert, s_uncert, uncert_voxels;
+    // the uncertainty voxel grid as one more (dense, single-feature) table: n_uncert chunks x (per-launch) point splits, after the
+    // level units, with partial images of their own
+    uint32_t n_uncert, s_uncert, uncert_voxels;       // s_uncert: the splits the workgroup budget was planned with (small lists)
     uint32_t role_mask;           // profiling knob (NARUTO_DEBUG_SCATTER_ROLES): bit 0 dense, 1 hashed, 2 uncertainty units do their work
 };
 
@@ -767,26 +767,46 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
             }
         }
     } else {
-        // dense (coarse) levels: consecutive points of a ray stay in one cell for several samples, so a thread
-        // walks a run of consecutive points and sums their contributions per corner in registers, touching
-        // LDS only when the cell changes (5-8x fewer, and far less conflicting, LDS atomics)
+        // dense (coarse) levels: consecutive points of a ray stay in one cell for several samples, so a thread walks a run of
+        // consecutive points and sums their contributions per corner in registers (5-8x fewer, and far less conflicting, LDS adds).
+        // The sums of up to kDenseSlots cells are kept and written out ONCE at the end of the run: a flush inside the point loop
+        // is a divergent branch that the whole wave executes as soon as one lane changes cell -- i.e. at nearly every point, 128
+        // instructions each (measured: the dense units were issue-bound on exactly that).
         const float scale = lt.scale[T];
         const uint32_t res = lt.res[T], size = lt.size[T], r2 = res * res;
+        const bool one_chunk = size <= kChunk;                   // levels 0..2 at office0: every corner is in THE chunk
+        constexpr int kDenseSlots = 3;
         for (uint32_t r0 = m_lo + threadIdx.x * kScatterRun; r0 < m_hi; r0 += kScatterThreads * kScatterRun) {
-            float a0[8];
-            uint32_t cur = 0xFFFFFFFFu;
-            bool have = false;
+            float a0[kDenseSlots][8];
+            uint32_t cells[kDenseSlots];
+            int used = 0;
+            uint32_t last = 0xFFFFFFFFu;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) a0[c] = 0.0f;
+            for (int sl = 0; sl < kDenseSlots; ++sl) {
+                cells[sl] = 0u;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) a0[sl][c] = 0.0f;
+            }
             auto flush = [&]() {
-                if (!have) return;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    uint32_t i = cur + (uint32_t)(c & 1) + ((c & 2) ? res : 0u) + ((c & 4) ? r2 : 0u);
-                    if (i >= size) i %= size;
-                    fix_add(acc, i, chunk, a0[c]);
-                    a0[c] = 0.0f;
+                for (int sl = 0; sl < kDenseSlots; ++sl) {
+                    if (!__any(sl < used)) continue;                  // wave-uniform: nobody filled this slot
+                    if (sl < used) {
+                        // wrap-around (points outside the box) is rare: the modulo sits behind a wave-uniform test
+                        const bool wrap = __any(cells[sl] >= size - (1u + res + r2));      // (size > 1 + res + res^2 for every dense level)
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            uint32_t i = cells[sl] + (uint32_t)(c & 1) + ((c & 2) ? res : 0u) + ((c & 4) ? r2 : 0u);
+                            if (wrap && i >= size) i %= size;
+                            if (one_chunk) atomicAdd(acc + i, to_fix40(a0[sl][c]));
+                            else fix_add(acc, i, chunk, a0[sl][c]);
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) a0[sl][c] = 0.0f;
                 }
+                used = 0;
+                last = 0xFFFFFFFFu;
             };
             // the whole run's inputs up front (list layout: ten 16-byte loads; otherwise 32 scalar loads, all independent): one
             // point at a time the run is a chain of kScatterRun memory round trips
@@ -815,24 +835,30 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
 #pragma unroll
             for (int k = 0; k < kScatterRun; ++k) {
                 const uint32_t m = r0 + k;
-                if (m >= m_hi) break;
-                const float g = rg[k];
-                if (g == 0.0f) continue;
+                const float g = (m < m_hi) ? rg[k] : 0.0f;
+                const bool live = g != 0.0f;
                 const float x = rx[k], y = ry[k], z = rz[k];
                 const float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
                 const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
                 const uint32_t cell = (uint32_t)(int)fx + (uint32_t)(int)fy * res + (uint32_t)(int)fz * r2;
-                if (!have || cell != cur) {
-                    flush();
-                    cur = cell;
-                    have = true;
+                const bool new_cell = live && cell != last;
+                if (__any(new_cell && used == kDenseSlots)) {          // a lane is out of slots (a run across > kDenseSlots cells): rare
+                    if (new_cell && used == kDenseSlots) flush();
+                }
+                if (new_cell) {
+#pragma unroll
+                    for (int sl = 0; sl < kDenseSlots; ++sl) cells[sl] = sl == used ? cell : cells[sl];
+                    ++used;
+                    last = cell;
                 }
                 const float wx = px - fx, wy = py - fy, wz = pz - fz;
                 const float ux = 1.0f - wx, uy = 1.0f - wy, uz = 1.0f - wz;
+                const float gl = live ? g : 0.0f;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    const float w = ((c & 1) ? wx : ux) * ((c & 2) ? wy : uy) * ((c & 4) ? wz : uz);
-                    a0[c] = fmaf(w, g, a0[c]);
+                    const float w = live ? ((c & 1) ? wx : ux) * ((c & 2) ? wy : uy) * ((c & 4) ? wz : uz) : 0.0f;      // (padding entries may hold anything)
+#pragma unroll
+                    for (int sl = 0; sl < kDenseSlots; ++sl) a0[sl][c] = fmaf(sl == used - 1 ? w : 0.0f, gl, a0[sl][c]);
                 }
             }
             flush();
@@ -844,7 +870,9 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
 struct UncertScatter {
     const float* g;
     UncertTab ut;
-    uint32_t partial_off;       // first float of the uncertainty image inside a partial table's feature plane 0
+    float* partial;             // [n_splits][voxels_pad] partial images of the grid's gradient
+    uint32_t voxels_pad;
+    uint32_t n_splits;          // point splits per 16 384-voxel chunk: chosen per launch from the list's capacity
     uint32_t first;             // list entries before this one carry no cotangent (a multiple of 4: 16-byte aligned rows)
 };
 
@@ -868,13 +896,13 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
         // ---- uncertainty-grid units (training list layout only): d(loss)/d(uncert_grid) = scatter of the raw[...,4] cotangents with
         // grid_sample's trilinear weights, accumulated in the same fixed point -- no float atomics, order independent
         const uint32_t ub = pos - n_blocks;
-        if (unc.g == nullptr || ub >= plan.n_uncert * plan.s_uncert || !(plan.role_mask & 4u)) return;
-        const uint32_t chunk = ub / plan.s_uncert, split = ub % plan.s_uncert;
+        if (unc.g == nullptr || ub >= plan.n_uncert * unc.n_splits || !(plan.role_mask & 4u)) return;
+        const uint32_t chunk = ub / unc.n_splits, split = ub % unc.n_splits;
         for (uint32_t i = threadIdx.x; i < kChunk; i += kScatterThreads) acc[i] = 0ull;
         __syncthreads();
         // the smoothness lattice at the front of the list carries no raw[...,4] cotangent: the units share the points behind it
         const uint32_t first = unc.first < M ? unc.first : M, Mu = M - first;
-        const uint32_t per = ((Mu + plan.s_uncert - 1u) / plan.s_uncert + 3u) & ~3u;
+        const uint32_t per = ((Mu + unc.n_splits - 1u) / unc.n_splits + 3u) & ~3u;
         const uint32_t m_lo = first + (split * per < Mu ? split * per : Mu);
         const uint32_t m_hi = m_lo + per < M ? m_lo + per : M;
         const uint32_t chunk_base = chunk * kChunk;
@@ -892,43 +920,64 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
                 rz[4 * h] = Z.x; rz[4 * h + 1] = Z.y; rz[4 * h + 2] = Z.z; rz[4 * h + 3] = Z.w;
                 rg[4 * h] = G.x; rg[4 * h + 1] = G.y; rg[4 * h + 2] = G.z; rg[4 * h + 3] = G.w;
             }
-            int32_t cur[8];
-            float a0[8];
-            bool have = false;
+            // sums of up to kSlots base voxels, written out once at the end of the run (a flush inside the point loop is a divergent
+            // branch the whole wave executes at nearly every point)
+            constexpr int kSlots = 3;
+            float a0[kSlots][8];
+            uint32_t keys[kSlots];
+            int used = 0;
+            uint32_t last = 0xFFFFFFFFu;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) { cur[c] = -1; a0[c] = 0.0f; }
+            for (int sl = 0; sl < kSlots; ++sl) {
+                keys[sl] = 0u;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) a0[sl][c] = 0.0f;
+            }
             auto flush = [&]() {
-                if (!have) return;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    fix_add_rel(acc, (uint32_t)cur[c] - chunk_base, a0[c] * 256.0f);      // idx -1 (outside the grid) wraps out of every chunk
-                    a0[c] = 0.0f;
+                for (int sl = 0; sl < kSlots; ++sl) {
+                    if (!__any(sl < used)) continue;
+                    if (sl < used) {
+                        int32_t ui[8];
+                        uncert_base_corners(unc.ut, keys[sl], ui);
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) fix_add_rel(acc, (uint32_t)ui[c] - chunk_base, a0[sl][c] * 256.0f);      // idx -1 wraps out of every chunk
+                    }
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) a0[sl][c] = 0.0f;
                 }
+                used = 0;
+                last = 0xFFFFFFFFu;
             };
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                if (r0 + (uint32_t)k >= m_hi) break;
-                if (rg[k] == 0.0f) continue;
-                int32_t ui[8];
-                float uw[8];
-                uncert_corners(unc.ut, rx[k], ry[k], rz[k], ui, uw);
-                bool same = have;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) same = same && ui[c] == cur[c];
-                if (!same) {
-                    flush();
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) cur[c] = ui[c];
-                    have = true;
+                const float g = (r0 + (uint32_t)k < m_hi) ? rg[k] : 0.0f;
+                const bool live = g != 0.0f;
+                float fx, fy, fz;
+                const uint32_t key = uncert_base(unc.ut, rx[k], ry[k], rz[k], fx, fy, fz);
+                const bool new_cell = live && key != last;
+                if (__any(new_cell && used == kSlots)) {
+                    if (new_cell && used == kSlots) flush();
                 }
+                if (new_cell) {
 #pragma unroll
-                for (int c = 0; c < 8; ++c) a0[c] = fmaf(uw[c], rg[k], a0[c]);
+                    for (int sl = 0; sl < kSlots; ++sl) keys[sl] = sl == used ? key : keys[sl];
+                    ++used;
+                    last = key;
+                }
+                const float gl = live ? g : 0.0f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float w = live ? ((c & 1) ? fx : 1.0f - fx) * ((c & 2) ? fy : 1.0f - fy) * ((c & 4) ? fz : 1.0f - fz) : 0.0f;
+#pragma unroll
+                    for (int sl = 0; sl < kSlots; ++sl) a0[sl][c] = fmaf(sl == used - 1 ? w : 0.0f, gl, a0[sl][c]);
+                }
             }
             flush();
         }
         __syncthreads();
         const uint32_t n_e = plan.uncert_voxels - chunk_base < kChunk ? plan.uncert_voxels - chunk_base : kChunk;
-        float* out = partial + (size_t)split * n_params + unc.partial_off + chunk_base;          // feature plane 0 of this split's partial table
+        float* out = unc.partial + (size_t)split * unc.voxels_pad + chunk_base;
         for (uint32_t i = threadIdx.x; i < n_e; i += kScatterThreads) out[i] = (float)((double)(long long)acc[i] * kFixInv);
         return;
     }
@@ -978,13 +1027,14 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
 // grid's optimiser steps every 5th iteration, its gradient adds up in between -- reference coslam.py:397-399)
 struct UncertReduce {
     float* d_uncert;            // NULL: nothing to do
-    uint32_t n_voxels, n_splits, partial_off;
+    const float* partial;       // [n_splits][voxels_pad]
+    uint32_t n_voxels, n_splits, voxels_pad;
 };
-__device__ __forceinline__ void uncert_reduce_body(const float* __restrict__ partial, size_t n_plane, const UncertReduce& u, uint32_t block) {
+__device__ __forceinline__ void uncert_reduce_body(const UncertReduce& u, uint32_t block) {
     const uint32_t v = block * 256u + threadIdx.x;
     if (u.d_uncert == nullptr || v >= u.n_voxels) return;
     float s = 0.0f;
-    for (uint32_t k = 0; k < u.n_splits; ++k) s += partial[(size_t)k * 2u * n_plane + u.partial_off + v];
+    for (uint32_t k = 0; k < u.n_splits; ++k) s += u.partial[(size_t)k * u.voxels_pad + v];
     u.d_uncert[v] += s;
 }
 
@@ -993,7 +1043,7 @@ __device__ __forceinline__ void uncert_reduce_body(const float* __restrict__ par
 __global__ __launch_bounds__(256) void k_scatter_reduce(LevelTab lt, uint32_t atomic_levels, const float* __restrict__ partial, uint32_t s_dense,
                                                         uint32_t s_hashed, size_t n_params, size_t n_plane, float* __restrict__ d_table, int overwrite,
                                                         uint32_t n_table_blocks, UncertReduce unc) {
-    if (blockIdx.x >= n_table_blocks) { uncert_reduce_body(partial, n_plane, unc, blockIdx.x - n_table_blocks); return; }
+    if (blockIdx.x >= n_table_blocks) { uncert_reduce_body(unc, blockIdx.x - n_table_blocks); return; }
     if (d_table == nullptr) return;
     const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // float4 index of the output = entries 2 i4, 2 i4 + 1
     if (i4 * 4 >= n_params) return;
@@ -1983,7 +2033,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 __global__ __launch_bounds__(256) void k_bwd_finish(LevelTab lt, const float* __restrict__ partial, uint32_t s_dense, uint32_t s_hashed, size_t n_params,
                                                     size_t n_plane, const float* __restrict__ wpartials, uint32_t n_wblocks, NarutoGrads g, AdamFuse adam,
                                                     uint32_t n_table_blocks, UncertReduce unc) {
-    if (blockIdx.x >= n_table_blocks + kAccFloats / 32) { uncert_reduce_body(partial, n_plane, unc, blockIdx.x - n_table_blocks - kAccFloats / 32); return; }
+    if (blockIdx.x >= n_table_blocks + kAccFloats / 32) { uncert_reduce_body(unc, blockIdx.x - n_table_blocks - kAccFloats / 32); return; }
     if (blockIdx.x >= n_table_blocks) {
         wgrad_reduce_body(wpartials, n_wblocks, g, 1, blockIdx.x - n_table_blocks, &adam);
         return;

@@ -767,46 +767,26 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
             }
         }
     } else {
-        // dense (coarse) levels: consecutive points of a ray stay in one cell for several samples, so a thread walks a run of
-        // consecutive points and sums their contributions per corner in registers (5-8x fewer, and far less conflicting, LDS adds).
-        // The sums of up to kDenseSlots cells are kept and written out ONCE at the end of the run: a flush inside the point loop
-        // is a divergent branch that the whole wave executes as soon as one lane changes cell -- i.e. at nearly every point, 128
-        // instructions each (measured: the dense units were issue-bound on exactly that).
+        // dense (coarse) levels: consecutive points of a ray stay in one cell for several samples, so a thread
+        // walks a run of consecutive points and sums their contributions per corner in registers, touching
+        // LDS only when the cell changes (5-8x fewer, and far less conflicting, LDS atomics)
         const float scale = lt.scale[T];
         const uint32_t res = lt.res[T], size = lt.size[T], r2 = res * res;
-        const bool one_chunk = size <= kChunk;                   // levels 0..2 at office0: every corner is in THE chunk
-        constexpr int kDenseSlots = 3;
         for (uint32_t r0 = m_lo + threadIdx.x * kScatterRun; r0 < m_hi; r0 += kScatterThreads * kScatterRun) {
-            float a0[kDenseSlots][8];
-            uint32_t cells[kDenseSlots];
-            int used = 0;
-            uint32_t last = 0xFFFFFFFFu;
+            float a0[8];
+            uint32_t cur = 0xFFFFFFFFu;
+            bool have = false;
 #pragma unroll
-            for (int sl = 0; sl < kDenseSlots; ++sl) {
-                cells[sl] = 0u;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) a0[sl][c] = 0.0f;
-            }
+            for (int c = 0; c < 8; ++c) a0[c] = 0.0f;
             auto flush = [&]() {
+                if (!have) return;
 #pragma unroll
-                for (int sl = 0; sl < kDenseSlots; ++sl) {
-                    if (!__any(sl < used)) continue;                  // wave-uniform: nobody filled this slot
-                    if (sl < used) {
-                        // wrap-around (points outside the box) is rare: the modulo sits behind a wave-uniform test
-                        const bool wrap = __any(cells[sl] >= size - (1u + res + r2));      // (size > 1 + res + res^2 for every dense level)
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) {
-                            uint32_t i = cells[sl] + (uint32_t)(c & 1) + ((c & 2) ? res : 0u) + ((c & 4) ? r2 : 0u);
-                            if (wrap && i >= size) i %= size;
-                            if (one_chunk) atomicAdd(acc + i, to_fix40(a0[sl][c]));
-                            else fix_add(acc, i, chunk, a0[sl][c]);
-                        }
-                    }
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) a0[sl][c] = 0.0f;
+                for (int c = 0; c < 8; ++c) {
+                    uint32_t i = cur + (uint32_t)(c & 1) + ((c & 2) ? res : 0u) + ((c & 4) ? r2 : 0u);
+                    if (i >= size) i %= size;
+                    fix_add(acc, i, chunk, a0[c]);
+                    a0[c] = 0.0f;
                 }
-                used = 0;
-                last = 0xFFFFFFFFu;
             };
             // the whole run's inputs up front (list layout: ten 16-byte loads; otherwise 32 scalar loads, all independent): one
             // point at a time the run is a chain of kScatterRun memory round trips
@@ -835,30 +815,24 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
 #pragma unroll
             for (int k = 0; k < kScatterRun; ++k) {
                 const uint32_t m = r0 + k;
-                const float g = (m < m_hi) ? rg[k] : 0.0f;
-                const bool live = g != 0.0f;
+                if (m >= m_hi) break;
+                const float g = rg[k];
+                if (g == 0.0f) continue;
                 const float x = rx[k], y = ry[k], z = rz[k];
                 const float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
                 const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
                 const uint32_t cell = (uint32_t)(int)fx + (uint32_t)(int)fy * res + (uint32_t)(int)fz * r2;
-                const bool new_cell = live && cell != last;
-                if (__any(new_cell && used == kDenseSlots)) {          // a lane is out of slots (a run across > kDenseSlots cells): rare
-                    if (new_cell && used == kDenseSlots) flush();
-                }
-                if (new_cell) {
-#pragma unroll
-                    for (int sl = 0; sl < kDenseSlots; ++sl) cells[sl] = sl == used ? cell : cells[sl];
-                    ++used;
-                    last = cell;
+                if (!have || cell != cur) {
+                    flush();
+                    cur = cell;
+                    have = true;
                 }
                 const float wx = px - fx, wy = py - fy, wz = pz - fz;
                 const float ux = 1.0f - wx, uy = 1.0f - wy, uz = 1.0f - wz;
-                const float gl = live ? g : 0.0f;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    const float w = live ? ((c & 1) ? wx : ux) * ((c & 2) ? wy : uy) * ((c & 4) ? wz : uz) : 0.0f;      // (padding entries may hold anything)
-#pragma unroll
-                    for (int sl = 0; sl < kDenseSlots; ++sl) a0[sl][c] = fmaf(sl == used - 1 ? w : 0.0f, gl, a0[sl][c]);
+                    const float w = ((c & 1) ? wx : ux) * ((c & 2) ? wy : uy) * ((c & 4) ? wz : uz);
+                    a0[c] = fmaf(w, g, a0[c]);
                 }
             }
             flush();
@@ -920,58 +894,37 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
                 rz[4 * h] = Z.x; rz[4 * h + 1] = Z.y; rz[4 * h + 2] = Z.z; rz[4 * h + 3] = Z.w;
                 rg[4 * h] = G.x; rg[4 * h + 1] = G.y; rg[4 * h + 2] = G.z; rg[4 * h + 3] = G.w;
             }
-            // sums of up to kSlots base voxels, written out once at the end of the run (a flush inside the point loop is a divergent
-            // branch the whole wave executes at nearly every point)
-            constexpr int kSlots = 3;
-            float a0[kSlots][8];
-            uint32_t keys[kSlots];
-            int used = 0;
-            uint32_t last = 0xFFFFFFFFu;
+            int32_t cur[8];
+            float a0[8];
+            bool have = false;
 #pragma unroll
-            for (int sl = 0; sl < kSlots; ++sl) {
-                keys[sl] = 0u;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) a0[sl][c] = 0.0f;
-            }
+            for (int c = 0; c < 8; ++c) { cur[c] = -1; a0[c] = 0.0f; }
             auto flush = [&]() {
+                if (!have) return;
 #pragma unroll
-                for (int sl = 0; sl < kSlots; ++sl) {
-                    if (!__any(sl < used)) continue;
-                    if (sl < used) {
-                        int32_t ui[8];
-                        uncert_base_corners(unc.ut, keys[sl], ui);
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) fix_add_rel(acc, (uint32_t)ui[c] - chunk_base, a0[sl][c] * 256.0f);      // idx -1 wraps out of every chunk
-                    }
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) a0[sl][c] = 0.0f;
+                for (int c = 0; c < 8; ++c) {
+                    fix_add_rel(acc, (uint32_t)cur[c] - chunk_base, a0[c] * 256.0f);      // idx -1 (outside the grid) wraps out of every chunk
+                    a0[c] = 0.0f;
                 }
-                used = 0;
-                last = 0xFFFFFFFFu;
             };
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const float g = (r0 + (uint32_t)k < m_hi) ? rg[k] : 0.0f;
-                const bool live = g != 0.0f;
-                float fx, fy, fz;
-                const uint32_t key = uncert_base(unc.ut, rx[k], ry[k], rz[k], fx, fy, fz);
-                const bool new_cell = live && key != last;
-                if (__any(new_cell && used == kSlots)) {
-                    if (new_cell && used == kSlots) flush();
-                }
-                if (new_cell) {
+                if (r0 + (uint32_t)k >= m_hi) break;
+                if (rg[k] == 0.0f) continue;
+                int32_t ui[8];
+                float uw[8];
+                uncert_corners(unc.ut, rx[k], ry[k], rz[k], ui, uw);
+                bool same = have;
 #pragma unroll
-                    for (int sl = 0; sl < kSlots; ++sl) keys[sl] = sl == used ? key : keys[sl];
-                    ++used;
-                    last = key;
-                }
-                const float gl = live ? g : 0.0f;
+                for (int c = 0; c < 8; ++c) same = same && ui[c] == cur[c];
+                if (!same) {
+                    flush();
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const float w = live ? ((c & 1) ? fx : 1.0f - fx) * ((c & 2) ? fy : 1.0f - fy) * ((c & 4) ? fz : 1.0f - fz) : 0.0f;
-#pragma unroll
-                    for (int sl = 0; sl < kSlots; ++sl) a0[sl][c] = fmaf(sl == used - 1 ? w : 0.0f, gl, a0[sl][c]);
+                    for (int c = 0; c < 8; ++c) cur[c] = ui[c];
+                    have = true;
                 }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) a0[c] = fmaf(uw[c], rg[k], a0[c]);
             }
             flush();
         }

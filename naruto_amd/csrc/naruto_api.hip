@@ -103,10 +103,10 @@ struct ScatterWs {
 // entries per feature plane of a partial table: the tiled levels
 inline size_t partial_plane(const NarutoField* f) { return (size_t)f->n_tiled_entries; }
 // the uncertainty grid's units: point splits per chunk for a list of up to M points -- the planned count for the mapping batches
-// (workgroup budget), more for long lists (a unit should not stream more than ~64 k points), at most kMaxUncertSplits
+// (workgroup budget), more for long lists (a unit should not stream more than ~100 k active points), at most kMaxUncertSplits
 constexpr uint32_t kMaxUncertSplits = 32;
 inline uint32_t uncert_splits(const NarutoField* f, uint32_t M) {
-    uint32_t s = (M + 65535u) / 65536u;
+    uint32_t s = (M + 262143u) / 262144u;             // M is the list's CAPACITY (all samples); about a third of it carries a cotangent
     if (s < f->plan.s_uncert) s = f->plan.s_uncert;
     const uint32_t cap = f->plan.n_uncert ? (64u / f->plan.n_uncert > 1u ? 64u / f->plan.n_uncert : 1u) : 1u;
     if (s > cap) s = cap;

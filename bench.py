@@ -522,6 +522,18 @@ def main():
                 l2_bytes = n_rays * S_tot * (16 * 4.5 * 64 + 4 * 64) + dom.get("alg_bytes_incl_saved", 0) - n_rays * S_tot * (16 * 8 * 8 + 32)
                 roof["l2_bytes_model"] = int(l2_bytes)
                 roof["l2_frac"] = round(l2_bytes / dom["ms"] / 1e6 / L2_PEAK_GBS, 4)
+            # the hash gather (north star: "HBM GB/s on the hash gather") always gets its own object, dominant or not
+            fwd = next(r for r in rows if r["kernel"].startswith("k_query_fwd<color>") and "launch" in r)
+            it = next(r for r in rows if r["kernel"].endswith("as launched by the iteration"))
+            l2_bytes = n_rays * S_tot * (16 * 4.5 * 64 + 4 * 64) + fwd["alg_bytes_incl_saved"] - n_rays * S_tot * (16 * 8 * 8 + 32)
+            gprof, gsrc = pmc_profile(args.workload, fwd["kernel"])
+            out["roofline_gather"] = {"bound": "hbm", "kernel": fwd["kernel"], "launch": fwd["launch"], "kernel_ms": fwd["ms"], "kernel_ms_in_iteration": it["ms"],
+                                      "alg_bytes": fwd["alg_bytes"], "achieved": fwd["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": round(fwd["GBps"] / HBM_PEAK_GBS, 4), "alg_bytes_incl_saved": fwd["alg_bytes_incl_saved"],
+                                      "frac_incl_saved": round(fwd["alg_bytes_incl_saved"] / fwd["ms"] / 1e6 / HBM_PEAK_GBS, 4),
+                                      "l2_bytes_model": int(l2_bytes), "l2_frac": round(l2_bytes / fwd["ms"] / 1e6 / L2_PEAK_GBS, 4),
+                                      "mfma_util": round(fwd["TFLOPs"] / mfma_peak, 6), "traffic": gprof.get("traffic_bytes"),
+                                      "traffic_source": f"profiles/{gsrc}" if gsrc else None}
             prof, src = pmc_profile(args.workload, dom["kernel"])
             if prof.get("traffic_bytes") is not None:
                 roof["traffic"] = prof["traffic_bytes"]                      # bytes per launch (FETCH_SIZE + WRITE_SIZE), same launch shape

@@ -1,0 +1,20 @@
+#!/bin/bash
+# copy the judged evidence of tools/measure_round.sh from gpurun_out/ (scratch) into profiles/ (tracked)
+set -eu
+TAG=${1:-r02}
+cd "$(dirname "$0")/.."
+G=gpurun_out; P=profiles
+for f in bench_default bench_bf16 bench_eval_fp32 bench_eval_bf16 bench_office0_2048x43 bench_office0_8192x43 bench_mp3d_2048x256 bench_unit1024_131072x43 bench_T22_fp32 bench_T22_bf16; do
+  [ -s $G/${TAG}_$f.json ] && tail -1 $G/${TAG}_$f.json | python -m json.tool > $P/${TAG}_$f.json
+done
+cp $G/${TAG}_bf16_error_study.txt $P/ 2>/dev/null || true
+grep -v "amdgpu.ids" $G/${TAG}_bf16_error_study.txt > $P/${TAG}_bf16_error_study.txt 2>/dev/null || true
+for w in office0_2048x128 unit1024_T22_131072x43; do
+  for k in kernel_trace pmc_FETCH_SIZE pmc_WRITE_SIZE; do cp $G/${TAG}_${w}_$k.txt $P/ 2>/dev/null || true; done
+  tail -1 $G/${TAG}_${w}_bench_under_rocprof.json | python -m json.tool > $P/${TAG}_${w}_bench_under_rocprof.json 2>/dev/null || true
+done
+cp $G/${TAG}_office0_2048x128_bf16_kernel_trace.txt $P/ 2>/dev/null || true
+python tools/pmc_json.py office0_2048x128 $G/${TAG}_office0_2048x128_pmc_FETCH_SIZE.txt $G/${TAG}_office0_2048x128_pmc_WRITE_SIZE.txt \
+       unit1024_T22_131072x43 $G/${TAG}_unit1024_T22_131072x43_pmc_FETCH_SIZE.txt $G/${TAG}_unit1024_T22_131072x43_pmc_WRITE_SIZE.txt > $P/${TAG}_pmc.json
+tail -3 $G/${TAG}_pytest_gpu.log > $P/${TAG}_pytest_gpu_summary.txt
+ls -la $P | tail -30

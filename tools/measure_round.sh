@@ -1,0 +1,27 @@
+#!/bin/bash
+# The round's measurement set on the GPU box (through gpurun, from the repo root):
+#   bash tools/measure_round.sh r02      -> gpurun_out/<tag>_*  (copy what is to be judged into profiles/ with tools/collect_profiles.sh)
+# parity suite + smoke, the bench lines (default / bf16 / eval / other workloads / T=2^22), rocprofv3 kernel traces and the
+# FETCH_SIZE / WRITE_SIZE passes for the default and the T=2^22 workload, the bf16 error study.
+set -u
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+mkdir -p gpurun_out
+python -c "import __graft_entry__ as g; g.build(); g.smoke()" > gpurun_out/${TAG}_build_smoke.log 2>&1; tail -1 gpurun_out/${TAG}_build_smoke.log
+timeout 2400 python -m pytest tests -m gpu -q --maxfail=10 > gpurun_out/${TAG}_pytest_gpu.log 2>&1
+echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest_gpu.log
+tail -4 gpurun_out/${TAG}_pytest_gpu.log | cut -c1-300
+timeout 900 python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err; cut -c1-200 gpurun_out/${TAG}_bench_default.json
+timeout 600 python bench.py --mlp bf16 --no-cpu-baseline > gpurun_out/${TAG}_bench_bf16.json 2> /dev/null; cut -c1-200 gpurun_out/${TAG}_bench_bf16.json
+for m in fp32 bf16; do timeout 600 python bench.py --workload office0_8192x43_eval --mlp $m --no-cpu-baseline > gpurun_out/${TAG}_bench_eval_$m.json 2> /dev/null; cut -c1-200 gpurun_out/${TAG}_bench_eval_$m.json; done
+for w in office0_2048x43 office0_8192x43 mp3d_2048x256 unit1024_131072x43; do
+  timeout 600 python bench.py --workload $w --no-cpu-baseline --steps 20 > gpurun_out/${TAG}_bench_$w.json 2> /dev/null; cut -c1-160 gpurun_out/${TAG}_bench_$w.json; echo
+done
+for m in fp32 bf16; do timeout 900 python bench.py --workload unit1024_T22_131072x43 --mlp $m --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${TAG}_bench_T22_$m.json 2> /dev/null; cut -c1-160 gpurun_out/${TAG}_bench_T22_$m.json; echo; done
+timeout 600 python tools/bf16_error_study.py > gpurun_out/${TAG}_bf16_error_study.txt 2>&1
+bash tools/profile_round.sh $TAG office0_2048x128 30 > gpurun_out/${TAG}_prof_default.log 2>&1; tail -12 gpurun_out/${TAG}_prof_default.log
+bash tools/profile_round.sh $TAG unit1024_T22_131072x43 8 > gpurun_out/${TAG}_prof_T22.log 2>&1; tail -10 gpurun_out/${TAG}_prof_T22.log
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/${TAG}_ktbf -o kt -- python $R/bench.py --mlp bf16 --no-cpu-baseline --steps 30 > /dev/null 2> $R/gpurun_out/${TAG}_ktbf.log
+python $R/tools/prof_summary.py $(find $R/gpurun_out/${TAG}_ktbf -name "*.db" | head -1) > $R/gpurun_out/${TAG}_office0_2048x128_bf16_kernel_trace.txt; rm -rf $R/gpurun_out/${TAG}_ktbf

@@ -538,6 +538,12 @@ def main():
             if prof.get("traffic_bytes") is not None:
                 roof["traffic"] = prof["traffic_bytes"]                      # bytes per launch (FETCH_SIZE + WRITE_SIZE), same launch shape
                 roof["traffic_source"] = f"profiles/{src}"
+                roof["traffic_GBps"] = round(prof["traffic_bytes"] / dom["ms"] / 1e6, 1)       # what actually crossed the L2 <-> fabric boundary per second
+                roof["traffic_frac"] = round(prof["traffic_bytes"] / dom["ms"] / 1e6 / HBM_PEAK_GBS, 4)
+            g_ = out["roofline_gather"]
+            if g_.get("traffic") is not None:
+                g_["traffic_GBps"] = round(g_["traffic"] / g_["kernel_ms"] / 1e6, 1)
+                g_["traffic_frac"] = round(g_["traffic"] / g_["kernel_ms"] / 1e6 / HBM_PEAK_GBS, 4)
             out["roofline"] = roof
             out["kernels"] = rows
             out["kernels_ms_sum"] = round(sum(r["ms"] for r in rows if r["bound"] is not None), 4)

@@ -852,9 +852,17 @@ int naruto_render_fwd(const NarutoField* f, const NarutoParams* p, const NarutoR
             return fail(NARUTO_ERR_LAUNCH, "render_fwd: cannot reserve %d bytes of LDS: %s", bytes, hipGetErrorString(hipGetLastError()));
         attr_set = true;
     }
+    const bool bf = f->desc.mlp_mode == NARUTO_MLP_BF16;
+    if (S <= 64u) {              // short rays: 16 rays per workgroup, samples packed into full 64-sample tiles
+        uint32_t blocks = (r->n_rays + kPackRays - 1u) / kPackRays;
+        if (blocks > cu_count(f) * 4u) blocks = cu_count(f) * 4u;
+        if (bf) hipLaunchKernelGGL(k_render_fwd_packed<true>, dim3(blocks), dim3(256), render_packed_lds_bytes(S), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, a);
+        else hipLaunchKernelGGL(k_render_fwd_packed<false>, dim3(blocks), dim3(256), render_packed_lds_bytes(S), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, a);
+        return check_launch("render_fwd_packed");
+    }
     uint32_t blocks = (r->n_rays + 3u) / 4u;
     if (blocks > cu_count(f) * 4u) blocks = cu_count(f) * 4u;
-    if (f->desc.mlp_mode == NARUTO_MLP_BF16)
+    if (bf)
         hipLaunchKernelGGL(k_render_fwd<true>, dim3(blocks), dim3(256), ray_scratch_bytes(S), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, a);
     else
         hipLaunchKernelGGL(k_render_fwd<false>, dim3(blocks), dim3(256), ray_scratch_bytes(S), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, a);

@@ -117,4 +117,82 @@ __global__ __launch_bounds__(256, 2) void k_render_fwd(LevelTab lt, UncertTab ut
     }
 }
 
+// Rays of at most 64 samples (the shipped 32 + 11): one ray per wave leaves a third of every tile's lanes idle, so a workgroup takes
+// kPackRays rays, tiles their samples back to back into 64-sample tiles over its four waves, keeps the raw values of all of them in
+// LDS and composites ray by ray afterwards (16 rays x 43 samples = 688 samples = 11 tiles: 98 % of the lanes carry a sample).
+constexpr uint32_t kPackRays = 16;
+inline size_t render_packed_lds_bytes(uint32_t S) { return (size_t)kPackRays * kRayFields * S * sizeof(float); }
+
+template <bool BF>
+__global__ __launch_bounds__(256, 2) void k_render_fwd_packed(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, RenderArgs a) {
+    using Lds = std::conditional_t<BF, FwdLdsBf, FwdLds>;
+    __shared__ Lds L;
+    extern __shared__ float ray_lds[];
+    if constexpr (BF) stage_fwd_weights_bf<256>(L, p, threadIdx.x);
+    else stage_fwd_weights<256>(L, p, threadIdx.x);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t S = a.nu + a.nr;
+    const float inv_S = 1.0f / (float)S;
+    const float2* __restrict__ table = reinterpret_cast<const float2*>(p.table);
+    auto image = [&](uint32_t r) { return ray_scratch(ray_lds, (int)r, S); };          // ray r of the group: kRayFields x S floats
+    for (uint32_t n0 = blockIdx.x * kPackRays; n0 < a.n_rays; n0 += gridDim.x * kPackRays) {
+        const uint32_t R = a.n_rays - n0 < kPackRays ? a.n_rays - n0 : kPackRays;
+        // A1: wave w samples rays w, w + 4, ...
+        for (uint32_t r = (uint32_t)wave; r < R; r += 4u) {
+            const RayScratch rs = image(r);
+            sample_z_ray(n0 + r, a.target_d, a.near_, a.far_, a.nu, a.nr, a.range_d, a.rand, a.rng, a.z_vals, rs.wb, rs.gw, lane, rs.z);
+        }
+        __syncthreads();
+        // A2..A5 on the group's samples, 64 at a time
+        const uint32_t T = R * S, n_tiles = (T + 63u) / 64u;
+        for (uint32_t tq = (uint32_t)wave; tq < n_tiles; tq += 4u) {
+            const uint32_t g_raw = tq * 64u + (uint32_t)lane;
+            const bool valid = g_raw < T;
+            const uint32_t g = valid ? g_raw : T - 1u;
+            uint32_t s;
+            const uint32_t r = fast_divmod(g, S, inv_S, s);
+            const RayScratch rs = image(r);
+            const uint32_t n = n0 + r;
+            const float t = rs.z[s];
+            const float px = __fadd_rn(a.rays_o[3 * (size_t)n], __fmul_rn(a.rays_d[3 * (size_t)n], t));
+            const float py = __fadd_rn(a.rays_o[3 * (size_t)n + 1], __fmul_rn(a.rays_d[3 * (size_t)n + 1], t));
+            const float pz = __fadd_rn(a.rays_o[3 * (size_t)n + 2], __fmul_rn(a.rays_d[3 * (size_t)n + 2], t));
+            const float x = __fdiv_rn(__fsub_rn(px, bt.bmin[0]), bt.bext[0]);
+            const float y = __fdiv_rn(__fsub_rn(py, bt.bmin[1]), bt.bext[1]);
+            const float z = __fdiv_rn(__fsub_rn(pz, bt.bmin[2]), bt.bext[2]);
+            const float u = uncert_sample(ut, p.uncert_grid, x, y, z);
+            FwdTileOut to;
+            if constexpr (BF) fwd_tile_bf<true>(L, lt, table, x, y, z, nullptr, nullptr, 0u, 0u, 0u, lane, to);
+            else fwd_tile<true>(L, lt, table, x, y, z, nullptr, nullptr, 0u, 0u, 0u, lane, to);
+            if (valid) {
+                rs.c0[s] = to.rgb[0]; rs.c1[s] = to.rgb[1]; rs.c2[s] = to.rgb[2];
+                rs.sdf[s] = to.sdf;
+                rs.u[s] = u;
+                if (a.raw != nullptr) {
+                    float* o = a.raw + ((size_t)n * S + s) * 5;
+                    o[0] = to.rgb[0]; o[1] = to.rgb[1]; o[2] = to.rgb[2]; o[3] = to.sdf; o[4] = u;
+                }
+            }
+        }
+        __syncthreads();
+        // A6 + A7: wave w composites rays w, w + 4, ...
+        for (uint32_t r = (uint32_t)wave; r < R; r += 4u) {
+            const RayScratch rs = image(r);
+            const uint32_t n = n0 + r;
+            const RayWeights rw = ray_weights(rs, S, a.trunc, a.sc_factor, lane);
+            const RayOut o = ray_composite(rs, rw, n, S, a.white_bkgd, a.weights, lane);
+            if (lane == 0) {
+                if (a.rgb) { a.rgb[3 * (size_t)n] = o.rgb[0]; a.rgb[3 * (size_t)n + 1] = o.rgb[1]; a.rgb[3 * (size_t)n + 2] = o.rgb[2]; }
+                if (a.disp) a.disp[n] = o.disp;
+                if (a.acc) a.acc[n] = o.acc;
+                if (a.depth) a.depth[n] = o.depth;
+                if (a.depth_var) a.depth_var[n] = o.depth_var;
+                if (a.uncert_map) a.uncert_map[n] = o.uncert;
+            }
+        }
+        __syncthreads();                             // the images are reused by the next group
+    }
+}
+
 }  // namespace naruto

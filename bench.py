@@ -444,8 +444,15 @@ def main():
     rays = {k: torch.from_numpy(v[lo:hi]).to(dev) for k, v in all_rays.items()}
     del all_rays
     from naruto_amd.trainer import pack_rays
-    rays["rays_o"], rays["rays_d"], rays["target_rgb"], rays["target_d"] = pack_rays(rays["rays_o"], rays["rays_d"], rays["target_rgb"],
-                                                                                      rays["target_d"])
+    bufs = tr.ray_buffers()
+    if bufs is not None:
+        # the batch sits where the ray assembly (KeyframeRayStore.assemble_batch(out=...)) writes it: the replay's own input buffers
+        for b, k in zip(bufs, ("rays_o", "rays_d", "target_rgb", "target_d")):
+            b.copy_(rays[k].reshape(b.shape))
+            rays[k] = b
+    else:
+        rays["rays_o"], rays["rays_d"], rays["target_rgb"], rays["target_d"] = pack_rays(rays["rays_o"], rays["rays_d"], rays["target_rgb"],
+                                                                                          rays["target_d"])
 
     def step():
         tr.step(rays["rays_o"], rays["rays_d"], rays["target_rgb"], rays["target_d"], smooth=True, n_rays_total=n_total)

@@ -167,6 +167,13 @@ typedef struct NarutoExtraPoints {
  * over the point list the MLP_ONLY call left in the workspace.  Not with the fused optimiser. */
 #define NARUTO_TRAIN_BWD_MLP_ONLY 4u
 #define NARUTO_TRAIN_BWD_TABLE_ONLY 8u
+/* Forward and backward issued back to back (single process): naruto_train_forward(finalize = NARUTO_TRAIN_FWD_DEFER_TAIL) stops
+ * after the loss stage, and naruto_train_backward(flags | NARUTO_TRAIN_BWD_DEFERRED_TAIL) starts with ONE launch that is the loss
+ * tail (one workgroup: losses[10], the iteration counter), the composite backward and the compaction -- instead of three.
+ * losses / sums are then valid after the BACKWARD call.  Both must be given together; above 4096 rays both calls run the
+ * ordinary sequence (same results). */
+#define NARUTO_TRAIN_FWD_DEFER_TAIL 2
+#define NARUTO_TRAIN_BWD_DEFERRED_TAIL 16u
 size_t naruto_query_bwd_workspace(const NarutoField* f, uint32_t M);
 int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, const NarutoPoints* pts,
                      const float* feat_save, const float* d_raw, const float* d_geo,

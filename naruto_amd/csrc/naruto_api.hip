@@ -79,7 +79,8 @@ int ray_lds_attr() {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_composite_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_composite_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_composite_bwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_loss_stage), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_loss_stage), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_loss_bwd_fused), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
         return fail(NARUTO_ERR_LAUNCH, "per-ray kernels: cannot reserve %d bytes of LDS: %s", bytes, hipGetErrorString(hipGetLastError()));
     done = true;
     return NARUTO_OK;
@@ -88,6 +89,7 @@ int ray_lds_attr() {
 constexpr uint32_t kBwdMaxBlocks = 512;     // fp32: one 145 KB-LDS block per CU; bf16 mode: two 53 KB blocks per CU
 
 inline size_t al256(size_t b) { return (b + 255u) / 256u * 256u; }
+inline LevelSplits level_splits(const NarutoField* f) { LevelSplits ls; memcpy(ls.s, f->plan.s_lvl, sizeof(ls.s)); return ls; }
 
 // rows of the binned scatter's count matrix: one per kBinRound points, at most kBinMaxRows
 inline uint32_t bin_rows(uint32_t M) {
@@ -119,7 +121,8 @@ ScatterWs scatter_ws(const NarutoField* f, void* base, uint32_t M) {
     ScatterWs w{};
     char* b = reinterpret_cast<char*>(base);
     size_t off = 0;
-    const uint32_t smax = f->plan.s_dense > f->plan.s_hashed ? f->plan.s_dense : f->plan.s_hashed;
+    uint32_t smax = 1;
+    for (int l = 0; l < kLevels; ++l) smax = f->plan.s_lvl[l] > smax ? f->plan.s_lvl[l] : smax;
     w.partial = reinterpret_cast<float*>(b + off);
     off += al256((f->plan.n_dense + f->plan.n_hashed) ? (size_t)smax * partial_plane(f) * 2u * sizeof(float) : 16u);
     w.unc_partial = reinterpret_cast<float*>(b + off);
@@ -155,7 +158,7 @@ int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const f
     }
     if (d_table == nullptr && adam == nullptr && us.g == nullptr) return NARUTO_OK;
     ScatterPlan plan = f->plan;
-    if (d_table == nullptr && adam == nullptr) plan.n_dense = plan.n_hashed = 0;        // only the uncertainty grid's gradient is wanted
+    if (d_table == nullptr && adam == nullptr) { plan.n_dense = plan.n_hashed = 0; plan.n_level_blocks = 0; }        // only the uncertainty grid's gradient is wanted
     if (f->plan.n_dense + f->plan.n_hashed > 0) {
         static bool attr_set = false;
         const size_t lds = (size_t)kChunk * sizeof(unsigned long long);
@@ -164,8 +167,7 @@ int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const f
                 return fail(NARUTO_ERR_LAUNCH, "hash_scatter: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(hipGetLastError()));
             attr_set = true;
         }
-        const uint32_t blocks = (plan.n_dense * plan.s_dense + plan.n_hashed * plan.s_hashed + (us.g != nullptr ? plan.n_uncert * us.n_splits : 0u) + 7u) /
-                                8u * 8u;      // XCD-aware order: multiple of 8
+        const uint32_t blocks = ((uint32_t)plan.n_level_blocks + (us.g != nullptr ? plan.n_uncert * us.n_splits : 0u) + 7u) / 8u * 8u;      // XCD-aware order: multiple of 8
         hipLaunchKernelGGL(k_hash_scatter_lds, dim3(blocks), dim3(kScatterThreads), lds, st, f->lt, f->bt, ps, M, d_feat, stride_m, stride_l, plan,
                            w.partial, 2u * n_plane, m_dev, scale_dev, us);
         if (int rc = check_launch("hash_scatter_lds")) return rc;
@@ -174,7 +176,7 @@ int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const f
             const uint32_t n_unc_blocks = ur.d_uncert != nullptr ? (ur.n_voxels + 255u) / 256u : 0u;
             if (n_table_blocks + n_unc_blocks > 0) {
                 hipLaunchKernelGGL(k_scatter_reduce, dim3(n_table_blocks + n_unc_blocks), dim3(256), 0, st, f->lt, f->plan.atomic_levels, w.partial,
-                                   f->plan.s_dense, f->plan.s_hashed, n_tiled_params, n_plane, d_table, overwrite, n_table_blocks, ur);
+                                   level_splits(f), n_tiled_params, n_plane, d_table, overwrite, n_table_blocks, ur);
                 if (int rc = check_launch("scatter_reduce")) return rc;
             }
         }
@@ -346,6 +348,31 @@ int naruto_field_create(const NarutoFieldDesc* d, NarutoField** out) {
         if (const char* e0 = getenv("NARUTO_DEBUG_SCATTER_ROLES")) f->plan.role_mask = (uint32_t)atoi(e0);
         if (const char* e3 = getenv("NARUTO_DEBUG_SCATTER_SPLITS_UNCERT")) { const uint32_t v = (uint32_t)atoi(e3); f->plan.s_uncert = v < 1u ? 1u : (v > 8u ? 8u : v); }
         if (const char* e2 = getenv("NARUTO_DEBUG_SCATTER_SPLITS_DENSE")) f->plan.s_dense = (uint32_t)atoi(e2) < 1 ? 1u : ((uint32_t)atoi(e2) > 8u ? 8u : (uint32_t)atoi(e2));
+        for (uint32_t l = 0; l < (uint32_t)kLevels; ++l) f->plan.s_lvl[l] = (uint8_t)(((f->lt.hashed >> l) & 1u) ? f->plan.s_hashed : f->plan.s_dense);
+        // NARUTO_DEBUG_SCATTER_SPLITS_LEVELS="l:s,l:s,...": per-level override
+        if (const char* e4 = getenv("NARUTO_DEBUG_SCATTER_SPLITS_LEVELS")) {
+            const char* q = e4;
+            while (*q) {
+                char* end = nullptr;
+                const long l = strtol(q, &end, 10);
+                if (end == q || *end != ':') break;
+                q = end + 1;
+                const long v = strtol(q, &end, 10);
+                if (end == q) break;
+                if (l >= 0 && l < kLevels && v >= 1 && v <= 8) f->plan.s_lvl[l] = (uint8_t)v;
+                q = *end == ',' ? end + 1 : end;
+            }
+        }
+        uint32_t nb = 0;
+        for (uint32_t u = 0; u < f->plan.n_dense + f->plan.n_hashed; ++u) {
+            const uint32_t s = f->plan.s_lvl[f->plan.level[u]];
+            for (uint32_t k = 0; k < s; ++k, ++nb) {
+                if (nb >= (uint32_t)kMaxLevelBlocks) { delete f; return fail(NARUTO_ERR_INVALID, "field_create: scatter plan exceeds its workgroup table"); }
+                f->plan.blk_unit[nb] = (uint8_t)u;
+                f->plan.blk_split[nb] = (uint8_t)k;
+            }
+        }
+        f->plan.n_level_blocks = (uint16_t)nb;
     }
     *out = f;
     return NARUTO_OK;
@@ -567,8 +594,8 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
             ur.voxels_pad = uncert_pad(f);
         }
         const uint32_t n_unc_blocks = unc_scatter ? (ur.n_voxels + 255u) / 256u : 0u;
-        hipLaunchKernelGGL(k_bwd_finish, dim3(n_table_blocks + kAccFloats / 32 + n_unc_blocks), dim3(256), 0, (hipStream_t)stream, f->lt, scatter_ws, f->plan.s_dense,
-                           f->plan.s_hashed, n_params, partial_plane(f), partials, blocks, *g, *adam, n_table_blocks, ur);
+        hipLaunchKernelGGL(k_bwd_finish, dim3(n_table_blocks + kAccFloats / 32 + n_unc_blocks), dim3(256), 0, (hipStream_t)stream, f->lt, scatter_ws, level_splits(f),
+                           n_params, partial_plane(f), partials, blocks, *g, *adam, n_table_blocks, ur);
         return check_launch("bwd_finish");
     }
     const bool want_w = g->sdf_w0 || g->sdf_w1 || g->col_w0 || g->col_w1;
@@ -695,6 +722,18 @@ TvArgs tv_args(const NarutoTrainStep* t) {
     a.inv_p3 = 1.0f / ((float)t->smooth_points * (float)t->smooth_points * (float)t->smooth_points);
     return a;
 }
+// NARUTO_TRAIN_FWD_DEFER_TAIL / NARUTO_TRAIN_BWD_DEFERRED_TAIL apply up to kFusedTailMaxRays rays; beyond that both calls run the ordinary path
+inline bool tail_rides_in_backward(const NarutoTrainStep* t) { return t->n_rays <= kFusedTailMaxRays && t->ray_count != nullptr; }
+LossTailArgs loss_tail_args(const NarutoTrainStep* t, const TrainWs& w, uint32_t n_ray_blocks, uint32_t n_tv_blocks, float tv_inv_p3, int finalize) {
+    LossTailArgs tl{};
+    tl.partials = reinterpret_cast<const double*>(w.terms); tl.n_ray_blocks = n_ray_blocks;
+    tl.tv_partial = w.tv_partial; tl.n_tv_blocks = n_tv_blocks; tl.tv_inv_p3 = tv_inv_p3;
+    tl.sums = t->sums; tl.losses = t->losses; tl.loss_weights = t->loss_weights;
+    tl.n_rays_total = t->n_rays_total ? t->n_rays_total : t->n_rays; tl.S = t->n_samples_d + t->n_range_d;
+    tl.finalize = finalize;
+    tl.rng = t->rng;                                        // the iteration counter advances once per forward, used or not
+    return tl;
+}
 }  // namespace
 
 size_t naruto_train_workspace(const NarutoField* f, const NarutoTrainStep* t) {
@@ -741,21 +780,18 @@ int naruto_train_forward(const NarutoField* f, const NarutoParams* p, const Naru
     a.tv_scale_dev = t->loss_weights != nullptr ? t->loss_weights + 8 : nullptr;
     a.tv_scale_host = t->smooth_grad_scale != 0.0f ? t->smooth_grad_scale : 1.0f;
     a.n_tv_blocks = t->smooth_points != 0 ? w.n_tv_blocks : 0u;
+    const bool deferred = finalize == NARUTO_TRAIN_FWD_DEFER_TAIL && tail_rides_in_backward(t);
+    if (deferred) a.ray_count = t->ray_count;
     if (int rc = ray_lds_attr()) return rc;
     hipLaunchKernelGGL(k_loss_stage, dim3(a.n_ray_blocks + a.n_tv_blocks), dim3(64 * kRaysPerBlock), ray_scratch_bytes(S), st, a);
     if (int rc = check_launch("loss_stage")) return rc;
-    LossTailArgs tl{};
-    tl.partials = a.partials; tl.n_ray_blocks = a.n_ray_blocks;
+    if (deferred) return NARUTO_OK;                          // the tail is a workgroup of the backward's first launch
+    LossTailArgs tl = loss_tail_args(t, w, a.n_ray_blocks, a.n_tv_blocks, tva.inv_p3, finalize != 0);
     if (a.n_ray_blocks > 4u * kTailRows) {          // large batch: fold the per-workgroup rows first
-        hipLaunchKernelGGL(k_loss_fold, dim3(kTailRows), dim3(64), 0, st, a.partials, a.n_ray_blocks, w.fold);
+        hipLaunchKernelGGL(k_loss_fold, dim3(kTailRows), dim3(64), 0, st, tl.partials, a.n_ray_blocks, w.fold);
         if (int rc = check_launch("loss_fold")) return rc;
         tl.partials = w.fold; tl.n_ray_blocks = kTailRows;
     }
-    tl.tv_partial = w.tv_partial; tl.n_tv_blocks = a.n_tv_blocks; tl.tv_inv_p3 = tva.inv_p3;
-    tl.sums = t->sums; tl.losses = t->losses; tl.loss_weights = t->loss_weights;
-    tl.n_rays_total = t->n_rays_total ? t->n_rays_total : N; tl.S = S;
-    tl.finalize = finalize;
-    tl.rng = t->rng;                                        // the iteration counter advances once per forward, used or not
     hipLaunchKernelGGL(k_loss_tail, dim3(1), dim3(256), 0, st, tl);
     return check_launch("loss_tail");
 }
@@ -798,8 +834,24 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
                 f->desc.trunc * f->desc.sc_factor};
     if ((flags & NARUTO_TRAIN_BWD_MLP_ONLY) && (flags & NARUTO_TRAIN_BWD_TABLE_ONLY)) return fail(NARUTO_ERR_INVALID, "train_backward: pick one phase");
     const bool table_only = (flags & NARUTO_TRAIN_BWD_TABLE_ONLY) != 0u;
+    if ((flags & NARUTO_TRAIN_BWD_DEFERRED_TAIL) && (flags & (NARUTO_TRAIN_BWD_MLP_ONLY | NARUTO_TRAIN_BWD_TABLE_ONLY)))
+        return fail(NARUTO_ERR_INVALID, "train_backward: the deferred tail belongs to the one-piece backward");
+    const bool deferred = (flags & NARUTO_TRAIN_BWD_DEFERRED_TAIL) != 0u && tail_rides_in_backward(t);
     if (int rc = ray_lds_attr()) return rc;
-    if (!table_only) {
+    if (deferred) {
+        const bool smooth_d = t->smooth_points != 0 && (g->table != nullptr || opt != nullptr);
+        const BwdWs bwd = bwd_ws(f, w.bwd, list_cap(M + w.n3));
+        FusedBwdArgs fa{};
+        fa.n_rays = N; fa.S = S; fa.trunc = f->desc.trunc; fa.sc_factor = f->desc.sc_factor; fa.white_bkgd = f->desc.white_bkgd;
+        fa.raw = t->raw; fa.z_vals = t->z_vals; fa.la = la; fa.d_raw = t->d_raw;
+        fa.partials = reinterpret_cast<const double*>(w.terms); fa.n_ray_blocks = (N + kRaysPerBlock - 1) / kRaysPerBlock;
+        fa.ray_count = t->ray_count; fa.ray_off = t->ray_offset; fa.active_idx = t->active_idx; fa.n_active = t->n_active;
+        fa.n_front = smooth_d ? w.n3 : 0u; fa.n_list = bwd.n_total;
+        fa.tail = loss_tail_args(t, w, fa.n_ray_blocks, t->smooth_points != 0 ? w.n_tv_blocks : 0u, tv_args(t).inv_p3, 1);
+        hipLaunchKernelGGL(k_loss_bwd_fused, dim3(fa.n_ray_blocks + 1u), dim3(64 * kRaysPerBlock), ray_scratch_bytes(S), st, fa);
+        if (int rc = check_launch("loss_bwd_fused")) return rc;
+    }
+    if (!table_only && !deferred) {
         hipLaunchKernelGGL(k_composite_bwd<true>, dim3((N + kRaysPerBlock - 1) / kRaysPerBlock), dim3(64 * kRaysPerBlock), ray_scratch_bytes(S), st, N, S, f->desc.trunc,
                            f->desc.sc_factor, f->desc.white_bkgd, t->raw, t->z_vals, cot, la, t->d_raw, 0, t->ray_count);
         if (int rc = check_launch("loss_bwd")) return rc;
@@ -808,12 +860,12 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
     const uint32_t n_front = smooth ? w.n3 : 0u;
     const BwdWs bw = bwd_ws(f, w.bwd, list_cap(M + w.n3));
     const uint32_t* block_sums = nullptr;
-    if (!table_only && N > 4u * kCompactBlock) {     // large batch: two-level prefix of the per-ray counts
+    if (!table_only && !deferred && N > 4u * kCompactBlock) {     // large batch: two-level prefix of the per-ray counts
         hipLaunchKernelGGL(k_count_blocks, dim3((N + kCompactBlock - 1u) / kCompactBlock), dim3(256), 0, st, N, t->ray_count, w.block_sums);
         if (int rc = check_launch("count_blocks")) return rc;
         block_sums = w.block_sums;
     }
-    if (!table_only) {
+    if (!table_only && !deferred) {
         hipLaunchKernelGGL(k_compact, dim3((N + 3u) / 4u), dim3(256), 0, st, N, S, t->ray_count, t->ray_offset, t->active_idx, t->n_active, n_front, bw.n_total,
                            block_sums);
         if (int rc = check_launch("compact")) return rc;

@@ -592,6 +592,7 @@ constexpr uint32_t kChunk = 1u << kChunkLog2;       // entries per LDS image: ON
 constexpr int kMaxChunksPerLevel = 8;
 constexpr int kMaxUnits = kLevels * kMaxChunksPerLevel * 2;      // unit = (level, chunk, feature)
 constexpr int kScatterThreads = 1024;
+constexpr int kMaxLevelBlocks = 512;
 constexpr float kFixScale = 1099511627776.0f;        // 2^40
 constexpr double kFixInv = 1.0 / 1099511627776.0;
 
@@ -602,7 +603,10 @@ struct ScatterPlan {
     uint8_t level[kMaxUnits];
     uint8_t chunk[kMaxUnits];     // bit 7: feature, bits 0..6: chunk
     uint32_t n_dense, n_hashed;   // LDS-tiled (level, chunk) units of non-hashed / hashed levels
-    uint32_t s_dense, s_hashed;   // point splits per unit
+    uint32_t s_dense, s_hashed;   // default point splits per unit of a dense / hashed level
+    uint8_t s_lvl[kLevels];       // point splits per unit, by level (the partial tables hold s_lvl[level] planes of a level's entries)
+    uint16_t n_level_blocks;      // workgroups of the level units = sum over units of s_lvl[level of the unit]
+    uint8_t blk_unit[kMaxLevelBlocks], blk_split[kMaxLevelBlocks];     // level workgroup (in unit order) -> unit, split
     uint32_t atomic_levels;       // bit l: level l goes through the global-atomic kernel instead
     // the uncertainty voxel grid as one more (dense, single-feature) table: n_uncert chunks x (per-launch) point splits, after the
     // level units, with partial images of their own
@@ -863,8 +867,7 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
     // pos = (id % 8) * (grid / 8) + id / 8.  (Measured: a single level alone 20-24 us, all levels together 78 us with the
     // naive order -- the kernel was bound by re-streaming the list through the fabric, not by its arithmetic.)
     uint32_t unit, split, n_splits;
-    const uint32_t dense_blocks = plan.n_dense * plan.s_dense;
-    const uint32_t n_blocks = dense_blocks + plan.n_hashed * plan.s_hashed;
+    const uint32_t n_blocks = plan.n_level_blocks;
     const uint32_t pos = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     if (pos >= n_blocks) {
         // ---- uncertainty-grid units (training list layout only): d(loss)/d(uncert_grid) = scatter of the raw[...,4] cotangents with
@@ -934,17 +937,10 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
         for (uint32_t i = threadIdx.x; i < n_e; i += kScatterThreads) out[i] = (float)((double)(long long)acc[i] * kFixInv);
         return;
     }
-    if (!(plan.role_mask & (pos < dense_blocks ? 1u : 2u))) return;
-    if (pos < dense_blocks) {
-        n_splits = plan.s_dense;
-        unit = pos / n_splits;
-        split = pos % n_splits;
-    } else {
-        n_splits = plan.s_hashed;
-        const uint32_t b = pos - dense_blocks;
-        unit = plan.n_dense + b / n_splits;
-        split = b % n_splits;
-    }
+    unit = plan.blk_unit[pos];
+    split = plan.blk_split[pos];
+    if (!(plan.role_mask & (unit < plan.n_dense ? 1u : 2u))) return;
+    n_splits = plan.s_lvl[plan.level[unit]];
     const int level = plan.level[unit];
     const uint32_t chunk = plan.chunk[unit] & 0x7Fu, feat = plan.chunk[unit] >> 7;
     d_feat += feat;
@@ -993,8 +989,9 @@ __device__ __forceinline__ void uncert_reduce_body(const UncertReduce& u, uint32
 
 // d_table += sum over the level's splits of partial[split], for the entry ranges of the LDS-tiled levels
 // (n_params: floats of the tiled levels; n_plane: entries per feature plane of a partial table; blocks >= n_table_blocks: uncertainty grid)
-__global__ __launch_bounds__(256) void k_scatter_reduce(LevelTab lt, uint32_t atomic_levels, const float* __restrict__ partial, uint32_t s_dense,
-                                                        uint32_t s_hashed, size_t n_params, size_t n_plane, float* __restrict__ d_table, int overwrite,
+struct LevelSplits { uint8_t s[kLevels]; };
+__global__ __launch_bounds__(256) void k_scatter_reduce(LevelTab lt, uint32_t atomic_levels, const float* __restrict__ partial, LevelSplits ls,
+                                                        size_t n_params, size_t n_plane, float* __restrict__ d_table, int overwrite,
                                                         uint32_t n_table_blocks, UncertReduce unc) {
     if (blockIdx.x >= n_table_blocks) { uncert_reduce_body(unc, blockIdx.x - n_table_blocks); return; }
     if (d_table == nullptr) return;
@@ -1005,7 +1002,7 @@ __global__ __launch_bounds__(256) void k_scatter_reduce(LevelTab lt, uint32_t at
 #pragma unroll
     for (int l = 1; l < kLevels; ++l) level += entry >= lt.off[l] ? 1 : 0;
     if ((atomic_levels >> level) & 1u) return;
-    const uint32_t n_splits = ((lt.hashed >> level) & 1u) ? s_hashed : s_dense;
+    const uint32_t n_splits = ls.s[level];
     const size_t n_entries = n_plane;
     float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (uint32_t k = 0; k < n_splits; ++k) {
@@ -1983,7 +1980,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 // tables; MLP weights: sum of the per-workgroup dW partials) applies the Adam step in place -- the gradients need not be
 // written (g pointers may be NULL), k_adam_multi and one more pass over parameters + moments disappear.
 // Single process only: data parallelism needs the gradients all-reduced first.
-__global__ __launch_bounds__(256) void k_bwd_finish(LevelTab lt, const float* __restrict__ partial, uint32_t s_dense, uint32_t s_hashed, size_t n_params,
+__global__ __launch_bounds__(256) void k_bwd_finish(LevelTab lt, const float* __restrict__ partial, LevelSplits ls, size_t n_params,
                                                     size_t n_plane, const float* __restrict__ wpartials, uint32_t n_wblocks, NarutoGrads g, AdamFuse adam,
                                                     uint32_t n_table_blocks, UncertReduce unc) {
     if (blockIdx.x >= n_table_blocks + kAccFloats / 32) { uncert_reduce_body(unc, blockIdx.x - n_table_blocks - kAccFloats / 32); return; }
@@ -1997,7 +1994,7 @@ __global__ __launch_bounds__(256) void k_bwd_finish(LevelTab lt, const float* __
     int level = 0;
 #pragma unroll
     for (int l = 1; l < kLevels; ++l) level += entry >= lt.off[l] ? 1 : 0;
-    const uint32_t n_splits = ((lt.hashed >> level) & 1u) ? s_hashed : s_dense;
+    const uint32_t n_splits = ls.s[level];
     const size_t n_entries = n_plane;
     float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (uint32_t k = 0; k < n_splits; ++k) {

@@ -373,15 +373,13 @@ struct LossArgs {
     uint64_t n_total; float depth_trunc, rgb_missing, trunc_sc;
 };
 
+// one wave = ray n (ray_lds: the workgroup's dynamic LDS); la.sums may point into LDS
 template <bool LOSS>
-__global__ __launch_bounds__(64 * kRaysPerBlock) void k_composite_bwd(uint32_t n_rays, uint32_t S, float trunc, float sc_factor, int white_bkgd,
-                                                                      const float* __restrict__ raw, const float* __restrict__ z_vals,
-                                                                      CompositeCot cot, LossArgs la, float* __restrict__ d_raw, int accumulate,
-                                                                      uint32_t* __restrict__ ray_count) {
-    extern __shared__ float ray_lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t n = blockIdx.x * kRaysPerBlock + wave;
-    if (n >= n_rays) return;
+__device__ __forceinline__ void composite_bwd_ray(float* ray_lds, uint32_t n, int lane, int wave, uint32_t S, float trunc, float sc_factor, int white_bkgd,
+                                                  const float* __restrict__ raw, const float* __restrict__ z_vals, const CompositeCot& cot, const LossArgs& la,
+                                                  float* __restrict__ d_raw, int accumulate, uint32_t* __restrict__ ray_count) {
+    // inlined into two kernels (k_composite_bwd, k_loss_bwd_fused) that must produce the same bits: only the fmaf()s written below fuse
+#pragma clang fp contract(off)
     const RayScratch rs = ray_scratch(ray_lds, wave, S);
     load_ray(rs, raw, z_vals, n, S, lane);
     const RayWeights rw = ray_weights(rs, S, trunc, sc_factor, lane);
@@ -472,6 +470,18 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_composite_bwd(uint32_t n
         last_nz = wave_max_u32(last_nz);
         if (lane == 0) ray_count[n] = last_nz;
     }
+}
+
+template <bool LOSS>
+__global__ __launch_bounds__(64 * kRaysPerBlock) void k_composite_bwd(uint32_t n_rays, uint32_t S, float trunc, float sc_factor, int white_bkgd,
+                                                                      const float* __restrict__ raw, const float* __restrict__ z_vals,
+                                                                      CompositeCot cot, LossArgs la, float* __restrict__ d_raw, int accumulate,
+                                                                      uint32_t* __restrict__ ray_count) {
+    extern __shared__ float ray_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n = blockIdx.x * kRaysPerBlock + wave;
+    if (n >= n_rays) return;
+    composite_bwd_ray<LOSS>(ray_lds, n, lane, wave, S, trunc, sc_factor, white_bkgd, raw, z_vals, cot, la, d_raw, accumulate, ray_count);
 }
 
 // ray prefix lengths -> flat list of active sample indices (ray order, then sample order) + their number.

@@ -33,6 +33,7 @@ struct LossStageArgs {
     float* rgb; float* depth; float* uncert_map;
     double* partials;             // [n_ray_blocks][16]: per-workgroup shares of the loss sums
     uint32_t n_ray_blocks;
+    uint32_t* ray_count;          // or NULL.  [n_rays]: 1 + the last sample that can receive a non-zero cotangent (k_loss_bwd_fused's list lengths)
     // smoothness role (n_tv_blocks == 0: absent)
     TvArgs tv;
     const float* tv_feat; float* tv_d_list; double* tv_partial;     // d_list: the scatter's d_feat rows [16][cap][2]
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_stage(LossStageArgs
             const bool valid = depth_valid(td, a.depth_trunc);
             const float dm = td > 0.0f ? 1.0f : 0.0f;
             float fs = 0.0f, nfs = 0.0f, sl = 0.0f, nsdf = 0.0f;
+            uint32_t last = 0;
             for (uint32_t s = lane; s < S; s += 64) {
                 const float z = rs.z[s], sdf = rs.sdf[s];
                 const float front = z < (td - a.trunc_sc) ? 1.0f : 0.0f;
@@ -87,8 +89,14 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_stage(LossStageArgs
                 const float c = (z + sdf * a.trunc_sc) * sm - td * sm;
                 sl = fmaf(c, c, sl);
                 nsdf += sm != 0.0f ? 1.0f : 0.0f;
+                // every cotangent of the sample carries a factor wb (the rendering weight), front or sm
+                if (rs.wb[s] != 0.0f || front != 0.0f || sm != 0.0f) last = s + 1u;
             }
             fs = wave_sum(fs); nfs = wave_sum(nfs); sl = wave_sum(sl); nsdf = wave_sum(nsdf);
+            if (a.ray_count != nullptr) {
+                last = wave_max_u32(last);
+                if (lane == 0) a.ray_count[n] = last;
+            }
             if (lane == 0) {
                 if (a.rgb) { a.rgb[3 * (size_t)n] = o.rgb[0]; a.rgb[3 * (size_t)n + 1] = o.rgb[1]; a.rgb[3 * (size_t)n + 2] = o.rgb[2]; }
                 if (a.depth) a.depth[n] = o.depth;
@@ -178,59 +186,64 @@ __global__ __launch_bounds__(64) void k_loss_fold(const double* __restrict__ in,
     }
 }
 
-// one workgroup: per-workgroup partials -> sums[16], smoothness term, losses[10], iteration counter
-__global__ __launch_bounds__(256) void k_loss_tail(LossTailArgs a) {
-    __shared__ double red[4];
-    __shared__ double part[4][10];
-    __shared__ double s_sums[16];
+// The loss stage's rows -> sums of the slots in MASK, by one 256-thread workgroup in a fixed order: thread t owns rows t, t + 256, ...
+// (all of a thread's loads are independent and issued together: the rows were written by other XCDs, so every load is a trip to
+// memory), then a fixed-shape tree over the threads.  Leaves s_sums[k] in LDS (ends with a barrier).
+template <uint32_t MASK>
+__device__ __forceinline__ void wg_partial_sums(const double* __restrict__ partials, uint32_t n_rows, double (*part)[10], double* s_sums) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    {
-        // thread t owns workgroups t, t + 256, ...: all of a thread's loads are independent and issued together (the
-        // partials were written by other XCDs, so every load is a trip to memory), then a fixed-shape tree over the threads
-        double acc[10];
+    double acc[10];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) acc[k] = k == 9 ? 1e300 : 0.0;
-        for (uint32_t b0 = 0; b0 < a.n_ray_blocks; b0 += 1024u) {
-            double v[4][10];
+    for (int k = 0; k < 10; ++k) acc[k] = k == 9 ? 1e300 : 0.0;
+    for (uint32_t b0 = 0; b0 < n_rows; b0 += 1024u) {
+        double v[4][10];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t b = b0 + threadIdx.x + 256u * j;
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t b = b0 + threadIdx.x + 256u * j;
 #pragma unroll
-                for (int k = 0; k < 10; ++k) v[j][k] = b < a.n_ray_blocks ? a.partials[(size_t)b * 16 + k] : (k == 9 ? 1e300 : 0.0);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int k = 0; k < 9; ++k) acc[k] += v[j][k];
-                acc[9] = (v[j][9] < acc[9] || v[j][9] != v[j][9]) ? v[j][9] : acc[9];
-            }
+            for (int k = 0; k < 10; ++k)
+                if ((MASK >> k) & 1u) v[j][k] = b < n_rows ? partials[(size_t)b * 16 + k] : (k == 9 ? 1e300 : 0.0);
         }
 #pragma unroll
-        for (int k = 0; k < 10; ++k) {
-            double v = acc[k];
+        for (int j = 0; j < 4; ++j) {
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const double other = __shfl_xor(v, o, 64);
-                v = k == 9 ? ((other < v || other != other) ? other : v) : v + other;
-            }
-            if (lane == 0) part[wave][k] = v;
-        }
-        // the smoothness partials ride in the same round of loads
-        double tv = 0.0;
-        for (uint32_t i = threadIdx.x; i < a.n_tv_blocks; i += 256) tv += a.tv_partial[i];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) tv += __shfl_xor(tv, o, 64);
-        if (lane == 0) red[wave] = tv;
-        __syncthreads();
-        if (threadIdx.x < 10) {
-            const int k = threadIdx.x;
-            double v = part[0][k];
-            for (int i = 1; i < 4; ++i) v = k == 9 ? ((part[i][k] < v || part[i][k] != part[i][k]) ? part[i][k] : v) : v + part[i][k];
-            s_sums[k] = v;
-            a.sums[k] = v;
+            for (int k = 0; k < 9; ++k)
+                if ((MASK >> k) & 1u) acc[k] += v[j][k];
+            if ((MASK >> 9) & 1u) acc[9] = (v[j][9] < acc[9] || v[j][9] != v[j][9]) ? v[j][9] : acc[9];
         }
     }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        if (!((MASK >> k) & 1u)) continue;
+        double v = acc[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double other = __shfl_xor(v, o, 64);
+            v = k == 9 ? ((other < v || other != other) ? other : v) : v + other;
+        }
+        if (lane == 0) part[wave][k] = v;
+    }
     __syncthreads();
+    if (threadIdx.x < 10 && ((MASK >> threadIdx.x) & 1u)) {
+        const int k = threadIdx.x;
+        double v = part[0][k];
+        for (int i = 1; i < 4; ++i) v = k == 9 ? ((part[i][k] < v || part[i][k] != part[i][k]) ? part[i][k] : v) : v + part[i][k];
+        s_sums[k] = v;
+    }
+    __syncthreads();
+}
+
+// one workgroup: per-workgroup partials -> sums[16], smoothness term, losses[10], iteration counter
+__device__ __forceinline__ void loss_tail_body(const LossTailArgs& a, double* red, double (*part)[10], double* s_sums) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the smoothness partials ride in the same round of loads
+    double tv = 0.0;
+    for (uint32_t i = threadIdx.x; i < a.n_tv_blocks; i += 256) tv += a.tv_partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tv += __shfl_xor(tv, o, 64);
+    if (lane == 0) red[wave] = tv;
+    wg_partial_sums<0x3FFu>(a.partials, a.n_ray_blocks, part, s_sums);
+    if (threadIdx.x < 10) a.sums[threadIdx.x] = s_sums[threadIdx.x];
     if (threadIdx.x == 0) {
         // everything from LDS / registers: a store -> load round trip through global memory costs ~1 us each here
         float l[10];
@@ -245,6 +258,61 @@ __global__ __launch_bounds__(256) void k_loss_tail(LossTailArgs a) {
         }
         if (a.rng != nullptr) a.rng[1] += 1ull;
     }
+}
+
+__global__ __launch_bounds__(256) void k_loss_tail(LossTailArgs a) {
+    __shared__ double red[4];
+    __shared__ double part[4][10];
+    __shared__ double s_sums[16];
+    loss_tail_body(a, red, part, s_sums);
+}
+
+// The loss block's backward with the tail and the compaction riding along (single process, up to kFusedTailMaxRays rays): one launch
+// instead of k_loss_tail | k_composite_bwd | k_compact.  Every ray workgroup sums for itself what the composite backward needs from the
+// loss stage's rows (n_valid, n_fs, n_sdf: integers; the two real sums in the tail's own order, so all workgroups and the tail agree
+// bit for bit) and the list offset of its rays (the counts come from the loss stage: 1 + the last sample whose weight or loss masks are
+// non-zero -- every cotangent carries one of them as a factor); ONE extra workgroup is the tail (losses for the host, the iteration counter).
+constexpr uint32_t kFusedTailMaxRays = 4096;
+struct FusedBwdArgs {
+    uint32_t n_rays, S; float trunc, sc_factor; int white_bkgd;
+    const float* raw; const float* z_vals; LossArgs la; float* d_raw;
+    const double* partials; uint32_t n_ray_blocks;
+    const uint32_t* ray_count; uint32_t* ray_off; uint32_t* active_idx; uint32_t* n_active; uint32_t n_front; uint32_t* n_list;
+    LossTailArgs tail;
+};
+__global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_bwd_fused(FusedBwdArgs a) {
+    extern __shared__ float ray_lds[];
+    __shared__ double red[4];
+    __shared__ double part[4][10];
+    __shared__ double s_sums[16];
+    __shared__ uint32_t pre[kRaysPerBlock], cnt[kRaysPerBlock];
+    static_assert(kRaysPerBlock == 4, "the reductions below are written for four waves");
+    if (blockIdx.x == a.n_ray_blocks) { loss_tail_body(a.tail, red, part, s_sums); return; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t r0 = blockIdx.x * kRaysPerBlock, n = r0 + wave;
+    // list offset: the counts of the rays before this workgroup's (integer sums: any order)
+    uint32_t s = 0;
+#pragma unroll 4
+    for (uint32_t i = threadIdx.x; i < r0; i += 256u) s += a.ray_count[i];
+    const uint32_t c = n < a.n_rays ? a.ray_count[n] : 0u;
+    s = wave_sum_u32(s);
+    if (lane == 0) { pre[wave] = s; cnt[wave] = c; }
+    wg_partial_sums<0xD6u>(a.partials, a.n_ray_blocks, part, s_sums);         // slots 1, 2, 4, 6, 7
+    if (n >= a.n_rays) return;
+    uint32_t off = pre[0] + pre[1] + pre[2] + pre[3];
+    for (int w = 0; w < wave; ++w) off += cnt[w];
+    if (lane == 0) {
+        a.ray_off[n] = off;
+        if (n == a.n_rays - 1u) {
+            a.n_active[0] = off + c;
+            if (a.n_list != nullptr) a.n_list[0] = a.n_front + off + c;
+        }
+    }
+    for (uint32_t k = lane; k < c; k += 64) a.active_idx[off + k] = n * a.S + k;
+    LossArgs la = a.la;
+    la.sums = s_sums;
+    const CompositeCot cot{};
+    composite_bwd_ray<true>(ray_lds, n, lane, wave, a.S, a.trunc, a.sc_factor, a.white_bkgd, a.raw, a.z_vals, cot, la, a.d_raw, 0, nullptr);
 }
 
 // data-parallel tail of the loss stage: all-reduced sums -> losses[0..7], total -> losses[9]

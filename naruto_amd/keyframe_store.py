@@ -99,10 +99,12 @@ class KeyFrameStoreHIP:
         return rays, self.frame_ids[idx // self.num_rays_to_save]
 
     def assemble_batch(self, sample_num: int, current_rays: torch.Tensor, poses_all: torch.Tensor, min_pixels_cur: int,
-                       filter_depth: bool = False, return_ids: bool = False):
+                       filter_depth: bool = False, return_ids: bool = False, out=None):
         """coslam.py:310-344 fused: -> rays_o [N,3], rays_d [N,3], target_s [N,3], target_d [N,1], n_cur (and ids_all).
         N = sample_num + n_cur, n_cur = max(sample_num // n_kf, min_pixels_cur) (capped by the valid pixels).
-        current_rays [H*W,7]; poses_all [P,4,4] camera-to-world with the current frame's pose LAST (index -1)."""
+        current_rays [H*W,7]; poses_all [P,4,4] camera-to-world with the current frame's pose LAST (index -1).
+        ``out``: (rays_o, rays_d, target_s, target_d) to write into -- contiguous fp32 device tensors of exactly N rows, e.g. a
+        captured trainer's ``ray_buffers()``."""
         lib = _lib.load()
         n_kf = len(self)
         assert n_kf > 0, "no keyframe stored yet"
@@ -120,8 +122,14 @@ class KeyFrameStoreHIP:
                 cur_list = None                   # pixels 0 .. n_valid-1 of the unfiltered frame (coslam.py:318-327)
         n = sample_num + n_cur
         f32 = dict(dtype=torch.float32, device=self.device)
-        rays_o, rays_d, target_s = torch.empty(n, 3, **f32), torch.empty(n, 3, **f32), torch.empty(n, 3, **f32)
-        target_d = torch.empty(n, 1, **f32)
+        if out is not None:
+            rays_o, rays_d, target_s, target_d = out
+            for a, c in ((rays_o, 3), (rays_d, 3), (target_s, 3), (target_d, 1)):
+                if not (a.is_cuda and a.dtype == torch.float32 and a.is_contiguous() and a.numel() == n * c):
+                    raise RuntimeError(f"assemble_batch: out tensors must be contiguous fp32 device tensors of {n} rows")
+        else:
+            rays_o, rays_d, target_s = torch.empty(n, 3, **f32), torch.empty(n, 3, **f32), torch.empty(n, 3, **f32)
+            target_d = torch.empty(n, 1, **f32)
         ids = torch.empty(n, dtype=torch.int64, device=self.device) if return_ids else None
         self.counter += 1
         b = _lib.NarutoRayBatch()

@@ -8,6 +8,7 @@ is used for memory, streams and autograd bookkeeping only.  Mapping to the refer
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional, Sequence, Tuple
 
 import torch
@@ -620,6 +621,7 @@ class TrainStep:
                  device_rng: bool = True, seed: Optional[int] = None, rng_state: Optional[torch.Tensor] = None):
         lib = _lib.load()
         self.handle, self.group = handle, group
+        self.fuse_tail = os.environ.get("NARUTO_DEBUG_NO_FUSED_TAIL") is None     # run(): loss tail + compaction inside the backward's first launch
         self.params = {k: _f32c(params[k].detach(), k) for k in PARAM_NAMES}
         for k in PARAM_NAMES:
             assert self.params[k].data_ptr() == params[k].data_ptr(), f"{k}: parameters must be contiguous fp32 on the GPU"
@@ -735,6 +737,11 @@ class TrainStep:
         """One forward + backward.  Afterwards: self.losses[10], self.rgb / depth / uncert_map, gradients in self.grads.
         ``rand`` ([N,S], only with device_rng=False): the depth jitter to use instead of a fresh draw; the six lattice
         numbers in self.rand[N*S:] are then left as they are."""
+        if self.group is None and self.fuse_tail:
+            # back to back: the loss tail and the compaction ride in the backward's first launch (losses valid after the backward)
+            self.run_forward(rays_o, rays_d, target_rgb, target_d, rand, _defer_tail=True)
+            self.run_backward(_deferred_tail=True)
+            return self.losses
         self.run_forward(rays_o, rays_d, target_rgb, target_d, rand)
         if self.group is not None:
             from . import parallel
@@ -746,7 +753,7 @@ class TrainStep:
     # sums (a process group is set) or at the final losses (single process); run_backward finishes the losses from the
     # (all-reduced) sums if needed and runs the backward.  MappingTrainer captures them as separate hipGraph segments so
     # that the collectives stay ordinary eager RCCL calls between graph launches.
-    def run_forward(self, rays_o, rays_d, target_rgb, target_d, rand: Optional[torch.Tensor] = None):
+    def run_forward(self, rays_o, rays_d, target_rgb, target_d, rand: Optional[torch.Tensor] = None, _defer_tail: bool = False):
         lib = _lib.load()
         t = self.t
         for a, n in ((rays_o, "rays_o"), (rays_d, "rays_d"), (target_rgb, "target_rgb"), (target_d, "target_d")):
@@ -763,10 +770,10 @@ class TrainStep:
             st = _stream()
             if self._zero_table:
                 self.grads["table"].zero_()
-            check(lib.naruto_train_forward(self.handle.ptr, C.byref(self.ps), C.byref(t), 0 if self.group is not None else 1, st),
-                  "naruto_train_forward")
+            fin = 0 if self.group is not None else (_lib.TRAIN_FWD_DEFER_TAIL if _defer_tail else 1)
+            check(lib.naruto_train_forward(self.handle.ptr, C.byref(self.ps), C.byref(t), fin, st), "naruto_train_forward")
 
-    def run_backward(self, phase: int = 0):
+    def run_backward(self, phase: int = 0, _deferred_tail: bool = False):
         """phase 0: the whole backward.  Data parallel, for overlap: phase 1 = everything up to the MLP weight gradients (then
         complete in self.grads), phase 2 = the table scatter; the caller all-reduces the weight bucket in between."""
         lib = _lib.load()
@@ -782,11 +789,12 @@ class TrainStep:
                 return
             if self.group is not None:
                 check(lib.naruto_train_finalize(self.handle.ptr, C.byref(t), st), "naruto_train_finalize")
+            fl = self.flags | (_lib.TRAIN_BWD_DEFERRED_TAIL if _deferred_tail else 0)
             if self.opt is not None:
-                check(lib.naruto_train_backward(self.handle.ptr, C.byref(self.ps), C.byref(t), C.byref(self._gs_nograd), self.flags, C.byref(self.opt), st),
+                check(lib.naruto_train_backward(self.handle.ptr, C.byref(self.ps), C.byref(t), C.byref(self._gs_nograd), fl, C.byref(self.opt), st),
                       "naruto_train_backward")
             else:
-                check(lib.naruto_train_backward(self.handle.ptr, C.byref(self.ps), C.byref(t), C.byref(self.gs), self.flags, None, st),
+                check(lib.naruto_train_backward(self.handle.ptr, C.byref(self.ps), C.byref(t), C.byref(self.gs), fl, None, st),
                       "naruto_train_backward")
 
 

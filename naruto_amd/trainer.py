@@ -325,7 +325,10 @@ class MappingTrainer:
             st = self._static
             assert smooth == st['smooth'] and rays_o.shape[0] == st['rays_o'].shape[0], "captured for another configuration"
             src = getattr(rays_o, "_base", None)
-            if src is not None and src.numel() == st['flat'].numel() and src.is_contiguous() and all(
+            if rays_o.data_ptr() == st['rays_o'].data_ptr() and rays_d.data_ptr() == st['rays_d'].data_ptr() and \
+                    target_rgb.data_ptr() == st['target_rgb'].data_ptr() and target_d.data_ptr() == st['target_d'].data_ptr():
+                pass                                                      # the batch was assembled in ray_buffers(): nothing to copy
+            elif src is not None and src.numel() == st['flat'].numel() and src.is_contiguous() and all(
                     t._base is src for t in (rays_d, target_rgb, target_d)) and rays_o.data_ptr() == src.data_ptr():
                 st['flat'].copy_(src.reshape(-1), non_blocking=True)      # rays packed by pack_rays(): one copy
             else:
@@ -357,6 +360,15 @@ class MappingTrainer:
                 self.model.check_asserts()
             return ret, st['loss'][1 if uncert_step else 0]
         return self._iteration(rays_o, rays_d, target_rgb, target_d, smooth, uncert_step)
+
+    def ray_buffers(self):
+        """After capture(): the graph's own input buffers (rays_o [N,3], rays_d [N,3], target_rgb [N,3], target_d [N,1]).  A batch
+        written straight into them (``KeyframeRayStore.assemble_batch(..., out=trainer.ray_buffers())``) and passed to ``step``
+        reaches the replay without the device copy an outside batch needs.  None when nothing is captured."""
+        if self._graphs is None:
+            return None
+        st = self._static
+        return st['rays_o'], st['rays_d'], st['target_rgb'], st['target_d']
 
     def global_BA(self, batches, smooth: bool = True, n_rays_total: int = 0):
         """The optimisation loop of one ``global_BA`` call (coslam.py:361-399) over an iterable of ray batches

@@ -1397,6 +1397,74 @@ def test_train_step_device_rng(gpu):
         H.assert_close(losses[0].reshape(-1), ret_o["rgb_loss"].reshape(-1), 1e-6, f"iter{it}.rgb_loss", rel=1e-4)
 
 
+@pytest.mark.parametrize("n_rays,s_d,s_r", [(96, 32, 11), (401, 96, 32), (4096, 11, 5)])
+def test_train_step_with_the_tail_in_the_backward(gpu, n_rays, s_d, s_r):
+    """TrainStep.run() issues forward and backward back to back, so the loss tail and the compaction ride in the backward's first
+    launch (NARUTO_TRAIN_FWD_DEFER_TAIL / NARUTO_TRAIN_BWD_DEFERRED_TAIL).  Against the ordinary sequence (fuse_tail = False):
+    the same losses bit for bit (both reduce the loss stage's rows in one order); ray lists that cover the exact ones (the fused
+    launch takes each ray's length from the forward's masks, the ordinary one from the cotangents themselves: never shorter, and
+    equal unless a product underflows); the same gradients (bit for bit where the lists agree)."""
+    from naruto_amd import ops
+    cfg = H.office_cfg(12, perturb=1.0)
+    tr, cam = cfg["training"], cfg["cam"]
+    ora = H.make_oracle(cfg, 0.25, 31)
+    m = H.make_hip_from_oracle(cfg, ora, gpu)
+    rays = syn.random_rays(n_rays, cfg["mapping"]["bound"], seed=131, zero_depth_frac=0.1)
+    t = {k: torch.from_numpy(v) for k, v in rays.items()}
+    w = torch.tensor([tr["rgb_weight"], tr["depth_weight"], tr["sdf_weight"], tr["fs_weight"], 0.0, tr["uncert_weight"], 0.0, 0.0, 0.1, 0.0])
+    args = [t[k].to(gpu).contiguous() for k in ("rays_o", "rays_d", "target_rgb")] + [t["target_d"].to(gpu).reshape(-1).contiguous()]
+    out = []
+    for fuse in (False, True):
+        ts = ops.TrainStep(m._handle(), m._params(), torch.zeros_like(m.uncert_grid), n_rays, n_samples_d=s_d, n_range_d=s_r,
+                           near=cam["near"], far=cam["far"], range_d=tr["range_d"], depth_trunc=cam["depth_trunc"], rgb_missing=tr["rgb_missing"],
+                           perturb=True, loss_weights=w.to(gpu), smooth=(12, 0.1, 0.05), device_rng=True, seed=77)
+        ts.fuse_tail = fuse
+        for _ in range(2):                        # second iteration: the iteration counter advanced through the fused launch as well
+            losses = ts.run(*args).clone()
+        torch.cuda.synchronize()
+        assert ts.rng_state.cpu().tolist() == [77, 2]
+        out.append((losses.cpu(), ts.ray_count.cpu().clone(), int(ts.n_active.cpu()), {k: v.detach().cpu().clone() for k, v in ts.grads.items()},
+                    ts.sums.cpu().clone(), ts.ray_offset.cpu().clone()))
+    (l0, c0, n0, g0, s0, o0), (l1, c1, n1, g1, s1, o1) = out
+    assert torch.equal(l0, l1) and torch.equal(s0[:10], s1[:10]), (l0, l1)
+    assert bool((c1 >= c0).all()) and n1 >= n0 and n1 == int(c1.sum())
+    assert torch.equal(o1, torch.cumsum(c1.long(), 0).sub(c1.long()).to(o1.dtype))
+    assert float((c1 != c0).float().mean()) < 0.02, "the forward's masks predict the last non-zero cotangent"
+    same = bool((c1 == c0).all())
+    for k in g0:
+        if same:
+            assert torch.equal(g0[k], g1[k]), k
+        else:
+            grad_close(g1[k].reshape(-1).double(), g0[k].reshape(-1).double(), f"fused-tail.grad.{k}", frac=1e-6)
+
+
+def test_trainer_ray_buffers_skip_the_copy(gpu):
+    """A batch assembled straight into a captured trainer's ray_buffers() replays without the input copy and trains exactly
+    like the same batch handed over from outside (KeyFrameStoreHIP.assemble_batch(out=...) writes there)."""
+    from naruto_amd import trainer
+    cfg = H.office_cfg(12, perturb=1.0)
+    bound = torch.tensor(cfg["mapping"]["bound"])
+    torch.manual_seed(5)
+    a = trainer.MappingTrainer(cfg, bound, gpu, fused_adam=True)
+    b = trainer.MappingTrainer(cfg, bound, gpu, fused_adam=True)
+    b.model.load_state_dict(a.model.state_dict())
+    b.iter_state.copy_(a.iter_state)
+    assert a.ray_buffers() is None
+    a.capture(160, smooth=True)
+    b.capture(160, smooth=True)
+    bufs = b.ray_buffers()
+    for it in range(4):
+        rays = syn.random_rays(160, cfg["mapping"]["bound"], seed=900 + it, zero_depth_frac=0.1)
+        t = [torch.from_numpy(rays[k]).to(gpu) for k in ("rays_o", "rays_d", "target_rgb", "target_d")]
+        for dst, src in zip(bufs, t):
+            dst.copy_(src.reshape(dst.shape))
+        _, la = a.step(*t, smooth=True)
+        _, lb = b.step(*bufs, smooth=True)
+        assert torch.equal(la, lb)
+    for (n, p), (_, q) in zip(a.model.named_parameters(), b.model.named_parameters()):
+        assert torch.equal(p, q), n
+
+
 # --------------------------------------------------------------------------------------------- N1 / N2 ("next" rows)
 def test_active_ray_sampler_golden(gpu):
     """ActiveRaySamplerHIP against the reference's sampler (golden) and the oracle's deterministic variant."""
@@ -1748,6 +1816,14 @@ def test_keyframe_store_batch_assembly(gpu):
     assert torch.equal(o.cpu(), w_o)
     H.assert_close(d, w_d, 1e-6, "assemble.rays_d", rel=1e-6)           # torch.sum's association over the 3 products differs by an ulp
     assert torch.equal(s.cpu(), rows[:, 3:6]) and torch.equal(t.cpu(), rows[:, 6:7])
+    # the same draw written into caller-provided buffers (a captured trainer's ray_buffers())
+    st.counter = ctr - 1
+    bufs = tuple(torch.full((bs + n_cur, c), -7.0, device=gpu) for c in (3, 3, 3, 1))
+    o2, d2, s2, t2, n_cur2 = st.assemble_batch(bs, cur, poses, min_pixels_cur=40, filter_depth=True, out=bufs)
+    assert n_cur2 == n_cur and o2 is bufs[0] and t2 is bufs[3]
+    assert torch.equal(o2, o) and torch.equal(d2, d) and torch.equal(s2, s) and torch.equal(t2, t)
+    with pytest.raises(RuntimeError):
+        st.assemble_batch(bs, cur, poses, min_pixels_cur=40, filter_depth=True, out=tuple(b[:-1] for b in bufs))
     # sample_global_rays: distinct rows with their frame ids
     r2, f2 = st.sample_global_rays(128)
     assert r2.shape == (128, 7) and set(f2.cpu().tolist()) <= {0, 5, 10, 15}

@@ -300,6 +300,79 @@ __device__ __forceinline__ float2 hash_level_half_rt(const LevelTab& lt, int T, 
     return acc;
 }
 
+// The same in three steps, so that a caller can run step 1 for a GROUP of levels, then issue the whole group's loads back to back
+// (step 2: straight-line code, 8 loads per level in flight together), then blend (step 3).  In hash_level_half_rt's single-function
+// form the per-level branches (hashed / dense / dense with wrap) end a basic block after every level, the compiler keeps each
+// level's four loads between its own index arithmetic and its own blend, and a wave never has more than four gathers in flight.
+// Same arithmetic, same association: bit-identical features.
+struct HalfCorners {
+    uint32_t off[4];        // byte offsets of the four corners (y, z offsets) inside the level's table
+    float wxh, wy, wz;
+};
+__device__ __forceinline__ HalfCorners hash_level_half_index(const LevelTab& lt, int T, float x, float y, float z, uint32_t xh) {
+    const float scale = lt.scale[T];
+    const uint32_t res = lt.res[T];
+    const uint32_t size = lt.size[T];
+    const float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
+    const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+    const uint32_t gx = (uint32_t)(int)fx + xh, gy = (uint32_t)(int)fy, gz = (uint32_t)(int)fz;
+    const float wx = px - fx;
+    HalfCorners h;
+    h.wy = py - fy; h.wz = pz - fz;
+    h.wxh = xh ? wx : 1.0f - wx;
+    uint32_t idx[4];
+    if ((lt.hashed >> T) & 1u) {
+        const uint32_t mask = size - 1u;
+        const uint32_t hy0 = gy * kPrime1, hy1 = hy0 + kPrime1;
+        const uint32_t hz0 = gz * kPrime2, hz1 = hz0 + kPrime2;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) idx[c] = (gx ^ ((c & 1) ? hy1 : hy0) ^ ((c & 2) ? hz1 : hz0)) & mask;
+    } else {
+        const uint32_t r2 = res * res;
+        const uint32_t gmax = max(max(gx - xh, gy), gz);
+        if (__all(gmax <= res - 2u)) {                          // no wrap anywhere in the wave: 24-bit multiplies
+            const uint32_t base = gx + __umul24(gy, res) + __umul24(gz, r2);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) idx[c] = base + ((c & 1) ? res : 0u) + ((c & 2) ? r2 : 0u);
+        } else {
+            const uint32_t base = gx + gy * res + gz * r2;
+            const uint32_t magic = 0xFFFFFFFFu / size;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                uint32_t i = base + ((c & 1) ? res : 0u) + ((c & 2) ? r2 : 0u);
+                i -= __umulhi(i, magic) * size;
+                if (i >= size) i -= size;
+                idx[c] = i;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) h.off[c] = idx[c] << 3;
+    return h;
+}
+__device__ __forceinline__ void hash_level_half_load(const LevelTab& lt, int T, const float2* __restrict__ table, const HalfCorners& h, float2 (&v)[4]) {
+    const char* __restrict__ tl = reinterpret_cast<const char*>(table + lt.off[T]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#ifdef NARUTO_ABLATE_GATHER
+        v[c] = make_float2(__uint_as_float((h.off[c] >> 3) | 0x3f000000u), 0.25f);
+#else
+        v[c] = *reinterpret_cast<const float2*>(tl + h.off[c]);
+#endif
+    }
+}
+__device__ __forceinline__ float2 hash_level_half_blend(const HalfCorners& h, const float2 (&v)[4]) {
+    const float uy = 1.0f - h.wy, uz = 1.0f - h.wz;
+    float2 acc = make_float2(0.0f, 0.0f);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float w = (h.wxh * ((c & 1) ? h.wy : uy)) * ((c & 2) ? h.wz : uz);         // same association as hash_corners
+        acc.x = fmaf(w, v[c].x, acc.x);
+        acc.y = fmaf(w, v[c].y, acc.y);
+    }
+    return acc;
+}
+
 template <int T>
 __device__ __forceinline__ float2 hash_level(const LevelTab& lt, const float2* __restrict__ table, float x, float y, float z) {
     uint32_t idx[8];

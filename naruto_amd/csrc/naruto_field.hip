@@ -140,7 +140,7 @@ __device__ __forceinline__ void tv_encode_body(const LevelTab& lt, const BoxTab&
 }
 
 #ifndef NARUTO_GATHER_GROUP
-#define NARUTO_GATHER_GROUP 4
+#define NARUTO_GATHER_GROUP 1
 #endif
 #ifndef NARUTO_FWD_MINWAVES
 #define NARUTO_FWD_MINWAVES 2
@@ -221,10 +221,26 @@ __device__ __forceinline__ void fwd_tile(const FwdLds& L, const LevelTab& lt, co
         // B operand of the MFMA tile.
         float xa = x, xb = x, ya = y, yb = y, za = z, zb = z;
         swap32(xa, xb); swap32(ya, yb); swap32(za, zb);        // xa = x of points (0..31 | 0..31), xb = (32..63 | 32..63)
-#pragma unroll kGatherGroup
-        for (int T = 0; T < kLevels; ++T) {
-            const float2 pa = hash_level_half_rt(lt, T, table, xa, ya, za, (uint32_t)hh);
-            const float2 pb = hash_level_half_rt(lt, T, table, xb, yb, zb, (uint32_t)hh);
+        static_assert(kLevels % kGatherGroup == 0, "levels are gathered in whole groups");
+#pragma unroll 1
+        for (int T0 = 0; T0 < kLevels; T0 += kGatherGroup) {
+        HalfCorners ha[kGatherGroup], hb[kGatherGroup];
+#pragma unroll
+        for (int g = 0; g < kGatherGroup; ++g) {
+            ha[g] = hash_level_half_index(lt, T0 + g, xa, ya, za, (uint32_t)hh);
+            hb[g] = hash_level_half_index(lt, T0 + g, xb, yb, zb, (uint32_t)hh);
+        }
+        float2 va[kGatherGroup][4], vb[kGatherGroup][4];
+#pragma unroll
+        for (int g = 0; g < kGatherGroup; ++g) {
+            hash_level_half_load(lt, T0 + g, table, ha[g], va[g]);
+            hash_level_half_load(lt, T0 + g, table, hb[g], vb[g]);
+        }
+#pragma unroll
+        for (int g = 0; g < kGatherGroup; ++g) {
+            const int T = T0 + g;
+            const float2 pa = hash_level_half_blend(ha[g], va[g]);
+            const float2 pb = hash_level_half_blend(hb[g], vb[g]);
             float ua = pa.x, wa = pa.y, ub = pb.x, wb = pb.y;
             swap32(ua, wa);                      // low half: (own x-part of f0, partner's) ; high half: (partner's f1 part, own)
             swap32(ub, wb);
@@ -238,6 +254,7 @@ __device__ __forceinline__ void fwd_tile(const FwdLds& L, const LevelTab& lt, co
             const float a = L.s0[T * 64 + lane];
             hA = mfma32(a, b0, hA);
             hB = mfma32(a, b1, hB);
+        }
         }
         // OneBlob: three of a coordinate's 16 bins are non-zero, and the 64 points of a tile are neighbours on a ray, so
         // most of the 24 K pairs are exact zeros for every point of the tile: those matrix steps are skipped (a product
@@ -426,13 +443,30 @@ __device__ __forceinline__ void fwd_tile_bf(const FwdLdsBf& L, const LevelTab& l
         f32x16 hA = zero16(), hB = zero16(), cA = zero16(), cB = zero16();
         float xa = x, xb = x, ya = y, yb = y, za = z, zb = z;
         swap32(xa, xb); swap32(ya, yb); swap32(za, zb);        // xa = x of points (0..31 | 0..31), xb = (32..63 | 32..63)
+        static_assert(8 % kGatherGroup == 0, "a K block of eight levels is gathered in whole groups");
+#pragma unroll 1
         for (int kb = 0; kb < 2; ++kb) {
             float fa[8], fb[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e0 = 0; e0 < 8; e0 += kGatherGroup) {
+            HalfCorners ha[kGatherGroup], hb[kGatherGroup];
+#pragma unroll
+            for (int g = 0; g < kGatherGroup; ++g) {
+                ha[g] = hash_level_half_index(lt, 8 * kb + e0 + g, xa, ya, za, (uint32_t)hh);
+                hb[g] = hash_level_half_index(lt, 8 * kb + e0 + g, xb, yb, zb, (uint32_t)hh);
+            }
+            float2 va[kGatherGroup][4], vb[kGatherGroup][4];
+#pragma unroll
+            for (int g = 0; g < kGatherGroup; ++g) {
+                hash_level_half_load(lt, 8 * kb + e0 + g, table, ha[g], va[g]);
+                hash_level_half_load(lt, 8 * kb + e0 + g, table, hb[g], vb[g]);
+            }
+#pragma unroll
+            for (int g = 0; g < kGatherGroup; ++g) {
+                const int e = e0 + g;
                 const int T = 8 * kb + e;
-                const float2 pa = hash_level_half_rt(lt, T, table, xa, ya, za, (uint32_t)hh);
-                const float2 pb = hash_level_half_rt(lt, T, table, xb, yb, zb, (uint32_t)hh);
+                const float2 pa = hash_level_half_blend(ha[g], va[g]);
+                const float2 pb = hash_level_half_blend(hb[g], vb[g]);
                 float ua = pa.x, wa = pa.y, ub = pb.x, wb = pb.y;
                 swap32(ua, wa);
                 swap32(ub, wb);
@@ -443,6 +477,7 @@ __device__ __forceinline__ void fwd_tile_bf(const FwdLdsBf& L, const LevelTab& l
                     if (mA < M) *reinterpret_cast<float*>(fs + ((mA * 2u + (uint32_t)hh) << 2)) = fa[e];
                     if (mB < M) *reinterpret_cast<float*>(fs + ((mB * 2u + (uint32_t)hh) << 2)) = fb[e];
                 }
+            }
             }
             const u32x4_t w = L.s0[kb * 64 + lane];
             hA = mfma16(w, pack8(fa), hA);

@@ -250,6 +250,23 @@ class NarutoFieldHIP(nn.Module):
         return {'rgb': rgb_map, 'depth': depth_map, 'disp_map': disp_map, 'acc_map': acc_map, 'depth_var': depth_var,
                 'z_vals': z_vals, 'raw': raw, 'uncert_map': uncert_map}
 
+    def render_surface_color(self, rays_o, normal):
+        """Co-SLAM ``JointEncoding.render_surface_color`` [third_parties/coslam/model/scene_rep.py, not in tree; the mesh colour
+        function when ``mesh.render_color`` is set, reference coslam.py:446-447]: colour of surface points rendered along their
+        normals -- ``n_range_d`` samples at ``linspace(-trunc, trunc)`` around each point, through ``run_network`` and
+        ``raw2outputs``.  rays_o [N,3] world points, normal [N,3] -> rgb [N,3].  Without autograd: one launch."""
+        tr = self.config['training']
+        trunc, S = float(tr['trunc']), int(tr['n_range_d'])
+        rays_o = rays_o.to(self.bounding_box.device, torch.float32)
+        normal = normal.to(self.bounding_box.device, torch.float32)
+        if not torch.is_grad_enabled():
+            return ops.render_fused(self._handle(), self._params(), rays_o, normal, None, near=-trunc, far=trunc, n_samples_d=0, n_range_d=0,
+                                    range_d=0.0, n_samples=S, rand=None, want_raw=False)['rgb']
+        z_vals = torch.linspace(-trunc, trunc, steps=S).to(rays_o).repeat(rays_o.shape[0], 1)
+        raw = ops.field_query(self._handle(), self._params(), rays_o=rays_o, rays_d=normal, z_vals=z_vals, color=True)
+        raw = raw.reshape(z_vals.shape[0], z_vals.shape[1], 5)
+        return ops.composite(self._handle(), raw, z_vals)[0]
+
     # ------------------------------------------------------------------ A8
     def note_min_uncert(self, value: torch.Tensor):
         """Queue this iteration's ``uncert_map.min()`` (a device scalar) for the deferred check: an asynchronous copy into

@@ -14,7 +14,8 @@ What is different:
     triangle order and case table (tools/gen_mc_table.py) -- the surface is the same, the index order is not;
   * the result is a plain :class:`Mesh` (vertices float64 [V,3], faces int64 [F,3], vertex_colors uint8 [V,4] like
     trimesh's) with a binary-PLY ``export``; ``trimesh`` is not a dependency.  ``config['mesh']['render_color'] = True``
-    (vertex normals from trimesh + ``render_surface_color``) is not used by any shipped config and raises.
+    (no shipped config sets it) colours the vertices through ``render_surface_color`` along trimesh-style angle-weighted
+    vertex normals (:func:`vertex_normals`).
 """
 
 from __future__ import annotations
@@ -90,6 +91,35 @@ class Mesh:
             f.write(("\n".join(head) + "\n").encode("ascii"))
             f.write(vert.tobytes())
             f.write(face.tobytes())
+
+
+def vertex_normals(vertices: torch.Tensor, faces: torch.Tensor) -> torch.Tensor:
+    """trimesh's ``Trimesh.vertex_normals`` (third-party, unpinned; used by the reference at coslam_utils.py:180-181) restated:
+    unit face normals summed into their vertices with the triangle's corner ANGLE as weight (degenerate triangles -- a corner angle
+    below 1e-8 or a zero-area normal -- contribute nothing), then normalised; vertices without a contribution get a zero normal.
+    vertices [V,3] float64, faces [F,3] int64 -> [V,3] float64, on the tensors' device."""
+    v = vertices.to(torch.float64)
+    f = faces.to(torch.int64)
+    tri = v[f]                                                   # [F,3,3]
+
+    def unit(a):
+        n = torch.linalg.norm(a, dim=-1, keepdim=True)
+        ok = n > 2.220446049250313e-14                           # trimesh.util.unitize's tolerance (100 * float64 eps)
+        return torch.where(ok, a / torch.where(ok, n, torch.ones_like(n)), torch.zeros_like(a)), ok[..., 0]
+
+    e01, e02, e12 = tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0], tri[:, 2] - tri[:, 1]
+    fn, fn_ok = unit(torch.cross(e01, e02, dim=-1))
+    u, _ = unit(e01)
+    w2, _ = unit(e02)
+    w, _ = unit(e12)
+    a0 = torch.arccos(torch.clamp((u * w2).sum(-1), -1.0, 1.0))
+    a1 = torch.arccos(torch.clamp((-u * w).sum(-1), -1.0, 1.0))
+    ang = torch.stack([a0, a1, np.pi - a0 - a1], dim=-1)         # [F,3]
+    ang = torch.where(((ang < 1e-8).any(-1) | ~fn_ok)[:, None], torch.zeros_like(ang), ang)
+    out = torch.zeros_like(v)
+    for k in range(3):
+        out.index_add_(0, f[:, k], fn * ang[:, k:k + 1])
+    return unit(out)[0]
 
 
 def _float_colors_to_rgba8(color) -> np.ndarray:
@@ -175,8 +205,13 @@ def extract_mesh(query_fn: Callable, config, bounding_box: torch.Tensor, marchin
         color = color_func(vert_flat[:, None, :]) if len(vert_flat) else torch.zeros(0, 3, device=device)    # :169-176
         colors = _float_colors_to_rgba8(torch.reshape(color, (len(vert_flat), -1)))
     elif color_func is not None:
-        raise NotImplementedError("config['mesh']['render_color'] = True (render_surface_color with trimesh vertex normals) is not built: "
-                                  "no shipped config enables it")
+        # :178-186: colour rendered along the vertex normals; the reference hands over the METRIC vertices (not vert_flat)
+        if len(vertices):
+            normals = vertex_normals(vertices, triangles)
+            color = color_func(vertices.to(bounding_box.dtype), normals.to(bounding_box.dtype))
+        else:
+            color = torch.zeros(0, 3, device=device)
+        colors = _float_colors_to_rgba8(torch.reshape(color, (len(vertices), -1)))
     elif render_uncert:
         if len(vert_flat):
             raw_uncert = query_fn(vert_flat[:, None, :], return_uncert=True)[:, 0, 1].to(torch.float32)     # :202-206

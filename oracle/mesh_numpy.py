@@ -158,6 +158,37 @@ def check_closed(faces: np.ndarray) -> bool:
     return all((b, a) in fwd for (a, b) in fwd)
 
 
+def vertex_normals(vertices: np.ndarray, faces: np.ndarray) -> np.ndarray:
+    """trimesh.Trimesh.vertex_normals restated (third-party, unpinned, absent here -- "parity unpinned"; the reference uses it at
+    coslam_utils.py:180-181): trimesh.geometry.weighted_vertex_normals = unit face normals summed into their three vertices weighted
+    by the triangle's corner angle (trimesh.triangles.angles: triangles with any corner angle below tol.merge = 1e-8 count as
+    degenerate, all three weights zero), then unitized (zero vectors stay zero).  A plain loop over the faces."""
+    v = np.asarray(vertices, dtype=np.float64)
+    out = np.zeros_like(v)
+    for a, b, c in np.asarray(faces, dtype=np.int64):
+        n = np.cross(v[b] - v[a], v[c] - v[a])
+        ln = np.linalg.norm(n)
+        if not ln > 100 * np.finfo(np.float64).eps:
+            continue
+        n = n / ln
+
+        def unit(e):
+            le = np.linalg.norm(e)
+            return e / le if le > 100 * np.finfo(np.float64).eps else np.zeros(3)
+        u, w2, w = unit(v[b] - v[a]), unit(v[c] - v[a]), unit(v[c] - v[b])
+        a0 = np.arccos(np.clip(np.dot(u, w2), -1, 1))
+        a1 = np.arccos(np.clip(np.dot(-u, w), -1, 1))
+        ang = np.array([a0, a1, np.pi - a0 - a1])
+        if (ang < 1e-8).any():
+            continue
+        out[a] += n * ang[0]; out[b] += n * ang[1]; out[c] += n * ang[2]
+    ln = np.linalg.norm(out, axis=1)
+    ok = ln > 100 * np.finfo(np.float64).eps
+    out[ok] /= ln[ok, None]
+    out[~ok] = 0.0
+    return out
+
+
 def extract_mesh(query_fn, config, bounding_box, table, marching_cube_bound=None, color_func=None, voxel_size=None, isolevel=0.0,
                  render_uncert=True, lut=None):
     """coslam_utils.py:100-226 with ``marching_cubes`` above in place of the third-party module.
@@ -197,4 +228,10 @@ def extract_mesh(query_fn, config, bounding_box, table, marching_cube_bound=None
                 u = np.concatenate(u, 0).astype(np.float32)
                 un = (u - u.min()) / (u.max() - u.min())                                                      # :210
                 colors = jet_colors(un.flatten(), jet_lut() if lut is None else lut)                          # :213-214
+    elif color_func is not None and config["mesh"]["render_color"]:                                          # :178-186
+        normals = vertex_normals(vertices, faces)
+        with torch.no_grad():
+            c = [color_func(torch.from_numpy(vertices[i:i + chunk]).to(bounding_box), torch.from_numpy(normals[i:i + chunk]).to(bounding_box)).cpu().numpy()
+                 for i in range(0, vertices.shape[0], chunk)]
+        colors = np.reshape(np.concatenate(c, 0).astype(np.float32), [vertices.shape[0], -1]) if len(c) else np.zeros((0, 3), np.float32)
     return {"vol": vol, "verts_index": verts_index, "faces": faces, "vertices": vertices, "colors": colors}

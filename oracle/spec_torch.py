@@ -420,6 +420,15 @@ class OracleField(nn.Module):
                 'depth_var': depth_var, 'z_vals': z_vals, 'raw': raw, 'uncert_map': uncert_map,
                 'weights': weights}
 
+    def render_surface_color(self, rays_o, normal):
+        """Co-SLAM JointEncoding.render_surface_color [third_parties/coslam/model/scene_rep.py, not in tree; call site reference
+        coslam.py:446-447 via extract_mesh, coslam_utils.py:178-186]: n_range_d samples at linspace(-trunc, trunc) along the normal."""
+        tr = self.config['training']
+        z_vals = torch.linspace(-tr['trunc'], tr['trunc'], steps=tr['n_range_d']).to(rays_o).repeat(rays_o.shape[0], 1)
+        pts = rays_o[..., None, :] + normal[..., None, :] * z_vals[..., :, None]
+        raw = self.run_network(pts)
+        return raw2outputs(raw, z_vals, tr['trunc'], self.config['data']['sc_factor'], tr['white_bkgd'])[0]
+
     # -- A8 ----------------------------------------------------------------------
     def forward(self, rays_o, rays_d, target_rgb, target_d, global_step=0, rand=None):
         rend = self.render_rays(rays_o, rays_d, target_d=target_d, rand=rand)

@@ -1955,6 +1955,53 @@ def test_extract_mesh_golden(gpu, tmp_path):
             assert (np.abs(got - want).max(-1) > 0).mean() < 0.02          # a jet bin edge may flip with the 1e-6 noise of the uncertainty
 
 
+def test_render_surface_color(gpu):
+    """Co-SLAM's render_surface_color (the mesh colour function under mesh.render_color): n_range_d samples at linspace(-trunc, trunc)
+    along a surface normal, run_network + raw2outputs -> rgb.  The one-launch no-grad form and the differentiable operator chain
+    against the oracle; then extract_mesh with mesh.render_color = True (trimesh-style angle-weighted vertex normals) against the
+    oracle's restatement."""
+    from naruto_amd import mesh as M
+    from oracle import mesh_numpy as MN
+    cfg = H.office_cfg(12)
+    ora = H.make_oracle(cfg, 0.25, 61).eval()
+    m = H.make_hip_from_oracle(cfg, ora, gpu).eval()
+    rs = np.random.RandomState(61)
+    bb = np.asarray(cfg["mapping"]["bound"])
+    pts = torch.from_numpy((bb[:, 0] + rs.uniform(0.1, 0.9, (777, 3)) * (bb[:, 1] - bb[:, 0])).astype(np.float32))
+    nrm = rs.normal(size=(777, 3))
+    nrm = torch.from_numpy((nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32))
+    with torch.no_grad():
+        want = ora.render_surface_color(pts, nrm)
+        got = m.render_surface_color(pts.to(gpu), nrm.to(gpu))
+    assert got.shape == (777, 3)
+    H.assert_close(got, want, TOL_OUT, "render_surface_color (one launch)", rel=1e-5)
+    got_g = m.render_surface_color(pts.to(gpu), nrm.to(gpu))
+    assert got_g.requires_grad
+    H.assert_close(got_g, want, TOL_OUT, "render_surface_color (operators)", rel=1e-5)
+    g_hip = torch.autograd.grad(got_g.sum(), m.decoder.color_net.model[2].weight)[0]
+    g_ora = torch.autograd.grad(ora.render_surface_color(pts, nrm).sum(), ora.col_w1 if hasattr(ora, "col_w1") else list(ora.parameters())[-1])[0]
+    if g_ora.shape == g_hip.shape:
+        H.assert_close(g_hip, g_ora, 1e-6 * float(g_ora.abs().max()) + 1e-9, "render_surface_color d/d(colour layer 2)", rel=1e-4)
+    # the mesh colour branch
+    table = H.load_golden("mc_table")
+    cfg["mesh"] = dict(cfg.get("mesh", {}), render_color=True)
+    mcb = torch.tensor(cfg["mapping"]["bound"], dtype=torch.float32)
+    o = MN.extract_mesh(ora.query_sdf, cfg, ora.bounding_box, table, marching_cube_bound=mcb, voxel_size=0.4, isolevel=1e9, render_uncert=False)
+    srt = np.sort(o["vol"].reshape(-1).astype(np.float64))
+    mid = srt[int(0.3 * len(srt)):int(0.7 * len(srt))]
+    at = int(np.argmax(np.diff(mid)))
+    iso = float(np.float32(0.5 * (mid[at] + mid[at + 1])))
+    mesh = M.extract_mesh(m.query_sdf, cfg, m.bounding_box, marching_cube_bound=mcb, color_func=m.render_surface_color, voxel_size=0.4, isolevel=iso)
+    want = MN.extract_mesh(ora.query_sdf, cfg, ora.bounding_box, table, marching_cube_bound=mcb, color_func=ora.render_surface_color, voxel_size=0.4,
+                           isolevel=iso)
+    assert len(want["faces"]) > 0 and float(np.abs(o["vol"] - iso).min()) > 2e-5
+    assert np.array_equal(mesh.faces, want["faces"])
+    n_dev = M.vertex_normals(torch.from_numpy(mesh.vertices).to(gpu), torch.from_numpy(mesh.faces).to(gpu)).cpu().numpy()
+    assert np.abs(n_dev - MN.vertex_normals(mesh.vertices, mesh.faces)).max() < 1e-9
+    diff = np.abs(mesh.vertex_colors[:, :3].astype(np.float64) - np.round(np.clip(want["colors"], 0, 1) * 255.0))
+    assert diff.max() <= 1.0, diff.max()
+
+
 @pytest.mark.parametrize("case", list(range(4)))
 def test_extract_mesh_random_configs(gpu, case):
     """N4 over drawn scene boxes, marching-cubes bounds, voxel sizes / resolutions, metric transforms and isolevels: the SDF

@@ -190,3 +190,29 @@ def test_mesh_entry_points_validate_arguments(built_lib):
     assert lib.naruto_lattice_points(dims, None, None, None, None, None) < 0
     big = (C.c_uint32 * 3)(2048, 2048, 2048)
     assert lib.naruto_mesh_workspace(big) == 0
+
+
+def test_vertex_normals_match_the_loop_restatement():
+    """naruto_amd.mesh.vertex_normals (vectorised torch) against oracle.mesh_numpy.vertex_normals (a loop over the faces of
+    trimesh's angle-weighted rule) on a closed surface with a degenerate triangle and an unreferenced vertex thrown in; on a cube
+    the angle weights make every corner normal the (1,1,1)/sqrt(3) diagonal whichever way its faces are split."""
+    import numpy as np
+    import torch
+    from naruto_amd import mesh as M
+    from oracle import mesh_numpy as MN
+    corners = np.array([[x, y, z] for x in (0., 1.) for y in (0., 1.) for z in (0., 1.)])
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]       # outward-facing
+    faces = []
+    for q, (a, b, c, d) in enumerate(quads):
+        faces += [(a, b, c), (a, c, d)] if q % 2 == 0 else [(a, b, d), (b, c, d)]
+    faces = np.array(faces)
+    n = M.vertex_normals(torch.from_numpy(corners), torch.from_numpy(faces)).numpy()
+    want = (corners * 2 - 1) / np.sqrt(3.0)
+    assert np.abs(n - want).max() < 1e-12
+    rs = np.random.RandomState(3)
+    v = np.concatenate([corners + rs.normal(scale=0.05, size=corners.shape), [[5., 5., 5.]]])           # vertex 8: unreferenced
+    f = np.concatenate([faces, [[0, 0, 3]], [[1, 2, 2]]])                                                # degenerate triangles
+    got = M.vertex_normals(torch.from_numpy(v), torch.from_numpy(f)).numpy()
+    ref = MN.vertex_normals(v, f)
+    assert np.abs(got - ref).max() < 1e-12
+    assert np.all(got[8] == 0.0) and np.allclose(np.linalg.norm(got[:8], axis=1), 1.0)

@@ -434,10 +434,11 @@ def main():
     torch.manual_seed(0)                                     # identical replicas on every rank
     tr = MappingTrainer(cfg, torch.tensor(cfg["mapping"]["bound"], dtype=torch.float32), dev, 0.1, group=group,
                         fused_adam=not args.torch_adam)
-    # Single process: the whole iteration replays from one hipGraph.  Data parallel: eager launches by default -- 14 launches
-    # and two collectives with no host sync in between, so the host runs ahead of the GPU (0.284 ms at world size 1 with
-    # NARUTO_FORCE_DIST=1), and nothing depends on capturing a multi-rank collective.  NARUTO_GRAPH_DIST=segmented|whole opts in.
-    use_graph = (not args.no_graph) and (group is None or os.environ.get("NARUTO_GRAPH_DIST", "") in ("segmented", "whole"))
+    # Single process: the whole iteration replays from one hipGraph.  Data parallel: three graph segments (forward | backward |
+    # optimiser) with the two collectives as ordinary eager RCCL calls in between -- no collective is captured, and the host issues
+    # 3 replays + 2 collectives per step instead of ~14 launches (world size 1 with NARUTO_FORCE_DIST=1: 0.30 ms segmented, 0.41 ms
+    # eager: the eager step is bound by the host).  NARUTO_GRAPH_DIST=eager|whole selects the other forms.
+    use_graph = (not args.no_graph) and (group is None or os.environ.get("NARUTO_GRAPH_DIST", "segmented") in ("segmented", "whole"))
     if use_graph:
         tr.capture(n_rays, smooth=True, n_rays_total=n_total)
     all_rays = bench_rays(cfg, n_total)

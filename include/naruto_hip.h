@@ -174,6 +174,10 @@ typedef struct NarutoExtraPoints {
  * ordinary sequence (same results). */
 #define NARUTO_TRAIN_FWD_DEFER_TAIL 2
 #define NARUTO_TRAIN_BWD_DEFERRED_TAIL 16u
+/* Data parallel counterpart: the forward ran with finalize = 0 and t->sums now holds the ALL-REDUCED sums.  The backward (one piece
+ * or its MLP_ONLY phase) then replaces naruto_train_finalize | composite backward | compaction by the same single launch, whose
+ * extra workgroup turns the sums into losses[0..7] and the total.  Do not call naruto_train_finalize in addition. */
+#define NARUTO_TRAIN_BWD_SUMS_GIVEN 32u
 size_t naruto_query_bwd_workspace(const NarutoField* f, uint32_t M);
 int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, const NarutoPoints* pts,
                      const float* feat_save, const float* d_raw, const float* d_geo,

@@ -781,7 +781,7 @@ int naruto_train_forward(const NarutoField* f, const NarutoParams* p, const Naru
     a.tv_scale_host = t->smooth_grad_scale != 0.0f ? t->smooth_grad_scale : 1.0f;
     a.n_tv_blocks = t->smooth_points != 0 ? w.n_tv_blocks : 0u;
     const bool deferred = finalize == NARUTO_TRAIN_FWD_DEFER_TAIL && tail_rides_in_backward(t);
-    if (deferred) a.ray_count = t->ray_count;
+    if (tail_rides_in_backward(t)) a.ray_count = t->ray_count;      // list lengths for the backward's fused first launch (either flag)
     if (int rc = ray_lds_attr()) return rc;
     hipLaunchKernelGGL(k_loss_stage, dim3(a.n_ray_blocks + a.n_tv_blocks), dim3(64 * kRaysPerBlock), ray_scratch_bytes(S), st, a);
     if (int rc = check_launch("loss_stage")) return rc;
@@ -834,9 +834,13 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
                 f->desc.trunc * f->desc.sc_factor};
     if ((flags & NARUTO_TRAIN_BWD_MLP_ONLY) && (flags & NARUTO_TRAIN_BWD_TABLE_ONLY)) return fail(NARUTO_ERR_INVALID, "train_backward: pick one phase");
     const bool table_only = (flags & NARUTO_TRAIN_BWD_TABLE_ONLY) != 0u;
-    if ((flags & NARUTO_TRAIN_BWD_DEFERRED_TAIL) && (flags & (NARUTO_TRAIN_BWD_MLP_ONLY | NARUTO_TRAIN_BWD_TABLE_ONLY)))
-        return fail(NARUTO_ERR_INVALID, "train_backward: the deferred tail belongs to the one-piece backward");
-    const bool deferred = (flags & NARUTO_TRAIN_BWD_DEFERRED_TAIL) != 0u && tail_rides_in_backward(t);
+    if ((flags & NARUTO_TRAIN_BWD_DEFERRED_TAIL) && (flags & (NARUTO_TRAIN_BWD_MLP_ONLY | NARUTO_TRAIN_BWD_TABLE_ONLY | NARUTO_TRAIN_BWD_SUMS_GIVEN)))
+        return fail(NARUTO_ERR_INVALID, "train_backward: the deferred tail belongs to the one-piece single-process backward");
+    const bool sums_given = (flags & NARUTO_TRAIN_BWD_SUMS_GIVEN) != 0u && !table_only;
+    const bool deferred = ((flags & NARUTO_TRAIN_BWD_DEFERRED_TAIL) != 0u || sums_given) && tail_rides_in_backward(t);
+    if (sums_given && !deferred) {           // too many rays for the fused launch: the ordinary finalize, then the ordinary sequence
+        if (int rc = naruto_train_finalize(f, t, stream)) return rc;
+    }
     if (int rc = ray_lds_attr()) return rc;
     if (deferred) {
         const bool smooth_d = t->smooth_points != 0 && (g->table != nullptr || opt != nullptr);
@@ -848,6 +852,7 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
         fa.ray_count = t->ray_count; fa.ray_off = t->ray_offset; fa.active_idx = t->active_idx; fa.n_active = t->n_active;
         fa.n_front = smooth_d ? w.n3 : 0u; fa.n_list = bwd.n_total;
         fa.tail = loss_tail_args(t, w, fa.n_ray_blocks, t->smooth_points != 0 ? w.n_tv_blocks : 0u, tv_args(t).inv_p3, 1);
+        fa.sums_given = sums_given ? 1 : 0;
         hipLaunchKernelGGL(k_loss_bwd_fused, dim3(fa.n_ray_blocks + 1u), dim3(64 * kRaysPerBlock), ray_scratch_bytes(S), st, fa);
         if (int rc = check_launch("loss_bwd_fused")) return rc;
     }

@@ -279,6 +279,8 @@ struct FusedBwdArgs {
     const double* partials; uint32_t n_ray_blocks;
     const uint32_t* ray_count; uint32_t* ray_off; uint32_t* active_idx; uint32_t* n_active; uint32_t n_front; uint32_t* n_list;
     LossTailArgs tail;
+    int sums_given;               // data parallel: la.sums holds the ALL-REDUCED sums (the forward ran its tail with finalize = 0); the extra
+                                  // workgroup then only turns them into losses[0..7] and the total
 };
 __global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_bwd_fused(FusedBwdArgs a) {
     extern __shared__ float ray_lds[];
@@ -287,7 +289,14 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_bwd_fused(FusedBwdA
     __shared__ double s_sums[16];
     __shared__ uint32_t pre[kRaysPerBlock], cnt[kRaysPerBlock];
     static_assert(kRaysPerBlock == 4, "the reductions below are written for four waves");
-    if (blockIdx.x == a.n_ray_blocks) { loss_tail_body(a.tail, red, part, s_sums); return; }
+    if (blockIdx.x == a.n_ray_blocks) {
+        if (!a.sums_given) loss_tail_body(a.tail, red, part, s_sums);
+        else if (threadIdx.x == 0) {
+            loss_finalize_body(a.la.sums, a.tail.n_rays_total, a.S, a.tail.losses);
+            if (a.tail.loss_weights != nullptr) loss_total(a.tail.losses, a.tail.loss_weights); else a.tail.losses[9] = 0.0f;
+        }
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t r0 = blockIdx.x * kRaysPerBlock, n = r0 + wave;
     // list offset: the counts of the rays before this workgroup's (integer sums: any order)
@@ -297,7 +306,12 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_bwd_fused(FusedBwdA
     const uint32_t c = n < a.n_rays ? a.ray_count[n] : 0u;
     s = wave_sum_u32(s);
     if (lane == 0) { pre[wave] = s; cnt[wave] = c; }
-    wg_partial_sums<0xD6u>(a.partials, a.n_ray_blocks, part, s_sums);         // slots 1, 2, 4, 6, 7
+    if (!a.sums_given) {
+        wg_partial_sums<0xD6u>(a.partials, a.n_ray_blocks, part, s_sums);     // slots 1, 2, 4, 6, 7
+    } else {
+        if (threadIdx.x < 10) s_sums[threadIdx.x] = a.la.sums[threadIdx.x];
+        __syncthreads();
+    }
     if (n >= a.n_rays) return;
     uint32_t off = pre[0] + pre[1] + pre[2] + pre[3];
     for (int w = 0; w < wave; ++w) off += cnt[w];

@@ -780,16 +780,18 @@ class TrainStep:
         t = self.t
         with torch.cuda.device(self.device):
             st = _stream()
+            # data parallel: self.sums holds the all-reduced sums; finalize + composite backward + compaction are one launch
+            given = _lib.TRAIN_BWD_SUMS_GIVEN if (self.group is not None and self.fuse_tail) else 0
             if phase != 0:
                 assert self.opt is None, "the fused optimiser runs the backward in one piece"
-                if phase == 1 and self.group is not None:
+                if phase == 1 and self.group is not None and not given:
                     check(lib.naruto_train_finalize(self.handle.ptr, C.byref(t), st), "naruto_train_finalize")
-                fl = self.flags | (_lib.TRAIN_BWD_MLP_ONLY if phase == 1 else _lib.TRAIN_BWD_TABLE_ONLY)
+                fl = self.flags | (_lib.TRAIN_BWD_MLP_ONLY | given if phase == 1 else _lib.TRAIN_BWD_TABLE_ONLY)
                 check(lib.naruto_train_backward(self.handle.ptr, C.byref(self.ps), C.byref(t), C.byref(self.gs), fl, None, st), "naruto_train_backward")
                 return
-            if self.group is not None:
+            if self.group is not None and not given:
                 check(lib.naruto_train_finalize(self.handle.ptr, C.byref(t), st), "naruto_train_finalize")
-            fl = self.flags | (_lib.TRAIN_BWD_DEFERRED_TAIL if _deferred_tail else 0)
+            fl = self.flags | (_lib.TRAIN_BWD_DEFERRED_TAIL if _deferred_tail else 0) | given
             if self.opt is not None:
                 check(lib.naruto_train_backward(self.handle.ptr, C.byref(self.ps), C.byref(t), C.byref(self._gs_nograd), fl, C.byref(self.opt), st),
                       "naruto_train_backward")

@@ -432,7 +432,8 @@ class MappingTrainer:
         pool = None
         import os
         segmented = self.group is not None and self.direct and os.environ.get("NARUTO_GRAPH_DIST", "segmented") != "whole"
-        # (bench.py runs data-parallel jobs eagerly unless NARUTO_GRAPH_DIST is set: same speed, nothing to capture)
+        # with a process group its watchdog thread polls events while this thread captures: only this thread's calls may end the capture
+        cap_mode = "thread_local" if self.group is not None else "global"
         if segmented:
             # Data parallel: forward | backward | optimiser as three graph segments; the two all-reduces (loss sums, flat
             # gradient) run between them as eager RCCL calls on the same stream.  (Capturing the collectives inside one graph
@@ -443,19 +444,19 @@ class MappingTrainer:
             args = (st['rays_o'], st['rays_d'], st['target_rgb'], st['target_d'].reshape(-1))
             seg = {'opt': [None, None]}
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool), torch.no_grad():
+            with torch.cuda.graph(g, pool=pool, capture_error_mode=cap_mode), torch.no_grad():
                 ts.run_forward(*args)
             pool = g.pool()
             seg['fwd'] = g
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool), torch.no_grad():
+            with torch.cuda.graph(g, pool=pool, capture_error_mode=cap_mode), torch.no_grad():
                 ts.run_backward()
             seg['bwd'] = g
             for name, p in self.model._params().items():
                 p.grad = ts.grads[name]
             for variant in (False, True):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool), torch.no_grad():
+                with torch.cuda.graph(g, pool=pool, capture_error_mode=cap_mode), torch.no_grad():
                     self.map_optimizer.step()
                     if variant:
                         self.uncert_optim.step(zero_grad=True)
@@ -469,7 +470,7 @@ class MappingTrainer:
             graphs = [seg['fwd']]
         for variant in (() if segmented else (False, True)):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            with torch.cuda.graph(g, pool=pool, capture_error_mode=cap_mode):
                 ret, loss = self._iteration(st['rays_o'], st['rays_d'], st['target_rgb'], st['target_d'], smooth, variant, check=False)
             pool = g.pool()
             st['ret'][1 if variant else 0] = ret

@@ -455,7 +455,7 @@ int naruto_smoothness_fwd(const NarutoField* f, const float* table, uint32_t sam
     float* feat = reinterpret_cast<float*>(workspace);
     double* partial = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + (((size_t)n3 * kFeat * sizeof(float) + 63) / 64) * 64);
     const uint32_t nb = (n3 * kFeat + 255u) / 256u;
-    hipLaunchKernelGGL(k_tv_encode, dim3(16u * ((n3 + 255u) / 256u)), dim3(256), 0, (hipStream_t)stream, f->lt, f->bt, a, rand6,
+    hipLaunchKernelGGL(k_tv_encode, dim3(tv_encode_blocks(n3)), dim3(256), 0, (hipStream_t)stream, f->lt, f->bt, a, rand6,
                        static_cast<const uint64_t*>(nullptr), reinterpret_cast<const float2*>(table), x_out, feat);
     if (int rc = check_launch("tv_encode")) return rc;
     hipLaunchKernelGGL(k_tv_loss, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, feat, d_feat, partial);
@@ -757,7 +757,9 @@ int naruto_train_forward(const NarutoField* f, const NarutoParams* p, const Naru
     const BwdWs bw = bwd_ws(f, w.bwd, list_cap(M + w.n3));
     if (t->smooth_points != 0) {
         SampleArgs sa{N, t->target_d, t->near_, t->far_, t->n_samples_d, t->n_range_d, t->range_d, jitter, jitter_rng, t->z_vals, (N + 3u) / 4u};
-        hipLaunchKernelGGL(k_sample_encode, dim3(sa.n_ray_blocks + 16u * ((w.n3 + 255u) / 256u)), dim3(256), (size_t)4u * 2u * S * sizeof(float), st, sa, f->lt,
+        static const int dbg_roles = getenv("NARUTO_DEBUG_SAMPLE_ROLES") ? atoi(getenv("NARUTO_DEBUG_SAMPLE_ROLES")) : 3;   // profiling knob: 1 rays, 2 lattice
+        if (dbg_roles == 2) sa.n_rays = 0;
+        hipLaunchKernelGGL(k_sample_encode, dim3(sa.n_ray_blocks + (dbg_roles == 1 ? 0u : tv_encode_blocks(w.n3))), dim3(256), (size_t)4u * 2u * S * sizeof(float), st, sa, f->lt,
                            f->bt, tva, t->rand6, t->rng, reinterpret_cast<const float2*>(p->table), bw.x_soa, w.tv_feat);
         if (int rc = check_launch("sample_encode")) return rc;
     } else {

@@ -103,17 +103,28 @@ struct TvArgs {
     uint32_t cap;
 };
 
+// The lattice encode is bound by the gather rate (3.8 M 8-byte gathers from all over the table: distinct 64-byte lines per load
+// instruction are what costs, tools/gather_coalesce_bench.hip), so it uses the forward's pairing: the two halves of a wave work on
+// the same 32 points and lane half xh fetches the four corners with x offset xh -- x-neighbour corners mostly share a line.
+// A thread keeps its lattice position for kTvLevels levels.
+#ifndef NARUTO_TV_LEVELS
+#define NARUTO_TV_LEVELS 4
+#endif
+constexpr int kTvLevels = NARUTO_TV_LEVELS;
+static_assert(kLevels % kTvLevels == 0, "the lattice encode handles whole groups of levels");
+constexpr uint32_t kTvPointsPerBlock = 128;          // 256 threads = 4 waves x 32 points x 2 x-halves
+inline uint32_t tv_encode_blocks(uint32_t n3) { return (uint32_t)(kLevels / kTvLevels) * ((n3 + kTvPointsPerBlock - 1u) / kTvPointsPerBlock); }
+
 __device__ __forceinline__ void tv_encode_body(const LevelTab& lt, const BoxTab& bt, const TvArgs& a, const float* __restrict__ rand6,
                                                const uint64_t* __restrict__ rng, const float2* __restrict__ table, float* __restrict__ x_out,
                                                float* __restrict__ feat, uint32_t block) {
-    // thread = (level, point), the point index fastest: 16x the parallelism of a thread per point for this small
-    // (n^3 = 29 791) problem, and neighbouring lanes are neighbouring lattice points of ONE level, which share cells
-    // (cache lines) on the coarse levels
     const uint32_t n3 = a.n * a.n * a.n;
-    const uint32_t per_level = (n3 + 255u) / 256u;
-    const uint32_t level = block / per_level;
-    const uint32_t m = (block % per_level) * 256u + threadIdx.x;
-    if (m >= n3) return;
+    const uint32_t per_group = (n3 + kTvPointsPerBlock - 1u) / kTvPointsPerBlock;
+    const uint32_t group = block / per_group;
+    const uint32_t lane = threadIdx.x & 63u, xh = lane >> 5;
+    const uint32_t m_raw = (block % per_group) * kTvPointsPerBlock + (threadIdx.x >> 6) * 32u + (lane & 31u);
+    const bool valid = m_raw < n3;
+    const uint32_t m = valid ? m_raw : n3 - 1u;           // padding lanes redo the last point (both halves of a pair stay in step), stores masked
     uint32_t ijk[3], jk;
     const float inv_n = 1.0f / (float)a.n;
     ijk[0] = fast_divmod(m, a.n * a.n, inv_n * inv_n, jk);
@@ -128,15 +139,32 @@ __device__ __forceinline__ void tv_encode_body(const LevelTab& lt, const BoxTab&
         const float offset = r_off * offset_max + a.margin;
         const float p = ((float)ijk[d] + r_jit) * a.voxel + bt.bmin[d] + offset;
         xn[d] = __fdiv_rn(p - bt.bmin[d], bt.bext[d]);
-        if (level == 0) {
+        if (group == 0 && xh == 0u && valid) {
             if (a.cap != 0) x_out[(size_t)d * a.cap + m] = xn[d];
             else x_out[3 * (size_t)m + d] = xn[d];
         }
-        if (level == 0 && d == 0 && a.cap != 0) x_out[3 * (size_t)a.cap + m] = 0.0f;        // row 3: no raw[...,4] cotangent at lattice points
+        if (group == 0 && xh == 0u && valid && d == 0 && a.cap != 0) x_out[3 * (size_t)a.cap + m] = 0.0f;   // row 3: no raw[...,4] cotangent at lattice points
     }
-    const float2 f = hash_level_rt(lt, (int)level, table, xn[0], xn[1], xn[2]);
-    if (a.cap != 0) reinterpret_cast<float2*>(feat)[(size_t)level * n3 + m] = f;
-    else reinterpret_cast<float2*>(feat + (size_t)m * kFeat)[level] = f;
+    HalfCorners h[kTvLevels];
+#pragma unroll
+    for (int g = 0; g < kTvLevels; ++g) h[g] = hash_level_half_index(lt, (int)group * kTvLevels + g, xn[0], xn[1], xn[2], xh);
+    float2 v[kTvLevels][4];
+#pragma unroll
+    for (int g = 0; g < kTvLevels; ++g) hash_level_half_load(lt, (int)group * kTvLevels + g, table, h[g], v[g]);
+#pragma unroll
+    for (int g = 0; g < kTvLevels; ++g) {
+        const uint32_t level = group * kTvLevels + g;
+        const float2 part = hash_level_half_blend(h[g], v[g]);
+        // sum of the two x halves, in the forward's order (x offset 0 first)
+        float lo_x = part.x, hi_x = part.x, lo_y = part.y, hi_y = part.y;
+        swap32(lo_x, hi_x);                   // lo_x = (own | partner's) for the low half ... only the low half's result is stored
+        swap32(lo_y, hi_y);
+        const float2 f = make_float2(lo_x + hi_x, lo_y + hi_y);
+        if (xh == 0u && valid) {
+            if (a.cap != 0) reinterpret_cast<float2*>(feat)[(size_t)level * n3 + m] = f;
+            else reinterpret_cast<float2*>(feat + (size_t)m * kFeat)[level] = f;
+        }
+    }
 }
 
 #ifndef NARUTO_GATHER_GROUP

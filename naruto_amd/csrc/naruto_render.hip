@@ -44,19 +44,38 @@ __device__ __forceinline__ void sample_z_ray(uint32_t n, const float* __restrict
             else us[s] = use_near_far ? linspace_at(near_, far_, nr, s - nu) : __fadd_rn(linspace_at(-range_d, range_d, nr, s - nu), d);
         }
         wave_lds_sync();
+        // Both lists are arithmetic progressions (non-decreasing), so "how many of the other list lie below v" is a division away;
+        // the estimate is then walked to the exact count by comparing the ACTUAL list values (the comparisons decide, as in a
+        // merge: ties keep the uniform element first), one or two LDS reads instead of a 32-step scan / 7-step binary search.
+        const float u0 = nu ? us[0] : 0.0f, u_step = nu > 1 ? (us[nu - 1] - us[0]) / (float)(nu - 1) : 0.0f;
+        const float r0 = nr ? us[nu] : 0.0f, r_step = nr > 1 ? (us[nu + nr - 1] - us[nu]) / (float)(nr - 1) : 0.0f;
         for (uint32_t s = lane; s < S; s += 64) {
             const float v = us[s];
             uint32_t rank;
-            if (s < nu) {                                 // uniform element: rank = i + #{R < U[i]}
-                rank = s;
-                for (uint32_t k = 0; k < nr; ++k) rank += us[nu + k] < v ? 1u : 0u;
-            } else {                                      // near-surface element: rank = k + #{U <= R[k]} (binary search)
-                uint32_t lo = 0, hi = nu;
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (us[mid] <= v) lo = mid + 1; else hi = mid;
+            if (u_step < 0.0f || r_step < 0.0f) {         // far < near or range_d < 0 (no shipped config): the plain scans
+                if (s < nu) {
+                    rank = s;
+                    for (uint32_t k = 0; k < nr; ++k) rank += us[nu + k] < v ? 1u : 0u;
+                } else {
+                    uint32_t lo = 0, hi = nu;
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (us[mid] <= v) lo = mid + 1; else hi = mid;
+                    }
+                    rank = (s - nu) + lo;
                 }
-                rank = (s - nu) + lo;
+            } else if (s < nu) {                          // uniform element: rank = i + #{R < U[i]}
+                const float e = (v - r0) / r_step;        // R[k] < v  <=>  k < e (up to rounding)
+                uint32_t c = !(e > 0.0f) ? 0u : (e >= (float)nr ? nr : (uint32_t)e);         // NaN (zero step) -> 0, then walked up
+                while (c < nr && us[nu + c] < v) ++c;
+                while (c > 0u && !(us[nu + c - 1u] < v)) --c;
+                rank = s + c;
+            } else {                                      // near-surface element: rank = k + #{U <= R[k]}
+                const float e = (v - u0) / u_step + 1.0f; // U[i] <= v  <=>  i + 1 <= e (up to rounding)
+                uint32_t c = !(e > 0.0f) ? 0u : (e >= (float)nu ? nu : (uint32_t)e);
+                while (c < nu && us[c] <= v) ++c;
+                while (c > 0u && !(us[c - 1u] <= v)) --c;
+                rank = (s - nu) + c;
             }
             zs[rank] = v;
         }

@@ -172,6 +172,19 @@ def kernel_table(tr, rays, cfg, iters: int):
     bwd_ms = events_ms(lambda: _lib.check(lib.naruto_train_backward(h.ptr, CT.byref(ts.ps), CT.byref(t), CT.byref(ts.gs), ts.flags, None, st())), iters)
     # the field query in the launch shape the ITERATION uses (one wave per ray, depth-ordered early termination when S % 64 == 0)
     qit_ms = events_ms(lambda: _lib.check(lib.naruto_debug_train_query_fwd(h.ptr, CT.byref(ts.ps), CT.byref(t), st())), iters)
+    # the table scatter in the launch shape the ITERATION uses: k_hash_scatter_lds alone over the list the backward above left behind
+    # (smoothness lattice + active samples; level units + uncertainty-grid units).  Algorithmic bytes: SURVEY 8(d) counts the
+    # backward as a read-modify-write of the gather term -- per list point 2 x (16 levels x 8 corners x 8 B), per active sample
+    # 2 x 32 B of uncertainty-grid corners -- plus what the launch streams in per list point: 128 B of feature cotangents, 16 B of
+    # position + raw[...,4] cotangent.  Fields with binned levels (T > 2^17) spread the scatter over five kernels: no such row.
+    n_act = int(ts.n_active.item())
+    n_lat = (int(trc["smooth_pts"]) - 1) ** 3
+    if lib.naruto_debug_train_scatter(h.ptr, CT.byref(ts.ps), CT.byref(t), st()) == 0:
+        sc_it_ms = events_ms(lambda: _lib.check(lib.naruto_debug_train_scatter(h.ptr, CT.byref(ts.ps), CT.byref(t), st())), iters)
+        sc_it_bytes = (n_act + n_lat) * (2 * 16 * 8 * 8 + 128 + 16) + n_act * 2 * 32
+        rows.append({"kernel": "k_hash_scatter_lds as launched by the iteration", "ms": round(sc_it_ms, 5), "alg_bytes": int(sc_it_bytes), "alg_flops": 0,
+                     "GBps": round(sc_it_bytes / sc_it_ms / 1e6, 1), "TFLOPs": 0.0, "bound": None, "list_points": n_act + n_lat,
+                     "alg_bytes_all_samples": int((M + n_lat) * (2 * 16 * 8 * 8 + 128 + 16) + M * 2 * 32)})
     for name, ms in (("naruto_train_forward (4 launches, eager)", fwd_ms), ("naruto_train_backward (eager)", bwd_ms),
                      ("k_query_fwd<color> as launched by the iteration", qit_ms)):
         rows.append({"kernel": name, "ms": round(ms, 5), "alg_bytes": 0, "alg_flops": 0, "GBps": 0.0, "TFLOPs": 0.0, "bound": None})
@@ -506,6 +519,12 @@ def main():
         if not args.no_kernels:
             rows = kernel_table(tr, rays, cfg, max(10, min(args.steps, 50)))
             dom = max((r for r in rows if r["bound"] is not None), key=lambda r: r["ms"])
+            # the dominant kernel OF THE ITERATION: the table scatter when its launch (iteration shape, timed alone) outlasts the field
+            # query's launch of the iteration; otherwise the largest modular row (the field query over all samples)
+            sc_it = next((r for r in rows if r["kernel"].startswith("k_hash_scatter_lds as launched")), None)
+            q_it = next(r for r in rows if r["kernel"].startswith("k_query_fwd<color> as launched"))
+            if sc_it is not None and sc_it["ms"] >= q_it["ms"]:
+                dom = dict(sc_it, kernel="k_hash_scatter_lds", bound="hbm", launch="as launched by the iteration (lattice + active samples, level + uncertainty-grid units)")
             if dom["bound"] == "mfma":
                 roof = {"bound": "mfma", "achieved": dom["TFLOPs"], "peak": mfma_peak, "unit": "TFLOP/s",
                         "frac": round(dom["TFLOPs"] / mfma_peak, 4), "traffic": None}
@@ -517,6 +536,12 @@ def main():
             roof["alg_bytes"] = dom["alg_bytes"]
             if "launch" in dom:
                 roof["launch"] = dom["launch"]
+            if "alg_bytes_all_samples" in dom:
+                # SURVEY 8(d)'s figure over ALL samples of the batch (the reference scatters every sample; this launch only the active
+                # prefix + the lattice): reported beside, never as frac
+                roof["list_points"] = dom["list_points"]
+                roof["alg_bytes_all_samples"] = dom["alg_bytes_all_samples"]
+                roof["frac_all_samples"] = round(dom["alg_bytes_all_samples"] / dom["ms"] / 1e6 / HBM_PEAK_GBS, 4)
             if "alg_bytes_incl_saved" in dom:
                 b2 = dom["alg_bytes_incl_saved"]
                 roof["alg_bytes_incl_saved"] = b2

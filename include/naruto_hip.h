@@ -408,6 +408,9 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
 /* Measurement aid (bench.py): ONLY the field-query launch of naruto_train_forward, in the launch shape the iteration uses (one wave
  * per ray with early termination when S % 64 == 0); t->z_vals must hold a previous forward's depths. */
 int naruto_debug_train_query_fwd(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, void* stream);
+/* profiling (bench.py's roofline): k_hash_scatter_lds alone, over the point list the preceding naruto_train_backward left in the
+ * workspace, in the launch shape of the iteration; writes the scatter's partial tables only (no gradient, no parameter). */
+int naruto_debug_train_scatter(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, void* stream);
 
 /* Hardware self-checks used by the GPU tests: the MFMA / permlane layouts the kernels rely on.
  * out: device buffer of 64*16 floats; returns 0 and fills out (see tests/test_gpu_parity.py: test_mfma_layout, test_permlane32_swap). */

@@ -172,6 +172,7 @@ SIGNATURES = {
     "naruto_train_forward": (_I, [_V, C.POINTER(NarutoParams), C.POINTER(NarutoTrainStep), _I, _V]),
     "naruto_train_finalize": (_I, [_V, C.POINTER(NarutoTrainStep), _V]),
     "naruto_debug_train_query_fwd": (_I, [_V, C.POINTER(NarutoParams), C.POINTER(NarutoTrainStep), _V]),
+    "naruto_debug_train_scatter": (_I, [_V, C.POINTER(NarutoParams), C.POINTER(NarutoTrainStep), _V]),
     "naruto_render_fwd": (_I, [_V, C.POINTER(NarutoParams), C.POINTER(NarutoRender), _V]),
     "naruto_train_backward": (_I, [_V, C.POINTER(NarutoParams), C.POINTER(NarutoTrainStep), C.POINTER(NarutoGrads), _U32,
                                    C.POINTER(NarutoFusedAdam), _V]),

@@ -811,6 +811,27 @@ int naruto_debug_train_query_fwd(const NarutoField* f, const NarutoParams* p, co
     return launch_train_query(f, p, t, (hipStream_t)stream);
 }
 
+// profiling: k_hash_scatter_lds ALONE over the point list the last naruto_train_backward left in the workspace, in the launch shape
+// the iteration uses (lattice front + active samples, level units + uncertainty-grid units); writes only the partial tables
+int naruto_debug_train_scatter(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, void* stream) {
+    if (int rc = train_check(f, p, t, "debug_train_scatter")) return rc;
+    if (f->bplan.n_levels != 0) return fail(NARUTO_ERR_INVALID, "debug_train_scatter: this field has binned levels (the tiled launch is not its whole scatter)");
+    const uint32_t N = t->n_rays, S = t->n_samples_d + t->n_range_d, M = N * S;
+    const TrainWs w = train_ws(f, t);
+    const uint32_t cap = list_cap(M + w.n3);
+    const BwdWs bw = bwd_ws(f, w.bwd, cap);
+    const uint32_t n_front = t->smooth_points != 0 ? w.n3 : 0u;
+    PointSrc pss{};
+    pss.xsoa = bw.x_soa;
+    pss.M = cap;
+    pss.S = 1;
+    const uint32_t* cnt = n_front > 0 ? bw.n_total : t->n_active;
+    const float* unc_g = f->plan.n_uncert != 0 ? bw.x_soa + 3u * (size_t)cap : nullptr;
+    // d_table / d_uncert only select the roles here: without the reduce nothing is written through them
+    return launch_scatter(f, pss, cap, bw.d_feat, (size_t)2, (size_t)2 * (size_t)cap, const_cast<float*>(p->table), bw.scatter_ws, (hipStream_t)stream, cnt, nullptr, 1, false,
+                          nullptr, unc_g, unc_g != nullptr ? const_cast<float*>(p->uncert_grid) : nullptr, n_front);
+}
+
 int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, const NarutoGrads* g, uint32_t flags,
                           const NarutoFusedAdam* opt, void* stream) {
     if (int rc = train_check(f, p, t, "train_backward")) return rc;

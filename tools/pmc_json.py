@@ -16,7 +16,7 @@ import sys
 NAMES = {"k_query_fwd<color>": ["k_query_fwdILb1"], "k_query_bwd": ["k_query_bwd"],
          "k_hash_scatter+reduce+k_wgrad_reduce": ["k_hash_scatter_lds", "k_scatter_reduce", "k_hash_scatter_atomic", "k_bwd_post", "k_wgrad_reduce", "k_bin_count",
                                                   "k_bin_colscan", "k_bin_start", "k_bin_fill", "k_bin_apply"],
-         "k_bin_fill": ["k_bin_fill"], "k_bin_apply": ["k_bin_apply"], "k_bin_count": ["k_bin_count"], "k_bwd_finish": ["k_bwd_finish"], "k_tv_encode": ["k_tv_encode"],
+         "k_hash_scatter_lds": ["k_hash_scatter_lds"], "k_bin_fill": ["k_bin_fill"], "k_bin_apply": ["k_bin_apply"], "k_bin_count": ["k_bin_count"], "k_bwd_finish": ["k_bwd_finish"], "k_tv_encode": ["k_tv_encode"],
          "k_loss_stage": ["k_loss_stage"], "k_composite_bwd<loss>": ["k_composite_bwdILb1"], "k_adam_multi": ["k_adam_multi"]}
 
 

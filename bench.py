@@ -453,7 +453,14 @@ def main():
     # eager: the eager step is bound by the host).  NARUTO_GRAPH_DIST=eager|whole selects the other forms.
     use_graph = (not args.no_graph) and (group is None or os.environ.get("NARUTO_GRAPH_DIST", "segmented") in ("segmented", "whole"))
     if use_graph:
-        tr.capture(n_rays, smooth=True, n_rays_total=n_total)
+        try:
+            tr.capture(n_rays, smooth=True, n_rays_total=n_total)
+        except Exception as e:                      # data parallel only: a failed capture must not cost the run -- eager launches instead
+            if group is None:
+                raise
+            print(f"[bench] rank {rank}: graph capture failed ({e!r}); continuing with eager launches", file=sys.stderr, flush=True)
+            tr._graphs, tr._static = None, None
+            torch.cuda.synchronize()
     all_rays = bench_rays(cfg, n_total)
     rays = {k: torch.from_numpy(v[lo:hi]).to(dev) for k, v in all_rays.items()}
     del all_rays
@@ -506,7 +513,7 @@ def main():
                                    f"({n_total} rays per step over {world} GPU), hash L16 F2 T2^{cfg['grid']['hash_size']} ({n_params * 4 / 1e6:.1f} MB of parameters), "
                                    f"MLP 2x32 {args.mlp}, uncert grid; one global_BA mapping iteration incl. smoothness + Adam",
                        "rays_per_gpu": n_rays, "rays_per_step": n_total, "samples_per_ray": S_tot, "parallelism": f"ray-sharded dp{world}",
-                       "optimizer": "torch.optim.Adam" if args.torch_adam else "fused HIP Adam", "hip_graph": bool(use_graph)},
+                       "optimizer": "torch.optim.Adam" if args.torch_adam else "fused HIP Adam", "hip_graph": bool(use_graph and tr._graphs is not None)},
         }
         # whole-step roofline figures: per ray S x 3168 B + 44 B and S x 31104 FLOP; per step Adam's 28 B / parameter
         mfma_peak = FP32_MFMA_PEAK_TF if args.mlp == "fp32" else BF16_MFMA_PEAK_TF

@@ -29,7 +29,10 @@ namespace naruto {
 constexpr int kBinLog2 = 13;
 constexpr uint32_t kBinEntries = 1u << kBinLog2;         // entries per bin: x 2 features x int64 = 128 KB of LDS
 constexpr int kMaxBinsPerLevel = 2048;                   // log2_hashmap_size <= 24
-constexpr int kBinRound = 512;                           // points sorted per LDS round of k_bin_fill
+#ifndef NARUTO_BIN_ROUND
+#define NARUTO_BIN_ROUND 1024
+#endif
+constexpr int kBinRound = NARUTO_BIN_ROUND;              // points sorted per LDS round of k_bin_fill (= its threads)
 constexpr int kBinThreads = 256;
 constexpr int kBinMaxRows = 256;
 constexpr int kBinApplyThreads = 1024;
@@ -133,8 +136,10 @@ __global__ __launch_bounds__(1024) void k_bin_start(const uint32_t* __restrict__
     if (threadIdx.x == 0) starts[n_bins] = carry;
 }
 
-// k_bin_fill: 512 threads, one point per thread and round.  Dynamic LDS: | items[kBinRound * 8] | hist[nb_max] | off[nb_max] |
-// base[nb_max] | wave_tot[8] | -- 54 KB at 512 bins per level (T = 2^22), so two workgroups (16 waves) share a CU.  While an
+// k_bin_fill: kBinRound threads, one point per thread and round.  Dynamic LDS: | items[kBinRound * 8] | hist[nb_max] | off[nb_max] |
+// base[nb_max] | wave_tot[16] | -- 102 KB at 1 024 points per round and 512 bins per level (T = 2^22): one 16-wave workgroup per CU.
+// (Rounds of 512 points, two workgroups per CU: a (round, bin) run is 8 items = 96 B on average and ends in partly written lines --
+// 5.0 GB written for 3.6 GB of items; 1 024-point rounds: 2.08 -> 1.77 ms at T = 2^22.)  While an
 // item sits in LDS its first word carries the bin next to the entry (rel | bin << 13); the bin is stripped on the way out.
 constexpr int kBinFillThreads = kBinRound;
 inline size_t bin_fill_lds_bytes(uint32_t nb_max) { return (size_t)kBinRound * 8u * sizeof(BinItem) + 3u * (size_t)nb_max * sizeof(uint32_t) + 64u; }

@@ -178,6 +178,18 @@ typedef struct NarutoExtraPoints {
  * or its MLP_ONLY phase) then replaces naruto_train_finalize | composite backward | compaction by the same single launch, whose
  * extra workgroup turns the sums into losses[0..7] and the total.  Do not call naruto_train_finalize in addition. */
 #define NARUTO_TRAIN_BWD_SUMS_GIVEN 32u
+/* The model's sub-modules called on their own (forward only; the query entry points above never need them -- they evaluate all of
+ * this in registers).  naruto_oneblob_fwd = embedpos_fn(x) (tcnn OneBlob, 16 bins): x [M,3] -> out [M,48].
+ * naruto_decoder_fwd, by `part`:
+ *   NARUTO_DECODER_FULL      decoder(embed, embed_pos) (decoder.py:99-116):  a = embed [M,33] (channel 0 = uncertainty sample, 1..32 =
+ *                            hash features), b = embed_pos [M,48] -> out [M,5] = (rgb pre-sigmoid, sdf, the uncertainty channel)
+ *   NARUTO_DECODER_SDF_NET   sdf_net(cat(embed, embed_pos)) (decoder.py:29-41): a = [M,81], b unused -> out [M,17] = (sdf, geo15, uncertainty)
+ *   NARUTO_DECODER_COLOR_NET color_net(cat(embed_pos, geo)):                    a = [M,63], b unused -> out [M,3] (pre-sigmoid)          */
+#define NARUTO_DECODER_FULL 0
+#define NARUTO_DECODER_SDF_NET 1
+#define NARUTO_DECODER_COLOR_NET 2
+int naruto_oneblob_fwd(const NarutoField* f, uint32_t M, const float* x, float* out, void* stream);
+int naruto_decoder_fwd(const NarutoField* f, const NarutoParams* p, uint32_t M, int part, const float* a, const float* b, float* out, void* stream);
 size_t naruto_query_bwd_workspace(const NarutoField* f, uint32_t M);
 int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, const NarutoPoints* pts,
                      const float* feat_save, const float* d_raw, const float* d_geo,

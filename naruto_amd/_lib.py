@@ -14,7 +14,7 @@ from typing import List, Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NARUTO_HIP_LIB") or os.path.join(_HERE, "libnaruto_hip.so")      # override: kernel experiments only
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["naruto_api.hip", "naruto_field.hip", "naruto_binned.hip", "naruto_render.hip", "naruto_rays.hip", "naruto_train.hip", "naruto_renderfused.hip", "naruto_planner.hip", "naruto_mesh.hip",
+SOURCES = ["naruto_api.hip", "naruto_field.hip", "naruto_binned.hip", "naruto_render.hip", "naruto_rays.hip", "naruto_train.hip", "naruto_renderfused.hip", "naruto_planner.hip", "naruto_mesh.hip", "naruto_parts.hip",
            "naruto_mc_table.inc", "naruto_common.h"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "naruto_hip.h")
 
@@ -171,6 +171,8 @@ SIGNATURES = {
     "naruto_train_workspace": (C.c_size_t, [_V, C.POINTER(NarutoTrainStep)]),
     "naruto_train_forward": (_I, [_V, C.POINTER(NarutoParams), C.POINTER(NarutoTrainStep), _I, _V]),
     "naruto_train_finalize": (_I, [_V, C.POINTER(NarutoTrainStep), _V]),
+    "naruto_oneblob_fwd": (_I, [_V, C.c_uint32, _V, _V, _V]),
+    "naruto_decoder_fwd": (_I, [_V, C.POINTER(NarutoParams), C.c_uint32, C.c_int, _V, _V, _V, _V]),
     "naruto_debug_train_query_fwd": (_I, [_V, C.POINTER(NarutoParams), C.POINTER(NarutoTrainStep), _V]),
     "naruto_debug_train_scatter": (_I, [_V, C.POINTER(NarutoParams), C.POINTER(NarutoTrainStep), _V]),
     "naruto_render_fwd": (_I, [_V, C.POINTER(NarutoParams), C.POINTER(NarutoRender), _V]),

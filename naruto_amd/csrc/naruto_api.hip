@@ -14,6 +14,7 @@
 #include "naruto_renderfused.hip"
 #include "naruto_planner.hip"
 #include "naruto_mesh.hip"
+#include "naruto_parts.hip"
 
 using namespace naruto;
 
@@ -414,6 +415,24 @@ int naruto_hash_encode_fwd(const NarutoField* f, uint32_t M, const float* x, con
     hipLaunchKernelGGL(k_hash_encode_fwd, dim3((M + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, f->lt, x,
                        reinterpret_cast<const float2*>(table), M, feat);
     return check_launch("hash_encode_fwd");
+}
+
+int naruto_oneblob_fwd(const NarutoField* f, uint32_t M, const float* x, float* out, void* stream) {
+    if (f == nullptr || x == nullptr || out == nullptr) return fail(NARUTO_ERR_INVALID, "oneblob_fwd: NULL argument");
+    if (M == 0) return NARUTO_OK;
+    hipLaunchKernelGGL(k_oneblob_fwd, dim3((M + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, M, x, out);
+    return check_launch("oneblob_fwd");
+}
+
+int naruto_decoder_fwd(const NarutoField* f, const NarutoParams* p, uint32_t M, int part, const float* a, const float* b, float* out, void* stream) {
+    if (f == nullptr || p == nullptr || a == nullptr || out == nullptr) return fail(NARUTO_ERR_INVALID, "decoder_fwd: NULL argument");
+    if (part < 0 || part > 2) return fail(NARUTO_ERR_INVALID, "decoder_fwd: part must be NARUTO_DECODER_FULL, _SDF_NET or _COLOR_NET");
+    if (part == NARUTO_DECODER_FULL && b == nullptr) return fail(NARUTO_ERR_INVALID, "decoder_fwd: the full decoder takes embed and embed_pos");
+    if (p->sdf_w0 == nullptr || p->sdf_w1 == nullptr || p->col_w0 == nullptr || p->col_w1 == nullptr) return fail(NARUTO_ERR_INVALID, "decoder_fwd: NULL weights");
+    if (M == 0) return NARUTO_OK;
+    const uint32_t lda = part == NARUTO_DECODER_FULL ? 1u + kFeat : (part == NARUTO_DECODER_SDF_NET ? 1u + kFeat + kPos : (uint32_t)kInCol);
+    hipLaunchKernelGGL(k_decoder_parts, dim3((M + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, M, part, a, lda, b, (uint32_t)kPos, *p, out);
+    return check_launch("decoder_fwd");
 }
 
 size_t naruto_scatter_workspace(const NarutoField* f, uint32_t M) {

@@ -5,7 +5,7 @@ dicts, same parameter and state_dict names, but every operator runs as hand-writ
 libnaruto_hip.so.  There is no PyTorch fallback: tensors must live on the GPU.
 
 Attribute surface kept: forward, render_rays, raw2outputs, sdf2weights,
-query_sdf, query_color, query_color_sdf, run_network, calc_embedding-free fused path,
+query_sdf, query_color, query_color_sdf, run_network, calc_embedding, render_surface_color,
 get_uncert_grid, embed_fn / embedpos_fn / decoder / color_net / sdf_net sub-modules, uncert_grid.
 """
 
@@ -34,39 +34,55 @@ class _HashGridEncoding(nn.Module):
 
 
 class _OneBlobEncoding(nn.Module):
-    """Parameter-free; exists so that ``embedpos_fn.params`` (empty) appears in the state_dict as with tcnn.
-    The encoding itself is fused into the query kernels."""
+    """Parameter-free; ``embedpos_fn.params`` (empty) appears in the state_dict as with tcnn.  The fused query kernels evaluate the
+    encoding in registers; called on its own (forward only) it runs ``naruto_oneblob_fwd``."""
 
-    def __init__(self, n_bins: int):
+    def __init__(self, owner: "NarutoFieldHIP", n_bins: int):
         super().__init__()
         self.params = nn.Parameter(torch.zeros(0))
         self.n_bins = n_bins
         self.n_output_dims = 3 * n_bins
+        object.__setattr__(self, "_owner", owner)
 
     def forward(self, x):
-        raise NotImplementedError("OneBlob is evaluated inside the fused query kernels; use query_sdf / query_color_sdf")
+        return ops.oneblob_encode(self._owner._handle(), x)
 
 
 class _Mlp(nn.Module):
-    """Weight holder with the reference's module path ``.model.{0,2}.weight`` (bias-free Linear, ReLU, Linear)."""
+    """Weight holder with the reference's module path ``.model.{0,2}.weight`` (bias-free Linear, ReLU, Linear).  The fused query
+    kernels evaluate the MLPs in registers; called on its own (forward only, reference decoder.py:29-41 for the sdf net) it runs
+    ``naruto_decoder_fwd``."""
 
-    def __init__(self, d_in: int, d_hidden: int, d_out: int):
+    def __init__(self, owner: "NarutoFieldHIP", part: int, d_in: int, d_hidden: int, d_out: int):
         super().__init__()
         self.model = nn.Sequential(nn.Linear(d_in, d_hidden, bias=False), nn.ReLU(inplace=True),
                                    nn.Linear(d_hidden, d_out, bias=False))
+        self._part = part
+        object.__setattr__(self, "_owner", owner)
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("the MLPs are evaluated inside the fused query kernels")
+    def forward(self, x, return_geo=True):
+        o = self._owner
+        ops._forward_only(x, *o._params().values(), what="sdf_net" if self._part == 1 else "color_net")
+        out = ops.decoder_part(o._handle(), o._params(), self._part, x)
+        if self._part == 1 and not return_geo:
+            return out[..., :1]
+        return out
 
 
 class _Decoder(nn.Module):
-    def __init__(self, in_sdf: int, in_col: int, hidden: int, hidden_col: int, geo: int):
-        super().__init__()
-        self.color_net = _Mlp(in_col, hidden_col, 3)
-        self.sdf_net = _Mlp(in_sdf, hidden, 1 + geo)
+    """``ColorSDFNet_v2_Naruto`` (reference decoder.py:81-116): holds the two nets; ``decoder(embed, embed_pos)`` on its own (forward
+    only) runs ``naruto_decoder_fwd``."""
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("the decoder is evaluated inside the fused query kernels")
+    def __init__(self, owner: "NarutoFieldHIP", in_sdf: int, in_col: int, hidden: int, hidden_col: int, geo: int):
+        super().__init__()
+        self.color_net = _Mlp(owner, 2, in_col, hidden_col, 3)
+        self.sdf_net = _Mlp(owner, 1, in_sdf, hidden, 1 + geo)
+        object.__setattr__(self, "_owner", owner)
+
+    def forward(self, embed, embed_pos):
+        o = self._owner
+        ops._forward_only(embed, embed_pos, *o._params().values(), what="decoder")
+        return ops.decoder_part(o._handle(), o._params(), 0, embed, embed_pos)
 
 
 class NarutoFieldHIP(nn.Module):
@@ -92,9 +108,9 @@ class NarutoFieldHIP(nn.Module):
         n_params = self._make_handle((1, 1, 1)).n_params
         self.input_ch = self.N_LEVELS * self.N_FEATURES
         self.input_ch_pos = 3 * config['pos']['n_bins']
-        self.embedpos_fn = _OneBlobEncoding(config['pos']['n_bins'])
+        self.embedpos_fn = _OneBlobEncoding(self, config['pos']['n_bins'])
         self.embed_fn = _HashGridEncoding(self, n_params, self.input_ch)
-        self.decoder = _Decoder(self.input_ch + self.input_ch_pos, self.input_ch_pos + dec['geo_feat_dim'],
+        self.decoder = _Decoder(self, self.input_ch + self.input_ch_pos, self.input_ch_pos + dec['geo_feat_dim'],
                                 dec['hidden_dim'], dec['hidden_dim_color'], dec['geo_feat_dim'])
         # the reference re-registers the two nets at top level (batchify(fn, None) returns the module itself)
         self.color_net = self.decoder.color_net
@@ -185,6 +201,15 @@ class NarutoFieldHIP(nn.Module):
         if not return_geo:
             return sdf
         return sdf, torch.reshape(geo, lead + [geo.shape[-1]])
+
+    def calc_embedding(self, x):
+        """scene_rep.py:58-64: embed_fn(x) with the trilinear sample of the uncertainty grid in front -> [M,33] (channel 0 = uncertainty,
+        x<->z quirk of the reference's grid_sample call included).  The query functions fuse this; on its own it is two launches
+        (differentiable w.r.t. the table through ``embed_fn``; the uncertainty channel comes out detached)."""
+        flat = torch.reshape(x, [-1, x.shape[-1]])
+        with torch.no_grad():
+            u = self.query_sdf(flat, return_uncert=True)[..., 1:2]
+        return torch.cat([u, self.embed_fn(flat)], dim=1)
 
     def query_color_sdf(self, query_points):
         """scene_rep.py:132-148: -> raw [M,5] = (rgb pre-sigmoid, sdf, uncert_raw)."""

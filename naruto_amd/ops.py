@@ -163,6 +163,44 @@ def render_fused(handle: "FieldHandle", params: Dict[str, torch.Tensor], rays_o,
 
 
 # ---------------------------------------------------------------------------------------------------
+# The model's sub-modules called on their own (forward only): embedpos_fn(x), decoder(embed, embed_pos), sdf_net(x), color_net(x)
+# ---------------------------------------------------------------------------------------------------
+def _forward_only(*tensors, what: str):
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise NotImplementedError(f"{what} on its own is forward only (call it under torch.no_grad()); gradients flow through "
+                                  "forward / render_rays / query_sdf / query_color_sdf, which evaluate it inside the fused kernels")
+
+
+def oneblob_encode(handle: "FieldHandle", x: torch.Tensor) -> torch.Tensor:
+    """embedpos_fn(x): tcnn OneBlob, 16 bins per coordinate.  x [..., 3] (normalised) -> [M, 48]."""
+    _forward_only(x, what="embedpos_fn")
+    lib = _lib.load()
+    x = _f32c(x.detach().reshape(-1, 3), "x")
+    out = torch.empty(x.shape[0], 48, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.naruto_oneblob_fwd(handle.ptr, x.shape[0], _p(x), _p(out), _stream()), "naruto_oneblob_fwd")
+    return out
+
+
+def decoder_part(handle: "FieldHandle", params: Dict[str, torch.Tensor], part: int, a: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """part 0: decoder(embed [M,33], embed_pos [M,48]) -> [M,5]; 1: sdf_net([M,81]) -> [M,17]; 2: color_net([M,63]) -> [M,3]."""
+    lib = _lib.load()
+    width_a, width_out = {0: (33, 5), 1: (81, 17), 2: (63, 3)}[part]
+    a = _f32c(a.detach().reshape(-1, a.shape[-1]), "input")
+    if a.shape[1] != width_a:
+        raise ValueError(f"expected {width_a} input channels, got {a.shape[1]}")
+    if b is not None:
+        b = _f32c(b.detach().reshape(-1, b.shape[-1]), "embed_pos")
+        if b.shape != (a.shape[0], 48):
+            raise ValueError(f"embed_pos: expected [{a.shape[0]}, 48], got {list(b.shape)}")
+    out = torch.empty(a.shape[0], width_out, dtype=torch.float32, device=a.device)
+    ps = _params_struct({k: _f32c(v.detach(), k) for k, v in params.items()})
+    with torch.cuda.device(a.device):
+        check(lib.naruto_decoder_fwd(handle.ptr, C.byref(ps), a.shape[0], part, _p(a), _p(b), _p(out), _stream()), "naruto_decoder_fwd")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
 # A3 alone: embed_fn(x)
 # ---------------------------------------------------------------------------------------------------
 class _HashEncode(torch.autograd.Function):

@@ -1955,6 +1955,38 @@ def test_extract_mesh_golden(gpu, tmp_path):
             assert (np.abs(got - want).max(-1) > 0).mean() < 0.02          # a jet bin edge may flip with the 1e-6 noise of the uncertainty
 
 
+def test_submodules_called_on_their_own(gpu):
+    """model.embedpos_fn(x), model.calc_embedding(x), model.decoder(embed, embed_pos), model.sdf_net(x), model.color_net(x): the
+    reference's sub-modules as standalone forward operators (scene_rep.py:58-64, decoder.py:29-41, 99-116) against the oracle's
+    pieces, and their composition against the fused query; with autograd enabled they refuse (the differentiable path is the fused one)."""
+    cfg = H.office_cfg(12)
+    ora = H.make_oracle(cfg, 0.25, 83).eval()
+    m = H.make_hip_from_oracle(cfg, ora, gpu).eval()
+    rs = np.random.RandomState(83)
+    x = torch.from_numpy(rs.uniform(-0.1, 1.1, (1234, 3)).astype(np.float32))
+    xg = x.to(gpu)
+    with torch.no_grad():
+        pos = m.embedpos_fn(xg)
+        H.assert_close(pos, S.oneblob_encode(x, 16), 1e-6, "embedpos_fn", rel=2e-6)           # fp32 evaluation of the quartic cdf: a few ulp at 0.75
+        emb = m.calc_embedding(xg)
+        H.assert_close(emb, ora.calc_embedding(x), TOL_OUT, "calc_embedding", rel=1e-5)
+        h_o = ora.sdf_net(ora.calc_embedding(x), S.oneblob_encode(x, 16))
+        h = m.sdf_net(torch.cat([emb, pos], -1))
+        assert h.shape == (1234, 17)
+        H.assert_close(h, h_o, TOL_OUT, "sdf_net", rel=1e-5)
+        assert torch.equal(m.sdf_net(torch.cat([emb, pos], -1), return_geo=False), h[:, :1])
+        raw = m.decoder(emb, pos)
+        H.assert_close(raw, ora.query_color_sdf(x), TOL_OUT, "decoder", rel=1e-5)
+        H.assert_close(raw, m.query_color_sdf(xg), TOL_OUT, "decoder vs the fused query", rel=1e-5)
+        rgb = m.color_net(torch.cat([pos, h[:, 1:16]], -1))
+        H.assert_close(rgb, raw[:, :3], 1e-7, "color_net", rel=1e-6)
+    with pytest.raises(NotImplementedError):
+        m.decoder(emb, pos)                              # parameters require grad and autograd is on
+    with pytest.raises(ValueError):
+        with torch.no_grad():
+            m.sdf_net(emb)
+
+
 def test_render_surface_color(gpu):
     """Co-SLAM's render_surface_color (the mesh colour function under mesh.render_color): n_range_d samples at linspace(-trunc, trunc)
     along a surface normal, run_network + raw2outputs -> rgb.  The one-launch no-grad form and the differentiable operator chain

@@ -87,7 +87,7 @@ int ray_lds_attr() {
     return NARUTO_OK;
 }
 
-constexpr uint32_t kBwdMaxBlocks = 512;     // fp32: one 145 KB-LDS block per CU; bf16 mode: two 53 KB blocks per CU
+constexpr uint32_t kBwdMaxBlocks = 512;     // fp32: one 145 KB-LDS block per CU; bf16 mode: NARUTO_BWD_BF_MINWAVES 53 KB blocks per CU
 
 inline size_t al256(size_t b) { return (b + 255u) / 256u * 256u; }
 inline LevelSplits level_splits(const NarutoField* f) { LevelSplits ls; memcpy(ls.s, f->plan.s_lvl, sizeof(ls.s)); return ls; }
@@ -565,8 +565,10 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
     const uint32_t n_tiles = bf ? (M + 63u) / 64u : (M + 31u) / 32u;
     const uint32_t waves = bf ? 4u : (uint32_t)kBwdWaves;
     uint32_t blocks = (n_tiles + waves - 1u) / waves;
-    uint32_t max_blocks = cu_count(f) * (bf ? 2u : 1u);
+    uint32_t max_blocks = cu_count(f) * (bf ? (uint32_t)NARUTO_BWD_BF_MINWAVES : 1u);
     if (max_blocks > kBwdMaxBlocks) max_blocks = kBwdMaxBlocks;
+    static const int dbg_blocks = getenv("NARUTO_DEBUG_BWD_BLOCKS") ? atoi(getenv("NARUTO_DEBUG_BWD_BLOCKS")) : 0;       // profiling knob
+    if (dbg_blocks > 0 && (uint32_t)dbg_blocks < max_blocks) max_blocks = (uint32_t)dbg_blocks;
     if (blocks > max_blocks) blocks = max_blocks;
     const PointSrc ps = make_points(pts);
     static bool attr_set = false;

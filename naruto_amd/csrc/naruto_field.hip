@@ -1809,8 +1809,12 @@ __device__ __forceinline__ f32x16 bwd_tile_bf(const BwdLdsBf& L, DwTiles& dw, co
     return df;
 }
 
+// Waves per SIMD of k_query_bwd_bf = its workgroups per CU.  Measured (headline batch, after the float atomics and the LDS epilogue
+// were gone): 2 (256 registers, 48 spilled to scratch; 512 workgroups, one 64-entry step per wave) 39.6 us; 1 (345 registers, no
+// spills; 256 workgroups, up to two steps per wave) 31.5 us -- the scratch reloads sit on the tile's dependent chain and cost more
+// than the second wave hides.
 #ifndef NARUTO_BWD_BF_MINWAVES
-#define NARUTO_BWD_BF_MINWAVES 2
+#define NARUTO_BWD_BF_MINWAVES 1
 #endif
 
 __global__ __launch_bounds__(256, NARUTO_BWD_BF_MINWAVES) void k_query_bwd_bf(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps, uint32_t M, uint32_t cap,

@@ -123,8 +123,11 @@ __global__ __launch_bounds__(256, 2) void k_render_fwd(LevelTab lt, UncertTab ut
 constexpr uint32_t kPackRays = 16;
 inline size_t render_packed_lds_bytes(uint32_t S) { return (size_t)kPackRays * kRayFields * S * sizeof(float); }
 
+#ifndef NARUTO_RENDER_PACKED_MINWAVES
+#define NARUTO_RENDER_PACKED_MINWAVES 2
+#endif
 template <bool BF>
-__global__ __launch_bounds__(256, 2) void k_render_fwd_packed(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, RenderArgs a) {
+__global__ __launch_bounds__(256, NARUTO_RENDER_PACKED_MINWAVES) void k_render_fwd_packed(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, RenderArgs a) {
     using Lds = std::conditional_t<BF, FwdLdsBf, FwdLds>;
     __shared__ Lds L;
     extern __shared__ float ray_lds[];

@@ -545,7 +545,7 @@ BwdWs bwd_ws(const NarutoField* f, void* workspace, uint32_t cap) {
 int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, const NarutoPoints* pts, const float* feat_save,
                    const float* d_raw, const float* d_geo, const uint32_t* active_idx, const uint32_t* n_active, const NarutoExtraPoints* extra,
                    uint32_t flags, const NarutoGrads* g, void* workspace, void* stream, uint32_t n_front, const uint32_t* n_list_dev,
-                   const AdamFuse* adam = nullptr) {
+                   const AdamFuse* adam = nullptr, const void* w_img = nullptr) {
     if ((active_idx == nullptr) != (n_active == nullptr)) return fail(NARUTO_ERR_INVALID, "query_bwd: active_idx and n_active go together");
     if (n_front > 0 && (extra != nullptr || n_list_dev == nullptr)) return fail(NARUTO_ERR_INVALID, "query_bwd: front list excludes extra points");
     const uint32_t E = n_front > 0 ? n_front : ((extra != nullptr && g != nullptr && g->table != nullptr) ? extra->n : 0u);
@@ -589,10 +589,10 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
     if (!phase_mlp) { /* the point list, d_feat and the wgrad partials are those of the preceding MLP-only call */ }
     else if (bf)
         hipLaunchKernelGGL(k_query_bwd_bf, dim3(blocks), dim3(256), kBwdBfLdsBytes, (hipStream_t)stream, f->lt, f->ut, f->bt, *p, ps, M, cap, feat_save, d_raw,
-                           d_geo, d_feat, x_list, g->uncert_grid, partials, active_idx, n_active, n_front, unc_atomic);
+                           d_geo, d_feat, x_list, g->uncert_grid, partials, active_idx, n_active, n_front, unc_atomic, w_img);
     else
         hipLaunchKernelGGL(k_query_bwd, dim3(blocks), dim3(64 * kBwdWaves), sizeof(BwdLds), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, ps, M, cap, feat_save, d_raw,
-                           d_geo, d_feat, x_list, g->uncert_grid, partials, active_idx, n_active, n_front, unc_atomic);
+                           d_geo, d_feat, x_list, g->uncert_grid, partials, active_idx, n_active, n_front, unc_atomic, w_img);
     if (int rc = check_launch("query_bwd")) return rc;
     if (adam != nullptr) {
         if (!phase_mlp || !phase_table) return fail(NARUTO_ERR_INVALID, "query_bwd: the fused optimiser runs the backward in one piece");
@@ -669,7 +669,7 @@ int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
 // ------------------------------------------------------------------------------------------------
 namespace {
 struct TrainWs {
-    float* terms; float* tv_feat; double* tv_partial; void* bwd; double* fold; uint32_t* block_sums;
+    float* terms; float* tv_feat; double* tv_partial; void* bwd; double* fold; uint32_t* block_sums; void* w_img;
     uint32_t n3, n_tv_blocks;
     size_t total;
 };
@@ -689,6 +689,7 @@ TrainWs train_ws(const NarutoField* f, const NarutoTrainStep* t) {
     w.tv_partial = reinterpret_cast<double*>(base + off); off += al((size_t)w.n_tv_blocks * sizeof(double));
     w.fold = reinterpret_cast<double*>(base + off);       off += al((size_t)kTailRows * 16u * sizeof(double));
     w.block_sums = reinterpret_cast<uint32_t*>(base + off); off += al(((size_t)t->n_rays / kCompactBlock + 2u) * sizeof(uint32_t));
+    w.w_img = base + off;                                 off += al(bwd_weight_image_bytes());
     w.bwd = base + off;                                   off += al(naruto_query_bwd_workspace(f, (uint32_t)(M + w.n3)));
     w.total = off;
     return w;
@@ -897,7 +898,9 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
         fa.n_front = smooth_d ? w.n3 : 0u; fa.n_list = bwd.n_total;
         fa.tail = loss_tail_args(t, w, fa.n_ray_blocks, t->smooth_points != 0 ? w.n_tv_blocks : 0u, tv_args(t).inv_p3, 1);
         fa.sums_given = sums_given ? 1 : 0;
-        hipLaunchKernelGGL(k_loss_bwd_fused, dim3(fa.n_ray_blocks + 1u), dim3(64 * kRaysPerBlock), ray_scratch_bytes(S), st, fa);
+        // one more workgroup prepares the MLP backward's weight images (the parameters do not change before k_query_bwd reads them)
+        fa.w_img = w.w_img; fa.w_bf = f->desc.mlp_mode == NARUTO_MLP_BF16 ? 1 : 0; fa.params = *p;
+        hipLaunchKernelGGL(k_loss_bwd_fused, dim3(fa.n_ray_blocks + 2u), dim3(64 * kRaysPerBlock), ray_scratch_bytes(S), st, fa);
         if (int rc = check_launch("loss_bwd_fused")) return rc;
     }
     if (!table_only && !deferred) {
@@ -922,10 +925,11 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
     NarutoPoints pts{};
     pts.rays_o = t->rays_o; pts.rays_d = t->rays_d; pts.z_vals = t->z_vals; pts.n_samples = S;
     const AdamFuse* ad = opt != nullptr ? &adam : nullptr;
+    const void* w_img = deferred ? w.w_img : nullptr;            // prepared by k_loss_bwd_fused just above
     if (n_front > 0)
-        return query_bwd_impl(f, p, M, &pts, t->feat_save, t->d_raw, nullptr, t->active_idx, t->n_active, nullptr, flags, g, w.bwd, stream, n_front, bw.n_total, ad);
+        return query_bwd_impl(f, p, M, &pts, t->feat_save, t->d_raw, nullptr, t->active_idx, t->n_active, nullptr, flags, g, w.bwd, stream, n_front, bw.n_total, ad, w_img);
     // no smoothness term: the workspace was sized for cap = M + n3 with n3 = 0
-    return query_bwd_impl(f, p, M, &pts, t->feat_save, t->d_raw, nullptr, t->active_idx, t->n_active, nullptr, flags, g, w.bwd, stream, 0u, nullptr, ad);
+    return query_bwd_impl(f, p, M, &pts, t->feat_save, t->d_raw, nullptr, t->active_idx, t->n_active, nullptr, flags, g, w.bwd, stream, 0u, nullptr, ad, w_img);
 }
 
 int naruto_render_fwd(const NarutoField* f, const NarutoParams* p, const NarutoRender* r, void* stream) {

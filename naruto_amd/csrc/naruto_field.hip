@@ -1286,6 +1286,18 @@ __device__ __forceinline__ void stage_bwd_weights(BwdLds& L, const NarutoParams&
 }
 
 // C-layout tile (units on regs/halves, points on lanes) -> [point][unit] stage
+// The backward's weight images are loop-invariant per ITERATION, not just per workgroup: when the caller has them prepared in global
+// memory (naruto_train_backward: one workgroup of the preceding launch stages them there) a workgroup fetches the bytes with
+// coalesced 16-byte loads instead of re-deriving them from the row-major weights (62 strided loads + index arithmetic per thread:
+// 3.7 us of k_query_bwd's 50, 4.5 us of k_query_bwd_bf's 31.5).
+constexpr size_t kBwdImageBytes = offsetof(BwdLds, xs);          // the weight part of BwdLds (the stages behind it are per-wave scratch)
+static_assert(kBwdImageBytes % 16 == 0, "weight images are copied in 16-byte pieces");
+template <int NT>
+__device__ __forceinline__ void fetch_weight_image(void* __restrict__ lds, const void* __restrict__ img, size_t bytes, int tid) {
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(img);
+    uint4* __restrict__ dst = reinterpret_cast<uint4*>(lds);
+    for (uint32_t i = (uint32_t)tid; i < (uint32_t)(bytes / 16u); i += (uint32_t)NT) dst[i] = src[i];
+}
 __device__ __forceinline__ void stage_ctile(float* __restrict__ buf, int ld, int col0, const f32x16& t, int j, int hh) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) buf[j * ld + col0 + crow(r, hh)] = t[r];
@@ -1366,11 +1378,14 @@ __global__ __launch_bounds__(64 * kBwdWaves) void k_query_bwd(LevelTab lt, Uncer
                                                    const float* __restrict__ feat_save, const float* __restrict__ d_raw,
                                                    const float* __restrict__ d_geo, float* __restrict__ d_feat, float* __restrict__ x_out,
                                                    float* __restrict__ d_uncert_grid, float* __restrict__ partials,
-                                                   const uint32_t* __restrict__ active_idx, const uint32_t* __restrict__ n_active, uint32_t list_off, int unc_atomic) {
+                                                   const uint32_t* __restrict__ active_idx, const uint32_t* __restrict__ n_active, uint32_t list_off, int unc_atomic,
+                                                   const void* __restrict__ w_img) {
     // list_off: position of this launch's first point in the scatter's point list (the smoothness lattice sits in front)
+    // w_img: the weight part of BwdLds prepared in global memory, or NULL (stage it here)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     BwdLds& L = *reinterpret_cast<BwdLds*>(smem_raw);
-    stage_bwd_weights<64 * kBwdWaves>(L, p, threadIdx.x);
+    if (w_img != nullptr) fetch_weight_image<64 * kBwdWaves>(smem_raw, w_img, kBwdImageBytes, threadIdx.x);
+    else stage_bwd_weights<64 * kBwdWaves>(L, p, threadIdx.x);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hh = lane >> 5, j = lane & 31;
@@ -1676,6 +1691,14 @@ __device__ __forceinline__ void stage_bwd_weights_bf(BwdLdsBf& L, const NarutoPa
 
 struct DwTiles { f32x16 w0a, w0b, w0c, w1, c0a, c0b, c1; };
 
+// one workgroup of 256 threads writes the image of the field's mode to global memory (the stage functions only need an lvalue)
+__device__ __forceinline__ void prepare_bwd_weight_image(void* __restrict__ img, int bf, const NarutoParams& p, int tid) {
+    if (bf) stage_bwd_weights_bf<256>(*reinterpret_cast<BwdLdsBf*>(img), p, tid);
+    else stage_bwd_weights<256>(*reinterpret_cast<BwdLds*>(img), p, tid);
+}
+static_assert(sizeof(BwdLdsBf) % 16 == 0, "weight images are copied in 16-byte pieces");
+inline size_t bwd_weight_image_bytes() { return kBwdImageBytes > sizeof(BwdLdsBf) ? kBwdImageBytes : sizeof(BwdLdsBf); }
+
 // P -> U: Y[point][unit] with lane = unit, registers = points, from the P form (lane = point, registers = units)
 __device__ __forceinline__ f32x16 to_units_on_lanes(const BwdLdsBf& L, const f32x16& yP, int lane) {
     f32x16 u = zero16();
@@ -1821,11 +1844,13 @@ __global__ __launch_bounds__(256, NARUTO_BWD_BF_MINWAVES) void k_query_bwd_bf(Le
                                                       const float* __restrict__ feat_save, const float* __restrict__ d_raw,
                                                       const float* __restrict__ d_geo, float* __restrict__ d_feat, float* __restrict__ x_out,
                                                       float* __restrict__ d_uncert_grid, float* __restrict__ partials,
-                                                      const uint32_t* __restrict__ active_idx, const uint32_t* __restrict__ n_active, uint32_t list_off, int unc_atomic) {
+                                                      const uint32_t* __restrict__ active_idx, const uint32_t* __restrict__ n_active, uint32_t list_off, int unc_atomic,
+                                                      const void* __restrict__ w_img) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     BwdLdsBf& L = *reinterpret_cast<BwdLdsBf*>(smem_raw);
 #ifndef NARUTO_ABL_BF_NOSTAGE
-    stage_bwd_weights_bf<256>(L, p, threadIdx.x);
+    if (w_img != nullptr) fetch_weight_image<256>(smem_raw, w_img, sizeof(BwdLdsBf), threadIdx.x);
+    else stage_bwd_weights_bf<256>(L, p, threadIdx.x);
 #endif
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

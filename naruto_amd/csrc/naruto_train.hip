@@ -279,6 +279,7 @@ struct FusedBwdArgs {
     const double* partials; uint32_t n_ray_blocks;
     const uint32_t* ray_count; uint32_t* ray_off; uint32_t* active_idx; uint32_t* n_active; uint32_t n_front; uint32_t* n_list;
     LossTailArgs tail;
+    void* w_img; int w_bf; NarutoParams params;       // w_img != NULL: workgroup n_ray_blocks + 1 prepares the MLP backward's weight images there
     int sums_given;               // data parallel: la.sums holds the ALL-REDUCED sums (the forward ran its tail with finalize = 0); the extra
                                   // workgroup then only turns them into losses[0..7] and the total
 };
@@ -289,6 +290,7 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_bwd_fused(FusedBwdA
     __shared__ double s_sums[16];
     __shared__ uint32_t pre[kRaysPerBlock], cnt[kRaysPerBlock];
     static_assert(kRaysPerBlock == 4, "the reductions below are written for four waves");
+    if (blockIdx.x == a.n_ray_blocks + 1u) { prepare_bwd_weight_image(a.w_img, a.w_bf, a.params, threadIdx.x); return; }
     if (blockIdx.x == a.n_ray_blocks) {
         if (!a.sums_given) loss_tail_body(a.tail, red, part, s_sums);
         else if (threadIdx.x == 0) {

@@ -258,6 +258,7 @@ int naruto_field_create(const NarutoFieldDesc* d, NarutoField** out) {
         f->lt.scale[l] = scale;
         f->lt.res[l] = res;
         f->lt.size[l] = (uint32_t)params;
+        f->lt.magic[l] = 0xFFFFFFFFu / (uint32_t)params;
         f->lt.off[l] = (uint32_t)offset;
         f->offset[l] = (uint32_t)offset;
         offset += params;

@@ -30,6 +30,8 @@ struct LevelTab {
     uint32_t res[kLevels];
     uint32_t off[kLevels];       // in entries (float2)
     uint32_t size[kLevels];      // entries in the level
+    uint32_t magic[kLevels];     // 0xFFFFFFFF / size: i % size = i - mulhi(i, magic) * size, at most one correction (dense levels' wrap
+                                 // path; computed once on the host -- in the kernels the division is ~20 instructions per level and round)
     uint32_t hashed;             // bit l set: level l uses the spatial hash (size is 2^T)
 };
 
@@ -140,7 +142,7 @@ __device__ __forceinline__ void hash_corners(const LevelTab& lt, float x, float 
         for (int c = 0; c < 8; ++c) {
             uint32_t i = base + (uint32_t)(c & 1) + ((c & 2) ? res : 0u) + ((c & 4) ? r2 : 0u);
             if (i >= size) {              // only out-of-box / wrap-around corners: i % size by multiply-high (<= 1 correction)
-                i -= __umulhi(i, 0xFFFFFFFFu / size) * size;
+                i -= __umulhi(i, lt.magic[T]) * size;
                 if (i >= size) i -= size;
             }
             idx[c] = i;
@@ -173,7 +175,7 @@ __device__ __forceinline__ float2 hash_level_rt(const LevelTab& lt, int T, const
     } else {
         const uint32_t r2 = res * res;
         const uint32_t base = gx + gy * res + gz * r2;
-        const uint32_t magic = 0xFFFFFFFFu / size;           // i % size = i - floor(i * magic / 2^32) * size, at most one correction
+        const uint32_t magic = lt.magic[T];           // i % size = i - floor(i * magic / 2^32) * size, at most one correction
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             uint32_t i = base + (uint32_t)(c & 1) + ((c & 2) ? res : 0u) + ((c & 4) ? r2 : 0u);
@@ -221,7 +223,7 @@ __device__ __forceinline__ void hash_corners_rt(const LevelTab& lt, int T, float
     } else {
         const uint32_t r2 = res * res;
         const uint32_t base = gx + gy * res + gz * r2;
-        const uint32_t magic = 0xFFFFFFFFu / size;
+        const uint32_t magic = lt.magic[T];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             uint32_t i = base + (uint32_t)(c & 1) + ((c & 2) ? res : 0u) + ((c & 4) ? r2 : 0u);
@@ -268,7 +270,7 @@ __device__ __forceinline__ float2 hash_level_half_rt(const LevelTab& lt, int T, 
             for (int c = 0; c < 4; ++c) idx[c] = base + ((c & 1) ? res : 0u) + ((c & 2) ? r2 : 0u);
         } else {
             const uint32_t base = gx + gy * res + gz * r2;
-            const uint32_t magic = 0xFFFFFFFFu / size;
+            const uint32_t magic = lt.magic[T];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 uint32_t i = base + ((c & 1) ? res : 0u) + ((c & 2) ? r2 : 0u);
@@ -336,7 +338,7 @@ __device__ __forceinline__ HalfCorners hash_level_half_index(const LevelTab& lt,
             for (int c = 0; c < 4; ++c) idx[c] = base + ((c & 1) ? res : 0u) + ((c & 2) ? r2 : 0u);
         } else {
             const uint32_t base = gx + gy * res + gz * r2;
-            const uint32_t magic = 0xFFFFFFFFu / size;
+            const uint32_t magic = lt.magic[T];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 uint32_t i = base + ((c & 1) ? res : 0u) + ((c & 2) ? r2 : 0u);

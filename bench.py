@@ -554,7 +554,7 @@ def main():
                 roof["alg_bytes_incl_saved"] = b2
                 roof["frac_incl_saved"] = round(b2 / dom["ms"] / 1e6 / HBM_PEAK_GBS, 4)
             if dom["kernel"].startswith("k_query_fwd"):
-                it = next(r for r in rows if r["kernel"].endswith("as launched by the iteration"))
+                it = next(r for r in rows if r["kernel"].startswith("k_query_fwd<color> as launched"))
                 roof["kernel_ms_in_iteration"] = it["ms"]
                 roof["mfma_util"] = round(dom["TFLOPs"] / mfma_peak, 6)
                 # L2 line rate (MI355X_MICROARCH.md: ~34.5 TB/s aggregate): a wave's 64 8-byte gathers touch ~36 distinct 64-byte
@@ -564,7 +564,7 @@ def main():
                 roof["l2_frac"] = round(l2_bytes / dom["ms"] / 1e6 / L2_PEAK_GBS, 4)
             # the hash gather (north star: "HBM GB/s on the hash gather") always gets its own object, dominant or not
             fwd = next(r for r in rows if r["kernel"].startswith("k_query_fwd<color>") and "launch" in r)
-            it = next(r for r in rows if r["kernel"].endswith("as launched by the iteration"))
+            it = next(r for r in rows if r["kernel"].startswith("k_query_fwd<color> as launched"))
             l2_bytes = n_rays * S_tot * (16 * 4.5 * 64 + 4 * 64) + fwd["alg_bytes_incl_saved"] - n_rays * S_tot * (16 * 8 * 8 + 32)
             gprof, gsrc = pmc_profile(args.workload, fwd["kernel"])
             out["roofline_gather"] = {"bound": "hbm", "kernel": fwd["kernel"], "launch": fwd["launch"], "kernel_ms": fwd["ms"], "kernel_ms_in_iteration": it["ms"],

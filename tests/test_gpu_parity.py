@@ -502,6 +502,64 @@ def test_hash_encode_backward_large_tables(gpu, log2_T):
     grad_close(got_p, want, f"T{log2_T}.grad.table (permuted)")
 
 
+def test_configs4_in_its_defining_form(gpu):
+    """BASELINE configs[4] as named: unit cube, finest level 1024^3, T = 2^22 (281 MB, HBM-resident table: counting-sort scatter), MLPs in
+    the bf16 mode -- one mapping iteration (reduced ray count, smoothness lattice included) against the CPU oracle.  The table and
+    uncertainty paths are fp32 in both modes, so the losses and the gradient directions are bounded as in the bf16 study
+    (tools/bf16_error_study.py), and against the exact mode of the same library the table gradient stays within the bf16 noise of
+    the cotangents that feed it."""
+    from naruto_amd import config as C, ops
+    cfg = C.unit_cube_config(1024, 22, perturb=1.0)
+    tr, cam = cfg["training"], cfg["cam"]
+    ora = H.make_oracle(cfg, 0.05, 53)
+    N = 301
+    S_tot = tr["n_samples_d"] + tr["n_range_d"]
+    rays = syn.random_rays(N, cfg["mapping"]["bound"], seed=53, zero_depth_frac=0.1)
+    rays["target_d"] = (rays["target_d"] * 0.25).astype(np.float32)
+    t = {k: torch.from_numpy(v) for k, v in rays.items()}
+    r6 = torch.tensor([0.35, 0.1, 0.75, 0.2, 0.9, 0.5])
+    rand = torch.rand(N, S_tot, generator=torch.Generator().manual_seed(5))
+    sp, vox, mar, w_s = 12, 0.02, 0.01, 0.5
+    w = torch.tensor([tr["rgb_weight"], tr["depth_weight"], tr["sdf_weight"], tr["fs_weight"], 0.0, tr["uncert_weight"], 0.0, 0.0, w_s, 0.0])
+    ora.train()
+    ret_o = ora.forward(t["rays_o"], t["rays_d"], t["target_rgb"], t["target_d"], rand=rand)
+    sm_o = S.smoothness(ora, sp, vox, mar, r6[:3], r6[3:])
+    total_o = S.total_loss(ret_o, tr) + w_s * sm_o
+    total_o.backward()
+    go = H.ora_grads(ora)
+    args = [t[k].to(gpu).contiguous() for k in ("rays_o", "rays_d", "target_rgb")] + [t["target_d"].to(gpu).reshape(-1).contiguous()]
+    out = {}
+    for mode in ("fp32", "bf16"):
+        c = C.unit_cube_config(1024, 22, perturb=1.0)
+        c["decoder"]["mlp_precision"] = mode
+        m = H.make_hip_from_oracle(c, ora, gpu)
+        assert m._handle().n_params == ora.table.numel()
+        ts = ops.TrainStep(m._handle(), m._params(), torch.zeros_like(m.uncert_grid), N, n_samples_d=tr["n_samples_d"], n_range_d=tr["n_range_d"],
+                           near=cam["near"], far=cam["far"], range_d=tr["range_d"], depth_trunc=cam["depth_trunc"], rgb_missing=tr["rgb_missing"],
+                           perturb=True, loss_weights=w.to(gpu), smooth=(sp, vox, mar), device_rng=False)
+        ts.rand[N * S_tot:].copy_(r6)
+        losses = ts.run(*args, rand=rand.to(gpu)).clone()
+        torch.cuda.synchronize()
+        out[mode] = (losses.cpu(), {k: v.detach().double().cpu().reshape(-1) for k, v in ts.grads.items()})
+        del ts, m
+    lb, gb = out["bf16"]
+    la, ga = out["fp32"]
+    for i, k in enumerate(("rgb_loss", "depth_loss", "sdf_loss", "fs_loss")):
+        ref = float(ret_o[k].detach())
+        assert abs(float(lb[i]) - ref) <= 5e-3 * abs(ref) + 1e-6, f"bf16 T22 {k}: {float(lb[i])} vs {ref}"
+    H.assert_close(lb[8].reshape(-1), sm_o.reshape(-1), 1e-7, "bf16 T22 smoothness term (fp32 path)", rel=1e-4)
+    assert abs(float(lb[9]) - float(total_o.detach())) <= 5e-3 * abs(float(total_o.detach()))
+    for k in ("table", "sdf_w0", "sdf_w1", "col_w0", "col_w1"):
+        want = go[k].reshape(-1).double()
+        cos = float(torch.dot(gb[k], want) / (gb[k].norm() * want.norm() + 1e-300))
+        assert cos >= 0.99, f"bf16 T22 grad {k}: cosine {cos:.5f} against the oracle"
+        rel = float((gb[k] - ga[k]).norm() / (ga[k].norm() + 1e-300))
+        assert rel <= 0.12, f"bf16 T22 grad {k}: relative l2 distance {rel:.4f} from the exact mode"
+    # the exact mode on the same inputs is the parity statement (as in test_train_step_large_tables)
+    for k in ("table", "sdf_w0", "sdf_w1", "col_w0", "col_w1"):
+        grad_close(ga[k], go[k].reshape(-1), f"fp32 T22 grad.{k}")
+
+
 @pytest.mark.parametrize("log2_T", [18, 20, 22])
 def test_train_step_large_tables(gpu, log2_T):
     """The trainer's fast path (naruto_train_forward / naruto_train_backward) on the unit-cube volume of configs[4] with 2^18 ..

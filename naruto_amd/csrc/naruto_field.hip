@@ -840,6 +840,7 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
         const float scale = lt.scale[T];
         const uint32_t res = lt.res[T], size = lt.size[T], r2 = res * res;
         const bool single_chunk = size <= kChunk;          // levels of one chunk: every entry is this unit's
+        const uint32_t magic = lt.magic[T];
         const uint32_t interior = size - (1u + res + r2);  // cells below this number have all eight corners inside the level (res >= 2: size >= res^3 > 1 + res + res^2)
         for (uint32_t r0 = m_lo + threadIdx.x * kScatterRun; r0 < m_hi; r0 += kScatterThreads * kScatterRun) {
             float a0[8];
@@ -860,7 +861,8 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
                         uint32_t i = cur + (uint32_t)(c & 1) + ((c & 2) ? res : 0u) + ((c & 4) ? r2 : 0u);
-                        if (i >= size) i %= size;
+                        i -= __umulhi(i, magic) * size;           // i % size by multiply-high with the level's constant: at most one correction
+                        if (i >= size) i -= size;
                         fix_add_rel(acc, i - chunk_base, a0[c]);
                         a0[c] = 0.0f;
                     }

@@ -185,8 +185,8 @@ def kernel_table(tr, rays, cfg, iters: int):
         rows.append({"kernel": "k_hash_scatter_lds as launched by the iteration", "ms": round(sc_it_ms, 5), "alg_bytes": int(sc_it_bytes), "alg_flops": 0,
                      "GBps": round(sc_it_bytes / sc_it_ms / 1e6, 1), "TFLOPs": 0.0, "bound": None, "list_points": n_act + n_lat,
                      "alg_bytes_all_samples": int((M + n_lat) * (2 * 16 * 8 * 8 + 128 + 16) + M * 2 * 32)})
-    for name, ms in (("naruto_train_forward (4 launches, eager)", fwd_ms), ("naruto_train_backward (eager)", bwd_ms),
-                     ("k_query_fwd<color> as launched by the iteration", qit_ms)):
+    for name, ms in (("naruto_train_forward (eager)", fwd_ms), ("naruto_train_backward (eager)", bwd_ms),
+                     ("k_query_fwd<color> as launched by the iteration (with the loss stage in the same launch when S % 64 == 0)", qit_ms)):
         rows.append({"kernel": name, "ms": round(ms, 5), "alg_bytes": 0, "alg_flops": 0, "GBps": 0.0, "TFLOPs": 0.0, "bound": None})
     rows.append({"kernel": "(active sample fraction)", "ms": 0.0, "alg_bytes": 0, "alg_flops": 0, "GBps": 0.0, "TFLOPs": 0.0,
                  "bound": "hbm", "fraction": round(frac, 4)})

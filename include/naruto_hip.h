@@ -417,8 +417,9 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
                           uint32_t flags, const NarutoFusedAdam* opt /* NULL: gradients only; else g's table / weight
                           pointers may be NULL (gradients not materialised) */, void* stream);
 
-/* Measurement aid (bench.py): ONLY the field-query launch of naruto_train_forward, in the launch shape the iteration uses (one wave
- * per ray with early termination when S % 64 == 0); t->z_vals must hold a previous forward's depths. */
+/* Measurement aid (bench.py): ONLY the field-query launch of naruto_train_forward, exactly as the iteration issues it (one wave per ray
+ * with early termination when S % 64 == 0 -- and then with the loss stage riding in the same launch, k_query_fwd_loss); t->z_vals
+ * must hold a previous forward's depths. */
 int naruto_debug_train_query_fwd(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, void* stream);
 /* profiling (bench.py's roofline): k_hash_scatter_lds alone, over the point list the preceding naruto_train_backward left in the
  * workspace, in the launch shape of the iteration; writes the scatter's partial tables only (no gradient, no parameter). */

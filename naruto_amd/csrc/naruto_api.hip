@@ -72,6 +72,9 @@ uint32_t cu_count(const NarutoField* f) { return f->n_cu > 0 ? (uint32_t)f->n_cu
 // 16-byte aligned and the scatter can stream it with 16-byte loads
 inline uint32_t list_cap(uint32_t n) { return (n + 3u) & ~3u; }
 
+// k_query_fwd_loss keeps its weights (21 KB, static) next to the rays' images: two workgroups per CU up to this much dynamic LDS
+constexpr size_t kFwdLossMaxRayLds = 48u * 1024u;       // S <= 384 samples per ray
+
 // the per-ray kernels keep one ray per wave in dynamic LDS (kRayFields x S floats): allow the kMaxSamples case (128 KB)
 int ray_lds_attr() {
     static bool done = false;
@@ -81,7 +84,9 @@ int ray_lds_attr() {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_composite_bwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_composite_bwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_loss_stage), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_loss_bwd_fused), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_loss_bwd_fused), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_fwd_loss<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLossMaxRayLds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_fwd_loss<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLossMaxRayLds) != hipSuccess)
         return fail(NARUTO_ERR_LAUNCH, "per-ray kernels: cannot reserve %d bytes of LDS: %s", bytes, hipGetErrorString(hipGetLastError()));
     done = true;
     return NARUTO_OK;
@@ -713,7 +718,10 @@ int train_check(const NarutoField* f, const NarutoParams* p, const NarutoTrainSt
 }
 // A2..A5 of the training forward: k_query_fwd over the batch's samples, one wave per ray with depth-ordered early termination
 // when the samples per ray are a multiple of 64 (otherwise flat 64-sample tiles)
-int launch_train_query(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, hipStream_t st) {
+// loss != NULL: the loss stage may ride in the field query's launch (k_query_fwd_loss: the depth-ordered walk only); *fused tells
+int launch_train_query(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, hipStream_t st, const LossStageArgs* loss = nullptr,
+                       bool* fused = nullptr) {
+    if (fused != nullptr) *fused = false;
     const uint32_t N = t->n_rays, S = t->n_samples_d + t->n_range_d, M = N * S;
     PointSrc ps{};
     ps.rays_o = t->rays_o; ps.rays_d = t->rays_d; ps.z_vals = t->z_vals; ps.S = S;
@@ -728,6 +736,18 @@ int launch_train_query(const NarutoField* f, const NarutoParams* p, const Naruto
         ee.tiles_per_ray = S / 64u;
         blocks = (N + 3u) / 4u;
         if (blocks > cu_count(f) * 4u) blocks = cu_count(f) * 4u;
+    }
+    static const bool no_fuse = getenv("NARUTO_DEBUG_NO_FUSED_LOSS_STAGE") != nullptr;      // A/B knob: the two launches instead
+    if (loss != nullptr && ee.tiles_per_ray != 0u && ray_scratch_bytes(S) <= kFwdLossMaxRayLds && !no_fuse) {
+        if (int rc = ray_lds_attr()) return rc;
+        if (f->desc.mlp_mode == NARUTO_MLP_BF16)
+            hipLaunchKernelGGL(k_query_fwd_loss<true>, dim3(blocks + loss->n_tv_blocks), dim3(256), ray_scratch_bytes(S), st, f->lt, f->ut, f->bt, *p, ps, M, t->raw,
+                               t->feat_save, ee, *loss, blocks);
+        else
+            hipLaunchKernelGGL(k_query_fwd_loss<false>, dim3(blocks + loss->n_tv_blocks), dim3(256), ray_scratch_bytes(S), st, f->lt, f->ut, f->bt, *p, ps, M, t->raw,
+                               t->feat_save, ee, *loss, blocks);
+        if (fused != nullptr) *fused = true;
+        return check_launch("query_fwd_loss");
     }
     if (f->desc.mlp_mode == NARUTO_MLP_BF16)
         hipLaunchKernelGGL(k_query_fwd_bf<true>, dim3(blocks), dim3(256), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
@@ -756,6 +776,23 @@ LossTailArgs loss_tail_args(const NarutoTrainStep* t, const TrainWs& w, uint32_t
     tl.finalize = finalize;
     tl.rng = t->rng;                                        // the iteration counter advances once per forward, used or not
     return tl;
+}
+LossStageArgs loss_stage_args(const NarutoField* f, const NarutoTrainStep* t, const TrainWs& w, const BwdWs& bw, const TvArgs& tva) {
+    const uint32_t N = t->n_rays, S = t->n_samples_d + t->n_range_d;
+    LossStageArgs a{};
+    a.n_rays = N; a.S = S;
+    a.trunc = f->desc.trunc; a.sc_factor = f->desc.sc_factor; a.trunc_sc = f->desc.trunc * f->desc.sc_factor;
+    a.depth_trunc = t->depth_trunc; a.rgb_missing = t->rgb_missing; a.white_bkgd = f->desc.white_bkgd;
+    a.raw = t->raw; a.z_vals = t->z_vals; a.target_rgb = t->target_rgb; a.target_d = t->target_d;
+    a.rgb = t->rgb; a.depth = t->depth; a.uncert_map = t->uncert_map;
+    a.partials = reinterpret_cast<double*>(w.terms);       // n_rays/4 x 16 doubles fit the n_rays x 16 floats of the modular path
+    a.n_ray_blocks = (N + kRaysPerBlock - 1) / kRaysPerBlock;
+    a.tv = tva; a.tv_feat = w.tv_feat; a.tv_d_list = bw.d_feat; a.tv_partial = w.tv_partial;
+    a.tv_scale_dev = t->loss_weights != nullptr ? t->loss_weights + 8 : nullptr;
+    a.tv_scale_host = t->smooth_grad_scale != 0.0f ? t->smooth_grad_scale : 1.0f;
+    a.n_tv_blocks = t->smooth_points != 0 ? w.n_tv_blocks : 0u;
+    if (tail_rides_in_backward(t)) a.ray_count = t->ray_count;      // list lengths for the backward's fused first launch (either flag)
+    return a;
 }
 }  // namespace
 
@@ -790,26 +827,19 @@ int naruto_train_forward(const NarutoField* f, const NarutoParams* p, const Naru
                            t->z_vals);
         if (int rc = check_launch("sample_z")) return rc;
     }
-    // A2..A5
-    if (int rc = launch_train_query(f, p, t, st)) return rc;
-    // A6..A8 (+ the lattice's TV term), then the one-workgroup tail
-    LossStageArgs a{};
-    a.n_rays = N; a.S = S;
-    a.trunc = f->desc.trunc; a.sc_factor = f->desc.sc_factor; a.trunc_sc = f->desc.trunc * f->desc.sc_factor;
-    a.depth_trunc = t->depth_trunc; a.rgb_missing = t->rgb_missing; a.white_bkgd = f->desc.white_bkgd;
-    a.raw = t->raw; a.z_vals = t->z_vals; a.target_rgb = t->target_rgb; a.target_d = t->target_d;
-    a.rgb = t->rgb; a.depth = t->depth; a.uncert_map = t->uncert_map;
-    a.partials = reinterpret_cast<double*>(w.terms);       // n_rays/4 x 16 doubles fit the n_rays x 16 floats of the modular path
-    a.n_ray_blocks = (N + kRaysPerBlock - 1) / kRaysPerBlock;
-    a.tv = tva; a.tv_feat = w.tv_feat; a.tv_d_list = bw.d_feat; a.tv_partial = w.tv_partial;
-    a.tv_scale_dev = t->loss_weights != nullptr ? t->loss_weights + 8 : nullptr;
-    a.tv_scale_host = t->smooth_grad_scale != 0.0f ? t->smooth_grad_scale : 1.0f;
-    a.n_tv_blocks = t->smooth_points != 0 ? w.n_tv_blocks : 0u;
+    // A2..A5 and A6..A8 (+ the lattice's TV term): one launch where the forward walks one ray per wave, else two; then the one-workgroup tail
+    LossStageArgs a = loss_stage_args(f, t, w, bw, tva);
     const bool deferred = finalize == NARUTO_TRAIN_FWD_DEFER_TAIL && tail_rides_in_backward(t);
-    if (tail_rides_in_backward(t)) a.ray_count = t->ray_count;      // list lengths for the backward's fused first launch (either flag)
     if (int rc = ray_lds_attr()) return rc;
-    hipLaunchKernelGGL(k_loss_stage, dim3(a.n_ray_blocks + a.n_tv_blocks), dim3(64 * kRaysPerBlock), ray_scratch_bytes(S), st, a);
-    if (int rc = check_launch("loss_stage")) return rc;
+    bool loss_done = false;
+    if (int rc = launch_train_query(f, p, t, st, &a, &loss_done)) return rc;
+    if (!loss_done) {
+        static const int dbg_ls_roles = getenv("NARUTO_DEBUG_LOSS_STAGE_ROLES") ? atoi(getenv("NARUTO_DEBUG_LOSS_STAGE_ROLES")) : 3;     // profiling knob: 1 rays, 2 lattice
+        if (dbg_ls_roles == 1) a.n_tv_blocks = 0;
+        if (dbg_ls_roles == 2) a.n_rays = 0;
+        hipLaunchKernelGGL(k_loss_stage, dim3(a.n_ray_blocks + a.n_tv_blocks), dim3(64 * kRaysPerBlock), ray_scratch_bytes(S), st, a);
+        if (int rc = check_launch("loss_stage")) return rc;
+    }
     if (deferred) return NARUTO_OK;                          // the tail is a workgroup of the backward's first launch
     LossTailArgs tl = loss_tail_args(t, w, a.n_ray_blocks, a.n_tv_blocks, tva.inv_p3, finalize != 0);
     if (a.n_ray_blocks > 4u * kTailRows) {          // large batch: fold the per-workgroup rows first
@@ -831,7 +861,14 @@ int naruto_train_finalize(const NarutoField* f, const NarutoTrainStep* t, void* 
 
 int naruto_debug_train_query_fwd(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, void* stream) {
     if (int rc = train_check(f, p, t, "debug_train_query_fwd")) return rc;
-    return launch_train_query(f, p, t, (hipStream_t)stream);
+    // exactly the launch naruto_train_forward issues for the field query: with the loss stage riding in it where that applies
+    const uint32_t M = t->n_rays * (t->n_samples_d + t->n_range_d);
+    const TrainWs w = train_ws(f, t);
+    TvArgs tva = tv_args(t);
+    tva.cap = list_cap(M + w.n3);
+    const BwdWs bw = bwd_ws(f, w.bwd, list_cap(M + w.n3));
+    const LossStageArgs a = loss_stage_args(f, t, w, bw, tva);
+    return launch_train_query(f, p, t, (hipStream_t)stream, &a, nullptr);
 }
 
 // profiling: k_hash_scatter_lds ALONE over the point list the last naruto_train_backward left in the workspace, in the launch shape

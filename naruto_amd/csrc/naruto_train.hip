@@ -60,6 +60,78 @@ __device__ __forceinline__ void loss_total(float* __restrict__ losses, const flo
     losses[9] = t;
 }
 
+// the loss stage's work on one ray whose raw values / depths sit in the wave's LDS image rs (load_ray's layout): compositing, per-ray
+// loss terms -> t[10], the rendered outputs, the ray's list length for the backward
+__device__ __forceinline__ void loss_stage_ray(const LossStageArgs& a, const RayScratch& rs, uint32_t n, int lane, float* __restrict__ t) {
+    const uint32_t S = a.S;
+    const RayWeights rw = ray_weights(rs, S, a.trunc, a.sc_factor, lane);
+    const RayOut o = ray_composite(rs, rw, n, S, a.white_bkgd, nullptr, lane);
+    const float td = a.target_d[n];
+    const bool valid = depth_valid(td, a.depth_trunc);
+    const float dm = td > 0.0f ? 1.0f : 0.0f;
+    float fs = 0.0f, nfs = 0.0f, sl = 0.0f, nsdf = 0.0f;
+    uint32_t last = 0;
+    for (uint32_t s = lane; s < S; s += 64) {
+        const float z = rs.z[s], sdf = rs.sdf[s];
+        const float front = z < (td - a.trunc_sc) ? 1.0f : 0.0f;
+        const float back = z > (td + a.trunc_sc) ? 1.0f : 0.0f;
+        const float sm = (1.0f - front) * (1.0f - back) * dm;
+        const float e = sdf * front - front;
+        fs = fmaf(e, e, fs);
+        nfs += front;
+        const float c = (z + sdf * a.trunc_sc) * sm - td * sm;
+        sl = fmaf(c, c, sl);
+        nsdf += sm != 0.0f ? 1.0f : 0.0f;
+        // every cotangent of the sample carries a factor wb (the rendering weight), front or sm
+        if (rs.wb[s] != 0.0f || front != 0.0f || sm != 0.0f) last = s + 1u;
+    }
+    fs = wave_sum(fs); nfs = wave_sum(nfs); sl = wave_sum(sl); nsdf = wave_sum(nsdf);
+    if (a.ray_count != nullptr) {
+        last = wave_max_u32(last);
+        if (lane == 0) a.ray_count[n] = last;
+    }
+    if (lane == 0) {
+        if (a.rgb) { a.rgb[3 * (size_t)n] = o.rgb[0]; a.rgb[3 * (size_t)n + 1] = o.rgb[1]; a.rgb[3 * (size_t)n + 2] = o.rgb[2]; }
+        if (a.depth) a.depth[n] = o.depth;
+        if (a.uncert_map) a.uncert_map[n] = o.uncert;
+        const float w = rgb_weight(valid, a.rgb_missing);
+        float s0 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float e = o.rgb[c] * w - a.target_rgb[3 * (size_t)n + c] * w;
+            s0 = fmaf(e, e, s0);
+        }
+        const float D = o.depth, u = o.uncert;
+        t[0] = s0;
+        t[1] = valid ? (D - td) * (D - td) : 0.0f;
+        t[2] = valid ? 1.0f : 0.0f;
+        t[3] = fs; t[4] = nfs; t[5] = sl; t[6] = nsdf;
+        t[7] = valid ? 1.0f / (2.0f * (u + 1e-9f)) : 0.0f;
+        t[8] = valid ? logf(u + 1e-9f) : 0.0f;
+        t[9] = u;
+    }
+}
+// a ray slot past the end of the batch: neutral terms
+__device__ __forceinline__ void loss_stage_no_ray(int lane, float* __restrict__ t) {
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) t[k] = k == 9 ? __builtin_huge_valf() : 0.0f;
+    }
+}
+// the four rays' terms (after a barrier) -> this group's row of the sums, fixed order; one coherent store per slot
+__device__ __forceinline__ void loss_stage_row(const LossStageArgs& a, const float (*terms)[10], uint32_t group) {
+    if (threadIdx.x < 10) {
+        const int k = threadIdx.x;
+        double v = (double)terms[0][k];
+#pragma unroll
+        for (int w = 1; w < kRaysPerBlock; ++w) {
+            const double u = (double)terms[w][k];
+            v = k == 9 ? ((u < v || u != u) ? u : v) : v + u;
+        }
+        a.partials[(size_t)group * 16 + k] = v;
+    }
+}
+
 __global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_stage(LossStageArgs a) {
     extern __shared__ float ray_lds[];
     __shared__ double red[4];
@@ -68,75 +140,83 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_stage(LossStageArgs
     if (blockIdx.x < a.n_ray_blocks) {
         const uint32_t n = blockIdx.x * kRaysPerBlock + wave;
         if (n < a.n_rays) {
-            const uint32_t S = a.S;
-            const RayScratch rs = ray_scratch(ray_lds, wave, S);
-            load_ray(rs, a.raw, a.z_vals, n, S, lane);
-            const RayWeights rw = ray_weights(rs, S, a.trunc, a.sc_factor, lane);
-            const RayOut o = ray_composite(rs, rw, n, S, a.white_bkgd, nullptr, lane);
-            const float td = a.target_d[n];
-            const bool valid = depth_valid(td, a.depth_trunc);
-            const float dm = td > 0.0f ? 1.0f : 0.0f;
-            float fs = 0.0f, nfs = 0.0f, sl = 0.0f, nsdf = 0.0f;
-            uint32_t last = 0;
-            for (uint32_t s = lane; s < S; s += 64) {
-                const float z = rs.z[s], sdf = rs.sdf[s];
-                const float front = z < (td - a.trunc_sc) ? 1.0f : 0.0f;
-                const float back = z > (td + a.trunc_sc) ? 1.0f : 0.0f;
-                const float sm = (1.0f - front) * (1.0f - back) * dm;
-                const float e = sdf * front - front;
-                fs = fmaf(e, e, fs);
-                nfs += front;
-                const float c = (z + sdf * a.trunc_sc) * sm - td * sm;
-                sl = fmaf(c, c, sl);
-                nsdf += sm != 0.0f ? 1.0f : 0.0f;
-                // every cotangent of the sample carries a factor wb (the rendering weight), front or sm
-                if (rs.wb[s] != 0.0f || front != 0.0f || sm != 0.0f) last = s + 1u;
-            }
-            fs = wave_sum(fs); nfs = wave_sum(nfs); sl = wave_sum(sl); nsdf = wave_sum(nsdf);
-            if (a.ray_count != nullptr) {
-                last = wave_max_u32(last);
-                if (lane == 0) a.ray_count[n] = last;
-            }
-            if (lane == 0) {
-                if (a.rgb) { a.rgb[3 * (size_t)n] = o.rgb[0]; a.rgb[3 * (size_t)n + 1] = o.rgb[1]; a.rgb[3 * (size_t)n + 2] = o.rgb[2]; }
-                if (a.depth) a.depth[n] = o.depth;
-                if (a.uncert_map) a.uncert_map[n] = o.uncert;
-                const float w = rgb_weight(valid, a.rgb_missing);
-                float s0 = 0.0f;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float e = o.rgb[c] * w - a.target_rgb[3 * (size_t)n + c] * w;
-                    s0 = fmaf(e, e, s0);
-                }
-                const float D = o.depth, u = o.uncert;
-                float* t = terms[wave];
-                t[0] = s0;
-                t[1] = valid ? (D - td) * (D - td) : 0.0f;
-                t[2] = valid ? 1.0f : 0.0f;
-                t[3] = fs; t[4] = nfs; t[5] = sl; t[6] = nsdf;
-                t[7] = valid ? 1.0f / (2.0f * (u + 1e-9f)) : 0.0f;
-                t[8] = valid ? logf(u + 1e-9f) : 0.0f;
-                t[9] = u;
-            }
-        } else if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < 10; ++k) terms[wave][k] = k == 9 ? __builtin_huge_valf() : 0.0f;
+            const RayScratch rs = ray_scratch(ray_lds, wave, a.S);
+            load_ray(rs, a.raw, a.z_vals, n, a.S, lane);
+            loss_stage_ray(a, rs, n, lane, terms[wave]);
+        } else {
+            loss_stage_no_ray(lane, terms[wave]);
         }
         __syncthreads();
-        if (threadIdx.x < 10) {          // this workgroup's share of the sums, fixed order; one coherent store per slot
-            const int k = threadIdx.x;
-            double v = (double)terms[0][k];
-#pragma unroll
-            for (int w = 1; w < kRaysPerBlock; ++w) {
-                const double u = (double)terms[w][k];
-                v = k == 9 ? ((u < v || u != u) ? u : v) : v + u;
-            }
-            a.partials[(size_t)blockIdx.x * 16 + k] = v;
-        }
+        loss_stage_row(a, terms, blockIdx.x);
     } else {
         tv_loss_list_body(a.tv, a.tv_feat, a.tv_d_list, a.tv_scale_dev, a.tv_scale_host, a.tv_partial, blockIdx.x - a.n_ray_blocks, a.n_tv_blocks, red);
     }
 }
+
+// The training forward's field query WITH the loss stage (rays of S = 64 k samples, the depth-ordered walk of k_query_fwd: one wave
+// per ray): a wave keeps its ray's raw values in its LDS image while it walks the tiles (they still go to memory for the backward) and
+// runs the loss stage's ray work from there when the ray is done -- the loss stage's launch, its reload of raw and its trip through
+// the launch queue go away; the smoothness term's workgroups ride behind the ray workgroups (they start as soon as workgroups of
+// early-terminated rays retire).  Same arithmetic in the same order as k_query_fwd<true> | k_loss_stage: same bits.
+template <bool BF>
+__global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps, uint32_t M, float* __restrict__ raw,
+                                                           float* __restrict__ feat_save, EarlyExit ee, LossStageArgs a, uint32_t n_fwd_blocks) {
+    using Lds = std::conditional_t<BF, FwdLdsBf, FwdLds>;
+    __shared__ Lds L;
+    __shared__ double red[4];
+    __shared__ float terms[kRaysPerBlock][10];
+    extern __shared__ float ray_lds[];
+    if (blockIdx.x >= n_fwd_blocks) {
+        tv_loss_list_body(a.tv, a.tv_feat, a.tv_d_list, a.tv_scale_dev, a.tv_scale_host, a.tv_partial, blockIdx.x - n_fwd_blocks, a.n_tv_blocks, red);
+        return;
+    }
+    if constexpr (BF) stage_fwd_weights_bf<256>(L, p, threadIdx.x);
+    else stage_fwd_weights<256>(L, p, threadIdx.x);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31;
+    const float2* __restrict__ table = reinterpret_cast<const float2*>(p.table);
+    const uint32_t tpr = ee.tiles_per_ray, S = a.S;                  // S == 64 tpr
+    const uint32_t n_groups = (a.n_rays + (uint32_t)kRaysPerBlock - 1u) / (uint32_t)kRaysPerBlock;
+    const RayScratch rs = ray_scratch(ray_lds, wave, S);
+    for (uint32_t group = blockIdx.x; group < n_groups; group += n_fwd_blocks) {          // uniform over the workgroup: barriers inside
+        const uint32_t task = group * (uint32_t)kRaysPerBlock + (uint32_t)wave;
+        if (task < a.n_rays) {
+            EeState ees{false, 0.0f, 0.0f, 0.0f};
+            uint32_t tq = 0;
+            for (; tq < tpr; ++tq) {
+                const uint32_t tile = task * tpr + tq;
+                const uint32_t m = tile * 64u + (uint32_t)lane;          // M = n_rays * S: no padding lanes
+                float x, y, z;
+                load_point(ps, bt, m, x, y, z);
+                const float u = uncert_sample(ut, p.uncert_grid, x, y, z);
+                FwdTileOut to;
+                if constexpr (BF) fwd_tile_bf<true>(L, lt, table, x, y, z, feat_save, nullptr, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to);
+                else fwd_tile<true>(L, lt, table, x, y, z, feat_save, nullptr, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to);
+                float* o = raw + (size_t)m * 5;
+                o[0] = to.rgb[0]; o[1] = to.rgb[1]; o[2] = to.rgb[2]; o[3] = to.sdf; o[4] = u;
+                const uint32_t s = tq * 64u + (uint32_t)lane;
+                rs.c0[s] = to.rgb[0]; rs.c1[s] = to.rgb[1]; rs.c2[s] = to.rgb[2]; rs.sdf[s] = to.sdf; rs.u[s] = u;
+                rs.z[s] = ps.z_vals[m];
+                if (tq + 1u < tpr && ee_after_tile(ees, ee, ps, m, tq, tpr, tile, task, to.sdf, lane, raw)) { ++tq; break; }
+            }
+            // tiles that were not evaluated: raw is zeros there (ee_after_tile wrote them), the image gets the same
+            for (uint32_t s = tq * 64u + (uint32_t)lane; s < S; s += 64u) {
+                rs.c0[s] = 0.0f; rs.c1[s] = 0.0f; rs.c2[s] = 0.0f; rs.sdf[s] = 0.0f; rs.u[s] = 0.0f;
+                rs.z[s] = ps.z_vals[(size_t)task * S + s];
+            }
+            wave_lds_sync();
+            loss_stage_ray(a, rs, task, lane, terms[wave]);
+        } else {
+            loss_stage_no_ray(lane, terms[wave]);
+        }
+        __syncthreads();
+        loss_stage_row(a, terms, group);
+        __syncthreads();                                   // terms are rewritten by the next group
+    }
+}
+template __global__ void k_query_fwd_loss<false>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t);
+template __global__ void k_query_fwd_loss<true>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t);
 
 // A1 | the smoothness lattice's points + hash features, one launch: workgroups [0, n_ray_blocks) sample the depths of four
 // rays each (one per wave, 2 S floats of dynamic LDS per wave), the rest are k_tv_encode's workgroups

@@ -532,6 +532,8 @@ def main():
             q_it = next(r for r in rows if r["kernel"].startswith("k_query_fwd<color> as launched"))
             if sc_it is not None and sc_it["ms"] >= q_it["ms"]:
                 dom = dict(sc_it, kernel="k_hash_scatter_lds", bound="hbm", launch="as launched by the iteration (lattice + active samples, level + uncertainty-grid units)")
+            elif sc_it is not None:
+                dom = next(r for r in rows if r["kernel"].startswith("k_query_fwd<color>") and "launch" in r)      # the field query over all samples
             if dom["bound"] == "mfma":
                 roof = {"bound": "mfma", "achieved": dom["TFLOPs"], "peak": mfma_peak, "unit": "TFLOP/s",
                         "frac": round(dom["TFLOPs"] / mfma_peak, 4), "traffic": None}

@@ -95,7 +95,47 @@ int ray_lds_attr() {
 constexpr uint32_t kBwdMaxBlocks = 512;     // fp32: one 145 KB-LDS block per CU; bf16 mode: NARUTO_BWD_BF_MINWAVES 53 KB blocks per CU
 
 inline size_t al256(size_t b) { return (b + 255u) / 256u * 256u; }
-inline LevelSplits level_splits(const NarutoField* f) { LevelSplits ls; memcpy(ls.s, f->plan.s_lvl, sizeof(ls.s)); return ls; }
+// Point splits per level for a launch over a list of up to M points.  The plan's own counts (field_create) are an integer partition of
+// the CUs for lists of a few hundred thousand points, where every workgroup is one round.  A long list is cut finer, so that the
+// hardware's workgroup scheduler evens out the unit types over several rounds -- at 3.4 M points the hashed units (2 splits) took
+// 3.4 ms while the dense units (4 splits) were done after 0.85 ms and their CUs idled.  Hashed levels only.  More splits cost partial tables (read
+// once more each by the reduce), nothing else: the sums are fixed point.
+inline uint32_t split_multiplier(uint32_t M) {
+    static const int dbg = getenv("NARUTO_DEBUG_SCATTER_SPLIT_MULT") ? atoi(getenv("NARUTO_DEBUG_SCATTER_SPLIT_MULT")) : 0;      // profiling knob
+    if (dbg > 0) return (uint32_t)dbg;
+    return M > 1500000u ? 4u : 1u;            // measured (131 072 x 43 rays, T = 2^16): x2 no gain, x4 6.42 -> 5.70 ms; at 352 k / 554 k points x2 and x4 lose
+}
+inline LevelSplits level_splits(const NarutoField* f, uint32_t M) {
+    LevelSplits ls;
+    for (uint32_t mult = split_multiplier(M);; mult >>= 1) {
+        uint32_t blocks = 0;
+        for (int l = 0; l < kLevels; ++l) {
+            // hashed levels only: the dense units are bound by their LDS adds and gain nothing from shorter shares (T = 2^22, where only
+            // dense levels are tiled: 10.12 -> 10.63 ms with the multiplier on them)
+            const uint32_t s = (uint32_t)f->plan.s_lvl[l] * (((f->lt.hashed >> l) & 1u) && mult ? mult : 1u);
+            ls.s[l] = (uint8_t)(s > 8u ? 8u : s);
+        }
+        for (uint32_t u = 0; u < f->plan.n_dense + f->plan.n_hashed; ++u) blocks += ls.s[f->plan.level[u]];
+        if (blocks <= (uint32_t)kMaxLevelBlocks || mult <= 1u) break;          // (field_create checked the plan's own counts)
+    }
+    return ls;
+}
+// the field's scatter plan with the splits of this launch and the workgroup -> (unit, split) table that goes with them
+inline ScatterPlan scatter_plan(const NarutoField* f, uint32_t M) {
+    ScatterPlan plan = f->plan;
+    const LevelSplits ls = level_splits(f, M);
+    memcpy(plan.s_lvl, ls.s, sizeof(plan.s_lvl));
+    uint32_t nb = 0;
+    for (uint32_t u = 0; u < plan.n_dense + plan.n_hashed; ++u) {
+        const uint32_t sp = plan.s_lvl[plan.level[u]];
+        for (uint32_t k = 0; k < sp && nb < (uint32_t)kMaxLevelBlocks; ++k, ++nb) {
+            plan.blk_unit[nb] = (uint8_t)u;
+            plan.blk_split[nb] = (uint8_t)k;
+        }
+    }
+    plan.n_level_blocks = (uint16_t)nb;
+    return plan;
+}
 
 // rows of the binned scatter's count matrix: one per kBinRound points, at most kBinMaxRows
 inline uint32_t bin_rows(uint32_t M) {
@@ -128,7 +168,8 @@ ScatterWs scatter_ws(const NarutoField* f, void* base, uint32_t M) {
     char* b = reinterpret_cast<char*>(base);
     size_t off = 0;
     uint32_t smax = 1;
-    for (int l = 0; l < kLevels; ++l) smax = f->plan.s_lvl[l] > smax ? f->plan.s_lvl[l] : smax;
+    const LevelSplits ls_ = level_splits(f, M);
+    for (int l = 0; l < kLevels; ++l) smax = ls_.s[l] > smax ? ls_.s[l] : smax;
     w.partial = reinterpret_cast<float*>(b + off);
     off += al256((f->plan.n_dense + f->plan.n_hashed) ? (size_t)smax * partial_plane(f) * 2u * sizeof(float) : 16u);
     w.unc_partial = reinterpret_cast<float*>(b + off);
@@ -163,7 +204,7 @@ int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const f
         ur.d_uncert = d_uncert; ur.partial = w.unc_partial; ur.n_voxels = f->plan.uncert_voxels; ur.n_splits = us.n_splits; ur.voxels_pad = us.voxels_pad;
     }
     if (d_table == nullptr && adam == nullptr && us.g == nullptr) return NARUTO_OK;
-    ScatterPlan plan = f->plan;
+    ScatterPlan plan = scatter_plan(f, M);
     if (d_table == nullptr && adam == nullptr) { plan.n_dense = plan.n_hashed = 0; plan.n_level_blocks = 0; }        // only the uncertainty grid's gradient is wanted
     if (f->plan.n_dense + f->plan.n_hashed > 0) {
         static bool attr_set = false;
@@ -182,7 +223,7 @@ int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const f
             const uint32_t n_unc_blocks = ur.d_uncert != nullptr ? (ur.n_voxels + 255u) / 256u : 0u;
             if (n_table_blocks + n_unc_blocks > 0) {
                 hipLaunchKernelGGL(k_scatter_reduce, dim3(n_table_blocks + n_unc_blocks), dim3(256), 0, st, f->lt, f->plan.atomic_levels, w.partial,
-                                   level_splits(f), n_tiled_params, n_plane, d_table, overwrite, n_table_blocks, ur);
+                                   level_splits(f, M), n_tiled_params, n_plane, d_table, overwrite, n_table_blocks, ur);
                 if (int rc = check_launch("scatter_reduce")) return rc;
             }
         }
@@ -621,7 +662,8 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
             ur.voxels_pad = uncert_pad(f);
         }
         const uint32_t n_unc_blocks = unc_scatter ? (ur.n_voxels + 255u) / 256u : 0u;
-        hipLaunchKernelGGL(k_bwd_finish, dim3(n_table_blocks + kAccFloats / 32 + n_unc_blocks), dim3(256), 0, (hipStream_t)stream, f->lt, scatter_ws, level_splits(f),
+        hipLaunchKernelGGL(k_bwd_finish, dim3(n_table_blocks + kAccFloats / 32 + n_unc_blocks), dim3(256), 0, (hipStream_t)stream, f->lt, scatter_ws,
+                           level_splits(f, cnt != nullptr ? cap : M),
                            n_params, partial_plane(f), partials, blocks, *g, *adam, n_table_blocks, ur);
         return check_launch("bwd_finish");
     }

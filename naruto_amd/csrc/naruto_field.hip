@@ -655,7 +655,7 @@ constexpr uint32_t kChunk = 1u << kChunkLog2;       // entries per LDS image: ON
 constexpr int kMaxChunksPerLevel = 8;
 constexpr int kMaxUnits = kLevels * kMaxChunksPerLevel * 2;      // unit = (level, chunk, feature)
 constexpr int kScatterThreads = 1024;
-constexpr int kMaxLevelBlocks = 512;
+constexpr int kMaxLevelBlocks = 1024;       // (16 levels' units) x up to 8 splits
 constexpr float kFixScale = 1099511627776.0f;        // 2^40
 constexpr double kFixInv = 1.0 / 1099511627776.0;
 

@@ -134,6 +134,9 @@ inline ScatterPlan scatter_plan(const NarutoField* f, uint32_t M) {
         }
     }
     plan.n_level_blocks = (uint16_t)nb;
+    // a level's slice of the list (16 B per point and feature) stays in an XCD's 4 MB L2 up to ~300 k points
+    static const int dbg_xcd = getenv("NARUTO_DEBUG_SCATTER_XCD_AWARE") ? atoi(getenv("NARUTO_DEBUG_SCATTER_XCD_AWARE")) : -1;       // profiling knob
+    plan.xcd_aware = (uint8_t)(dbg_xcd >= 0 ? (dbg_xcd != 0) : (M <= 300000u));
     return plan;
 }
 

@@ -669,6 +669,7 @@ struct ScatterPlan {
     uint32_t s_dense, s_hashed;   // default point splits per unit of a dense / hashed level
     uint8_t s_lvl[kLevels];       // point splits per unit, by level (the partial tables hold s_lvl[level] planes of a level's entries)
     uint16_t n_level_blocks;      // workgroups of the level units = sum over units of s_lvl[level of the unit]
+    uint8_t xcd_aware;            // 1: the workgroups of a level share an XCD (their list slice is re-read from its L2); 0: natural order
     uint8_t blk_unit[kMaxLevelBlocks], blk_split[kMaxLevelBlocks];     // level workgroup (in unit order) -> unit, split
     uint32_t atomic_levels;       // bit l: level l goes through the global-atomic kernel instead
     // the uncertainty voxel grid as one more (dense, single-feature) table: n_uncert chunks x (per-launch) point splits, after the
@@ -952,7 +953,9 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
     // naive order -- the kernel was bound by re-streaming the list through the fabric, not by its arithmetic.)
     uint32_t unit, split, n_splits;
     const uint32_t n_blocks = plan.n_level_blocks;
-    const uint32_t pos = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    // (lists too long for an L2 -- plan.xcd_aware = 0 -- take the natural order: nothing to re-read from, and a level's workgroups
+    // would queue on one XCD's 32 CUs while others idle)
+    const uint32_t pos = plan.xcd_aware ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     if (pos >= n_blocks) {
         // ---- uncertainty-grid units (training list layout only): d(loss)/d(uncert_grid) = scatter of the raw[...,4] cotangents with
         // grid_sample's trilinear weights, accumulated in the same fixed point -- no float atomics, order independent

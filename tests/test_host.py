@@ -216,3 +216,26 @@ def test_vertex_normals_match_the_loop_restatement():
     ref = MN.vertex_normals(v, f)
     assert np.abs(got - ref).max() < 1e-12
     assert np.all(got[8] == 0.0) and np.allclose(np.linalg.norm(got[:8], axis=1), 1.0)
+
+
+def test_bench_host_helpers():
+    """bench.py's host-side pieces that need no GPU: every named workload resolves to a config with the sampling its name states,
+    and the committed PMC passes are found per workload and kernel (roofline.traffic)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for name in bench.WORKLOADS:
+        cfg, n_rays = bench.workload(name)
+        tr = cfg["training"]
+        assert n_rays > 0 and tr["n_samples_d"] + tr["n_range_d"] > 1
+        if "x" in name.split("_")[-1] or "x" in name.split("_")[-2]:
+            tok = [t for t in name.split("_") if "x" in t and t[0].isdigit()][0]
+            n, s_ = (int(v) for v in tok.split("x"))
+            assert n == n_rays and s_ == tr["n_samples_d"] + tr["n_range_d"], name
+    prof, src = bench.pmc_profile("office0_2048x128", "k_query_fwd<color>")
+    assert src is not None and prof["traffic_bytes"] > 0 and prof["fetch_bytes"] > 0
+    prof, src = bench.pmc_profile("unit1024_T22_131072x43", "k_query_fwd<color>")
+    assert src is not None and prof["traffic_bytes"] > 1e9            # the 2^22-entry table is HBM resident
+    assert bench.pmc_profile("office0_2048x128", "no such kernel") == ({}, None)
+    assert bench.physical_cores() >= 1

@@ -4,6 +4,8 @@ Tolerances (north_star: outputs within 1e-4 fp32 of the reference PyTorch path o
   TOL_OUT  = 1e-4 absolute on every rendered / queried output (values are O(1));
   gradients: 1e-4 of the largest gradient magnitude of that tensor + 1e-3 relative.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1494,6 +1496,70 @@ def test_train_step_with_the_tail_in_the_backward(gpu, n_rays, s_d, s_r):
             assert torch.equal(g0[k], g1[k]), k
         else:
             grad_close(g1[k].reshape(-1).double(), g0[k].reshape(-1).double(), f"fused-tail.grad.{k}", frac=1e-6)
+
+
+_KNOB_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import helpers as H
+from naruto_amd import ops, synthetic as syn
+gpu = torch.device("cuda", 0)
+cfg = H.office_cfg(12, perturb=1.0, n_samples_d=117)                 # 117 + 11 = 128 samples: the forward walks one ray per wave
+tr, cam = cfg["training"], cfg["cam"]
+ora = H.make_oracle(cfg, 0.25, 19)
+m = H.make_hip_from_oracle(cfg, ora, gpu)
+N = 333
+rays = syn.random_rays(N, cfg["mapping"]["bound"], seed=19, zero_depth_frac=0.1)
+w = torch.tensor([tr["rgb_weight"], tr["depth_weight"], tr["sdf_weight"], tr["fs_weight"], 0.0, tr["uncert_weight"], 0.0, 0.0, 0.1, 0.0])
+ts = ops.TrainStep(m._handle(), m._params(), torch.zeros_like(m.uncert_grid), N, n_samples_d=tr["n_samples_d"], n_range_d=tr["n_range_d"],
+                   near=cam["near"], far=cam["far"], range_d=tr["range_d"], depth_trunc=cam["depth_trunc"], rgb_missing=tr["rgb_missing"],
+                   perturb=True, loss_weights=w.to(gpu), smooth=(12, 0.1, 0.05), device_rng=True, seed=5)
+args = [torch.from_numpy(rays[k]).to(gpu).contiguous() for k in ("rays_o", "rays_d", "target_rgb")] + [torch.from_numpy(rays["target_d"]).to(gpu).reshape(-1).contiguous()]
+for _ in range(2):
+    losses = ts.run(*args).clone()
+torch.cuda.synchronize()
+out = {"losses": losses.cpu().numpy(), "rgb": ts.rgb.cpu().numpy(), "depth": ts.depth.cpu().numpy(), "sums": ts.sums.cpu().numpy()[:10]}
+out.update({"g_" + k: v.detach().cpu().numpy() for k, v in ts.grads.items()})
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_launch_variants_give_the_same_bits(gpu, tmp_path):
+    """The launch-structure choices of the training path are claimed to change no bit of any result: the loss stage inside the field
+    query's launch vs its own launch, the loss tail + compaction inside the backward's first launch vs three launches, the scatter's
+    workgroup order and (fixed-point sums) its point splits.  Each knob is an environment variable read once per process, so the same
+    iteration runs in fresh interpreters and the saved losses, rendered maps, sums and gradients are compared bit for bit."""
+    import subprocess, sys
+    script = tmp_path / "iteration.py"
+    script.write_text(_KNOB_SCRIPT)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    results = {}
+    variants = {"default": {}, "no_fused_loss_stage": {"NARUTO_DEBUG_NO_FUSED_LOSS_STAGE": "1"}, "no_fused_tail": {"NARUTO_DEBUG_NO_FUSED_TAIL": "1"},
+                "natural_order": {"NARUTO_DEBUG_SCATTER_XCD_AWARE": "0"}, "no_early_exit": {"NARUTO_DEBUG_NO_EARLY_EXIT": "1"}}
+    for name, env in variants.items():
+        out = tmp_path / f"{name}.npz"
+        e = dict(os.environ)
+        e.update(env)
+        subprocess.run([sys.executable, str(script), root, str(out)], check=True, env=e, timeout=600)
+        results[name] = dict(np.load(out))
+    ref = results["default"]
+    for name, r in results.items():
+        for k, v in ref.items():
+            assert np.array_equal(v, r[k], equal_nan=True), f"{name}: {k} differs from the default launch structure"
+    # the scatter's point splits repartition fixed-point sums: the table gradient keeps its bits; the dense levels pre-sum runs of 8
+    # points in fp32 per thread, and a split boundary moves with the split count, so they are compared to the accumulation noise
+    out = tmp_path / "splits_x4.npz"
+    e = dict(os.environ)
+    e["NARUTO_DEBUG_SCATTER_SPLIT_MULT"] = "4"
+    subprocess.run([sys.executable, str(script), root, str(out)], check=True, env=e, timeout=600)
+    r = dict(np.load(out))
+    for k, v in ref.items():
+        if k == "g_table":
+            d = np.abs(v - r[k])
+            assert float(d.max()) <= 1e-6 * float(np.abs(v).max()), f"split multiplier: table gradient moved by {d.max():.3e}"
+            assert float((d > 0).mean()) < 0.2
+        else:
+            assert np.array_equal(v, r[k], equal_nan=True), f"split multiplier: {k} differs"
 
 
 def test_trainer_ray_buffers_skip_the_copy(gpu):

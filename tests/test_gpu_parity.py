@@ -1202,16 +1202,21 @@ def test_train_step_direct_against_oracle(gpu, n_samples_d):
         assert 0 < n_stopped < N, f"early termination: {n_stopped} of {N} rays stopped after the first tile"
 
 
-@pytest.mark.parametrize("workload", ["office0_2048x128", "office0_8192x43", "mp3d_2048x256"])
+@pytest.mark.parametrize("workload", ["office0_2048x128", "office0_4100x128", "office0_8192x43", "mp3d_2048x256"])
 def test_train_step_full_size_against_oracle(gpu, workload):
     """BASELINE.json's configurations at their full per-GPU sizes -- configs[1] 2048 rays x 128 samples, configs[2] 8192
     rays with the shipped sampling, configs[3]'s per-GPU shard 2048 rays x 256 samples on the MP3D volume; 2^16-entry
     tables, smoothness term, the trainer's fast path (early termination, active-sample compaction, LDS-tiled scatter over
-    all CUs) -- against the CPU oracle on the same jitter draw: every loss, the rendered maps and every gradient."""
+    all CUs) -- against the CPU oracle on the same jitter draw: every loss, the rendered maps and every gradient.  4 100 rays x 128
+    samples: more ray groups than the forward has workgroups (a workgroup walks two groups with the loss stage riding along), a
+    partly filled last group, and beyond the 4 096 rays up to which the loss tail and the compaction ride in the backward's first
+    launch (so the ordinary tail / compaction launches with the two-level prefix run)."""
     from naruto_amd import ops
     from naruto_amd import config as C
     if workload == "office0_2048x128":
         cfg, N = H.office_cfg(16, perturb=1.0, n_samples_d=117), 2048
+    elif workload == "office0_4100x128":
+        cfg, N = H.office_cfg(16, perturb=1.0, n_samples_d=117), 4100
     elif workload == "office0_8192x43":
         cfg, N = H.office_cfg(16, perturb=1.0), 8192
     else:

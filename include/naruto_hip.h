@@ -36,7 +36,7 @@ typedef struct NarutoField NarutoField;
 typedef struct NarutoFieldDesc {
     uint32_t n_levels;            /* tcnn n_levels; this build supports 16                      */
     uint32_t n_features;          /* tcnn n_features_per_level; this build supports 2           */
-    uint32_t log2_hashmap_size;   /* config grid.hash_size                                      */
+    uint32_t log2_hashmap_size;   /* config grid.hash_size; 4 .. 24                              */
     uint32_t base_resolution;     /* 16                                                         */
     float    per_level_scale;     /* exp2(log2(desired_res / base_res) / (n_levels-1))           */
     uint32_t n_bins;              /* OneBlob bins per input dim; this build supports 16          */

@@ -280,7 +280,7 @@ int naruto_field_create(const NarutoFieldDesc* d, NarutoField** out) {
         return fail(NARUTO_ERR_INVALID, "create: this build supports n_levels=16, n_features=2 (got %u, %u)", d->n_levels, d->n_features);
     if (d->n_bins != kBins || d->hidden_dim != kHidden || d->hidden_dim_color != kHidden || d->geo_feat_dim != kGeo)
         return fail(NARUTO_ERR_INVALID, "create: this build supports n_bins=16, hidden_dim=32, hidden_dim_color=32, geo_feat_dim=15");
-    if (d->log2_hashmap_size < 4 || d->log2_hashmap_size > 28) return fail(NARUTO_ERR_INVALID, "create: log2_hashmap_size out of range");
+    if (d->log2_hashmap_size < 4 || d->log2_hashmap_size > 24) return fail(NARUTO_ERR_INVALID, "create: log2_hashmap_size out of range");
     if (d->uncert_dims[0] == 0 || d->uncert_dims[1] == 0 || d->uncert_dims[2] == 0) return fail(NARUTO_ERR_INVALID, "create: empty uncert grid");
     if (d->uncert_dims[0] > 1000 || d->uncert_dims[1] > 1000 || d->uncert_dims[2] > 1000) return fail(NARUTO_ERR_INVALID, "create: uncert grid axes of more than 1000 voxels are not supported");
     if (!(d->trunc > 0.0f)) return fail(NARUTO_ERR_INVALID, "create: trunc must be > 0");

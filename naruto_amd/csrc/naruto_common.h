@@ -20,6 +20,11 @@ constexpr int kInSdf = kFeat + kPos;   // 80
 constexpr int kInCol = kPos + kGeo;    // 63
 constexpr uint32_t kPrime1 = 2654435761u;
 constexpr uint32_t kPrime2 = 805459861u;
+// A hashed level has a power-of-two size of at most 2^24 entries (naruto_field_create), so only the low 24 bits of
+// g * prime survive the mask: (g mod 2^24) * (prime mod 2^24) has the same low 24 bits, and v_mul_u32_u24 issues at the full
+// rate where the 32-bit multiply takes four slots.  Bits 24.. of the result are garbage and are masked off with the index.
+constexpr uint32_t kPrime1Low = kPrime1 & 0xFFFFFFu;
+constexpr uint32_t kPrime2Low = kPrime2 & 0xFFFFFFu;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -116,8 +121,9 @@ __device__ __forceinline__ void finish_point(const PointSrc& ps, const BoxTab& b
 // pos_fract, linear interpolation, coherent prime hash).  Weight order is tcnn's:
 // w = ((1 * wx') * wy') * wz', corners enumerated with bit0 = x, bit1 = y, bit2 = z.
 // ---------------------------------------------------------------------------------------------
+// f: the six per-axis factors {1 - wx, wx, 1 - wy, wy, 1 - wz, wz}; corner c weighs f[c & 1] * f[2 + (c >> 1 & 1)] * f[4 + (c >> 2)]
 template <int T>
-__device__ __forceinline__ void hash_corners(const LevelTab& lt, float x, float y, float z, uint32_t (&idx)[8], float (&w)[8]) {
+__device__ __forceinline__ void hash_corner_index(const LevelTab& lt, float x, float y, float z, uint32_t (&idx)[8], float (&f)[6]) {
     const float scale = lt.scale[T];
     const uint32_t res = lt.res[T];
     const uint32_t size = lt.size[T];
@@ -128,8 +134,8 @@ __device__ __forceinline__ void hash_corners(const LevelTab& lt, float x, float 
     const float ux = 1.0f - wx, uy = 1.0f - wy, uz = 1.0f - wz;
     if ((lt.hashed >> T) & 1u) {
         const uint32_t mask = size - 1u;
-        const uint32_t hy0 = gy * kPrime1, hy1 = hy0 + kPrime1;
-        const uint32_t hz0 = gz * kPrime2, hz1 = hz0 + kPrime2;
+        const uint32_t hy0 = __umul24(gy, kPrime1Low), hy1 = hy0 + kPrime1Low;
+        const uint32_t hz0 = __umul24(gz, kPrime2Low), hz1 = hz0 + kPrime2Low;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const uint32_t cx = gx + (uint32_t)(c & 1);
@@ -148,10 +154,14 @@ __device__ __forceinline__ void hash_corners(const LevelTab& lt, float x, float 
             idx[c] = i;
         }
     }
+    f[0] = ux; f[1] = wx; f[2] = uy; f[3] = wy; f[4] = uz; f[5] = wz;
+}
+template <int T>
+__device__ __forceinline__ void hash_corners(const LevelTab& lt, float x, float y, float z, uint32_t (&idx)[8], float (&w)[8]) {
+    float f[6];
+    hash_corner_index<T>(lt, x, y, z, idx, f);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        w[c] = ((c & 1) ? wx : ux) * ((c & 2) ? wy : uy) * ((c & 4) ? wz : uz);
-    }
+    for (int c = 0; c < 8; ++c) w[c] = f[c & 1] * f[2 + ((c >> 1) & 1)] * f[4 + (c >> 2)];
 }
 
 // Same arithmetic with the level as a RUNTIME (wave-uniform) index: lets the per-level work sit in a real loop
@@ -168,8 +178,8 @@ __device__ __forceinline__ float2 hash_level_rt(const LevelTab& lt, int T, const
     uint32_t idx[8];
     if ((lt.hashed >> T) & 1u) {
         const uint32_t mask = size - 1u;
-        const uint32_t hy0 = gy * kPrime1, hy1 = hy0 + kPrime1;
-        const uint32_t hz0 = gz * kPrime2, hz1 = hz0 + kPrime2;
+        const uint32_t hy0 = __umul24(gy, kPrime1Low), hy1 = hy0 + kPrime1Low;
+        const uint32_t hz0 = __umul24(gz, kPrime2Low), hz1 = hz0 + kPrime2Low;
 #pragma unroll
         for (int c = 0; c < 8; ++c) idx[c] = ((gx + (uint32_t)(c & 1)) ^ ((c & 2) ? hy1 : hy0) ^ ((c & 4) ? hz1 : hz0)) & mask;
     } else {
@@ -216,8 +226,8 @@ __device__ __forceinline__ void hash_corners_rt(const LevelTab& lt, int T, float
     const float ux = 1.0f - wx, uy = 1.0f - wy, uz = 1.0f - wz;
     if ((lt.hashed >> T) & 1u) {
         const uint32_t mask = size - 1u;
-        const uint32_t hy0 = gy * kPrime1, hy1 = hy0 + kPrime1;
-        const uint32_t hz0 = gz * kPrime2, hz1 = hz0 + kPrime2;
+        const uint32_t hy0 = __umul24(gy, kPrime1Low), hy1 = hy0 + kPrime1Low;
+        const uint32_t hz0 = __umul24(gz, kPrime2Low), hz1 = hz0 + kPrime2Low;
 #pragma unroll
         for (int c = 0; c < 8; ++c) idx[c] = ((gx + (uint32_t)(c & 1)) ^ ((c & 2) ? hy1 : hy0) ^ ((c & 4) ? hz1 : hz0)) & mask;
     } else {
@@ -254,8 +264,8 @@ __device__ __forceinline__ float2 hash_level_half_rt(const LevelTab& lt, int T, 
     uint32_t idx[4];
     if ((lt.hashed >> T) & 1u) {
         const uint32_t mask = size - 1u;
-        const uint32_t hy0 = gy * kPrime1, hy1 = hy0 + kPrime1;
-        const uint32_t hz0 = gz * kPrime2, hz1 = hz0 + kPrime2;
+        const uint32_t hy0 = __umul24(gy, kPrime1Low), hy1 = hy0 + kPrime1Low;
+        const uint32_t hz0 = __umul24(gz, kPrime2Low), hz1 = hz0 + kPrime2Low;
 #pragma unroll
         for (int c = 0; c < 4; ++c) idx[c] = (gx ^ ((c & 1) ? hy1 : hy0) ^ ((c & 2) ? hz1 : hz0)) & mask;
     } else {
@@ -325,8 +335,8 @@ __device__ __forceinline__ HalfCorners hash_level_half_index(const LevelTab& lt,
     uint32_t idx[4];
     if ((lt.hashed >> T) & 1u) {
         const uint32_t mask = size - 1u;
-        const uint32_t hy0 = gy * kPrime1, hy1 = hy0 + kPrime1;
-        const uint32_t hz0 = gz * kPrime2, hz1 = hz0 + kPrime2;
+        const uint32_t hy0 = __umul24(gy, kPrime1Low), hy1 = hy0 + kPrime1Low;
+        const uint32_t hz0 = __umul24(gz, kPrime2Low), hz1 = hz0 + kPrime2Low;
 #pragma unroll
         for (int c = 0; c < 4; ++c) idx[c] = (gx ^ ((c & 1) ? hy1 : hy0) ^ ((c & 2) ? hz1 : hz0)) & mask;
     } else {

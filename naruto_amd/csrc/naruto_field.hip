@@ -723,7 +723,7 @@ constexpr int kScatterBatch = 4;   // independent point loads in flight per thre
 #endif
 constexpr int kScatterRun = NARUTO_SCATTER_RUN;     // consecutive points per thread on the dense (coarse) levels (a multiple of 4)
 #ifndef NARUTO_LIST_VEC
-#define NARUTO_LIST_VEC 2
+#define NARUTO_LIST_VEC 4
 #endif
 constexpr uint32_t kListVec = NARUTO_LIST_VEC;      // 2 or 4 consecutive points per lane in the hashed levels' list stream
 
@@ -742,13 +742,52 @@ __device__ __forceinline__ unsigned long long to_fix40_scaled(float t) {
 }
 __device__ __forceinline__ unsigned long long to_fix40(float v) { return to_fix40_scaled(v * 256.0f); }
 
-// rel = entry index relative to this workgroup's chunk; in the chunk iff rel < kChunk (unsigned compare: entries below the
-// chunk wrap to huge values).  t256 = contribution * 2^8.
-__device__ __forceinline__ void fix_add_rel(unsigned long long* __restrict__ acc, uint32_t rel, float t256) {
-    if (rel < kChunk) atomicAdd(acc + rel, to_fix40_scaled(t256));          // ds_add_u64
+// The same fixed point through the fp64 pipe (gfx950 issues one v_fma_f64 per lane and clock, like fp32): M + v with M = 1.5 * 2^12
+// has ulp 2^-40 while |v| < 2^11, so the add -- or the fma that forms v -- rounds v to the nearest multiple of 2^-40 and leaves
+// that integer, two's complement, in the mantissa: bits(M + v) - bits(M).  bits(M) = 0x40B80000'00000000: the low word is zero, the
+// subtraction is ONE 32-bit add on the high word.  Three instructions (convert, add, high-word add) for the seven above, and a
+// product of doubles costs what a product of floats does.  Callers clamp to +-kFixClamp (a cotangent beyond that is not a gradient).
+#ifndef NARUTO_FIX_F64
+#define NARUTO_FIX_F64 1
+#endif
+constexpr double kFixMagic = 6144.0;
+constexpr float kFixClamp = 2047.0f;
+__device__ __forceinline__ unsigned long long fix40_bits(double magic_sum) {
+    return (unsigned long long)__double_as_longlong(magic_sum) - 0x40B8000000000000ull;
 }
-__device__ __forceinline__ void fix_add(unsigned long long* __restrict__ acc, uint32_t idx, uint32_t chunk, float v) {
-    fix_add_rel(acc, idx - chunk * kChunk, v * 256.0f);
+__device__ __forceinline__ float fix_clamp(float v) { return __builtin_amdgcn_fmed3f(v, -kFixClamp, kFixClamp); }
+// v: the contribution itself (no 2^8)
+__device__ __forceinline__ unsigned long long to_fix40_sum(float v) {
+#if NARUTO_FIX_F64
+    return fix40_bits((double)fix_clamp(v) + kFixMagic);
+#else
+    return to_fix40(v);
+#endif
+}
+
+// rel = entry index relative to this workgroup's chunk; in the chunk iff rel < kChunk (unsigned compare: entries below the
+// chunk wrap to huge values).
+__device__ __forceinline__ void fix_add_rel(unsigned long long* __restrict__ acc, uint32_t rel, float v) {
+    if (rel < kChunk) atomicAdd(acc + rel, to_fix40_sum(v));          // ds_add_u64
+}
+// one list point's eight contributions g * w_c of a hashed level: the products run in fp64 (g * fx exact, the rest rounded to 53 bits)
+// and the last one is the fma that rounds onto the 2^-40 lattice
+__device__ __forceinline__ void fix_add_corners(unsigned long long* __restrict__ acc, const uint32_t (&idx)[8], uint32_t chunk_base, const float (&f)[6], float g) {
+#if NARUTO_FIX_F64
+    const double gd = (double)fix_clamp(g);
+    const double gx0 = gd * (double)f[0], gx1 = gd * (double)f[1];
+    const double y0 = (double)f[2], y1 = (double)f[3], z0 = (double)f[4], z1 = (double)f[5];
+    const double gxy[4] = {gx0 * y0, gx1 * y0, gx0 * y1, gx1 * y1};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const uint32_t rel = idx[c] - chunk_base;
+        const double s = __fma_rn(gxy[c & 3], (c & 4) ? z1 : z0, kFixMagic);
+        if (rel < kChunk) atomicAdd(acc + rel, fix40_bits(s));
+    }
+#else
+#pragma unroll
+    for (int c = 0; c < 8; ++c) fix_add_rel(acc, idx[c] - chunk_base, (f[c & 1] * f[2 + ((c >> 1) & 1)] * f[4 + (c >> 2)]) * g);
+#endif
 }
 
 template <int T>
@@ -801,11 +840,9 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
                 for (uint32_t b = 0; b < V; ++b) {
                     if (base + b >= m_hi || q.g[b] == 0.0f) continue;
                     uint32_t idx[8];
-                    float w[8];
-                    hash_corners<T>(lt, q.x[b], q.y[b], q.z[b], idx, w);
-                    const float g256 = q.g[b] * 256.0f;
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) fix_add_rel(acc, idx[c] - chunk_base, w[c] * g256);
+                    float f[6];
+                    hash_corner_index<T>(lt, q.x[b], q.y[b], q.z[b], idx, f);
+                    fix_add_corners(acc, idx, chunk_base, f, q.g[b]);
                 }
             }
             return;
@@ -827,11 +864,9 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
             for (int b = 0; b < kScatterBatch; ++b) {
                 if (g[b] == 0.0f) continue;
                 uint32_t idx[8];
-                float w[8];
-                hash_corners<T>(lt, px[b], py[b], pz[b], idx, w);
-                const float g256 = g[b] * 256.0f;                  // the 2^8 of to_fix40 folded in once per point
-#pragma unroll
-                for (int c = 0; c < 8; ++c) fix_add_rel(acc, idx[c] - chunk_base, w[c] * g256);
+                float f[6];
+                hash_corner_index<T>(lt, px[b], py[b], pz[b], idx, f);
+                fix_add_corners(acc, idx, chunk_base, f, g[b]);
             }
         }
     } else {
@@ -849,9 +884,8 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
             bool have = false;
 #pragma unroll
             for (int c = 0; c < 8; ++c) a0[c] = 0.0f;
-            // the sums carry the 2^8 of the fixed-point conversion already (folded into the cotangent once per point: exact, a power
-            // of two).  Only the far corners of the level grid's last cells can pass the end of the level (index % size): whether ANY
-            // lane is there is decided once per flush, so the common flush is eight times {add, 7-instruction conversion, LDS add} --
+            // Only the far corners of the level grid's last cells can pass the end of the level (index % size): whether ANY
+            // lane is there is decided once per flush, so the common flush is eight times {add, conversion, LDS add} --
             // written with the wrap test and the generic conversion per corner, the compiler predicates an 11-instruction modulo
             // into every corner (35 instructions per corner instead of 16).  Measured gain: small (dense units 69 -> 65.7 us) --
             // a quarter of the benchmark's active samples lie outside the scene box, so most waves hold such a lane and take the
@@ -872,7 +906,7 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
                         const uint32_t rel = rel0 + (uint32_t)(c & 1) + ((c & 2) ? res : 0u) + ((c & 4) ? r2 : 0u);
-                        if (single_chunk || rel < kChunk) atomicAdd(acc + rel, to_fix40_scaled(a0[c]));
+                        if (single_chunk || rel < kChunk) atomicAdd(acc + rel, to_fix40_sum(a0[c]));
                         a0[c] = 0.0f;
                     }
                 }
@@ -906,7 +940,7 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
                 const uint32_t m = r0 + k;
                 if (m >= m_hi) break;
                 if (rg[k] == 0.0f) continue;
-                const float g = rg[k] * 256.0f;
+                const float g = rg[k];
                 const float x = rx[k], y = ry[k], z = rz[k];
                 const float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
                 const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
@@ -993,7 +1027,7 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
                 if (!have) return;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    fix_add_rel(acc, (uint32_t)cur[c] - chunk_base, a0[c]);              // idx -1 (outside the grid) wraps out of every chunk; the 2^8 is in a0
+                    fix_add_rel(acc, (uint32_t)cur[c] - chunk_base, a0[c]);              // idx -1 (outside the grid) wraps out of every chunk
                     a0[c] = 0.0f;
                 }
             };
@@ -1013,9 +1047,8 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
                     for (int c = 0; c < 8; ++c) cur[c] = ui[c];
                     have = true;
                 }
-                const float g256 = rg[k] * 256.0f;          // the 2^8 of the fixed-point conversion, once per point (exact)
 #pragma unroll
-                for (int c = 0; c < 8; ++c) a0[c] = fmaf(uw[c], g256, a0[c]);
+                for (int c = 0; c < 8; ++c) a0[c] = fmaf(uw[c], rg[k], a0[c]);
             }
             flush();
         }

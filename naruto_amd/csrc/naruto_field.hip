@@ -745,49 +745,50 @@ __device__ __forceinline__ unsigned long long to_fix40(float v) { return to_fix4
 // The same fixed point through the fp64 pipe (gfx950 issues one v_fma_f64 per lane and clock, like fp32): M + v with M = 1.5 * 2^12
 // has ulp 2^-40 while |v| < 2^11, so the add -- or the fma that forms v -- rounds v to the nearest multiple of 2^-40 and leaves
 // that integer, two's complement, in the mantissa: bits(M + v) - bits(M).  bits(M) = 0x40B80000'00000000: the low word is zero, the
-// subtraction is ONE 32-bit add on the high word.  Three instructions (convert, add, high-word add) for the seven above, and a
-// product of doubles costs what a product of floats does.  Callers clamp to +-kFixClamp (a cotangent beyond that is not a gradient).
+// subtraction is ONE 32-bit add on the high word, and a product of doubles costs what a product of floats does.
 #ifndef NARUTO_FIX_F64
 #define NARUTO_FIX_F64 1
 #endif
 constexpr double kFixMagic = 6144.0;
-constexpr float kFixClamp = 2047.0f;
+constexpr float kFixMagicRange = 2047.0f;
 __device__ __forceinline__ unsigned long long fix40_bits(double magic_sum) {
     return (unsigned long long)__double_as_longlong(magic_sum) - 0x40B8000000000000ull;
 }
-__device__ __forceinline__ float fix_clamp(float v) { return __builtin_amdgcn_fmed3f(v, -kFixClamp, kFixClamp); }
-// v: the contribution itself (no 2^8)
+
+// a sum of contributions: through the magic number when the caller knows |v| < 2^11 (wave-uniform MAGIC), else the fp32 split
+template <bool MAGIC>
 __device__ __forceinline__ unsigned long long to_fix40_sum(float v) {
-#if NARUTO_FIX_F64
-    return fix40_bits((double)fix_clamp(v) + kFixMagic);
-#else
-    return to_fix40(v);
-#endif
+    if constexpr (MAGIC && NARUTO_FIX_F64) return fix40_bits((double)v + kFixMagic);
+    else return to_fix40(v);
 }
 
 // rel = entry index relative to this workgroup's chunk; in the chunk iff rel < kChunk (unsigned compare: entries below the
-// chunk wrap to huge values).
+// chunk wrap to huge values).  v: the contribution (or a sum of contributions), |v| < 2^14.
 __device__ __forceinline__ void fix_add_rel(unsigned long long* __restrict__ acc, uint32_t rel, float v) {
-    if (rel < kChunk) atomicAdd(acc + rel, to_fix40_sum(v));          // ds_add_u64
+    if (rel < kChunk) atomicAdd(acc + rel, to_fix40(v));          // ds_add_u64
 }
-// one list point's eight contributions g * w_c of a hashed level: the products run in fp64 (g * fx exact, the rest rounded to 53 bits)
-// and the last one is the fma that rounds onto the 2^-40 lattice
+// One list point's eight contributions g * w_c to a level (f: the per-axis weight factors of hash_corner_index).  The products
+// run in fp64 -- g * fx is exact, the others round to 53 bits -- and the last one is the fma with M that lands on the 2^-40
+// lattice: 7 conversions + 6 multiplies + 8 x {fma, high-word add} for 12 multiplies + 8 x {multiply, 7-instruction split}.
+// A wave holding a cotangent beyond the magic number's range (not a gradient any more) takes the fp32 split, which reaches 2^14.
 __device__ __forceinline__ void fix_add_corners(unsigned long long* __restrict__ acc, const uint32_t (&idx)[8], uint32_t chunk_base, const float (&f)[6], float g) {
 #if NARUTO_FIX_F64
-    const double gd = (double)fix_clamp(g);
-    const double gx0 = gd * (double)f[0], gx1 = gd * (double)f[1];
-    const double y0 = (double)f[2], y1 = (double)f[3], z0 = (double)f[4], z1 = (double)f[5];
-    const double gxy[4] = {gx0 * y0, gx1 * y0, gx0 * y1, gx1 * y1};
+    if (!__builtin_expect(__any(!(fabsf(g) <= kFixMagicRange)), 0)) {
+        const double gd = (double)g;
+        const double gx0 = gd * (double)f[0], gx1 = gd * (double)f[1];
+        const double y0 = (double)f[2], y1 = (double)f[3], z0 = (double)f[4], z1 = (double)f[5];
+        const double gxy[4] = {gx0 * y0, gx1 * y0, gx0 * y1, gx1 * y1};
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const uint32_t rel = idx[c] - chunk_base;
-        const double s = __fma_rn(gxy[c & 3], (c & 4) ? z1 : z0, kFixMagic);
-        if (rel < kChunk) atomicAdd(acc + rel, fix40_bits(s));
+        for (int c = 0; c < 8; ++c) {
+            const uint32_t rel = idx[c] - chunk_base;
+            const double s = __fma_rn(gxy[c & 3], (c & 4) ? z1 : z0, kFixMagic);
+            if (rel < kChunk) atomicAdd(acc + rel, fix40_bits(s));
+        }
+        return;
     }
-#else
+#endif
 #pragma unroll
     for (int c = 0; c < 8; ++c) fix_add_rel(acc, idx[c] - chunk_base, (f[c & 1] * f[2 + ((c >> 1) & 1)] * f[4 + (c >> 2)]) * g);
-#endif
 }
 
 template <int T>
@@ -890,15 +891,17 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
             // into every corner (35 instructions per corner instead of 16).  Measured gain: small (dense units 69 -> 65.7 us) --
             // a quarter of the benchmark's active samples lie outside the scene box, so most waves hold such a lane and take the
             // wrap path anyway.
-            auto flush = [&]() {
-                if (!have) return;
+            // (the conversion of the flushed sums goes through the fp64 magic number when every cotangent of the wave's runs is small
+            // enough for a run's sum to stay inside its range -- decided once per run, wave-uniform -- and through the fp32 split otherwise)
+            auto flush_as = [&](auto magic_c) {
+                constexpr bool MAGIC = decltype(magic_c)::value;
                 if (__builtin_expect(__any(cur >= interior), 0)) {      // (points outside the box give huge cell numbers: also here)
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
                         uint32_t i = cur + (uint32_t)(c & 1) + ((c & 2) ? res : 0u) + ((c & 4) ? r2 : 0u);
                         i -= __umulhi(i, magic) * size;           // i % size by multiply-high with the level's constant: at most one correction
                         if (i >= size) i -= size;
-                        fix_add_rel(acc, i - chunk_base, a0[c]);
+                        if (i - chunk_base < kChunk) atomicAdd(acc + (i - chunk_base), to_fix40_sum<MAGIC>(a0[c]));
                         a0[c] = 0.0f;
                     }
                 } else {
@@ -906,10 +909,16 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
                         const uint32_t rel = rel0 + (uint32_t)(c & 1) + ((c & 2) ? res : 0u) + ((c & 4) ? r2 : 0u);
-                        if (single_chunk || rel < kChunk) atomicAdd(acc + rel, to_fix40_sum(a0[c]));
+                        if (single_chunk || rel < kChunk) atomicAdd(acc + rel, to_fix40_sum<MAGIC>(a0[c]));
                         a0[c] = 0.0f;
                     }
                 }
+            };
+            bool magic_ok = false;
+            auto flush = [&]() {
+                if (!have) return;
+                if (magic_ok) flush_as(std::true_type{});
+                else flush_as(std::false_type{});
             };
             // the whole run's inputs up front (list layout: ten 16-byte loads; otherwise 32 scalar loads, all independent): one
             // point at a time the run is a chain of kScatterRun memory round trips
@@ -934,6 +943,12 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
                     rg[k] = d_feat[m * sm32 + (uint32_t)T * sl32];
                     load_point(ps, bt, m, rx[k], ry[k], rz[k]);
                 }
+            }
+            {
+                float gmax = 0.0f;
+#pragma unroll
+                for (int k = 0; k < kScatterRun; ++k) gmax = fmaxf(gmax, fabsf(rg[k]));
+                magic_ok = !__any(!(gmax <= kFixMagicRange / (float)kScatterRun));           // (NaN: the split's problem)
             }
 #pragma unroll
             for (int k = 0; k < kScatterRun; ++k) {
@@ -1023,13 +1038,23 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
             bool have = false;
 #pragma unroll
             for (int c = 0; c < 8; ++c) { cur[c] = -1; a0[c] = 0.0f; }
-            auto flush = [&]() {
-                if (!have) return;
+            float gmax = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) gmax = fmaxf(gmax, fabsf(rg[k]));
+            const bool magic_ok = !__any(!(gmax <= kFixMagicRange / 8.0f));              // as in the dense units
+            auto flush_as = [&](auto magic_c) {
+                constexpr bool MAGIC = decltype(magic_c)::value;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    fix_add_rel(acc, (uint32_t)cur[c] - chunk_base, a0[c]);              // idx -1 (outside the grid) wraps out of every chunk
+                    const uint32_t rel = (uint32_t)cur[c] - chunk_base;                       // idx -1 (outside the grid) wraps out of every chunk
+                    if (rel < kChunk) atomicAdd(acc + rel, to_fix40_sum<MAGIC>(a0[c]));
                     a0[c] = 0.0f;
                 }
+            };
+            auto flush = [&]() {
+                if (!have) return;
+                if (magic_ok) flush_as(std::true_type{});
+                else flush_as(std::false_type{});
             };
 #pragma unroll
             for (int k = 0; k < 8; ++k) {

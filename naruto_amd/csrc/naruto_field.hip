@@ -734,6 +734,7 @@ constexpr uint32_t kListVec = NARUTO_LIST_VEC;      // 2 or 4 consecutive points
 // negative t, fract(t) = 1 + t is rounded to fp32 next to 1.0 and the contribution is off by up to 2^-33 -- a relative
 // 1e-4 for a typical 1e-6 contribution, every time.)
 __device__ __forceinline__ unsigned long long to_fix40_scaled(float t) {
+    t = fabsf(t) < 1073741824.0f ? t : 0.0f;                  // NaN, Inf and |v| >= 2^22 contribute nothing (the conversions below would saturate)
     const float hf = rintf(t);
     const float r = t - hf;
     const int lo = (int)(r * 4294967296.0f);                 // v_cvt_i32_f32 saturates at r = +1/2: one unit of 2^-40
@@ -755,7 +756,7 @@ __device__ __forceinline__ unsigned long long fix40_bits(double magic_sum) {
     return (unsigned long long)__double_as_longlong(magic_sum) - 0x40B8000000000000ull;
 }
 
-// a sum of contributions: through the magic number when the caller knows |v| < 2^11 (wave-uniform MAGIC), else the fp32 split
+// a sum of contributions: through the magic number when the caller knows |v| < 2^11, else the fp32 split
 template <bool MAGIC>
 __device__ __forceinline__ unsigned long long to_fix40_sum(float v) {
     if constexpr (MAGIC && NARUTO_FIX_F64) return fix40_bits((double)v + kFixMagic);
@@ -763,17 +764,18 @@ __device__ __forceinline__ unsigned long long to_fix40_sum(float v) {
 }
 
 // rel = entry index relative to this workgroup's chunk; in the chunk iff rel < kChunk (unsigned compare: entries below the
-// chunk wrap to huge values).  v: the contribution (or a sum of contributions), |v| < 2^14.
+// chunk wrap to huge values).  v: the contribution (or a sum of contributions), |v| < 2^22.
 __device__ __forceinline__ void fix_add_rel(unsigned long long* __restrict__ acc, uint32_t rel, float v) {
     if (rel < kChunk) atomicAdd(acc + rel, to_fix40(v));          // ds_add_u64
 }
 // One list point's eight contributions g * w_c to a level (f: the per-axis weight factors of hash_corner_index).  The products
 // run in fp64 -- g * fx is exact, the others round to 53 bits -- and the last one is the fma with M that lands on the 2^-40
 // lattice: 7 conversions + 6 multiplies + 8 x {fma, high-word add} for 12 multiplies + 8 x {multiply, 7-instruction split}.
-// A wave holding a cotangent beyond the magic number's range (not a gradient any more) takes the fp32 split, which reaches 2^14.
+// A point with a cotangent beyond the magic number's range (not a gradient any more) takes the fp32 split, which reaches 2^22; a
+// NaN / Inf cotangent adds nothing.  (Positions are this library's own: o + t d of finite rays.)
 __device__ __forceinline__ void fix_add_corners(unsigned long long* __restrict__ acc, const uint32_t (&idx)[8], uint32_t chunk_base, const float (&f)[6], float g) {
 #if NARUTO_FIX_F64
-    if (!__builtin_expect(__any(!(fabsf(g) <= kFixMagicRange)), 0)) {
+    if (__builtin_expect(fabsf(g) <= kFixMagicRange, 1)) {             // per LANE: what a point adds does not depend on its wave
         const double gd = (double)g;
         const double gx0 = gd * (double)f[0], gx1 = gd * (double)f[1];
         const double y0 = (double)f[2], y1 = (double)f[3], z0 = (double)f[4], z1 = (double)f[5];
@@ -786,6 +788,7 @@ __device__ __forceinline__ void fix_add_corners(unsigned long long* __restrict__
         }
         return;
     }
+    if (!(fabsf(g) < 4194304.0f)) return;                   // NaN / Inf / beyond the fixed point's range: the point adds nothing (as on the dense levels)
 #endif
 #pragma unroll
     for (int c = 0; c < 8; ++c) fix_add_rel(acc, idx[c] - chunk_base, (f[c & 1] * f[2 + ((c >> 1) & 1)] * f[4 + (c >> 2)]) * g);
@@ -891,8 +894,8 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
             // into every corner (35 instructions per corner instead of 16).  Measured gain: small (dense units 69 -> 65.7 us) --
             // a quarter of the benchmark's active samples lie outside the scene box, so most waves hold such a lane and take the
             // wrap path anyway.
-            // (the conversion of the flushed sums goes through the fp64 magic number when every cotangent of the wave's runs is small
-            // enough for a run's sum to stay inside its range -- decided once per run, wave-uniform -- and through the fp32 split otherwise)
+            // (the conversion of the flushed sums goes through the fp64 magic number when every cotangent of the run is small enough for
+            // the run's sums to stay inside its range -- decided once per run and lane -- and through the fp32 split otherwise)
             auto flush_as = [&](auto magic_c) {
                 constexpr bool MAGIC = decltype(magic_c)::value;
                 if (__builtin_expect(__any(cur >= interior), 0)) {      // (points outside the box give huge cell numbers: also here)
@@ -944,11 +947,14 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
                     load_point(ps, bt, m, rx[k], ry[k], rz[k]);
                 }
             }
-            {
-                float gmax = 0.0f;
+            // A point whose cotangent is NaN / Inf or beyond the fixed point's 2^22 adds nothing (and must not poison the register sums of
+            // its cell neighbours): its cotangent becomes 0.  magic_ok: per run, from the run's own VALID
+            // points (the rows behind the list's end hold stale values).
+            magic_ok = true;
 #pragma unroll
-                for (int k = 0; k < kScatterRun; ++k) gmax = fmaxf(gmax, fabsf(rg[k]));
-                magic_ok = !__any(!(gmax <= kFixMagicRange / (float)kScatterRun));           // (NaN: the split's problem)
+            for (int k = 0; k < kScatterRun; ++k) {
+                rg[k] = fabsf(rg[k]) < 4194304.0f ? rg[k] : 0.0f;
+                magic_ok = magic_ok && (r0 + (uint32_t)k >= m_hi || fabsf(rg[k]) <= kFixMagicRange / (float)kScatterRun);
             }
 #pragma unroll
             for (int k = 0; k < kScatterRun; ++k) {
@@ -1038,10 +1044,12 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
             bool have = false;
 #pragma unroll
             for (int c = 0; c < 8; ++c) { cur[c] = -1; a0[c] = 0.0f; }
-            float gmax = 0.0f;
+            bool magic_ok = true;                                                         // as in the dense units
 #pragma unroll
-            for (int k = 0; k < 8; ++k) gmax = fmaxf(gmax, fabsf(rg[k]));
-            const bool magic_ok = !__any(!(gmax <= kFixMagicRange / 8.0f));              // as in the dense units
+            for (int k = 0; k < 8; ++k) {
+                rg[k] = fabsf(rg[k]) < 4194304.0f ? rg[k] : 0.0f;
+                magic_ok = magic_ok && (r0 + (uint32_t)k >= m_hi || fabsf(rg[k]) <= kFixMagicRange / 8.0f);
+            }
             auto flush_as = [&](auto magic_c) {
                 constexpr bool MAGIC = decltype(magic_c)::value;
 #pragma unroll

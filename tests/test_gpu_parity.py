@@ -1907,6 +1907,33 @@ def test_scatter_small_contributions_are_exact(gpu, size):
     assert err.max() <= rel_tol * scale + abs_tol, f"table gradient off by {err.max():.3e} (scale {scale:.3e})"
 
 
+def test_scatter_drops_nan_cotangents(gpu):
+    """a point whose cotangent is NaN / Inf (or beyond the fixed point's 2^22) contributes nothing to the table gradient
+    -- the reference's float atomics would spread it -- and takes nothing of its neighbours with it (the dense levels sum the points
+    of a cell in registers first).  Every 97th point's cotangents are NaN, Inf or 1e9: the result must be the gradient of the same batch
+    with those cotangents zeroed, bit for bit on every level."""
+    cfg = H.office_cfg(12)
+    ora = H.make_oracle(cfg, 0.25, 59)
+    m = H.make_hip_from_oracle(cfg, ora, gpu)
+    rs = np.random.RandomState(59)
+    x = torch.from_numpy(rs.uniform(0, 1, (30000, 3)).astype(np.float32)).to(gpu)
+    c = torch.from_numpy((rs.standard_normal((30000, 32)) * 1e-3).astype(np.float32)).to(gpu)
+    bad = torch.arange(0, 30000, 97, device=gpu)
+    c_bad = c.clone()
+    c_bad[bad[0::3]] = float("nan")
+    c_bad[bad[1::3]] = float("inf")
+    c_bad[bad[2::3]] = 1e9
+    c_zero = c.clone()
+    c_zero[bad] = 0.0
+    grads = []
+    for cot in (c_bad, c_zero):
+        m.embed_fn.params.grad = None
+        m.query_sdf(x, embed=True).backward(cot)
+        grads.append(m.embed_fn.params.grad.clone())
+    assert torch.isfinite(grads[0]).all()
+    assert torch.equal(grads[0], grads[1])
+
+
 def test_active_ray_sampler_ties(gpu):
     """An all-zero cached uncertainty volume (the state before the first planner query): every candidate ties, the K
     lowest-index candidates are taken, exactly as the oracle's deterministic rule."""

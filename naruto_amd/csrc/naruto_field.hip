@@ -954,7 +954,7 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
 #pragma unroll
             for (int k = 0; k < kScatterRun; ++k) {
                 rg[k] = fabsf(rg[k]) < 4194304.0f ? rg[k] : 0.0f;
-                magic_ok = magic_ok && (r0 + (uint32_t)k >= m_hi || fabsf(rg[k]) <= kFixMagicRange / (float)kScatterRun);
+                magic_ok = magic_ok & ((r0 + (uint32_t)k >= m_hi) | (fabsf(rg[k]) <= kFixMagicRange / (float)kScatterRun));      // (no short circuits: they compile to branches)
             }
 #pragma unroll
             for (int k = 0; k < kScatterRun; ++k) {
@@ -1039,6 +1039,9 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
                 rz[4 * h] = Z.x; rz[4 * h + 1] = Z.y; rz[4 * h + 2] = Z.z; rz[4 * h + 3] = Z.w;
                 rg[4 * h] = G.x; rg[4 * h + 1] = G.y; rg[4 * h + 2] = G.z; rg[4 * h + 3] = G.w;
             }
+            // (keeps the 16-byte loads whole and up front: left alone, the compiler sinks the first point's three coordinates into the
+            // "cotangent is not zero" branch as scalar loads -- a memory round trip inside the run)
+            asm volatile("" : "+v"(rx[0]), "+v"(ry[0]), "+v"(rz[0]));
             int32_t cur[8];
             float a0[8];
             bool have = false;
@@ -1048,7 +1051,7 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 rg[k] = fabsf(rg[k]) < 4194304.0f ? rg[k] : 0.0f;
-                magic_ok = magic_ok && (r0 + (uint32_t)k >= m_hi || fabsf(rg[k]) <= kFixMagicRange / 8.0f);
+                magic_ok = magic_ok & ((r0 + (uint32_t)k >= m_hi) | (fabsf(rg[k]) <= kFixMagicRange / 8.0f));
             }
             auto flush_as = [&](auto magic_c) {
                 constexpr bool MAGIC = decltype(magic_c)::value;

@@ -1332,6 +1332,31 @@ constexpr int kGradLd = 33;    // row stride of the per-wave [32][32] stages
 constexpr int kAccTiles = 7;
 constexpr int kAccFloats = kAccTiles * 1024;
 
+// Block-level sum of the four waves' register tiles into a float image acc [tile][row][col] (the caller has a barrier behind it):
+// every (tile, row, col) belongs to exactly one lane of a wave, and in pass p wave w adds its quarter (w + p) & 3 of the 112
+// (tile, register) pairs -- all four waves work in every pass, no two on the same entries, each entry summed in a fixed wave order.
+template <int G>
+__device__ __forceinline__ void block_sum_quarter(float* __restrict__ acc, const f32x16* const (&tiles)[kAccTiles], bool first, int hh, int j) {
+    constexpr int kPer = kAccTiles * 16 / 4;
+    static_for<G * kPer, (G + 1) * kPer>([&](auto kc) {
+        constexpr int K = decltype(kc)::value, T = K / 16, R = K % 16;
+        float* a = &acc[T * 1024 + crow(R, hh) * 32 + j];
+        const float v = (*tiles[T])[R];
+        *a = first ? v : *a + v;
+    });
+}
+__device__ __forceinline__ void block_sum_tiles(float* __restrict__ acc, const f32x16* const (&tiles)[kAccTiles], int wave, int hh, int j) {
+    for (int p = 0; p < 4; ++p) {
+        switch ((wave + p) & 3) {
+            case 0: block_sum_quarter<0>(acc, tiles, p == 0, hh, j); break;
+            case 1: block_sum_quarter<1>(acc, tiles, p == 0, hh, j); break;
+            case 2: block_sum_quarter<2>(acc, tiles, p == 0, hh, j); break;
+            default: block_sum_quarter<3>(acc, tiles, p == 0, hh, j); break;
+        }
+        __syncthreads();
+    }
+}
+
 // Waves per workgroup: 33 KB of weight images + 20.4 KB of stages per wave <= 160 KB of LDS allows up to 6.  Measured on
 // MI355X: 4 waves (one per SIMD, 389 registers, software prefetch) 64 us (68 before the prefetch was made wait-free); 6 waves (2,2,1,1 per SIMD, 256 registers with
 // 42 spilled, no prefetch) 82 us -- the two SIMDs that hold two waves set the pace.  PMC at 4 waves: MFMA pipe 35 % busy,
@@ -1697,24 +1722,14 @@ __global__ __launch_bounds__(64 * kBwdWaves) void k_query_bwd(LevelTab lt, Uncer
             }
         }
     }
-    // block-level sum of the four waves' register tiles through the LDS image (plain stores / adds: every
-    // (tile,row,col) belongs to exactly one lane of a wave), then one coalesced write of the partial
+    // block-level sum of the four waves' register tiles through the LDS image, then one coalesced write of the partial
     static_assert(sizeof(L.xs) >= kAccFloats * sizeof(float), "the dW image must fit the xs stages");
     float* __restrict__ acc = &L.xs[0][0];
     __syncthreads();                     // every wave is done with its stages
-    for (int w = 0; w < kBwdWaves; ++w) {
-        if (wave == w) {
-            const f32x16* tiles[kAccTiles] = {&dW0a, &dW0b, &dW0c, &dW1, &dWc0a, &dWc0b, &dWc1};
-#pragma unroll
-            for (int t = 0; t < kAccTiles; ++t) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float* a = &acc[t * 1024 + crow(r, hh) * 32 + j];
-                    *a = (w == 0 ? 0.0f : *a) + (*tiles[t])[r];
-                }
-            }
-        }
-        __syncthreads();
+    {
+        static_assert(kBwdWaves == 4, "block_sum_tiles rotates four waves");
+        const f32x16* const tiles[kAccTiles] = {&dW0a, &dW0b, &dW0c, &dW1, &dWc0a, &dWc0b, &dWc1};
+        block_sum_tiles(acc, tiles, wave, hh, j);
     }
     float* __restrict__ out = partials + (size_t)blockIdx.x * kAccFloats;
     for (int e = threadIdx.x; e < kAccFloats; e += blockDim.x) out[e] = acc[e];
@@ -2047,26 +2062,12 @@ __global__ __launch_bounds__(256, NARUTO_BWD_BF_MINWAVES) void k_query_bwd_bf(Le
     if (dw.w0a[0] == 123.0f && dw.c1[3] == 5.0f) partials[lane] = dw.w1[2] + dw.w0b[1] + dw.w0c[1] + dw.c0a[1] + dw.c0b[1];
     return;
 #endif
-    // (plain stores / adds, wave after wave: every (tile,row,col) belongs to exactly one lane of a wave.  The int64 fixed-point image
-    // this replaced let the four waves add concurrently, but 448 ds_add_u64 and their conversions cost more than three barriers:
-    // 28.7 -> 27.7 us)
+    // (the int64 fixed-point image this replaced let the four waves add concurrently, but 448 ds_add_u64 and their conversions cost
+    // more than the float passes: 28.7 -> 27.7 us)
     {
         float* __restrict__ facc = reinterpret_cast<float*>(smem_raw);
-        const int wave = threadIdx.x >> 6;
-        for (int w = 0; w < 4; ++w) {
-            if (wave == w) {
-                const f32x16* tiles[kAccTiles] = {&dw.w0a, &dw.w0b, &dw.w0c, &dw.w1, &dw.c0a, &dw.c0b, &dw.c1};
-#pragma unroll
-                for (int t = 0; t < kAccTiles; ++t) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float* a = &facc[t * 1024 + crow(r, hh) * 32 + j];
-                        *a = (w == 0 ? 0.0f : *a) + (*tiles[t])[r];
-                    }
-                }
-            }
-            __syncthreads();
-        }
+        const f32x16* const tiles[kAccTiles] = {&dw.w0a, &dw.w0b, &dw.w0c, &dw.w1, &dw.c0a, &dw.c0b, &dw.c1};
+        block_sum_tiles(facc, tiles, threadIdx.x >> 6, hh, j);
         float* __restrict__ out = partials + (size_t)blockIdx.x * kAccFloats;
         for (int e = threadIdx.x; e < kAccFloats; e += 256) out[e] = facc[e];
     }

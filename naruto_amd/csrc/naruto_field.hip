@@ -1503,9 +1503,6 @@ __global__ __launch_bounds__(64 * kBwdWaves) void k_query_bwd(LevelTab lt, Uncer
     // w_img: the weight part of BwdLds prepared in global memory, or NULL (stage it here)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     BwdLds& L = *reinterpret_cast<BwdLds*>(smem_raw);
-    if (w_img != nullptr) fetch_weight_image<64 * kBwdWaves>(smem_raw, w_img, kBwdImageBytes, threadIdx.x);
-    else stage_bwd_weights<64 * kBwdWaves>(L, p, threadIdx.x);
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hh = lane >> 5, j = lane & 31;
     // M_eff points are processed: all M, or the compacted list of points whose cotangent is not identically 0
@@ -1559,6 +1556,10 @@ __global__ __launch_bounds__(64 * kBwdWaves) void k_query_bwd(LevelTab lt, Uncer
         nxt = load_tile(tile, load_index(tile));
         m_ahead = load_index(min(tile + tile_stride, last_tile));
     }
+    // the weight images arrive while the first tile's three dependent trips to memory (count -> list entry -> inputs) are under way
+    if (w_img != nullptr) fetch_weight_image<64 * kBwdWaves>(smem_raw, w_img, kBwdImageBytes, threadIdx.x);
+    else stage_bwd_weights<64 * kBwdWaves>(L, p, threadIdx.x);
+    __syncthreads();
     for (; tile < n_tiles; tile += tile_stride) {
         TileIn cur;
         if constexpr (kPrefetch) {
@@ -1956,23 +1957,31 @@ __global__ __launch_bounds__(256, NARUTO_BWD_BF_MINWAVES) void k_query_bwd_bf(Le
                                                       const void* __restrict__ w_img) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     BwdLdsBf& L = *reinterpret_cast<BwdLdsBf*>(smem_raw);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hh = lane >> 5, j = lane & 31;
+    const uint32_t M_eff = n_active != nullptr ? n_active[0] : M;
+    const uint32_t n_tiles = (M_eff + 63u) / 64u;                  // 64 list entries per wave and step: two 32-point tiles
+    // the first step's list entries: two of its three dependent trips to memory (count -> list entry -> inputs) run while the weight
+    // images arrive
+    const uint32_t tile_first = blockIdx.x * 4u + wave;
+    uint32_t m_first = 0;
+    if (tile_first < n_tiles) {
+        const uint32_t i0 = tile_first * 64u + lane < M_eff ? tile_first * 64u + lane : M_eff - 1u;
+        m_first = active_idx != nullptr ? active_idx[i0] : i0;
+    }
 #ifndef NARUTO_ABL_BF_NOSTAGE
     if (w_img != nullptr) fetch_weight_image<256>(smem_raw, w_img, sizeof(BwdLdsBf), threadIdx.x);
     else stage_bwd_weights_bf<256>(L, p, threadIdx.x);
 #endif
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int hh = lane >> 5, j = lane & 31;
-    const uint32_t M_eff = n_active != nullptr ? n_active[0] : M;
-    const uint32_t n_tiles = (M_eff + 63u) / 64u;                  // 64 list entries per wave and step: two 32-point tiles
     DwTiles dw{zero16(), zero16(), zero16(), zero16(), zero16(), zero16(), zero16()};
     float2* __restrict__ dfo = reinterpret_cast<float2*>(d_feat);
-    for (uint32_t tile = blockIdx.x * 4u + wave; tile < n_tiles; tile += gridDim.x * 4u) {
+    for (uint32_t tile = tile_first; tile < n_tiles; tile += gridDim.x * 4u) {
         // every lane owns one list entry for the per-point work (point, OneBlob, uncertainty corners, cotangent)
         const uint32_t i_raw = tile * 64u + lane;
         const bool valid = i_raw < M_eff;
         const uint32_t i_pt = valid ? i_raw : M_eff - 1u;
-        const uint32_t m = active_idx != nullptr ? active_idx[i_pt] : i_pt;
+        const uint32_t m = tile == tile_first ? m_first : (active_idx != nullptr ? active_idx[i_pt] : i_pt);
         float x, y, z;
         load_point(ps, bt, m, x, y, z);
         float g[5];

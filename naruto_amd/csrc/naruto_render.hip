@@ -393,14 +393,15 @@ struct LossArgs {
 };
 
 // one wave = ray n (ray_lds: the workgroup's dynamic LDS); la.sums may point into LDS
-template <bool LOSS>
+// LOADED: the caller has filled the wave's LDS image already (load_ray)
+template <bool LOSS, bool LOADED = false>
 __device__ __forceinline__ void composite_bwd_ray(float* ray_lds, uint32_t n, int lane, int wave, uint32_t S, float trunc, float sc_factor, int white_bkgd,
                                                   const float* __restrict__ raw, const float* __restrict__ z_vals, const CompositeCot& cot, const LossArgs& la,
                                                   float* __restrict__ d_raw, int accumulate, uint32_t* __restrict__ ray_count) {
     // inlined into two kernels (k_composite_bwd, k_loss_bwd_fused) that must produce the same bits: only the fmaf()s written below fuse
 #pragma clang fp contract(off)
     const RayScratch rs = ray_scratch(ray_lds, wave, S);
-    load_ray(rs, raw, z_vals, n, S, lane);
+    if constexpr (!LOADED) load_ray(rs, raw, z_vals, n, S, lane);
     const RayWeights rw = ray_weights(rs, S, trunc, sc_factor, lane);
     const RayOut o = ray_composite(rs, rw, n, S, 0, nullptr, lane);     // rgb WITHOUT the white background term
 

@@ -269,29 +269,46 @@ __global__ __launch_bounds__(64) void k_loss_fold(const double* __restrict__ in,
 // The loss stage's rows -> sums of the slots in MASK, by one 256-thread workgroup in a fixed order: thread t owns rows t, t + 256, ...
 // (all of a thread's loads are independent and issued together: the rows were written by other XCDs, so every load is a trip to
 // memory), then a fixed-shape tree over the threads.  Leaves s_sums[k] in LDS (ends with a barrier).
+// the loads of one 1 024-row slab (a thread's four rows) and their accumulation, separately: a caller with other loads to issue puts
+// them between the two so that all of them are in flight together
+template <uint32_t MASK>
+__device__ __forceinline__ void wg_partial_load(const double* __restrict__ partials, uint32_t n_rows, uint32_t b0, double (&v)[4][10]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t b = b0 + threadIdx.x + 256u * j;
+#pragma unroll
+        for (int k = 0; k < 10; ++k)
+            if ((MASK >> k) & 1u) v[j][k] = b < n_rows ? partials[(size_t)b * 16 + k] : (k == 9 ? 1e300 : 0.0);
+    }
+}
+template <uint32_t MASK>
+__device__ __forceinline__ void wg_partial_accumulate(const double (&v)[4][10], double (&acc)[10]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            if ((MASK >> k) & 1u) acc[k] += v[j][k];
+        if ((MASK >> 9) & 1u) acc[9] = (v[j][9] < acc[9] || v[j][9] != v[j][9]) ? v[j][9] : acc[9];
+    }
+}
+template <uint32_t MASK>
+__device__ __forceinline__ void wg_partial_reduce(double (&acc)[10], double (*part)[10], double* s_sums);
 template <uint32_t MASK>
 __device__ __forceinline__ void wg_partial_sums(const double* __restrict__ partials, uint32_t n_rows, double (*part)[10], double* s_sums) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double acc[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) acc[k] = k == 9 ? 1e300 : 0.0;
     for (uint32_t b0 = 0; b0 < n_rows; b0 += 1024u) {
         double v[4][10];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t b = b0 + threadIdx.x + 256u * j;
-#pragma unroll
-            for (int k = 0; k < 10; ++k)
-                if ((MASK >> k) & 1u) v[j][k] = b < n_rows ? partials[(size_t)b * 16 + k] : (k == 9 ? 1e300 : 0.0);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k)
-                if ((MASK >> k) & 1u) acc[k] += v[j][k];
-            if ((MASK >> 9) & 1u) acc[9] = (v[j][9] < acc[9] || v[j][9] != v[j][9]) ? v[j][9] : acc[9];
-        }
+        wg_partial_load<MASK>(partials, n_rows, b0, v);
+        wg_partial_accumulate<MASK>(v, acc);
     }
+    wg_partial_reduce<MASK>(acc, part, s_sums);
+}
+// the threads' sums -> s_sums[k] in LDS (fixed-shape tree; ends with a barrier)
+template <uint32_t MASK>
+__device__ __forceinline__ void wg_partial_reduce(double (&acc)[10], double (*part)[10], double* s_sums) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
         if (!((MASK >> k) & 1u)) continue;
@@ -381,15 +398,31 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_bwd_fused(FusedBwdA
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t r0 = blockIdx.x * kRaysPerBlock, n = r0 + wave;
+    // Every load of this workgroup that depends on nothing goes out first -- the counts of the rays before it, the loss stage's rows, its
+    // rays' raw values and depths (into the LDS image) -- so that they share ONE trip to memory instead of three behind one another.
+    constexpr int kCountLoads = (int)(kFusedTailMaxRays / 256u);
+    uint32_t cv[kCountLoads];
+#pragma unroll
+    for (int q = 0; q < kCountLoads; ++q) {
+        const uint32_t i = threadIdx.x + 256u * (uint32_t)q;
+        cv[q] = i < r0 ? a.ray_count[i] : 0u;
+    }
+    const uint32_t c = n < a.n_rays ? a.ray_count[n] : 0u;
+    double pv[4][10];
+    if (!a.sums_given) wg_partial_load<0xD6u>(a.partials, a.n_ray_blocks, 0u, pv);          // slots 1, 2, 4, 6, 7 (at most 1 024 rows here)
+    if (n < a.n_rays) load_ray(ray_scratch(ray_lds, wave, a.S), a.raw, a.z_vals, n, a.S, lane);
     // list offset: the counts of the rays before this workgroup's (integer sums: any order)
     uint32_t s = 0;
-#pragma unroll 4
-    for (uint32_t i = threadIdx.x; i < r0; i += 256u) s += a.ray_count[i];
-    const uint32_t c = n < a.n_rays ? a.ray_count[n] : 0u;
+#pragma unroll
+    for (int q = 0; q < kCountLoads; ++q) s += cv[q];
     s = wave_sum_u32(s);
     if (lane == 0) { pre[wave] = s; cnt[wave] = c; }
     if (!a.sums_given) {
-        wg_partial_sums<0xD6u>(a.partials, a.n_ray_blocks, part, s_sums);     // slots 1, 2, 4, 6, 7
+        double acc[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) acc[k] = k == 9 ? 1e300 : 0.0;
+        wg_partial_accumulate<0xD6u>(pv, acc);
+        wg_partial_reduce<0xD6u>(acc, part, s_sums);
     } else {
         if (threadIdx.x < 10) s_sums[threadIdx.x] = a.la.sums[threadIdx.x];
         __syncthreads();
@@ -408,7 +441,7 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_bwd_fused(FusedBwdA
     LossArgs la = a.la;
     la.sums = s_sums;
     const CompositeCot cot{};
-    composite_bwd_ray<true>(ray_lds, n, lane, wave, a.S, a.trunc, a.sc_factor, a.white_bkgd, a.raw, a.z_vals, cot, la, a.d_raw, 0, nullptr);
+    composite_bwd_ray<true, true>(ray_lds, n, lane, wave, a.S, a.trunc, a.sc_factor, a.white_bkgd, a.raw, a.z_vals, cot, la, a.d_raw, 0, nullptr);
 }
 
 // data-parallel tail of the loss stage: all-reduced sums -> losses[0..7], total -> losses[9]

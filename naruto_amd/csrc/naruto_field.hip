@@ -1605,17 +1605,27 @@ __global__ __launch_bounds__(64 * kBwdWaves) void k_query_bwd(LevelTab lt, Uncer
             h = mfma32(L.f.s0[T * 64 + lane], b, h);
         });
         const bool blob_fast = __all(oneblob_sparse_ok(x) && oneblob_sparse_ok(y) && oneblob_sparse_ok(z));
+        // (zero K pairs skipped as in the forward: a product with an exact 0.0f adds nothing; the stage still gets every column)
+        float eb[3][kBins];
+        uint32_t pairs = 0;
         static_for<0, 3>([&](auto dc) {
             constexpr int D = decltype(dc)::value;
-            float e[kBins];
-            oneblob16_auto(D == 0 ? x : (D == 1 ? y : z), blob_fast, e);
+            uint32_t pd;
+            oneblob16_auto(D == 0 ? x : (D == 1 ? y : z), blob_fast, eb[D], pd);
+            pairs |= pd << (8 * D);
+        });
+        pairs = blob_fast ? wave_or_u32(pairs) : 0xFFFFFFu;
+        static_for<0, 3>([&](auto dc) {
+            constexpr int D = decltype(dc)::value;
             static_for<0, 8>([&](auto qc) {
                 constexpr int Q = decltype(qc)::value;
                 constexpr int P = D * 8 + Q;
-                const float b = hh ? e[2 * Q + 1] : e[2 * Q];
+                const float b = hh ? eb[D][2 * Q + 1] : eb[D][2 * Q];
                 xs[j * kStageLd + kFeat + 2 * P + hh] = valid ? b : 0.0f;
-                h = mfma32(L.f.s0[(16 + P) * 64 + lane], b, h);
-                c = mfma32(L.f.c0p[P * 64 + lane], b, c);
+                if ((pairs >> P) & 1u) {
+                    h = mfma32(L.f.s0[(16 + P) * 64 + lane], b, h);
+                    c = mfma32(L.f.c0p[P * 64 + lane], b, c);
+                }
             });
         });
         f32x16 o = zero16();

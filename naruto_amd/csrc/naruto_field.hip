@@ -1511,7 +1511,13 @@ __global__ __launch_bounds__(64 * kBwdWaves) void k_query_bwd(LevelTab lt, Uncer
     float* __restrict__ xs = L.xs[wave];
     float* __restrict__ ga = L.ga[wave];
     float* __restrict__ gb = L.gb[wave];
-    f32x16 dW0a = zero16(), dW0b = zero16(), dW0c = zero16(), dW1 = zero16(), dWc0a = zero16(), dWc0b = zero16(), dWc1 = zero16();
+    f32x16 dW0a = zero16(), dW0b = zero16(), dW0c = zero16(), dW1 = zero16(), dWc0a = zero16(), dWc0b = zero16();
+    float pc1[3][16];               // dW(col_w1): this lane's partial sums  d_rgb[q] * relu(c)[unit crow(r, hh)]  over its points
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pc1[q][r] = 0.0f;
+    }
     // Inputs of a tile (list index -> sample index -> point, cotangent, saved hash features): with one wave per SIMD
     // nothing else hides these dependent trips to L2 / memory, so the NEXT tile's inputs are fetched while the current
     // tile computes (software prefetch, ~30 registers).
@@ -1651,25 +1657,13 @@ __global__ __launch_bounds__(64 * kBwdWaves) void k_query_bwd(LevelTab lt, Uncer
             dcv[r] = c[r] > 0.0f ? a : 0.0f;
             cact[r] = fmaxf(c[r], 0.0f);
         }
-        // ---- dW(col_w1)[q][i] = sum_pt d_rgb[q] * relu(c)[i]   (tile 6; G rows q<3 = this tile's rgb cotangents, which the
-        // lanes already hold: passed through the free "G" stage instead of being read back from d_raw -- that was an index
-        // load + a dependent cotangent load, two exposed round trips to memory in the middle of every tile)
-        stage_ctile(gb, kGradLd, 0, cact, j, hh);
-        if (hh == 0) {
+        // ---- dW(col_w1)[q][i] = sum_pt d_rgb[q] * relu(c)[i]: three rows of a 32 x 32 tile.  As 16 matrix instructions (+ two stages
+        // and 32 LDS reads per tile) 29 of 32 output rows were padding; the lane holds both factors of its point, so it keeps 48 partial
+        // sums in registers and the 32 points of a half are summed ONCE, after the tile loop (padding points carry zero cotangents).
 #pragma unroll
-            for (int q = 0; q < 3; ++q) ga[j * kGradLd + q] = g_rgb[q];             // padding points carry zeros
-        }
-        wave_lds_sync();
-        {
-            const int i = lane & 31;
-            float gv[16], xv[16];
+        for (int q = 0; q < 3; ++q) {
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                gv[t] = i < 3 ? ga[(2 * t + hh) * kGradLd + i] : 0.0f;
-                xv[t] = gb[(2 * t + hh) * kGradLd + i];
-            }
-#pragma unroll
-            for (int t = 0; t < 16; ++t) dWc1 = mfma32(gv[t], xv[t], dWc1);
+            for (int r = 0; r < 16; ++r) pc1[q][r] = fmaf(g_rgb[q], cact[r], pc1[q][r]);
         }
         // ---- dW(col_w0) = d_c^T . [OneBlob48 | out16]   (tiles 4, 5)
         stage_ctile(ga, kGradLd, 0, dcv, j, hh);
@@ -1737,6 +1731,30 @@ __global__ __launch_bounds__(64 * kBwdWaves) void k_query_bwd(LevelTab lt, Uncer
     static_assert(sizeof(L.xs) >= kAccFloats * sizeof(float), "the dW image must fit the xs stages");
     float* __restrict__ acc = &L.xs[0][0];
     __syncthreads();                     // every wave is done with its stages
+    // dW(col_w1): the 32 lanes of a half hold partial sums for the same 16 units; unit rows T[unit][point] in this wave's scratch behind
+    // the image (row stride 36 floats: 16-byte rows, the lanes' reads spread over the banks), one colour channel at a time, then lane
+    // i < 32 sums unit i's row in a fixed order -- which is tile 6's register layout (row q in register q of the low half)
+    f32x16 dWc1 = zero16();
+    {
+        static_assert(sizeof(L.xs) >= (kAccFloats + kBwdWaves * 32 * 36) * sizeof(float), "scratch for the dW(col_w1) rows");
+        float* __restrict__ T = acc + kAccFloats + wave * (32 * 36);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[crow(r, hh) * 36 + j] = pc1[q][r];
+            wave_lds_sync();
+            float sum = 0.0f;
+            if (lane < 32) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float4 v = *reinterpret_cast<const float4*>(&T[lane * 36 + 4 * k]);
+                    sum += v.x; sum += v.y; sum += v.z; sum += v.w;
+                }
+            }
+            dWc1[q] = sum;
+            wave_lds_sync();
+        }
+    }
     {
         static_assert(kBwdWaves == 4, "block_sum_tiles rotates four waves");
         const f32x16* const tiles[kAccTiles] = {&dW0a, &dW0b, &dW0c, &dW1, &dWc0a, &dWc0b, &dWc1};

@@ -2010,6 +2010,17 @@ __global__ __launch_bounds__(256, NARUTO_BWD_BF_MINWAVES) void k_query_bwd_bf(Le
         const bool valid = i_raw < M_eff;
         const uint32_t i_pt = valid ? i_raw : M_eff - 1u;
         const uint32_t m = tile == tile_first ? m_first : (active_idx != nullptr ? active_idx[i_pt] : i_pt);
+        // per-point scalars of point j (tile A) / j + 32 (tile B) in BOTH halves.  The saved features of both tiles are requested as soon
+        // as the list entries are known, together with the point and its cotangent: one trip to memory instead of three (point,
+        // features of A, features of B behind one another)
+        uint32_t mA = m, mB = m;
+        swap32u(mA, mB);
+        float ftA[kLevels], ftB[kLevels];
+#pragma unroll
+        for (int T = 0; T < kLevels; ++T) {
+            ftA[T] = feat_save[((size_t)T * M + mA) * 2 + hh];
+            ftB[T] = feat_save[((size_t)T * M + mB) * 2 + hh];
+        }
         float x, y, z;
         load_point(ps, bt, m, x, y, z);
         float g[5];
@@ -2048,9 +2059,6 @@ __global__ __launch_bounds__(256, NARUTO_BWD_BF_MINWAVES) void k_query_bwd_bf(Le
             blA[D] = lo;
             blB[D] = hi;
         });
-        // per-point scalars of point j (tile A) / j + 32 (tile B) in BOTH halves
-        uint32_t mA = m, mB = m;
-        swap32u(mA, mB);
         float gA[5], gB[5];
 #pragma unroll
         for (int q = 0; q < 5; ++q) { gA[q] = g[q]; gB[q] = g[q]; swap32(gA[q], gB[q]); }
@@ -2060,7 +2068,7 @@ __global__ __launch_bounds__(256, NARUTO_BWD_BF_MINWAVES) void k_query_bwd_bf(Le
             const uint32_t mt = half ? mB : mA, it = half ? iB : iA;
             float ft[kLevels];
 #pragma unroll
-            for (int T = 0; T < kLevels; ++T) ft[T] = feat_save[((size_t)T * M + mt) * 2 + hh];
+            for (int T = 0; T < kLevels; ++T) ft[T] = half ? ftB[T] : ftA[T];
             float f0[8], f1[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) { f0[q] = ft[q]; f1[q] = ft[8 + q]; }

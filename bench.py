@@ -60,6 +60,9 @@ WORKLOADS = {
     "unit1024_131072x43": (lambda: C.unit_cube_config(1024, 16, perturb=1.0), 131072, "configs[4] at T=2^16"),
     "unit1024_T22_131072x43": (lambda: C.unit_cube_config(1024, 22, perturb=1.0), 131072, "configs[4] at T=2^22 (HBM-resident table)"),
     "unit1024_T22_16384x43": (lambda: C.unit_cube_config(1024, 22, perturb=1.0), 16384, "configs[4] at T=2^22, reduced ray count"),
+    # the metric's second half: "mapping-iter ms" = one global_BA iteration END TO END (coslam.py:310-399): keyframe-store draw + pose
+    # transform (N2) -> active ray selection (N1, --active-ray) -> training step, shipped sampling, the reference's ray count
+    "office0_ba_iter": (lambda: C.office0_config(perturb=1.0), 2148, "metric 'mapping-iter ms': one global_BA iteration end to end, 2048 + max(2048 // n_kf, 100) rays x (32 + 11)"),
 }
 
 
@@ -225,9 +228,9 @@ def cpu_baseline(cfg, n_rays: int, device=None, budget_s: float = 30.0):
     """The oracle's mapping iteration (plain PyTorch ops; oracle/spec_torch.py, pinned against the reference by
     oracle/make_golden.py), same body as the timed GPU step: forward + losses + smoothness + backward + Adam.
 
-    Host (the reported ``cpu_baseline``): threads = PHYSICAL cores, 5 warm-ups, median of 20 iterations.  The
-    sample is bounded to ~``budget_s`` of CPU work: when 25 iterations of the workload itself would take longer, the rays keep
-    their count but use the SHIPPED sampling (32 + 11 samples per ray, coslam.yaml) and the line says so.
+    Host (the reported ``cpu_baseline``): the thread count is swept FIRST (on the cheap shipped sampling), then the
+    TIMED WORKLOAD ITSELF (its own samples per ray) runs at the best count: 5 warm-ups, median of 20 iterations, bounded to
+    ~``budget_s`` of CPU work by shrinking the iteration count, never the workload; the shipped 32 + 11 sampling is a second field.
     ``device`` given: the same oracle as unfused torch ops on the GPU -- the stand-in for "the reference in single-GPU PyTorch"
     (the reference itself needs the CUDA-only tiny-cuda-nn)."""
     import copy
@@ -235,8 +238,6 @@ def cpu_baseline(cfg, n_rays: int, device=None, budget_s: float = 30.0):
     on_gpu = device is not None
     dev = device if on_gpu else torch.device("cpu")
     n_threads_before = torch.get_num_threads()
-    if not on_gpu:
-        torch.set_num_threads(physical_cores())
 
     def build(c):
         torch.manual_seed(0)
@@ -274,52 +275,107 @@ def cpu_baseline(cfg, n_rays: int, device=None, budget_s: float = 30.0):
 
     trc = cfg["training"]
     S_tot = trc["n_samples_d"] + trc["n_range_d"]
-    note = ""
-    c = cfg
-    step = build(c)
-    step(0)                                         # cold
+
+    def stats(ts):
+        med = float(np.median(ts))
+        p10, p90 = (float(np.percentile(ts, q)) for q in (10, 90))
+        return med, ((p90 - p10) / med if med > 0 else 0.0), ((max(ts) - min(ts)) / med if med > 0 else 0.0)
+
+    if on_gpu:
+        step = build(cfg)
+        for i in range(3):
+            step(i)                                      # cold: allocator, kernel selection
+        med, ts = timed(step, 5, 25)
+        med, idr, full = stats(ts)
+        return {"value": round(n_rays / med, 1), "unit": "rays/s", "kind": "port, unfused torch ops on the same GPU",
+                "sample": f"median of 25 mapping iterations after 8 warm-ups, {n_rays} rays x {S_tot} samples (oracle/spec_torch.py: forward + losses + smoothness + "
+                          f"backward + Adam), {med * 1e3:.1f} ms/iter, spread (p90 - p10) / median {idr * 100:.0f} %, (max - min) / median {full * 100:.0f} %"}
+
+    # 1. thread count FIRST (many-core hosts: torch's CPU kernels stop scaling -- and fall back -- well before all cores: 128 threads
+    #    measured 4x SLOWER than 16 on the MI355X hosts), on the cheap shipped sampling (32 + 11 samples per ray), ascending, stopping
+    #    once a count is clearly past the optimum so that the sweep never runs the slow many-thread configurations
+    c43 = copy.deepcopy(cfg)
+    c43["training"]["n_samples_d"], c43["training"]["n_range_d"] = 32, 11
+    step43 = build(c43)
+    torch.set_num_threads(min(16, physical_cores()))
+    step43(0)                                           # cold
+    cand = sorted({n for n in (8, 16, 32, 64, physical_cores()) if n <= physical_cores()})
+    best, res = None, []
+    for n in cand:
+        torch.set_num_threads(n)
+        m_, _ = timed(step43, 1, 2)
+        res.append(f"{n}: {m_ * 1e3:.0f} ms")
+        if best is None or m_ < best[0]:
+            best = (m_, n)
+        elif m_ > 1.5 * best[0]:
+            break
+    used_threads = best[1]
+    torch.set_num_threads(used_threads)
+    sweep = "; thread sweep at 32 + 11 samples per ray (ms/iter, ascending until 1.5x past the best): " + ", ".join(res)
+    # 2. the TIMED WORKLOAD ITSELF at that thread count, bounded to ~budget_s: the iteration count shrinks before the workload does
+    step = build(cfg) if S_tot != 43 else step43
+    step(0)                                             # cold
     t0 = time.perf_counter()
     step(1)
     pilot = time.perf_counter() - t0
-    if not on_gpu and pilot * 25 > budget_s * 1.5 and S_tot > 43:
-        c = copy.deepcopy(cfg)
-        c["training"]["n_samples_d"], c["training"]["n_range_d"] = 32, 11
-        note = (f"; the workload's own {S_tot} samples per ray take {pilot:.2f} s per iteration here, so the sample keeps the ray count and uses the "
-                "SHIPPED 32 + 11 samples per ray (cost is proportional to the samples: divide the value by "
-                f"{S_tot / 43.0:.2f} for the workload's sampling)")
-        S_tot = 43
-        step = build(c)
-    sweep = ""
-    if not on_gpu:
-        # many-core hosts: torch's CPU kernels stop scaling (and fall back) well before all cores -- 128 threads measured 4x SLOWER
-        # than 16 on the MI355X hosts -- so the thread count is the best of a short sweep up to the physical cores
-        cand = sorted({n for n in (8, 16, 32, 64, physical_cores()) if n <= physical_cores()})
-        best, res = None, []
-        for n in cand:
-            torch.set_num_threads(n)
-            m_, _ = timed(step, 1, 2)
-            res.append(f"{n}: {m_ * 1e3:.0f} ms")
-            if best is None or m_ < best[0]:
-                best = (m_, n)
-        torch.set_num_threads(best[1])
-        used_threads = best[1]
-        sweep = "; thread sweep (ms/iter): " + ", ".join(res)
-    warm, iters = (5, 20) if not on_gpu else (2, 10)
+    warm = 5 if pilot * 25 <= budget_s * 1.2 else 2
+    iters = 20 if pilot * 25 <= budget_s * 1.2 else max(5, int(budget_s / max(pilot, 1e-6)) - warm)
     med, ts = timed(step, warm, iters)
-    if not on_gpu:
-        torch.set_num_threads(n_threads_before)
-    spread = (max(ts) - min(ts)) / med if med > 0 else 0.0
-    out = {"value": round(n_rays / med, 1), "unit": "rays/s", "kind": "port",
-           "sample": f"median of {iters} mapping iterations after {warm} warm-ups, {n_rays} rays x {S_tot} samples (oracle/spec_torch.py: forward + losses + "
-                     f"smoothness + backward + Adam), {med * 1e3:.0f} ms/iter, spread {spread * 100:.0f} %" + note}
-    if on_gpu:
-        out["kind"] = "port, unfused torch ops on the same GPU"
-    else:
-        out["cores"] = used_threads
-        out["physical_cores"] = physical_cores()
-        out["logical_cpus"] = os.cpu_count()
-        out["sample"] += sweep
-        out["samples_per_ray"] = S_tot
+    med, idr, full = stats(ts)
+    out = {"value": round(n_rays / med, 1), "unit": "rays/s", "cores": used_threads, "kind": "port",
+           "sample": f"median of {iters} mapping iterations after {warm} warm-ups of THE TIMED WORKLOAD, {n_rays} rays x {S_tot} samples (oracle/spec_torch.py: forward + "
+                     f"losses + smoothness + backward + Adam), {med * 1e3:.0f} ms/iter, spread (p90 - p10) / median {idr * 100:.0f} %, (max - min) / median "
+                     f"{full * 100:.0f} %" + sweep,
+           "samples_per_ray": S_tot, "physical_cores": physical_cores(), "logical_cpus": os.cpu_count()}
+    # 3. beside it: the shipped sampling (what a real NARUTO run executes)
+    if S_tot != 43:
+        med43, ts43 = timed(step43, 2, 8)
+        out["shipped_sampling"] = {"value": round(n_rays / med43, 1), "unit": "rays/s", "samples_per_ray": 43, "ms_per_iter": round(med43 * 1e3, 1)}
+    torch.set_num_threads(n_threads_before)
+    return out
+
+
+def dropin_timing(cfg, n_rays: int, dev, steps: int, warmup: int, which=None):
+    """The UNCHANGED caller: the reference's own global_BA loop body (coslam.py:361-399; restated in naruto_amd/dropin.py) around
+    ``NarutoFieldHIP`` -- model.forward (the fused training node), get_loss_from_ret as ten scalar torch ops with Co-SLAM's torch
+    smoothness through query_sdf(embed=True) autograd, loss.backward(retain_graph=True), torch.optim.Adam over 1.63 M parameters,
+    the uncertainty grid's Adam every 5th iteration: what INTEGRATION.md's two-line swap buys without touching anything else, and
+    the optional one-line changes after it.  Eager launches, wall clock with a device sync on both sides (the loop is host bound:
+    the caller's own ~60 small torch ops per iteration)."""
+    from naruto_amd.dropin import DropInCaller
+    from naruto_amd.field import NarutoFieldHIP
+    variants = (("swap_only", "torch", "reference", "the two-line swap at coslam.py:65, nothing else changed"),
+                ("fused_adam", "fused", "reference", "+ optim.Adam -> naruto_amd.FusedAdam in create_optimizer / init_uncert_grid_optim"),
+                ("fused_adam_fused_smoothness", "fused", "fused", "+ self.smoothness -> naruto_amd.trainer.smoothness (fused TV kernels)"))
+    rays = {k: torch.from_numpy(v).to(dev) for k, v in bench_rays(cfg, n_rays).items()}
+    out = {}
+    # The caller's own host-side torch ops (Co-SLAM builds the smoothness lattice on the CPU and copies it over in EVERY iteration)
+    # run with 8 intra-op threads here: with torch's default on these hosts (one thread per core, 128+) that lattice alone takes
+    # 10 - 50 ms per iteration -- listed once as `swap_only_default_threads`.
+    threads_before = torch.get_num_threads()
+    variants = variants + (("swap_only_default_threads", "torch", "reference", "as swap_only, torch's default intra-op thread count on this host"),)
+    for name, opt, sm, what in variants:
+        if which is not None and name not in which:
+            continue
+        torch.set_num_threads(threads_before if name.endswith("default_threads") else min(8, threads_before))
+        if name.endswith("default_threads"):
+            steps, warmup = min(steps, 10), min(warmup, 3)
+        torch.manual_seed(0)
+        m = NarutoFieldHIP(cfg, torch.tensor(cfg["mapping"]["bound"], dtype=torch.float32, device=dev)).to(dev).train()
+        caller = DropInCaller(m, cfg, 0.1, optimizer=opt, smoothness=sm)
+        for i in range(warmup):
+            caller.ba_iteration(i, rays["rays_o"], rays["rays_d"], rays["target_rgb"], rays["target_d"])
+        m.check_asserts(block=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            caller.ba_iteration(warmup + i, rays["rays_o"], rays["rays_d"], rays["target_rgb"], rays["target_d"])
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        m.check_asserts(block=True)
+        out[name] = {"ms_per_step": round(ms, 4), "rays_per_s": round(n_rays / ms * 1e3, 1), "change": what, "host_threads": torch.get_num_threads()}
+        del caller, m
+    torch.set_num_threads(threads_before)
     return out
 
 
@@ -393,6 +449,90 @@ def run_eval(args, dev):
     return out
 
 
+def run_ba_iter(args, dev):
+    """--workload office0_ba_iter: what ONE iteration of the reference's global_BA loop costs here end to end (coslam.py:310-399):
+    batch draw from the device-resident keyframe store + current frame and the pose transform (naruto_assemble_rays), the active ray
+    selection when mapping.active_ray is on (naruto_active_ray_select over the 4x oversampled batch), and the training iteration
+    (forward, losses incl. smoothness, backward, both Adams) -- one stream, one hipGraph (naruto_amd.ba_loop.FusedBA).  Synthetic
+    Replica-sized inputs: 680 x 1200 frames, 40 keyframes x 5 % of the pixels stored, [49,56,35] planner volume."""
+    from naruto_amd.active_ray_sampler import ActiveRaySamplerHIP
+    from naruto_amd.ba_loop import FusedBA
+    from naruto_amd.keyframe_store import KeyFrameStoreHIP
+    from naruto_amd.trainer import MappingTrainer
+    cfg, _ = workload(args.workload)
+    cfg["decoder"]["mlp_precision"] = args.mlp
+    cfg["mapping"].update(sample=2048, min_pixels_cur=100, filter_depth=True, keyframe_every=5, active_ray=bool(args.active_ray))
+    Hh, Ww, n_kf = 680, 1200, 40
+    R = int(Hh * Ww * 0.05)
+    torch.manual_seed(0)
+    g = torch.Generator(device=dev).manual_seed(0)
+    tr = MappingTrainer(cfg, torch.tensor(cfg["mapping"]["bound"], dtype=torch.float32), dev, 0.1, fused_adam=True)
+    store = KeyFrameStoreHIP(cfg, Hh, Ww, num_kf=n_kf + 8, num_rays_to_save=R, device=dev, seed=1)
+
+    def frame_rays(n):
+        d = torch.randn(n, 3, device=dev, generator=g)
+        d = d / d.norm(dim=-1, keepdim=True)
+        depth = 0.5 + 2.0 * torch.rand(n, 1, device=dev, generator=g)
+        depth[torch.rand(n, 1, device=dev, generator=g) < 0.05] = 0.0
+        return torch.cat([d, torch.rand(n, 3, device=dev, generator=g), depth], -1)
+    store.rays[:n_kf] = frame_rays(n_kf * R).reshape(n_kf, R, 7)
+    store.attach_ids(torch.arange(n_kf) * 5)
+    current = frame_rays(Hh * Ww)
+    bound = torch.tensor(cfg["mapping"]["bound"], dtype=torch.float32)
+    poses = torch.eye(4).repeat(n_kf + 1, 1, 1)
+    for p_ in poses:
+        q, _ = torch.linalg.qr(torch.randn(3, 3))
+        p_[:3, :3] = q
+        p_[:3, 3] = bound[:, 0] + (0.3 + 0.4 * torch.rand(3)) * (bound[:, 1] - bound[:, 0])
+    vol = (torch.rand(49, 56, 35) * 3 * (torch.rand(49, 56, 35) < 0.5)).numpy()
+    smp = ActiveRaySamplerHIP(config=cfg, num_uncert_sample=500, oversample_mul=4) if args.active_ray else None
+    res = {}
+    for mode in ("graph", "eager"):
+        ba = FusedBA(tr, store, smp, max_poses=256, use_graph=(mode == "graph"))
+        n_cur, n_train = ba.prepare(current, poses, vol if args.active_ray else None)
+        for i in range(args.warmup):
+            ba.iteration(i)
+        tr.model.check_asserts(block=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            ba.iteration(i)
+        torch.cuda.synchronize()
+        res[mode] = (time.perf_counter() - t0) / args.steps * 1e3
+        tr.model.check_asserts(block=True)
+        if mode == "graph":
+            per_call = []                          # a whole global_BA call of mapping.iters iterations incl. its per-call preparation
+            for _ in range(5):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ba.global_BA(current, poses, uncert_vol=vol if args.active_ray else None)
+                torch.cuda.synchronize()
+                per_call.append((time.perf_counter() - t0) * 1e3)
+            res["call"] = float(np.median(per_call))
+    # the pieces alone (HIP events, eager)
+    ba = FusedBA(tr, store, smp, max_poses=256, use_graph=False)
+    ba.prepare(current, poses, vol if args.active_ray else None)
+    bufs = ba._eager_bufs
+    t_pro = events_ms(lambda: ba._pro(*bufs), 50)
+    t_step = events_ms(lambda: tr.step(*bufs, smooth=True, uncert_step=False), 50)
+    trc = cfg["training"]
+    S_tot = trc["n_samples_d"] + trc["n_range_d"]
+    ms = res["graph"]
+    out = {"metric": "mapping-iter ms (one global_BA iteration end to end), Replica office_0", "value": round(ms, 4), "unit": "ms", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(ms, 4), "mapping_iter_ms": round(ms, 4), "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32" if args.mlp == "fp32" else "bf16 (MLP operands; fp32 accumulate, fp32 elsewhere)", "data": "synthetic",
+           "rays_per_s": round(n_train / ms * 1e3, 1),
+           "config": {"workload": f"{args.workload} = BASELINE {WORKLOADS[args.workload][2]}: office_0 bbox, {n_kf} keyframes x {R} stored rays, {Hh} x {Ww} current frame, "
+                                  f"mapping.sample 2048, active_ray {'on (4x oversampled batch of ' + str(ba.sample_num + n_cur) + ' rays, K = 500)' if args.active_ray else 'off'}, "
+                                  f"{n_train} rays x {S_tot} samples into the training step; hash L16 F2 T2^16, MLP 2x32 {args.mlp}; one hipGraph per iteration",
+                      "rays_per_step": n_train, "samples_per_ray": S_tot, "n_cur": n_cur, "active_ray": bool(args.active_ray)},
+           "eager_ms_per_iteration": round(res["eager"], 4),
+           "global_BA_call_ms": {"iters": int(cfg["mapping"]["iters"]), "ms": round(res["call"], 4),
+                                 "note": "per call: frame + pose upload into the static buffers, one valid-pixel count read back, mapping.iters replays"},
+           "pieces_eager_ms": {"assemble" + (" + active ray select" if args.active_ray else ""): round(t_pro, 5), "training step": round(t_step, 5)}}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -407,6 +547,11 @@ def main():
     ap.add_argument("--no-kernels", action="store_true")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the fused HIP Adam")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph")
+    ap.add_argument("--path", choices=("trainer", "dropin"), default="trainer",
+                    help="trainer: MappingTrainer's fused iteration (hipGraph replay), the headline; dropin: the reference's unchanged loop body "
+                         "(coslam.py:361-399) around NarutoFieldHIP is the timed step (its figures ride in the default line too, as `dropin`)")
+    ap.add_argument("--no-dropin", action="store_true")
+    ap.add_argument("--active-ray", action="store_true", help="office0_ba_iter: mapping.active_ray on (4x oversampled batch -> active ray selection)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON result.  RCCL writes its version banner to the C-level stdout (it lands in
@@ -425,9 +570,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    if args.workload.endswith("_eval"):
-        assert world == 1, "the eval workload is a single-GPU query path"
-        out = run_eval(args, dev)
+    if args.workload.endswith("_eval") or args.workload == "office0_ba_iter":
+        assert world == 1, "the eval / mapping-iteration workloads are single-GPU paths"
+        out = run_eval(args, dev) if args.workload.endswith("_eval") else run_ba_iter(args, dev)
         sys.stdout.flush()
         libc.fflush(None)
         os.dup2(real_stdout, 1)
@@ -436,6 +581,24 @@ def main():
         return
     cfg, n_workload = workload(args.workload)
     cfg["decoder"]["mlp_precision"] = args.mlp
+    if args.path == "dropin":
+        assert world == 1, "--path dropin times the single-process caller"
+        d = dropin_timing(cfg, n_workload, dev, args.steps, args.warmup, which=("swap_only",))["swap_only"]
+        trc = cfg["training"]
+        S_tot = trc["n_samples_d"] + trc["n_range_d"]
+        out = {"metric": "rendered rays/sec (train step), Replica office_0", "value": d["rays_per_s"], "unit": "rays/s", "n_gpus": 1, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": d["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32" if args.mlp == "fp32" else "bf16 (MLP operands; fp32 accumulate, fp32 elsewhere)", "data": "synthetic",
+               "config": {"workload": f"{args.workload} = BASELINE {WORKLOADS[args.workload][2]}: {n_workload} rays x {S_tot} samples, one global_BA iteration of the "
+                                      "reference's UNCHANGED loop body (coslam.py:361-399: model.forward, get_loss_from_ret with Co-SLAM's torch smoothness, "
+                                      "loss.backward(retain_graph=True), torch.optim.Adam, uncertainty-grid Adam every 5th) around NarutoFieldHIP, eager launches",
+                          "path": "dropin", "rays_per_gpu": n_workload, "samples_per_ray": S_tot}}
+        sys.stdout.flush()
+        libc.fflush(None)
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
+        return
     if args.scaling == "strong":
         n_total = n_workload
         assert n_total % world == 0, f"strong scaling: {n_total} rays do not split over {world} GPUs"
@@ -589,6 +752,15 @@ def main():
             out["roofline"] = roof
             out["kernels"] = rows
             out["kernels_ms_sum"] = round(sum(r["ms"] for r in rows if r["bound"] is not None), 4)
+        if not args.no_dropin and world == 1:
+            try:
+                d = dropin_timing(cfg, n_rays, dev, max(10, min(args.steps, 50)), 10)
+                out["dropin"] = d
+                out["dropin_ms_per_step"] = d["swap_only"]["ms_per_step"]
+                out["dropin_note"] = ("the reference's unchanged loop body around NarutoFieldHIP (bench.py dropin_timing, naruto_amd/dropin.py), eager, wall clock; "
+                                      "ms_per_step / value above are MappingTrainer's fused iteration under hipGraph replay")
+            except Exception as e:                               # informational: never fail the bench line over it
+                out["dropin"] = {"error": repr(e)[:300]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, n_rays)
             try:

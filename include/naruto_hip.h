@@ -313,6 +313,12 @@ typedef struct NarutoRayBatch {
     uint64_t seed, counter;
     float *rays_o, *rays_d, *target_s, *target_d;   /* [n_global+n_cur,3] x3, [n_global+n_cur]                      */
     int64_t* ids_out;          /* optional [n_global+n_cur]: pose index per ray, -1 for current-frame rays           */
+    /* For a launch that is CAPTURED in a hipGraph and replayed over a growing store (optional, device memory):
+     * rng = {seed, counter} -- the draw is keyed by (rng[0] ^ seed, rng[1] + counter), e.g. the trainer's iteration state, which
+     * the training forward advances once per iteration; dyn = {n_kf, n_poses, n_cur_pop} replaces the three host values, so new
+     * keyframes / poses / another current frame need no re-capture as long as n_global and n_cur stay the same.             */
+    const uint64_t* rng;
+    const uint64_t* dyn;
 } NarutoRayBatch;
 int naruto_assemble_rays(const NarutoRayBatch* b, void* stream);
 int naruto_sample_distinct(uint64_t n, uint32_t count, uint64_t seed, uint64_t counter, int64_t* out, void* stream);
@@ -399,6 +405,14 @@ typedef struct NarutoTrainStep {
     float *d_raw;                                     /* [N,S,5]          (backward)                          */
     uint32_t *ray_count, *ray_offset, *active_idx, *n_active;  /* [N] [N] [N*S] [1]  (backward)               */
     void *workspace;                                  /* naruto_train_workspace() bytes                       */
+    const float *loss_weight_parts[10];               /* naruto_train_backward only, optional: per-slot device SCALARS added to
+                                                         loss_weights (which may then be NULL = zeros) -- the cotangents autograd
+                                                         hands back for the scalar losses of an unchanged caller's weighted sum
+                                                         (coslam.py:154-174); gathered into the workspace by one tiny launch     */
+    float *min_uncert_running;                        /* optional [1]: every iteration folds its min(uncert_map) into this word
+                                                         (minimum; a NaN sticks) -- the reference's per-forward
+                                                         `assert uncert_map.min() > 0` (scene_rep.py:280) as a value the host can
+                                                         read whenever it likes, graph replays included; initialise to +inf   */
 } NarutoTrainStep;
 /* Optimiser in the backward (single process): the launch that finishes the gradients applies torch.optim.Adam
  * (amsgrad off, L2 weight decay; reference create_optimizer, coslam.py:409-419) to the table and the MLP weights in

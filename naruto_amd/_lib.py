@@ -64,7 +64,7 @@ class NarutoRayBatch(C.Structure):
                 ("keyframe_every", C.c_int64), ("n_global", C.c_uint32), ("current", C.c_void_p), ("cur_list", C.c_void_p),
                 ("n_cur_pop", C.c_uint64), ("n_cur", C.c_uint32), ("poses", C.c_void_p), ("n_poses", C.c_uint32),
                 ("seed", C.c_uint64), ("counter", C.c_uint64), ("rays_o", C.c_void_p), ("rays_d", C.c_void_p),
-                ("target_s", C.c_void_p), ("target_d", C.c_void_p), ("ids_out", C.c_void_p)]
+                ("target_s", C.c_void_p), ("target_d", C.c_void_p), ("ids_out", C.c_void_p), ("rng", C.c_void_p), ("dyn", C.c_void_p)]
 
 
 class NarutoFusedAdam(C.Structure):
@@ -85,7 +85,7 @@ class NarutoTrainStep(C.Structure):
         ("rgb", C.c_void_p), ("depth", C.c_void_p), ("uncert_map", C.c_void_p),
         ("sums", C.c_void_p), ("losses", C.c_void_p), ("d_raw", C.c_void_p),
         ("ray_count", C.c_void_p), ("ray_offset", C.c_void_p), ("active_idx", C.c_void_p), ("n_active", C.c_void_p),
-        ("workspace", C.c_void_p),
+        ("workspace", C.c_void_p), ("loss_weight_parts", C.c_void_p * 10), ("min_uncert_running", C.c_void_p),
     ]
 
 
@@ -222,3 +222,36 @@ def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = load().naruto_last_error().decode("utf-8", "replace")
         raise NarutoError(f"{what or 'libnaruto_hip'} failed ({rc}): {msg}")
+
+
+def kernel_resources(lib_path: str = None):
+    """Per kernel of the device code object embedded in the built library: the AMDGPU metadata notes the loader reads
+    (``.vgpr_count``, ``.agpr_count``, ``.vgpr_spill_count``, ``.sgpr_spill_count``, ``.private_segment_fixed_size`` = scratch bytes per
+    lane, ``.group_segment_fixed_size`` = static LDS).  Uses the ROCm LLVM tools (llvm-objcopy, clang-offload-bundler, llvm-readelf);
+    returns {demangled-ish kernel name: {field: int}}.  tests/test_host.py holds the hot kernels to zero scratch with it."""
+    import re
+    import tempfile
+    llvm = os.environ.get("ROCM_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+    lib_path = lib_path or LIB_PATH
+    with tempfile.TemporaryDirectory() as tmp:
+        fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "dev.co")
+        subprocess.run([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, lib_path], check=True)
+        subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True)
+        notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], check=True, capture_output=True, text=True).stdout
+    out, cur = {}, None
+    for line in notes.splitlines():
+        m = re.match(r"\s*-?\s*\.(\w+):\s*(\S+)\s*$", line)
+        if not m:
+            continue
+        key, val = m.group(1), m.group(2)
+        if key == "agpr_count":                      # first field of a kernel's record (fields are sorted by name)
+            cur = {"agpr_count": int(val)}
+        elif cur is not None and key == "name":
+            name = re.sub(r"^_ZN6naruto\d+", "", val)
+            name = re.sub(r"(ILb([01])E)?E.*$", lambda k: ("<%s>" % ("true" if k.group(2) == "1" else "false")) if k.group(2) else "", name)
+            out[name] = cur
+        elif cur is not None and key in ("vgpr_count", "vgpr_spill_count", "sgpr_spill_count", "sgpr_count", "private_segment_fixed_size",
+                                         "group_segment_fixed_size"):
+            cur[key] = int(val)
+    return out

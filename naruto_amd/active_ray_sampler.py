@@ -46,11 +46,13 @@ class ActiveRaySamplerHIP:
 
     def set_volume(self, uncert_vol, device) -> torch.Tensor:
         """Upload the planner's cached uncertainty volume once (call again whenever the planner refreshes it, every 5 frames in
-        the reference); ``sample_rays(..., uncert_vol=None, ...)`` then uses this copy."""
-        if torch.is_tensor(uncert_vol):
-            self._vol_dev = _f32c(uncert_vol.to(device), "uncert_vol")
+        the reference); ``sample_rays(..., uncert_vol=None, ...)`` then uses this copy.  A volume of the same shape is copied INTO
+        the existing device tensor, so a captured launch that reads it (naruto_amd.ba_loop.FusedBA) sees the refresh."""
+        src = uncert_vol if torch.is_tensor(uncert_vol) else torch.from_numpy(np.ascontiguousarray(uncert_vol, dtype=np.float32))
+        if self._vol_dev is not None and tuple(self._vol_dev.shape) == tuple(src.shape) and self._vol_dev.device == torch.device(device):
+            self._vol_dev.copy_(src, non_blocking=True)
         else:
-            self._vol_dev = torch.from_numpy(np.ascontiguousarray(uncert_vol, dtype=np.float32)).to(device)
+            self._vol_dev = _f32c(src.to(device), "uncert_vol")
         return self._vol_dev
 
     def _volume(self, uncert_vol, device) -> torch.Tensor:
@@ -64,21 +66,39 @@ class ActiveRaySamplerHIP:
         # id() nor the shape can tell a refreshed array from the old one
         return torch.from_numpy(np.ascontiguousarray(uncert_vol, dtype=np.float32)).to(device)
 
-    def sample_rays(self, rays_o, rays_d, target_s, target_d, idx_cur: List, uncert_vol, bbox: List):
+    def n_out(self, n_idx_cur: int) -> int:
+        """Rows of the selected batch: base + ceil(len(idx_cur) / oversample_mul)."""
+        return self.base_sample_num + (-((-int(n_idx_cur)) // self.oversample_mul))
+
+    def workspace_elems(self, n_total: int) -> int:
+        return _lib.load().naruto_active_ray_workspace(int(n_total), self.num_uncert_sample) // 4 + 4
+
+    def sample_rays(self, rays_o, rays_d, target_s, target_d, idx_cur, uncert_vol, bbox: List, out=None, workspace=None):
+        """active_ray_sampler.py:77-149.  ``idx_cur``: the current-frame indices (only their NUMBER is used, as in the reference) or
+        that number.  ``out`` = (rays_o, rays_d, target_s, target_d) to write into (e.g. a captured trainer's ``ray_buffers()``) and
+        ``workspace`` (int32, ``workspace_elems`` long) make the call allocation-free."""
         lib = _lib.load()
         rays_o, rays_d, target_s = _f32c(rays_o, "rays_o"), _f32c(rays_d, "rays_d"), _f32c(target_s, "target_s")
         td = _f32c(target_d, "target_d").reshape(-1)
         dev = rays_o.device
         vol = self._volume(uncert_vol, dev)
         n_total, base, K = rays_o.shape[0], self.base_sample_num, self.num_uncert_sample
-        n_tail = -((-len(idx_cur)) // self.oversample_mul)          # ceil(len / mul), as the reference's -len//mul slice
+        n_idx = int(idx_cur) if isinstance(idx_cur, int) else len(idx_cur)
+        n_tail = -((-n_idx) // self.oversample_mul)                 # ceil(len / mul), as the reference's -len//mul slice
         n_out = base + n_tail
-        o_out, d_out, s_out = (torch.empty(n_out, 3, device=dev) for _ in range(3))
-        t_out = torch.empty(n_out, 1, device=dev)
+        if out is not None:
+            o_out, d_out, s_out, t_out = out
+            for a, c in ((o_out, 3), (d_out, 3), (s_out, 3), (t_out, 1)):
+                if not (a.is_cuda and a.dtype == torch.float32 and a.is_contiguous() and a.numel() == n_out * c):
+                    raise RuntimeError(f"sample_rays: out tensors must be contiguous fp32 device tensors of {n_out} rows")
+        else:
+            o_out, d_out, s_out = (torch.empty(n_out, 3, device=dev) for _ in range(3))
+            t_out = torch.empty(n_out, 1, device=dev)
         dims = (C.c_uint32 * 3)(*vol.shape)
         bmin = (C.c_float * 3)(*(float(b[0]) for b in bbox))
         with torch.cuda.device(dev):
-            ws = torch.empty(lib.naruto_active_ray_workspace(n_total, K) // 4 + 4, dtype=torch.int32, device=dev)
+            ws = workspace if workspace is not None else torch.empty(self.workspace_elems(n_total), dtype=torch.int32, device=dev)
+            assert ws.dtype == torch.int32 and ws.numel() >= self.workspace_elems(n_total)
             _lib.check(lib.naruto_active_ray_select(n_total, base, K, n_tail, _p(rays_o), _p(rays_d), _p(target_s), _p(td), _p(vol), dims, bmin, 10.0,
                                                     _p(o_out), _p(d_out), _p(s_out), _p(t_out), _p(ws), _stream()), "naruto_active_ray_select")
         return o_out, d_out, s_out, t_out

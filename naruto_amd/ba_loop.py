@@ -1,0 +1,133 @@
+"""One mapping (bundle-adjustment) iteration end to end on the device: what the reference's ``CoSLAMNaruto.global_BA`` does per
+iteration (reference src/slam/coslam/coslam.py:310-399) --
+
+    rays, ids = keyframeDatabase.sample_global_rays(sample_num)                :325        Co-SLAM KeyFrameDatabase [not in tree]
+    idx_cur   = random.sample(valid pixels of the current frame, n_cur)         :332-340
+    rays_o, rays_d = poses_all[ids] applied to the camera-frame directions      :342-347
+    rays_* = active_ray_sampler.sample_rays(...)        (mapping.active_ray)     :349-359    src/slam/coslam/active_ray_sampler.py:77-149
+    ret = model.forward(...); loss = get_loss_from_ret(ret, smooth=True); loss.backward(); Adam     :361-399
+
+-- as ONE stream of launches: ``naruto_assemble_rays`` (N2) -> ``naruto_active_ray_select`` (N1) -> the fused training iteration
+(``MappingTrainer``), the first two writing straight into the iteration's input buffers, all of it recorded in one hipGraph.  What
+changes between replays lives in device memory: the draws are keyed by the trainer's {seed, iteration counter} (advanced by every
+forward), the keyframe / pose / valid-pixel counts sit in a three-word tensor the host refreshes once per ``global_BA`` call, the
+planner's uncertainty volume is refreshed in place.  The graph is re-captured only when the ray COUNT changes (n_cur = max(sample_num
+// n_kf, min_pixels_cur): constant once n_kf exceeds sample_num / min_pixels_cur, i.e. for all but the first ~20 keyframes).
+
+The reference draws with Python's ``random`` on the host and round-trips through numpy for the active rays; the drawn sets differ by
+construction (tests: same distribution properties, and the chained launches equal the three operators run one by one)."""
+
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from .active_ray_sampler import ActiveRaySamplerHIP
+from .keyframe_store import KeyFrameStoreHIP
+from .trainer import MappingTrainer
+
+
+class FusedBA:
+    def __init__(self, trainer: MappingTrainer, store: KeyFrameStoreHIP, sampler: Optional[ActiveRaySamplerHIP] = None,
+                 max_poses: int = 4096, use_graph: bool = True):
+        assert trainer.direct and trainer.group is None, "FusedBA drives the single-process fused trainer (MappingTrainer(fused_adam=True))"
+        self.trainer, self.store, self.sampler = trainer, store, sampler
+        self.config = trainer.config
+        self.device = trainer.device
+        self.use_graph = use_graph
+        mp = self.config['mapping']
+        self.active = sampler is not None
+        self.sample_num = sampler.oversample_num if self.active else int(mp['sample'])
+        self.min_pixels_cur = sampler.min_pixels_cur if self.active else int(mp['min_pixels_cur'])
+        self.filter_depth = bool(mp.get('filter_depth', False))
+        dev = self.device
+        self.current = torch.zeros(store.total_pixels, 7, dtype=torch.float32, device=dev)        # the current frame's rays, refreshed per call
+        self.poses = torch.zeros(int(max_poses), 4, 4, dtype=torch.float32, device=dev)
+        self.dyn = torch.zeros(3, dtype=torch.int64, device=dev)                                   # {n_kf, n_poses, n_cur_pop}
+        self._dyn_host = torch.zeros(3, dtype=torch.int64).pin_memory()
+        self._shape = None            # (n_cur, n_train) the graph was captured for
+        self._stage = None            # the oversampled batch between assembly and selection (active ray only)
+        self._ws = None
+        self.bbox = [[float(v) for v in row] for row in self.config['mapping']['bound']]
+
+    # ---------------------------------------------------------------------------------------------
+    def sizes(self, n_kf: int, n_valid_cur: int):
+        """(n_cur, n_train): current-frame rays drawn (coslam.py:332-340) and rays the training step sees."""
+        n_cur = max(self.sample_num // n_kf, self.min_pixels_cur)
+        if self.filter_depth:
+            n_cur = min(n_valid_cur, n_cur)
+        n_train = self.sampler.n_out(n_cur) if self.active else self.sample_num + n_cur
+        return n_cur, n_train
+
+    def _prologue(self, n_cur: int):
+        store, sampler = self.store, self.sampler
+        rng = self.trainer.iter_state
+
+        def prologue(rays_o, rays_d, target_rgb, target_d):
+            kw = dict(filter_depth=self.filter_depth, rng=rng, dyn=self.dyn, n_cur=n_cur, n_cur_pop=int(self._dyn_host[2]))
+            if not self.active:
+                store.assemble_batch(self.sample_num, self.current, self.poses, self.min_pixels_cur, out=(rays_o, rays_d, target_rgb, target_d), **kw)
+                return
+            store.assemble_batch(self.sample_num, self.current, self.poses, self.min_pixels_cur, out=self._stage, **kw)
+            sampler.sample_rays(*self._stage, n_cur, None, self.bbox, out=(rays_o, rays_d, target_rgb, target_d), workspace=self._ws)
+        return prologue
+
+    def prepare(self, current_rays: torch.Tensor, poses_all: torch.Tensor, uncert_vol=None, smooth: bool = True):
+        """Per ``global_BA`` call: the current frame's rays [H*W,7], all poses [P,4,4] (the current frame's LAST), optionally the
+        planner's refreshed uncertainty volume.  One count of the valid-depth pixels is read back (the reference does the same
+        filtering on the host, coslam.py:332-337); everything else is asynchronous."""
+        dev = self.device
+        cur = current_rays.to(dev, torch.float32).reshape(-1, 7)
+        assert cur.shape[0] == self.current.shape[0], "current_rays: one row per pixel of the frame the store was built for"
+        self.current.copy_(cur, non_blocking=True)
+        P = poses_all.shape[0]
+        assert P <= self.poses.shape[0], "more poses than FusedBA(max_poses=...)"
+        self.poses[:P].copy_(poses_all.to(dev, torch.float32), non_blocking=True)
+        n_kf = len(self.store)
+        assert n_kf > 0, "no keyframe stored yet"
+        n_valid = cur.shape[0]
+        if self.filter_depth:
+            n_valid = int(((cur[:, -1] > 0.0) & (cur[:, -1] <= self.config["cam"]["depth_trunc"])).sum().item())
+        self._dyn_host[0], self._dyn_host[1], self._dyn_host[2] = n_kf, P, max(n_valid, 1)
+        self.dyn.copy_(self._dyn_host, non_blocking=True)
+        if self.active and uncert_vol is not None:
+            self.sampler.set_volume(uncert_vol, dev)
+        n_cur, n_train = self.sizes(n_kf, n_valid)
+        if self._shape != (n_cur, n_train, smooth):
+            f32 = dict(dtype=torch.float32, device=dev)
+            n_stage = self.sample_num + n_cur
+            if self.active:
+                self._stage = (torch.empty(n_stage, 3, **f32), torch.empty(n_stage, 3, **f32), torch.empty(n_stage, 3, **f32), torch.empty(n_stage, 1, **f32))
+                self._ws = torch.empty(self.sampler.workspace_elems(n_stage), dtype=torch.int32, device=dev)
+            self._pro = self._prologue(n_cur)
+            if self.use_graph:
+                self.trainer.capture(n_train, smooth=smooth, prologue=self._pro)
+            else:
+                f = torch.zeros(n_train * 10, **f32)
+                from .trainer import unpack_rays
+                self._eager_bufs = unpack_rays(f, n_train)
+                self.trainer._graphs = None
+            self._shape = (n_cur, n_train, smooth)
+        return n_cur, n_train
+
+    def iteration(self, i: int, smooth: bool = True):
+        """Iteration ``i`` (0-based) of the current ``global_BA`` call: the uncertainty grid's Adam steps after iterations 5, 10, ...
+        (coslam.py:397-399)."""
+        tr = self.trainer
+        if self.use_graph:
+            bufs = tr.ray_buffers()
+            return tr.step(*bufs, smooth=smooth, uncert_step=(i + 1) % 5 == 0)           # the replay starts with the prologue's launches
+        bufs = self._eager_bufs
+        self._pro(*bufs)
+        return tr.step(*bufs, smooth=smooth, uncert_step=(i + 1) % 5 == 0)
+
+    def global_BA(self, current_rays: torch.Tensor, poses_all: torch.Tensor, n_iters: Optional[int] = None, uncert_vol=None, smooth: bool = True):
+        """The optimisation loop of one ``global_BA`` call (coslam.py:293-399 without pose optimisation: tracking is off in every
+        shipped config)."""
+        self.prepare(current_rays, poses_all, uncert_vol, smooth)
+        n_iters = int(self.config['mapping']['iters']) if n_iters is None else int(n_iters)
+        out = None
+        for i in range(n_iters):
+            out = self.iteration(i, smooth)
+        return out

@@ -720,7 +720,7 @@ int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
 // ------------------------------------------------------------------------------------------------
 namespace {
 struct TrainWs {
-    float* terms; float* tv_feat; double* tv_partial; void* bwd; double* fold; uint32_t* block_sums; void* w_img;
+    float* terms; float* tv_feat; double* tv_partial; void* bwd; double* fold; uint32_t* block_sums; void* w_img; float* w10;
     uint32_t n3, n_tv_blocks;
     size_t total;
 };
@@ -741,6 +741,7 @@ TrainWs train_ws(const NarutoField* f, const NarutoTrainStep* t) {
     w.fold = reinterpret_cast<double*>(base + off);       off += al((size_t)kTailRows * 16u * sizeof(double));
     w.block_sums = reinterpret_cast<uint32_t*>(base + off); off += al(((size_t)t->n_rays / kCompactBlock + 2u) * sizeof(uint32_t));
     w.w_img = base + off;                                 off += al(bwd_weight_image_bytes());
+    w.w10 = reinterpret_cast<float*>(base + off);         off += al(16u * sizeof(float));          // gathered loss_weight_parts
     w.bwd = base + off;                                   off += al(naruto_query_bwd_workspace(f, (uint32_t)(M + w.n3)));
     w.total = off;
     return w;
@@ -820,6 +821,7 @@ LossTailArgs loss_tail_args(const NarutoTrainStep* t, const TrainWs& w, uint32_t
     tl.n_rays_total = t->n_rays_total ? t->n_rays_total : t->n_rays; tl.S = t->n_samples_d + t->n_range_d;
     tl.finalize = finalize;
     tl.rng = t->rng;                                        // the iteration counter advances once per forward, used or not
+    tl.min_run = t->min_uncert_running;
     return tl;
 }
 LossStageArgs loss_stage_args(const NarutoField* f, const NarutoTrainStep* t, const TrainWs& w, const BwdWs& bw, const TvArgs& tva) {
@@ -900,7 +902,7 @@ int naruto_train_finalize(const NarutoField* f, const NarutoTrainStep* t, void* 
     if (f == nullptr || t == nullptr || t->sums == nullptr || t->losses == nullptr) return fail(NARUTO_ERR_INVALID, "train_finalize: NULL argument");
     const uint32_t S = t->n_samples_d + t->n_range_d;
     hipLaunchKernelGGL(k_loss_finalize_total, dim3(1), dim3(64), 0, (hipStream_t)stream, t->sums, t->n_rays_total ? t->n_rays_total : t->n_rays, S, t->losses,
-                       t->loss_weights);
+                       t->loss_weights, t->min_uncert_running);
     return check_launch("loss_finalize_total");
 }
 
@@ -937,9 +939,31 @@ int naruto_debug_train_scatter(const NarutoField* f, const NarutoParams* p, cons
                           nullptr, unc_g, unc_g != nullptr ? const_cast<float*>(p->uncert_grid) : nullptr, n_front);
 }
 
-int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, const NarutoGrads* g, uint32_t flags,
+int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t_in, const NarutoGrads* g, uint32_t flags,
                           const NarutoFusedAdam* opt, void* stream) {
-    if (int rc = train_check(f, p, t, "train_backward")) return rc;
+    if (int rc = train_check(f, p, t_in, "train_backward")) return rc;
+    // loss weights given as separate device scalars: gather them (+ the vector, if any) into the workspace first
+    NarutoTrainStep t_local;
+    const NarutoTrainStep* t = t_in;
+    {
+        bool parts = false;
+        for (int i = 0; i < 10; ++i) parts = parts || t_in->loss_weight_parts[i] != nullptr;
+        if (parts && (flags & NARUTO_TRAIN_BWD_TABLE_ONLY) == 0u) {
+            WeightParts wp{};
+            for (int i = 0; i < 10; ++i) wp.part[i] = t_in->loss_weight_parts[i];
+            wp.base = t_in->loss_weights;
+            const TrainWs w0 = train_ws(f, t_in);
+            hipLaunchKernelGGL(k_gather_loss_weights, dim3(1), dim3(64), 0, (hipStream_t)stream, wp, w0.w10);
+            if (int rc = check_launch("gather_loss_weights")) return rc;
+            t_local = *t_in;
+            t_local.loss_weights = w0.w10;
+            t = &t_local;
+        } else if (parts) {
+            t_local = *t_in;
+            t_local.loss_weights = train_ws(f, t_in).w10;            // gathered by the preceding MLP_ONLY call
+            t = &t_local;
+        }
+    }
     AdamFuse adam{};
     if (opt != nullptr) {
         if (opt->step_dev == nullptr) return fail(NARUTO_ERR_INVALID, "train_backward: the fused optimiser needs step_dev");
@@ -1287,19 +1311,6 @@ int naruto_mesh_emit(const uint32_t* dims, const float* sdf_vol, double isolevel
     return check_launch("mc_emit");
 }
 
-namespace {
-uint32_t half_bits_for(uint64_t n) {             // smallest h with 2^(2h) >= n
-    uint32_t h = 1;
-    while (h < 32u && (1ull << (2u * h)) < n) ++h;
-    return h;
-}
-uint64_t mix_key(uint64_t seed, uint64_t counter, uint64_t salt) {
-    uint64_t x = seed ^ (counter * 0x9E3779B97F4A7C15ull) ^ (salt * 0xD1342543DE82EF95ull);
-    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
-    return x;
-}
-}  // namespace
-
 int naruto_sample_distinct(uint64_t n, uint32_t count, uint64_t seed, uint64_t counter, int64_t* out, void* stream) {
     if (out == nullptr) return fail(NARUTO_ERR_INVALID, "sample_distinct: NULL output");
     if (count == 0) return NARUTO_OK;
@@ -1329,6 +1340,7 @@ int naruto_assemble_rays(const NarutoRayBatch* b, void* stream) {
     a.key_global = mix_key(b->seed, b->counter, 2); a.key_cur = mix_key(b->seed, b->counter, 3);
     a.hb_global = half_bits_for(a.n_pop); a.hb_cur = half_bits_for(a.n_cur_pop);
     a.rays_o = b->rays_o; a.rays_d = b->rays_d; a.target_s = b->target_s; a.target_d = b->target_d; a.ids_out = b->ids_out;
+    a.rng = b->rng; a.dyn = b->dyn; a.seed_host = b->seed; a.counter_host = b->counter;
     hipLaunchKernelGGL(k_assemble_rays, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("assemble_rays");
 }

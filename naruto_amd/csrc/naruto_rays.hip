@@ -171,6 +171,17 @@ __host__ __device__ __forceinline__ uint64_t perm_index(uint64_t i, uint64_t n, 
     return i;
 }
 
+__host__ __device__ __forceinline__ uint32_t half_bits_for(uint64_t n) {             // smallest h with 2^(2h) >= n
+    uint32_t h = 1;
+    while (h < 32u && (1ull << (2u * h)) < n) ++h;
+    return h;
+}
+__host__ __device__ __forceinline__ uint64_t mix_key(uint64_t seed, uint64_t counter, uint64_t salt) {
+    uint64_t x = seed ^ (counter * 0x9E3779B97F4A7C15ull) ^ (salt * 0xD1342543DE82EF95ull);
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+    return x;
+}
+
 struct AssembleArgs {
     const float* store;          // [n_pop, 7] = (direction 3, rgb 3, depth 1) of the stored keyframe rays
     uint64_t n_pop;              // n_kf * rays_per_kf
@@ -188,11 +199,23 @@ struct AssembleArgs {
     uint32_t hb_global, hb_cur;
     float* rays_o; float* rays_d; float* target_s; float* target_d;
     int64_t* ids_out;            // optional [n_global + n_cur]: pose index used per ray (-1 for current-frame rays)
+    // what changes between replays of a captured launch, read from device memory (either may be NULL = the host values above):
+    const uint64_t* rng;         // {seed, counter}: keys = mix(seed ^ seed_host, counter + counter_host, salt)
+    const uint64_t* dyn;         // {n_kf, n_poses, n_cur_pop}
+    uint64_t seed_host, counter_host;
 };
 
 __global__ __launch_bounds__(256) void k_assemble_rays(AssembleArgs a) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.n_global + a.n_cur) return;
+    if (a.rng != nullptr) {
+        const uint64_t seed = a.rng[0] ^ a.seed_host, counter = a.rng[1] + a.counter_host;
+        a.key_global = mix_key(seed, counter, 2); a.key_cur = mix_key(seed, counter, 3);
+    }
+    if (a.dyn != nullptr) {
+        a.n_pop = a.dyn[0] * a.rays_per_kf; a.n_poses = (uint32_t)a.dyn[1]; a.n_cur_pop = a.dyn[2];
+        a.hb_global = half_bits_for(a.n_pop); a.hb_cur = half_bits_for(a.n_cur_pop);
+    }
     const float* src;
     int64_t pose_id;
     if (r < a.n_global) {

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, NARUTO_RENDER_PACKED_MINWAVES) void k_render_f
     if constexpr (BF) stage_fwd_weights_bf<256>(L, p, threadIdx.x);
     else stage_fwd_weights<256>(L, p, threadIdx.x);
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // scalar: see k_query_fwd_loss
     const uint32_t S = a.nu + a.nr;
     const float inv_S = 1.0f / (float)S;
     const float2* __restrict__ table = reinterpret_cast<const float2*>(p.table);

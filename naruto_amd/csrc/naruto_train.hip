@@ -49,7 +49,16 @@ struct LossTailArgs {
     uint64_t n_rays_total; uint32_t S;
     int finalize;                 // 0: stop at sums (+ losses[8]); the caller all-reduces and calls k_loss_finalize_total
     uint64_t* rng;                // {seed, iteration counter} or NULL: the counter advances once per forward
+    float* min_run;               // or NULL: running minimum of losses[6] = min(uncert_map) over every iteration so far (NaN sticks)
 };
+
+// the reference asserts uncert_map.min() > 0 in every forward (scene_rep.py:280); here every iteration folds its minimum into one
+// device word that the host reads whenever it likes (a graph replay included): no iteration goes unchecked
+__device__ __forceinline__ void fold_min_uncert(float* __restrict__ min_run, float u) {
+    if (min_run == nullptr) return;
+    const float r = *min_run;
+    if (u < r || u != u) *min_run = u;
+}
 
 __device__ __forceinline__ void loss_total(float* __restrict__ losses, const float* __restrict__ w) {
     // total = sum_i w[i] * losses[i] over the differentiable slots; a zero weight drops the slot even if it holds NaN
@@ -173,7 +182,9 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
     if constexpr (BF) stage_fwd_weights_bf<256>(L, p, threadIdx.x);
     else stage_fwd_weights<256>(L, p, threadIdx.x);
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave index as a SCALAR: everything derived from it (the ray, its tiles, the wave's LDS image) then lives in SGPRs instead of
+    // vector registers -- what took this kernel from 9 spilled registers (40 bytes of scratch, reloaded inside the tile loop) to none
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int j = lane & 31;
     const float2* __restrict__ table = reinterpret_cast<const float2*>(p.table);
     const uint32_t tpr = ee.tiles_per_ray, S = a.S;                  // S == 64 tpr
@@ -333,6 +344,8 @@ __device__ __forceinline__ void wg_partial_reduce(double (&acc)[10], double (*pa
 // one workgroup: per-workgroup partials -> sums[16], smoothness term, losses[10], iteration counter
 __device__ __forceinline__ void loss_tail_body(const LossTailArgs& a, double* red, double (*part)[10], double* s_sums) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the running minimum's old value shares the partials' trip to memory
+    const float min_old = (threadIdx.x == 0 && a.min_run != nullptr && a.finalize) ? *a.min_run : 0.0f;
     // the smoothness partials ride in the same round of loads
     double tv = 0.0;
     for (uint32_t i = threadIdx.x; i < a.n_tv_blocks; i += 256) tv += a.tv_partial[i];
@@ -352,6 +365,7 @@ __device__ __forceinline__ void loss_tail_body(const LossTailArgs& a, double* re
             if (a.loss_weights != nullptr) loss_total(l, a.loss_weights);
 #pragma unroll
             for (int i = 0; i < 10; ++i) a.losses[i] = l[i];
+            if (a.min_run != nullptr && (l[6] < min_old || l[6] != l[6])) *a.min_run = l[6];
         }
         if (a.rng != nullptr) a.rng[1] += 1ull;
     }
@@ -393,6 +407,7 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_bwd_fused(FusedBwdA
         else if (threadIdx.x == 0) {
             loss_finalize_body(a.la.sums, a.tail.n_rays_total, a.S, a.tail.losses);
             if (a.tail.loss_weights != nullptr) loss_total(a.tail.losses, a.tail.loss_weights); else a.tail.losses[9] = 0.0f;
+            fold_min_uncert(a.tail.min_run, a.tail.losses[6]);
         }
         return;
     }
@@ -444,12 +459,20 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_bwd_fused(FusedBwdA
     composite_bwd_ray<true, true>(ray_lds, n, lane, wave, a.S, a.trunc, a.sc_factor, a.white_bkgd, a.raw, a.z_vals, cot, la, a.d_raw, 0, nullptr);
 }
 
+// loss weights handed over as separate device scalars (autograd's cotangents of an unchanged caller's scalar losses) -> one vector
+struct WeightParts { const float* part[10]; const float* base; };
+__global__ void k_gather_loss_weights(WeightParts wp, float* __restrict__ out) {
+    const int i = threadIdx.x;
+    if (i < 10) out[i] = (wp.base != nullptr ? wp.base[i] : 0.0f) + (wp.part[i] != nullptr ? *wp.part[i] : 0.0f);
+}
+
 // data-parallel tail of the loss stage: all-reduced sums -> losses[0..7], total -> losses[9]
 __global__ void k_loss_finalize_total(const double* __restrict__ sums, uint64_t n_total, uint32_t S, float* __restrict__ losses,
-                                      const float* __restrict__ loss_weights) {
+                                      const float* __restrict__ loss_weights, float* __restrict__ min_run) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     loss_finalize_body(sums, n_total, S, losses);
     if (loss_weights != nullptr) loss_total(losses, loss_weights); else losses[9] = 0.0f;
+    fold_min_uncert(min_run, losses[6]);
 }
 
 // ray prefix lengths -> flat active list, one launch: every workgroup (4 rays, one wave each) sums the counts of the

@@ -99,21 +99,30 @@ class KeyFrameStoreHIP:
         return rays, self.frame_ids[idx // self.num_rays_to_save]
 
     def assemble_batch(self, sample_num: int, current_rays: torch.Tensor, poses_all: torch.Tensor, min_pixels_cur: int,
-                       filter_depth: bool = False, return_ids: bool = False, out=None):
+                       filter_depth: bool = False, return_ids: bool = False, out=None, rng: Optional[torch.Tensor] = None,
+                       dyn: Optional[torch.Tensor] = None, n_cur: Optional[int] = None, n_cur_pop: Optional[int] = None):
         """coslam.py:310-344 fused: -> rays_o [N,3], rays_d [N,3], target_s [N,3], target_d [N,1], n_cur (and ids_all).
         N = sample_num + n_cur, n_cur = max(sample_num // n_kf, min_pixels_cur) (capped by the valid pixels).
         current_rays [H*W,7]; poses_all [P,4,4] camera-to-world with the current frame's pose LAST (index -1).
         ``out``: (rays_o, rays_d, target_s, target_d) to write into -- contiguous fp32 device tensors of exactly N rows, e.g. a
-        captured trainer's ``ray_buffers()``."""
+        captured trainer's ``ray_buffers()``.
+        For a launch captured in a hipGraph (naruto_amd.ba_loop.FusedBA): ``rng`` int64[2] device {seed, counter} keys the draws
+        instead of this store's host counter, ``dyn`` int64[3] device {n_kf, n_poses, n_cur_pop} replaces the host values at replay
+        time; ``n_cur`` / ``n_cur_pop`` then fix the current-frame draw's size and population up front (no device read-back; with
+        ``filter_depth`` in the reference's mode the population is the number of valid-depth pixels, counted by the caller)."""
         lib = _lib.load()
         n_kf = len(self)
         assert n_kf > 0, "no keyframe stored yet"
         cur = current_rays.to(self.device, torch.float32).reshape(-1, 7).contiguous()
         poses = poses_all.to(self.device, torch.float32).contiguous()
-        n_cur = max(sample_num // n_kf, int(min_pixels_cur))
+        fixed = n_cur is not None
+        if fixed:
+            assert n_cur_pop is not None and not (filter_depth and self.filter_depth_mode == "valid_only"), "fixed sizes: pass n_cur_pop (reference mode)"
+        else:
+            n_cur = max(sample_num // n_kf, int(min_pixels_cur))
+            n_cur_pop = cur.shape[0]
         cur_list = None
-        n_cur_pop = cur.shape[0]
-        if filter_depth:
+        if filter_depth and not fixed:
             valid = (cur[:, -1] > 0.0) & (cur[:, -1] <= self.config["cam"]["depth_trunc"])
             cur_list = torch.nonzero(valid).reshape(-1).to(torch.int32).contiguous()
             n_cur_pop = int(cur_list.shape[0])
@@ -140,6 +149,12 @@ class KeyFrameStoreHIP:
         b.poses, b.n_poses, b.seed, b.counter = poses.data_ptr(), poses.shape[0], self.seed, self.counter
         b.rays_o, b.rays_d, b.target_s, b.target_d = rays_o.data_ptr(), rays_d.data_ptr(), target_s.data_ptr(), target_d.data_ptr()
         b.ids_out = ids.data_ptr() if ids is not None else None
+        if rng is not None:
+            assert rng.is_cuda and rng.dtype == torch.int64 and rng.numel() >= 2
+            b.rng, b.seed, b.counter = rng.data_ptr(), 0, 0
+        if dyn is not None:
+            assert dyn.is_cuda and dyn.dtype == torch.int64 and dyn.numel() >= 3
+            b.dyn = dyn.data_ptr()
         with torch.cuda.device(self.device):
             check(lib.naruto_assemble_rays(C.byref(b), _stream()), "naruto_assemble_rays")
         out = (rays_o, rays_d, target_s, target_d, n_cur)

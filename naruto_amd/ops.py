@@ -19,8 +19,32 @@ from ._lib import NarutoFieldDesc, NarutoGrads, NarutoParams, NarutoPoints, chec
 PARAM_NAMES = ("table", "uncert_grid", "sdf_w0", "sdf_w1", "col_w0", "col_w1")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> C.c_void_p:
+    """torch's CURRENT stream on the current device as a hipStream_t."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _on_device:
+    """``with torch.cuda.device(dev)`` without its cost when ``dev`` already is the current device (every call of a single-GPU process)."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, dev):
+        self.idx = dev.index
+
+    def __enter__(self):
+        self.prev = torch.cuda.current_device()
+        if self.idx is not None and self.idx != self.prev:
+            torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *exc):
+        if self.idx is not None and self.idx != self.prev:
+            torch.cuda.set_device(self.prev)
+        return False
 
 
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -119,7 +143,7 @@ def sample_z(n_rays: int, target_d: Optional[torch.Tensor], near: float, far: fl
     if rand is not None:
         rand = _f32c(rand, "rand")
         assert rand.shape == (n_rays, S)
-    with torch.cuda.device(z.device):
+    with _on_device(z.device):
         check(lib.naruto_sample_z(n_rays, _p(target_d), near, far, n_samples_d, n_range_d, range_d, n_samples, _p(rand),
                                   _p(z), _stream()), "naruto_sample_z")
     return z
@@ -157,7 +181,7 @@ def render_fused(handle: "FieldHandle", params: Dict[str, torch.Tensor], rays_o,
     r.rgb, r.depth, r.disp, r.acc, r.depth_var, r.uncert_map = (_p(out[k]) for k in ("rgb", "depth", "disp_map", "acc_map", "depth_var", "uncert_map"))
     r.weights, r.raw, r.z_vals = _p(out.get("weights")), _p(out.get("raw")), _p(out.get("z_vals"))
     ps = _params_struct({k: _f32c(v.detach(), k) for k, v in params.items()})
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         check(lib.naruto_render_fwd(handle.ptr, C.byref(ps), C.byref(r), _stream()), "naruto_render_fwd")
     return out
 
@@ -177,7 +201,7 @@ def oneblob_encode(handle: "FieldHandle", x: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     x = _f32c(x.detach().reshape(-1, 3), "x")
     out = torch.empty(x.shape[0], 48, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on_device(x.device):
         check(lib.naruto_oneblob_fwd(handle.ptr, x.shape[0], _p(x), _p(out), _stream()), "naruto_oneblob_fwd")
     return out
 
@@ -195,7 +219,7 @@ def decoder_part(handle: "FieldHandle", params: Dict[str, torch.Tensor], part: i
             raise ValueError(f"embed_pos: expected [{a.shape[0]}, 48], got {list(b.shape)}")
     out = torch.empty(a.shape[0], width_out, dtype=torch.float32, device=a.device)
     ps = _params_struct({k: _f32c(v.detach(), k) for k, v in params.items()})
-    with torch.cuda.device(a.device):
+    with _on_device(a.device):
         check(lib.naruto_decoder_fwd(handle.ptr, C.byref(ps), a.shape[0], part, _p(a), _p(b), _p(out), _stream()), "naruto_decoder_fwd")
     return out
 
@@ -211,7 +235,7 @@ class _HashEncode(torch.autograd.Function):
         table = _f32c(table, "table")
         M = x.shape[0]
         feat = torch.empty(M, 32, dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _on_device(x.device):
             check(lib.naruto_hash_encode_fwd(handle.ptr, M, _p(x), _p(table), _p(feat), _stream()), "naruto_hash_encode_fwd")
         ctx.handle = handle
         ctx.set_materialize_grads(False)
@@ -226,7 +250,7 @@ class _HashEncode(torch.autograd.Function):
         if ctx.needs_input_grad[2] and d_feat is not None:
             d_feat = _f32c(d_feat, "d_feat")
             d_table = torch.zeros_like(table)
-            with torch.cuda.device(x.device):
+            with _on_device(x.device):
                 ws = torch.empty((lib.naruto_scatter_workspace(ctx.handle.ptr, x.shape[0]) + 3) // 4, dtype=torch.float32, device=x.device)
                 check(lib.naruto_hash_encode_bwd(ctx.handle.ptr, x.shape[0], _p(x), _p(d_feat), None, _p(d_table), _p(ws), _stream()),
                       "naruto_hash_encode_bwd")
@@ -251,7 +275,7 @@ class _Smoothness(torch.autograd.Function):
         x = torch.empty(n ** 3, 3, dtype=torch.float32, device=dev)
         d_feat = torch.empty(n ** 3, 32, dtype=torch.float32, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             ws = torch.empty((lib.naruto_smoothness_workspace(sample_points) + 3) // 4, dtype=torch.float32, device=dev)
             check(lib.naruto_smoothness_fwd(handle.ptr, _p(table), sample_points, voxel_size, margin, _p(rand6), _p(x), _p(d_feat), _p(loss),
                                             _p(ws), _stream()), "naruto_smoothness_fwd")
@@ -268,7 +292,7 @@ class _Smoothness(torch.autograd.Function):
             return None, None, None, None, None, None
         g = _f32c(g, "grad").reshape(1)
         d_table = torch.zeros_like(table)
-        with torch.cuda.device(x.device):
+        with _on_device(x.device):
             ws = torch.empty((lib.naruto_scatter_workspace(ctx.handle.ptr, x.shape[0]) + 3) // 4, dtype=torch.float32, device=x.device)
             check(lib.naruto_hash_encode_bwd(ctx.handle.ptr, x.shape[0], _p(x), _p(d_feat), _p(g), _p(d_table), _p(ws), _stream()),
                   "naruto_hash_encode_bwd")
@@ -304,7 +328,7 @@ class _FieldQuery(torch.autograd.Function):
         geo = torch.empty(M, 15, dtype=torch.float32, device=dev) if want_geo else None
         feat = torch.empty(16, M, 2, dtype=torch.float32, device=dev) if need_grad else None
         ps = _params_struct(params)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             check(lib.naruto_query_fwd(handle.ptr, C.byref(ps), M, C.byref(pts), _p(out) if color else None,
                                        None if color else _p(out), _p(geo), _p(feat), _stream()), "naruto_query_fwd")
         ctx.handle, ctx.color, ctx.want_geo, ctx.M = handle, color, want_geo, M
@@ -349,7 +373,7 @@ class _FieldQuery(torch.autograd.Function):
             setattr(gs, n, _p(grads[n]))
         ps = _params_struct(params)
         pts, _ = _points_struct(x, rays_o, rays_d, z_vals)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             ws_bytes = lib.naruto_query_bwd_workspace(ctx.handle.ptr, M)
             ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
             check(lib.naruto_query_bwd(ctx.handle.ptr, C.byref(ps), M, C.byref(pts), _p(feat), _p(d_raw), _p(d_geo), None, None,
@@ -375,7 +399,7 @@ class _Composite(torch.autograd.Function):
         rgb = torch.empty(N, 3, dtype=torch.float32, device=dev)
         disp, acc, depth, depth_var, um = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(5))
         weights = torch.empty(N, S, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             check(lib.naruto_composite_fwd(handle.ptr, N, S, _p(raw), _p(z_vals), _p(rgb), _p(disp), _p(acc), _p(weights),
                                            _p(depth), _p(depth_var), _p(um), _stream()), "naruto_composite_fwd")
         ctx.handle = handle
@@ -390,7 +414,7 @@ class _Composite(torch.autograd.Function):
         N, S = z_vals.shape
         cots = [None if g is None else _f32c(g, "cotangent") for g in (d_rgb, d_disp, d_acc, d_weights, d_depth, d_depth_var, d_um)]
         d_raw = torch.empty_like(raw)
-        with torch.cuda.device(raw.device):
+        with _on_device(raw.device):
             check(lib.naruto_composite_bwd(ctx.handle.ptr, N, S, _p(raw), _p(z_vals), *(_p(c) for c in cots), _p(d_raw), 0,
                                            _stream()), "naruto_composite_bwd")
         return None, d_raw, None
@@ -424,7 +448,7 @@ class _RenderLoss(torch.autograd.Function):
         sums = torch.empty(_lib.LOSS_NSUMS, dtype=torch.float64, device=dev)
         losses = torch.empty(8, dtype=torch.float32, device=dev)
         n_total = N
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             st = _stream()
             check(lib.naruto_composite_fwd(handle.ptr, N, S, _p(raw), _p(z_vals), _p(rgb), _p(disp), _p(acc), None, _p(depth),
                                            _p(depth_var), _p(um), st), "naruto_composite_fwd")
@@ -453,7 +477,7 @@ class _RenderLoss(torch.autograd.Function):
         if d_losses is None:
             d_losses = torch.zeros(8, dtype=torch.float32, device=dev)
         d_losses = _f32c(d_losses, "d_losses")
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             st = _stream()
             check(lib.naruto_loss_bwd(ctx.handle.ptr, N, S, _p(raw), _p(z_vals), _p(target_rgb), _p(target_d), ctx.depth_trunc,
                                       ctx.rgb_missing, _p(sums), ctx.n_total, _p(d_losses), _p(d_raw), None, st), "naruto_loss_bwd")
@@ -511,7 +535,7 @@ class _RenderTrain(torch.autograd.Function):
         ps = _params_struct(params)
         pts, _ = _points_struct(None, rays_o, rays_d, z_vals)
         n_total = N
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             st = _stream()
             check(lib.naruto_query_fwd(handle.ptr, C.byref(ps), M, C.byref(pts), _p(raw), None, None, _p(feat), st), "naruto_query_fwd")
             check(lib.naruto_composite_fwd(handle.ptr, N, S, _p(raw), _p(z_vals), _p(rgb), _p(disp), _p(acc), None, _p(depth),
@@ -578,7 +602,7 @@ class _RenderTrain(torch.autograd.Function):
             setattr(gs, n, _p(grads[n]))
         ps = _params_struct(params)
         pts, _ = _points_struct(None, rays_o, rays_d, z_vals)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             st = _stream()
             count = None if extra else torch.empty(N, dtype=torch.int32, device=dev)
             check(lib.naruto_loss_bwd(ctx.handle.ptr, N, S, _p(raw), _p(z_vals), _p(target_rgb), _p(target_d), ctx.depth_trunc,
@@ -643,6 +667,15 @@ def adam_multi_(entries, *, betas, step: int = 0, step_dev: Optional[torch.Tenso
         check(lib.naruto_adam_multi(segs, len(entries), betas[0], betas[1], step, _p(step_dev), flags, _stream()), "naruto_adam_multi")
 
 
+def adam_multi_segs(segs, n: int, dev, *, betas, step: int = 0, step_dev: Optional[torch.Tensor] = None, advance: bool = False,
+                    zero_grad: bool = False) -> None:
+    """adam_multi_ over a prebuilt NarutoAdamSeg array (FusedAdam keeps one and refreshes the gradient pointers per step)."""
+    lib = _lib.load()
+    flags = (_lib.ADAM_ADVANCE if advance else 0) | (_lib.ADAM_ZERO_GRAD if zero_grad else 0)
+    with _on_device(dev):
+        check(lib.naruto_adam_multi(segs, n, betas[0], betas[1], step, _p(step_dev), flags, _stream()), "naruto_adam_multi")
+
+
 class TrainStep:
     """The mapping iteration's forward + backward as two C calls on persistent buffers (naruto_train_forward /
     naruto_train_backward): no autograd graph, no per-iteration allocations or fills, a dozen launches.
@@ -656,7 +689,8 @@ class TrainStep:
     def __init__(self, handle: FieldHandle, params: Dict[str, torch.Tensor], uncert_grad: torch.Tensor, n_rays: int, *, n_samples_d: int,
                  n_range_d: int, near: float, far: float, range_d: float, depth_trunc: float, rgb_missing: float, perturb: bool,
                  loss_weights: torch.Tensor, smooth: Optional[Tuple[int, float, float]] = None, group=None, n_rays_total: int = 0,
-                 device_rng: bool = True, seed: Optional[int] = None, rng_state: Optional[torch.Tensor] = None):
+                 device_rng: bool = True, seed: Optional[int] = None, rng_state: Optional[torch.Tensor] = None,
+                 min_uncert_running: Optional[torch.Tensor] = None, own_grads: bool = True):
         lib = _lib.load()
         self.handle, self.group = handle, group
         self.fuse_tail = os.environ.get("NARUTO_DEBUG_NO_FUSED_TAIL") is None     # run(): loss tail + compaction inside the backward's first launch
@@ -693,16 +727,18 @@ class TrainStep:
         self.d_raw = torch.empty(N, S, 5, **f32)
         self.ray_count, self.ray_offset = torch.empty(N, **i32), torch.empty(N, **i32)
         self.active_idx, self.n_active = torch.empty(M, **i32), torch.zeros(1, **i32)
-        self.flat_grad = torch.zeros(sum(self.params[n].numel() for n in self.FLAT_NAMES), **f32)
-        self.grads, off = {}, 0
-        for n in self.FLAT_NAMES:
-            k = self.params[n].numel()
-            self.grads[n] = self.flat_grad[off:off + k].view_as(self.params[n])
-            off += k
-        n_table = self.params["table"].numel()
-        self.grad_bucket_table, self.grad_bucket_mlp = self.flat_grad[:n_table], self.flat_grad[n_table:]      # the two all-reduce buckets
-        assert uncert_grad.is_cuda and uncert_grad.dtype == torch.float32 and uncert_grad.is_contiguous()
-        self.grads["uncert_grid"] = uncert_grad
+        self.grads = {n: None for n in PARAM_NAMES}
+        if own_grads:
+            self.flat_grad = torch.zeros(sum(self.params[n].numel() for n in self.FLAT_NAMES), **f32)
+            off = 0
+            for n in self.FLAT_NAMES:
+                k = self.params[n].numel()
+                self.grads[n] = self.flat_grad[off:off + k].view_as(self.params[n])
+                off += k
+            n_table = self.params["table"].numel()
+            self.grad_bucket_table, self.grad_bucket_mlp = self.flat_grad[:n_table], self.flat_grad[n_table:]      # the two all-reduce buckets
+            assert uncert_grad.is_cuda and uncert_grad.dtype == torch.float32 and uncert_grad.is_contiguous()
+            self.grads["uncert_grid"] = uncert_grad
         world = 1
         if group is not None:
             from . import parallel
@@ -723,6 +759,10 @@ class TrainStep:
         t.ray_count, t.ray_offset, t.active_idx, t.n_active = _p(self.ray_count), _p(self.ray_offset), _p(self.active_idx), _p(self.n_active)
         self.ws = torch.empty((lib.naruto_train_workspace(handle.ptr, C.byref(t)) + 3) // 4, **f32)
         t.workspace = _p(self.ws)
+        if min_uncert_running is not None:      # float32[1] device word, +inf initially: every iteration's min(uncert_map) is folded into it
+            assert min_uncert_running.is_cuda and min_uncert_running.dtype == torch.float32 and min_uncert_running.numel() == 1
+            self.min_uncert_running = min_uncert_running
+            t.min_uncert_running = _p(min_uncert_running)
         self.t = t
         self.ps = _params_struct(self.params)
         self.gs = NarutoGrads()
@@ -804,7 +844,7 @@ class TrainStep:
             self.rand[:self.N * self.S].copy_(rand.reshape(-1))
         elif not self.device_rng and (self.perturb or t.smooth_points):
             self.rand.uniform_()                                # one RNG launch: jitter + lattice placement
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             st = _stream()
             if self._zero_table:
                 self.grads["table"].zero_()
@@ -816,7 +856,7 @@ class TrainStep:
         complete in self.grads), phase 2 = the table scatter; the caller all-reduces the weight bucket in between."""
         lib = _lib.load()
         t = self.t
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             st = _stream()
             # data parallel: self.sums holds the all-reduced sums; finalize + composite backward + compaction are one launch
             given = _lib.TRAIN_BWD_SUMS_GIVEN if (self.group is not None and self.fuse_tail) else 0
@@ -838,6 +878,119 @@ class TrainStep:
                       "naruto_train_backward")
 
 
+
+# ---------------------------------------------------------------------------------------------------
+# JointEncodingNaruto.forward in training mode for an UNCHANGED caller (reference coslam.py:361-399: model.forward ->
+# get_loss_from_ret -> loss.backward(retain_graph=True) -> Adam): one autograd node over naruto_train_forward / naruto_train_backward
+# ---------------------------------------------------------------------------------------------------
+class TrainNodeState(TrainStep):
+    """Persistent buffers of the fused training kernels for one ray count (z_vals, raw, saved features, cotangents, lists, workspace);
+    outputs and gradients are fresh tensors per call, so what the caller keeps (ret['rgb'], .grad) is never overwritten.  A second
+    backward over the SAME graph is fine (coslam.py:368 keeps it); a backward over a graph whose forward is no longer the latest one
+    for this state raises (its buffers have been reused)."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, own_grads=False, **kw)
+        self.version = 0
+        dev = self.device
+        self.w_unit = torch.zeros(10, dtype=torch.float32, device=dev)        # forward: the total in losses[9] is not meaningful yet
+        self.zero = torch.zeros((), dtype=torch.float32, device=dev)
+        self.losses_bwd = torch.zeros(10, dtype=torch.float32, device=dev)    # the backward's first launch rewrites losses[0..9]: keep the caller's copy out of it
+        self.t.loss_weights = _p(self.w_unit)
+
+
+class _TrainForward(torch.autograd.Function):
+    """(rays, targets, parameters) -> rgb [N,3], depth [N], rgb_loss, depth_loss, sdf_loss, fs_loss, psnr, uncert_loss, losses[10].
+    The scalar losses are separate outputs so that the caller's weighted sum (get_loss_from_ret, coslam.py:154-174) hands their
+    cotangents back as scalars: stacked, they ARE the loss-weight vector naruto_train_backward takes from device memory."""
+
+    @staticmethod
+    def forward(ctx, st: "TrainNodeState", rand, rays_o, rays_d, target_rgb, target_d, table, uncert_grid, sdf_w0, sdf_w1, col_w0, col_w1):
+        lib = _lib.load()
+        params = {"table": table, "uncert_grid": uncert_grid, "sdf_w0": sdf_w0, "sdf_w1": sdf_w1, "col_w0": col_w0, "col_w1": col_w1}
+        params = {k: _f32c(v, k) for k, v in params.items()}
+        rays_o, rays_d = _f32c(rays_o, "rays_o"), _f32c(rays_d, "rays_d")
+        target_rgb, target_d = _f32c(target_rgb, "target_rgb"), _f32c(target_d, "target_d").reshape(-1)
+        N = st.N
+        assert rays_o.shape[0] == N and target_d.numel() == N
+        dev = rays_o.device
+        rgb = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        depth = torch.empty(N, dtype=torch.float32, device=dev)
+        losses = torch.empty(10, dtype=torch.float32, device=dev)
+        t = st.t
+        t.rays_o, t.rays_d, t.target_rgb, t.target_d = _p(rays_o), _p(rays_d), _p(target_rgb), _p(target_d)
+        t.rgb, t.depth, t.losses, t.loss_weights = _p(rgb), _p(depth), _p(losses), _p(st.w_unit)
+        if rand is not None:
+            assert not st.device_rng, "an explicit jitter draw needs a state built with device_rng=False"
+            st.rand[:N * st.S].copy_(_f32c(rand, "rand").reshape(-1))
+        ps = _params_struct(params)
+        with _on_device(dev):
+            check(lib.naruto_train_forward(st.handle.ptr, C.byref(ps), C.byref(t), 1, _stream()), "naruto_train_forward")
+        st.version += 1
+        ctx.st, ctx.version = st, st.version
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(rays_o, rays_d, target_rgb, target_d, *(params[k] for k in PARAM_NAMES))
+        return rgb, depth, losses[0], losses[1], losses[2], losses[3], losses[4], losses[5], losses
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_depth, d0, d1, d2, d3, _d4, d5, d_vec):
+        lib = _lib.load()
+        st = ctx.st
+        if st.version != ctx.version:
+            raise RuntimeError("backward over a training graph whose buffers a later forward of the same ray count has reused; call backward "
+                               "before the next model.forward (the reference does, coslam.py:364-368), or set model.fused_train = False")
+        if d_rgb is not None or d_depth is not None:
+            raise NotImplementedError("the fused training node differentiates the losses only; to differentiate the rendered rgb / depth "
+                                      "as well set model.fused_train = False (the modular operators)")
+        rays_o, rays_d, target_rgb, target_d = ctx.saved_tensors[:4]
+        params = dict(zip(PARAM_NAMES, ctx.saved_tensors[4:10]))
+        dev = rays_o.device
+        # the caller's loss weights: cotangents of the scalar losses (device scalars, gathered by the backward's own first launch) and /
+        # or of the loss vector
+        parts = (d0, d1, d2, d3, None, d5)
+        if d_vec is None and all(p is None for p in parts):
+            return (None,) * 12
+        w = _f32c(d_vec, "d_losses") if d_vec is not None else None
+        keep = []
+        t = st.t
+        for i in range(10):
+            pi = parts[i] if i < 6 else None
+            if pi is not None:
+                pi = _f32c(pi, "loss cotangent")
+                keep.append(pi)
+            t.loss_weight_parts[i] = _p(pi)
+        need = ctx.needs_input_grad[6:12]
+        grads = {}
+        flat_names = [n for i, n in enumerate(PARAM_NAMES) if need[i] and n != "uncert_grid"]
+        flat = torch.empty(sum(params[n].numel() for n in flat_names), dtype=torch.float32, device=dev) if flat_names else None
+        off = 0
+        for n in flat_names:
+            k = params[n].numel()
+            grads[n] = flat[off:off + k].view_as(params[n])
+            off += k
+        overwrite = handle_supports_overwrite(st.handle)
+        if "table" in flat_names and not overwrite:
+            grads["table"].zero_()
+        for i, n in enumerate(PARAM_NAMES):
+            if not need[i]:
+                grads[n] = None
+            elif n == "uncert_grid":
+                grads[n] = torch.zeros_like(params[n])       # accumulated into by the scatter's grid units
+        gs = NarutoGrads()
+        for n in PARAM_NAMES:
+            setattr(gs, n, _p(grads[n]))
+        t.rays_o, t.rays_d, t.target_rgb, t.target_d = _p(rays_o), _p(rays_d), _p(target_rgb), _p(target_d)
+        t.loss_weights, t.losses = _p(w), _p(st.losses_bwd)
+        ps = _params_struct(params)
+        flags = _lib.BWD_OVERWRITE_WEIGHT_GRADS | (_lib.BWD_OVERWRITE_TABLE_GRAD if overwrite else 0) | _lib.TRAIN_BWD_SUMS_GIVEN
+        with _on_device(dev):
+            check(lib.naruto_train_backward(st.handle.ptr, C.byref(ps), C.byref(t), C.byref(gs), flags, None, _stream()), "naruto_train_backward")
+        return (None,) * 6 + tuple(grads[n] for n in PARAM_NAMES)
+
+
+def train_forward_node(st: "TrainNodeState", params: Dict[str, torch.Tensor], rays_o, rays_d, target_rgb, target_d, rand=None):
+    return _TrainForward.apply(st, rand, rays_o, rays_d, target_rgb, target_d, *(params[n] for n in PARAM_NAMES))
+
 # ---------------------------------------------------------------------------------------------------
 # A10 helper
 # ---------------------------------------------------------------------------------------------------
@@ -850,6 +1003,6 @@ def adam_step_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, e
         assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
     if step_dev is not None:
         assert step_dev.dtype == torch.int32 and step_dev.is_cuda
-    with torch.cuda.device(param.device):
+    with _on_device(param.device):
         check(lib.naruto_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, betas[0], betas[1], eps,
                                    weight_decay, step, _p(step_dev), _stream()), "naruto_adam_step")

@@ -81,24 +81,15 @@ def pack_rays(rays_o, rays_d, target_rgb, target_d):
     return unpack_rays(flat, n)
 
 
-class FusedAdam:
-    """torch.optim.Adam semantics (amsgrad off, L2 weight decay) as one HIP kernel per tensor; the step count
-    lives on the device so that the launch stays valid under hipGraph replay.  ``param_groups`` uses the
-    same dict keys as torch.optim.Adam (params / lr / eps / weight_decay / betas)."""
+class FusedAdam(optim.Optimizer):
+    """``torch.optim.Adam`` (amsgrad off, L2 weight decay, not maximize) as ONE HIP launch over all parameter tensors -- a
+    ``torch.optim.Optimizer`` subclass with Adam's constructor, so the reference's ``create_optimizer`` / ``init_uncert_grid_optim``
+    (coslam.py:240-243, 409-419) take it by changing ``optim.Adam`` to ``naruto_amd.FusedAdam`` and nothing else: same param-group keys,
+    ``zero_grad`` / ``step`` / ``state_dict`` / ``add_param_group``.  The step count lives on the device, so a captured launch stays
+    valid under hipGraph replay.  State per parameter: ``exp_avg``, ``exp_avg_sq`` (created with the optimiser)."""
 
-    def __init__(self, param_groups, betas=(0.9, 0.999), lr=1e-3, eps=1e-8, weight_decay=0.0):
-        if isinstance(param_groups, (list, tuple)) and param_groups and not isinstance(param_groups[0], dict):
-            param_groups = [{'params': list(param_groups)}]
-        self.param_groups = []
-        for g in param_groups:
-            g = dict(g)
-            g['params'] = list(g['params'])
-            g.setdefault('lr', lr)
-            g.setdefault('eps', eps)
-            g.setdefault('weight_decay', weight_decay)
-            g.setdefault('betas', betas)
-            self.param_groups.append(g)
-        self.state = {}
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         dev = self.param_groups[0]['params'][0].device
         self.step_dev = torch.zeros(2, dtype=torch.int32, device=dev)       # {completed steps, ticket word of k_adam_multi}
         # int32[1] device word that already holds THIS step's 1-based number when step() runs (MappingTrainer's iteration
@@ -106,42 +97,100 @@ class FusedAdam:
         self.external_step = None
         for g in self.param_groups:
             for p in g['params']:
-                self.state[p] = (torch.zeros_like(p), torch.zeros_like(p))
+                self._init_state(p)
 
-    def zero_grad(self, set_to_none: bool = True):
+    def _init_state(self, p):
+        if 'exp_avg' not in self.state[p]:
+            self.state[p]['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            self.state[p]['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        if hasattr(self, 'step_dev'):
+            for p in self.param_groups[-1]['params']:
+                self._init_state(p)
+
+    def moments(self, p):
+        st = self.state[p]
+        return st['exp_avg'], st['exp_avg_sq']
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd['naruto_step'] = int(self.step_dev[0].item())
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        step = state_dict.pop('naruto_step', None)
+        super().load_state_dict(state_dict)
+        if step is not None:
+            self.step_dev[0] = int(step)
+
+    def _plan(self):
+        """Per (betas) batch of <= 8 tensors: a reusable NarutoAdamSeg array with everything but the gradient pointers filled in."""
+        from . import _lib
+        plan, by_betas = [], {}
         for g in self.param_groups:
             for p in g['params']:
-                if set_to_none:
-                    p.grad = None
-                elif p.grad is not None:
-                    p.grad.zero_()
+                by_betas.setdefault(tuple(g['betas']), []).append((p, g))
+        for betas, items in by_betas.items():
+            for i in range(0, len(items), 8):
+                chunk = items[i:i + 8]
+                segs = (_lib.NarutoAdamSeg * len(chunk))()
+                for k, (p, g) in enumerate(chunk):
+                    m, v = self.moments(p)
+                    assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous(), "FusedAdam: contiguous fp32 parameters on the GPU"
+                    segs[k].param, segs[k].exp_avg, segs[k].exp_avg_sq, segs[k].n = p.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+                plan.append((betas, chunk, segs))
+        self._plan_key = tuple(p.data_ptr() for g in self.param_groups for p in g['params'])
+        self._plan_cache = plan
+        return plan
 
     @torch.no_grad()
-    def step(self, zero_grad: bool = False):
+    def step(self, closure=None, zero_grad: bool = False):
         """``zero_grad``: zero the gradients inside the same launch, once consumed."""
         from . import ops
-        by_betas = {}
-        for g in self.param_groups:
-            for p in g['params']:
-                if p.grad is None:
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        plan = getattr(self, "_plan_cache", None)
+        if plan is None or self._plan_key != tuple(p.data_ptr() for g in self.param_groups for p in g['params']):
+            plan = self._plan()
+        launches = []
+        for betas, chunk, segs in plan:
+            keep, n = [], 0
+            for p, g in chunk:
+                grad = p.grad
+                if grad is None:
                     continue
-                m, v = self.state[p]
-                by_betas.setdefault(tuple(g['betas']), []).append((p.data, p.grad.contiguous(), m, v, g['lr'], g['eps'], g['weight_decay']))
-        n_launches = sum((len(e) + 7) // 8 for e in by_betas.values())
+                if not grad.is_contiguous() or grad.dtype != torch.float32:
+                    grad = grad.contiguous().float()
+                    keep.append(grad)
+                sg = segs[n]
+                if sg.param != p.data_ptr():                  # a tensor without gradient before this one: re-pack (and re-plan next time)
+                    m, v = self.moments(p)
+                    sg.param, sg.exp_avg, sg.exp_avg_sq, sg.n = p.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+                    self._plan_cache = None
+                sg.grad, sg.lr, sg.eps, sg.weight_decay = grad.data_ptr(), g['lr'], g['eps'], g['weight_decay']
+                n += 1
+            if n:
+                launches.append((betas, segs, n, chunk[0][0].device))
+        if not launches:
+            return loss
         if self.external_step is not None:
-            for betas, entries in by_betas.items():
-                for i in range(0, len(entries), 8):
-                    ops.adam_multi_(entries[i:i + 8], betas=betas, step_dev=self.external_step, zero_grad=zero_grad)
-            return
-        if n_launches == 1:
+            for betas, segs, n, dev in launches:
+                ops.adam_multi_segs(segs, n, dev, betas=betas, step_dev=self.external_step, zero_grad=zero_grad)
+            return loss
+        if len(launches) == 1:
             # the common case: the kernel itself advances the device-side step count (no "step += 1" launch)
-            (betas, entries), = by_betas.items()
-            ops.adam_multi_(entries, betas=betas, step_dev=self.step_dev, advance=True, zero_grad=zero_grad)
-            return
+            betas, segs, n, dev = launches[0]
+            ops.adam_multi_segs(segs, n, dev, betas=betas, step_dev=self.step_dev, advance=True, zero_grad=zero_grad)
+            return loss
         self.step_dev[:1].add_(1)
-        for betas, entries in by_betas.items():
-            for i in range(0, len(entries), 8):
-                ops.adam_multi_(entries[i:i + 8], betas=betas, step_dev=self.step_dev, zero_grad=zero_grad)
+        for betas, segs, n, dev in launches:
+            ops.adam_multi_segs(segs, n, dev, betas=betas, step_dev=self.step_dev, zero_grad=zero_grad)
+        return loss
 
 
 class MappingTrainer:
@@ -155,6 +204,12 @@ class MappingTrainer:
                  fused_adam: bool = False):
         self.config = config
         self.device = torch.device(device)
+        mp = config.get('mapping', {})
+        if int(mp.get('map_accum_step', 1)) != 1 or int(mp.get('map_wait_step', 0)) != 0:
+            # coslam.py:370-376 steps the mapping Adam every map_accum_step-th iteration, and not before map_wait_step; every shipped
+            # config has 1 / 0 and the fused iteration steps every time
+            raise NotImplementedError("MappingTrainer steps the mapping optimiser every iteration: mapping.map_accum_step must be 1 and "
+                                      "mapping.map_wait_step 0 (drive NarutoFieldHIP from your own loop for gradient accumulation)")
         self.model = NarutoFieldHIP(config, bounding_box.to(self.device)).to(self.device)
         if fused_adam:
             self.map_optimizer = FusedAdam(
@@ -211,14 +266,15 @@ class MappingTrainer:
                                near=cam['near'], far=cam['far'], range_d=tr['range_d'], depth_trunc=cam['depth_trunc'],
                                rgb_missing=tr['rgb_missing'], perturb=tr['perturb'] > 0., loss_weights=self._loss_w,
                                smooth=(tr['smooth_pts'], tr['smooth_vox'], tr['smooth_margin']) if use_smooth else None,
-                               group=self.group, n_rays_total=self.model.n_rays_total, rng_state=self.iter_state)
+                               group=self.group, n_rays_total=self.model.n_rays_total, rng_state=self.iter_state,
+                               min_uncert_running=self.model.min_uncert_running())
             if self.fuse_optimizer and self.group is None and ops.handle_supports_overwrite(m._handle()):
                 # optimiser in the backward: the mapping Adam is applied by the launch that finishes the gradients
                 names = {id(p): n for n, p in m._params().items()}
                 entries = {}
                 for gp in self.map_optimizer.param_groups:
                     for p in gp['params']:
-                        mm, vv = self.map_optimizer.state[p]
+                        mm, vv = self.map_optimizer.moments(p)
                         entries[names[id(p)]] = (mm, vv, gp['lr'], gp['eps'], gp['weight_decay'])
                 betas = self.map_optimizer.param_groups[0]['betas']
                 assert all(tuple(gp['betas']) == tuple(betas) for gp in self.map_optimizer.param_groups)
@@ -347,16 +403,17 @@ class MappingTrainer:
                     parallel.allreduce_grads([self.model.uncert_grid], self.group)
                 seg['opt'][1 if uncert_step else 0].replay()
                 if self.iter % self.assert_every == 0:
-                    self.model.note_min_uncert(st['ret'][0]['_losses'][6])
+                    self.model.note_min_uncert(self.model.min_uncert_running())
                     self.model.check_asserts()
                 return st['ret'][0], st['loss'][0]
             self._graphs[1 if uncert_step else 0].replay()
             ret = st['ret'][1 if uncert_step else 0]
-            # the reference's in-line ``assert uncert_map.min() > 0`` (scene_rep.py:280) as a deferred check: queue this
-            # replay's minimum (asynchronous copy + event) and test whatever has landed -- no host sync; every
-            # ``assert_every``-th replay only (the copy is a separate ~2 us node on the stream)
+            # the reference's in-line ``assert uncert_map.min() > 0`` (scene_rep.py:280) as a deferred check: every replay folds its
+            # minimum into one device word (the loss tail does, NarutoTrainStep.min_uncert_running), and every ``assert_every``-th
+            # replay queues an asynchronous copy of that RUNNING minimum and tests whatever has landed -- no host sync, and no
+            # iteration goes unchecked
             if self.iter % self.assert_every == 0:
-                self.model.note_min_uncert(ret['_losses'][6])
+                self.model.note_min_uncert(self.model.min_uncert_running() if self.direct else ret['_losses'][6])
                 self.model.check_asserts()
             return ret, st['loss'][1 if uncert_step else 0]
         return self._iteration(rays_o, rays_d, target_rgb, target_d, smooth, uncert_step)
@@ -399,8 +456,10 @@ class MappingTrainer:
                 self.uncert_optim.step()
         return out
 
-    def capture(self, n_rays: int, smooth: bool = False, n_rays_total: int = 0, warmup: int = 3):
-        """Record the iteration into hipGraphs (static shapes: n_rays rays per call)."""
+    def capture(self, n_rays: int, smooth: bool = False, n_rays_total: int = 0, warmup: int = 3, prologue=None):
+        """Record the iteration into hipGraphs (static shapes: n_rays rays per call).
+        ``prologue(rays_o, rays_d, target_rgb, target_d)``: launches recorded IN FRONT of the iteration inside the same graphs -- the
+        ray assembly / active ray selection that fill the iteration's input buffers (naruto_amd.ba_loop.FusedBA); single process."""
         dev = self.device
         self.model.n_rays_total = n_rays_total
         flat = torch.zeros(n_rays * 10, device=dev)
@@ -417,7 +476,7 @@ class MappingTrainer:
         opt_snap = []
         for opt in (self.map_optimizer, self.uncert_optim):
             if isinstance(opt, FusedAdam):
-                opt_snap.append((opt.step_dev.clone(), [(m.clone(), v.clone()) for m, v in opt.state.values()]))
+                opt_snap.append((opt.step_dev.clone(), [(st_['exp_avg'].clone(), st_['exp_avg_sq'].clone()) for st_ in opt.state.values()]))
             else:
                 import copy
                 opt_snap.append(copy.deepcopy(opt.state_dict()))
@@ -425,6 +484,8 @@ class MappingTrainer:
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
             for i in range(warmup):
+                if prologue is not None:
+                    prologue(st['rays_o'], st['rays_d'], st['target_rgb'], st['target_d'])
                 self._iteration(st['rays_o'], st['rays_d'], st['target_rgb'], st['target_d'], smooth, i == warmup - 1, check=False)
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
@@ -434,6 +495,7 @@ class MappingTrainer:
         segmented = self.group is not None and self.direct and os.environ.get("NARUTO_GRAPH_DIST", "segmented") != "whole"
         # with a process group its watchdog thread polls events while this thread captures: only this thread's calls may end the capture
         cap_mode = "thread_local" if self.group is not None else "global"
+        assert prologue is None or not segmented, "a captured prologue belongs to the single-process graph"
         if segmented:
             # Data parallel: forward | backward | optimiser as three graph segments; the two all-reduces (loss sums, flat
             # gradient) run between them as eager RCCL calls on the same stream.  (Capturing the collectives inside one graph
@@ -471,11 +533,17 @@ class MappingTrainer:
         for variant in (() if segmented else (False, True)):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool, capture_error_mode=cap_mode):
+                if prologue is not None:
+                    prologue(st['rays_o'], st['rays_d'], st['target_rgb'], st['target_d'])
                 ret, loss = self._iteration(st['rays_o'], st['rays_d'], st['target_rgb'], st['target_d'], smooth, variant, check=False)
             pool = g.pool()
             st['ret'][1 if variant else 0] = ret
             st['loss'][1 if variant else 0] = loss
             graphs.append(g)
+        if self.direct and not segmented:
+            # the graphs hold the ADDRESSES of this TrainStep's buffers: keep it alive with them, whatever the LRU cache below evicts
+            tr_cfg = self.config['training']
+            st['ts'] = self._train_step(n_rays, bool(smooth and tr_cfg['smooth_weight'] > 0))
         # restore parameters and optimiser state to "before capture"
         with torch.no_grad():
             for p, q in zip(params, snap):
@@ -486,9 +554,9 @@ class MappingTrainer:
             for opt, sn in zip((self.map_optimizer, self.uncert_optim), opt_snap):
                 if isinstance(opt, FusedAdam):
                     opt.step_dev.copy_(sn[0])
-                    for (m, v), (m0, v0) in zip(opt.state.values(), sn[1]):
-                        m.copy_(m0)
-                        v.copy_(v0)
+                    for st_, (m0, v0) in zip(opt.state.values(), sn[1]):
+                        st_['exp_avg'].copy_(m0)
+                        st_['exp_avg_sq'].copy_(v0)
                 else:
                     # torch.optim.Adam creates its state lazily: a fresh optimiser has none before capture.  The captured graphs
                     # hold the state tensors' ADDRESSES, so restore by value into the existing tensors.

@@ -973,8 +973,8 @@ def test_capture_mid_training_keeps_the_trajectory(gpu):
         if it == 3:
             b.capture(176, smooth=True)
             assert torch.equal(b.iter_state.cpu(), a.iter_state.cpu())
-            for (ma, va), (mb, vb) in zip(a.map_optimizer.state.values(), b.map_optimizer.state.values()):
-                assert torch.equal(ma, mb) and torch.equal(va, vb)
+            for sa, sb in zip(a.map_optimizer.state.values(), b.map_optimizer.state.values()):
+                assert torch.equal(sa['exp_avg'], sb['exp_avg']) and torch.equal(sa['exp_avg_sq'], sb['exp_avg_sq'])
             # (the uncertainty grid's gradient goes through the fixed-point scatter as well: bit-identical between the two trainers)
             assert float(a.model.uncert_grid.grad.abs().max()) > 0
             assert torch.equal(b.model.uncert_grid.grad, a.model.uncert_grid.grad), "uncert-grid gradient carried over the capture"
@@ -2296,3 +2296,275 @@ def test_deferred_min_uncert_assert(gpu):
     with pytest.raises(AssertionError, match="uncert_map.min"):
         tr.step(o, d, s, t, smooth=True, n_rays_total=64)
         tr.model.check_asserts(block=True)
+
+
+# --------------------------------------------------------------------------------------------- the unchanged caller (coslam.py:361-399)
+def _weights_from(m):
+    return {n: p.detach().clone() for n, p in m.named_parameters()}
+
+
+@pytest.mark.parametrize("S_d", [32, 117])
+def test_fused_train_node_equals_the_modular_operators(gpu, S_d):
+    """model.forward in training mode: the ONE autograd node over naruto_train_forward / naruto_train_backward (the unchanged caller's
+    route) against the modular operators (field query | composite + losses) on the same rays and jitter draw -- losses, rendered maps
+    and every gradient, with the reference's get_loss_from_ret weights arriving as the cotangents of the scalar losses."""
+    cfg = H.office_cfg(14, perturb=1.0, n_samples_d=S_d)
+    ora = H.make_oracle(cfg, 0.2, 41)
+    rays = syn.random_rays(515, cfg["mapping"]["bound"], seed=41, zero_depth_frac=0.1)
+    t = [torch.from_numpy(rays[k]).to(gpu) for k in ("rays_o", "rays_d", "target_rgb", "target_d")]
+    rand = torch.rand(515, S_d + 11, device=gpu, generator=torch.Generator(gpu).manual_seed(5))
+    out = {}
+    for fused in (False, True):
+        m = H.make_hip_from_oracle(cfg, ora, gpu).train()
+        m.fused_train = fused
+        m.strict_assert = True
+        ret = m.forward(*t, rand=rand)
+        S.total_loss(ret, cfg["training"]).backward()
+        out[fused] = (ret, H.hip_grads(m))
+    for k in ("rgb", "depth", "rgb_loss", "depth_loss", "sdf_loss", "fs_loss", "psnr", "uncert_loss"):
+        H.assert_close(out[True][0][k].reshape(-1), out[False][0][k].reshape(-1), 1e-6, f"node.{k}", rel=1e-5)
+    for k, g in out[True][1].items():
+        want = out[False][1][k]
+        H.assert_close(g, want, 2e-6 * float(want.abs().max()), f"node.grad.{k}", rel=1e-4)
+
+
+def test_fused_train_node_autograd_contract(gpu):
+    """What an unchanged caller may do with the node: accumulate into existing .grad (no zero_grad in between), differentiate a SUBSET
+    of the losses, read ret after the next forward (outputs are fresh tensors), second backward over the same graph; and what it may
+    not: backward over a graph whose buffers a later forward has reused, cotangents on the rendered rgb / depth."""
+    cfg = H.office_cfg(12)
+    ora = H.make_oracle(cfg, 0.25, 7)
+    m = H.make_hip_from_oracle(cfg, ora, gpu).train()
+    ref = H.make_hip_from_oracle(cfg, ora, gpu).train()
+    ref.fused_train = False
+    rays = syn.random_rays(130, cfg["mapping"]["bound"], seed=7, zero_depth_frac=0.1)
+    t = [torch.from_numpy(rays[k]).to(gpu) for k in ("rays_o", "rays_d", "target_rgb", "target_d")]
+    # a subset of the losses with odd weights, twice without zero_grad: gradients accumulate
+    for model in (m, ref):
+        for rep in range(2):
+            ret = model.forward(*t)
+            (3.0 * ret["sdf_loss"] + 0.25 * ret["uncert_loss"]).backward()
+    for k, g in H.hip_grads(m).items():
+        want = H.hip_grads(ref)[k]
+        H.assert_close(g, want, 2e-6 * float(want.abs().max()) + 1e-30, f"contract.accumulate.{k}", rel=1e-4)
+    # outputs are fresh tensors: a kept ret is not overwritten by the next forward of the same ray count
+    ret1 = m.forward(*t)
+    keep = {k: ret1[k].clone() for k in ("rgb", "depth", "rgb_loss")}
+    t2 = [a.clone() for a in t]
+    t2[3] = t2[3] * 0.5
+    ret2 = m.forward(*t2)
+    for k, v in keep.items():
+        assert torch.equal(ret1[k], v), k
+    assert not torch.equal(ret2["depth"], ret1["depth"])
+    # ... but its graph's buffers are gone
+    with pytest.raises(RuntimeError, match="later forward"):
+        ret1["rgb_loss"].backward()
+    ret2["rgb_loss"].backward(retain_graph=True)
+    ret2["rgb_loss"].backward()                         # second backward over the same (latest) graph
+    with pytest.raises(NotImplementedError, match="fused_train"):
+        m.forward(*t)["rgb"].sum().backward()
+    # the dot-product form MappingTrainer's autograd path uses
+    m.zero_grad()
+    ref.zero_grad()
+    w = torch.tensor([5.0, 0.1, 1000.0, 10.0, 0.0, 0.005, 0.0, 0.0, 0.0, 0.0], device=gpu)
+    for model in (m, ref):
+        torch.dot(model.forward(*t)["_losses"], w).backward()
+    for k, g in H.hip_grads(m).items():
+        want = H.hip_grads(ref)[k]
+        H.assert_close(g, want, 2e-6 * float(want.abs().max()) + 1e-30, f"contract.dot.{k}", rel=1e-4)
+
+
+@pytest.mark.parametrize("optimizer", ["torch", "fused"])
+def test_dropin_caller_tracks_the_oracle(gpu, optimizer):
+    """The reference's UNCHANGED loop body (naruto_amd/dropin.py = coslam.py:154-174, 361-399 + Co-SLAM's torch smoothness through
+    query_sdf(embed=True) autograd, loss.backward(retain_graph=True), Adam, the uncertainty grid's Adam every 5th iteration) around
+    NarutoFieldHIP against the oracle driven by the same loop with the same host random draws: per-iteration losses and the
+    parameters after seven iterations."""
+    from naruto_amd.dropin import DropInCaller
+    cfg = H.office_cfg(12)
+    trc = cfg["training"]
+    ora = H.make_oracle(cfg, 0.1, 31).train()
+    m = H.make_hip_from_oracle(cfg, ora, gpu).train()
+    caller = DropInCaller(m, cfg, 0.1, optimizer=optimizer)            # init_uncert_grid_optim re-creates the grid (coslam.py:240-243)
+    with torch.no_grad():
+        m.uncert_grid.copy_(ora.uncert_grid)
+    g1, g2 = ora.param_groups()
+    o_map = torch.optim.Adam(g1, betas=(0.9, 0.99))
+    o_unc = torch.optim.Adam(g2, lr=1)
+    for it in range(7):
+        rays = syn.random_rays(256, cfg["mapping"]["bound"], seed=100 + it, zero_depth_frac=0.05)
+        t = {k: torch.from_numpy(v) for k, v in rays.items()}
+        torch.manual_seed(1000 + it)
+        ret_o = ora.forward(t["rays_o"], t["rays_d"], t["target_rgb"], t["target_d"])
+        sm = S.smoothness(ora, trc["smooth_pts"], trc["smooth_vox"], trc["smooth_margin"], torch.rand(3), torch.rand((1, 1, 1, 3)).reshape(3))
+        loss_o = S.total_loss(ret_o, trc, smooth_term=sm)
+        loss_o.backward()
+        o_map.step()
+        o_map.zero_grad()
+        if (it + 1) % 5 == 0:
+            o_unc.step()
+            o_unc.zero_grad()
+        torch.manual_seed(1000 + it)
+        ret_h, loss_h = caller.ba_iteration(it, *(t[k].to(gpu) for k in ("rays_o", "rays_d", "target_rgb", "target_d")))
+        for k in ("rgb_loss", "depth_loss", "sdf_loss", "fs_loss", "uncert_loss"):
+            H.assert_close(ret_h[k].reshape(-1), ret_o[k].reshape(-1), 1e-5, f"dropin.iter{it}.{k}", rel=2e-3)
+        H.assert_close(loss_h.reshape(-1), loss_o.reshape(-1), 1e-5, f"dropin.iter{it}.total", rel=2e-3)
+    m.check_asserts(block=True)
+
+    def frac_within(a, b, tol):
+        return ((a.detach().cpu() - b.detach()).abs() <= tol).float().mean().item()
+    assert frac_within(m.decoder.sdf_net.model[0].weight, ora.sdf_w0, 2e-3) > 0.995
+    assert frac_within(m.decoder.color_net.model[0].weight, ora.col_w0, 2e-3) > 0.995
+    assert frac_within(m.uncert_grid, ora.uncert_grid, 2e-2) > 0.995
+    # table entries the rays miss see only the smoothness term's gradient (weight 1e-6: ~1e-12, at the noise level of its own
+    # summation order) and Adam (eps 1e-15) turns a sign flip there into a full +-lr step: the bulk criterion is looser here than in
+    # the trajectories without the term, the per-iteration losses above are not
+    assert frac_within(m.embed_fn.params, ora.table, 2e-3) > 0.98
+    assert float((m.embed_fn.params.detach().cpu() - ora.table.detach()).abs().mean()) < 2e-4
+
+
+def test_dropin_variants_run_and_agree(gpu):
+    """INTEGRATION.md's optional one-line changes after the swap (FusedAdam; the fused smoothness) leave the first iteration's render
+    losses untouched and keep training: same rgb / depth / sdf / fs / uncert losses at iteration 0 (the smoothness lattice is drawn
+    differently), finite and decreasing total afterwards."""
+    from naruto_amd.dropin import DropInCaller
+    cfg = H.office_cfg(12)
+    ora = H.make_oracle(cfg, 0.1, 3)
+    rays = syn.random_rays(300, cfg["mapping"]["bound"], seed=3)
+    t = [torch.from_numpy(rays[k]).to(gpu) for k in ("rays_o", "rays_d", "target_rgb", "target_d")]
+    first = {}
+    for opt, sm in (("torch", "reference"), ("fused", "reference"), ("fused", "fused")):
+        m = H.make_hip_from_oracle(cfg, ora, gpu).train()
+        caller = DropInCaller(m, cfg, 0.1, optimizer=opt, smoothness=sm)
+        totals = []
+        for i in range(12):
+            ret, loss = caller.ba_iteration(i, *t)
+            if i == 0:
+                first[(opt, sm)] = {k: float(ret[k].detach()) for k in ("rgb_loss", "depth_loss", "sdf_loss", "fs_loss", "uncert_loss")}
+            totals.append(float(loss))
+        m.check_asserts(block=True)
+        assert all(np.isfinite(totals)) and totals[-1] < totals[0], totals
+    base = first[("torch", "reference")]
+    for key, d in first.items():
+        for k, v in d.items():
+            assert abs(v - base[k]) <= 1e-6 + 1e-5 * abs(base[k]), (key, k, v, base[k])
+
+
+def test_running_min_uncert_is_checked(gpu):
+    """The reference asserts uncert_map.min() > 0 in every forward (scene_rep.py:280).  Here every fused forward folds its minimum
+    into one device word and the host reads it late: a violation in ANY iteration -- not only the sampled ones -- is reported."""
+    cfg = H.office_cfg(12)
+    ora = H.make_oracle(cfg, 0.2, 9)
+    m = H.make_hip_from_oracle(cfg, ora, gpu).train()
+    rays = syn.random_rays(64, cfg["mapping"]["bound"], seed=9)
+    t = [torch.from_numpy(rays[k]).to(gpu) for k in ("rays_o", "rays_d", "target_rgb", "target_d")]
+    m.assert_every = 4
+    for i in range(5):
+        m.forward(*t)
+    m.check_asserts(block=True)
+    assert float(m.min_uncert_running()) > 0
+    good = m.uncert_grid.detach().clone()
+    with torch.no_grad():
+        m.uncert_grid.fill_(float("nan"))               # softplus(nan) + 0.01 = nan: the assertion must fire
+    m.forward(*t)                                       # call 6: not a sampled one
+    with torch.no_grad():
+        m.uncert_grid.copy_(good)
+    m.forward(*t)
+    with pytest.raises(AssertionError, match="uncert_map"):
+        m.forward(*t)                                   # call 8 queues the running minimum ...
+        m.check_asserts(block=True)                     # ... which still carries the NaN of call 6
+
+
+# --------------------------------------------------------------------------------------------- the mapping iteration end to end
+def _ba_scene(cfg, gpu, Hh=48, Ww=64, n_kf=6, R=400, seed=0):
+    """A small device-resident keyframe store + current frame + poses + planner volume."""
+    from naruto_amd.keyframe_store import KeyFrameStoreHIP
+    rs = np.random.RandomState(seed)
+    store = KeyFrameStoreHIP(cfg, Hh, Ww, num_kf=n_kf + 2, num_rays_to_save=R, device=gpu, seed=11)
+
+    def frame(fid):
+        d = rs.normal(size=(1, Hh, Ww, 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=-1, keepdims=True)
+        depth = rs.uniform(0.4, 2.5, (1, Hh, Ww)).astype(np.float32)
+        depth[rs.uniform(size=depth.shape) < 0.1] = 0.0
+        return {"direction": torch.from_numpy(d), "rgb": torch.from_numpy(rs.uniform(size=(1, Hh, Ww, 3)).astype(np.float32)),
+                "depth": torch.from_numpy(depth), "frame_id": torch.tensor([fid])}
+    every = cfg["mapping"]["keyframe_every"]
+    for k in range(n_kf):
+        store.add_keyframe(frame(k * every), filter_depth=cfg["mapping"]["filter_depth"])
+    cur = frame(n_kf * every)
+    current = torch.cat([cur["direction"], cur["rgb"], cur["depth"][..., None]], -1).reshape(-1, 7)
+    bound = np.array(cfg["mapping"]["bound"], np.float32)
+    poses = np.tile(np.eye(4, dtype=np.float32), (n_kf + 1, 1, 1))
+    for p in poses:
+        q, _ = np.linalg.qr(rs.normal(size=(3, 3)))
+        p[:3, :3] = q.astype(np.float32)
+        p[:3, 3] = bound[:, 0] + (0.3 + 0.4 * rs.uniform(size=3)) * (bound[:, 1] - bound[:, 0])
+    vol = (rs.uniform(0, 3, (49, 56, 35)) * (rs.uniform(size=(49, 56, 35)) < 0.5)).astype(np.float32)
+    return store, current, torch.from_numpy(poses), vol
+
+
+@pytest.mark.parametrize("active", [False, True])
+def test_fused_ba_iteration_equals_its_pieces(gpu, active):
+    """naruto_amd.ba_loop.FusedBA -- ray assembly (N2) -> active ray selection (N1) -> training iteration recorded in ONE hipGraph,
+    draws keyed by the trainer's device-side iteration counter, counts read from device memory -- against the same three operators
+    launched one by one: identical batches, identical losses, bit-identical parameters after two global_BA calls between which the
+    store grows by a keyframe (no re-capture: the ray count stays)."""
+    from naruto_amd import trainer
+    from naruto_amd.active_ray_sampler import ActiveRaySamplerHIP
+    from naruto_amd.ba_loop import FusedBA
+    cfg = H.office_cfg(12, perturb=1.0)
+    cfg["mapping"].update(sample=256, min_pixels_cur=40, filter_depth=True, keyframe_every=5)
+    bound = torch.tensor(cfg["mapping"]["bound"])
+    twins = []
+    for use_graph in (True, False):
+        torch.manual_seed(33)
+        tr = trainer.MappingTrainer(cfg, bound, gpu, fused_adam=True)
+        store, current, poses, vol = _ba_scene(cfg, gpu, n_kf=8)
+        smp = ActiveRaySamplerHIP(config=cfg, num_uncert_sample=48, oversample_mul=4) if active else None
+        twins.append((FusedBA(tr, store, smp, max_poses=64, use_graph=use_graph), current, poses, vol))
+    (a, cur, poses, vol), (b, _, _, _) = twins
+    b.trainer.model.load_state_dict(a.trainer.model.state_dict())
+    b.trainer.iter_state.copy_(a.trainer.iter_state)
+    for ba in (a, b):
+        n_cur, n_train = ba.prepare(cur, poses, vol if active else None)
+        assert n_cur == (160 if active else 40) and n_train == (256 + 40 if active else 256 + 40)
+    assert a.trainer._graphs is not None and b.trainer._graphs is None
+    losses = {}
+    for tag, ba in (("graph", a), ("eager", b)):
+        ls = []
+        for i in range(7):
+            ret, loss = ba.iteration(i)
+            ls.append(float(loss))
+        losses[tag] = ls
+    assert losses["graph"] == losses["eager"], losses
+    assert len(set(losses["graph"])) == 7, "every iteration draws another batch"
+    # the batch the last replay trained on, recomputed from the host-keyed operators: seed / counter of the iteration state BEFORE it
+    st = b.trainer.iter_state.cpu()
+    bufs = a.trainer.ray_buffers()
+    seed, counter = int(st[0]), int(st[1]) - 1
+    store = b.store
+    saved_seed, saved_counter = store.seed, store.counter
+    store.seed, store.counter = seed, counter - 1            # assemble_batch pre-increments its host counter
+    n_cur = 160 if active else 40
+    o, d, s_, t_, _ = store.assemble_batch(b.sample_num, b.current, b.poses[:poses.shape[0]], b.min_pixels_cur, filter_depth=True,
+                                           n_cur=n_cur, n_cur_pop=int(b._dyn_host[2]))
+    store.seed, store.counter = saved_seed, saved_counter
+    if active:
+        o, d, s_, t_ = b.sampler.sample_rays(o, d, s_, t_, n_cur, None, b.bbox)
+    for got, want, k in zip(bufs, (o, d, s_, t_), ("rays_o", "rays_d", "target_rgb", "target_d")):
+        assert torch.equal(got, want.reshape(got.shape)), k
+    # a second global_BA call after the store grew by a keyframe: same ray count -> same graph, new counts from device memory
+    for ba in (a, b):
+        fr_rs = np.random.RandomState(5)
+        Hh, Ww = 48, 64
+        dirs = fr_rs.normal(size=(1, Hh, Ww, 3)).astype(np.float32)
+        ba.store.add_keyframe({"direction": torch.from_numpy(dirs), "rgb": torch.from_numpy(fr_rs.uniform(size=(1, Hh, Ww, 3)).astype(np.float32)),
+                               "depth": torch.from_numpy(fr_rs.uniform(0.5, 2.0, (1, Hh, Ww)).astype(np.float32)), "frame_id": torch.tensor([40])}, filter_depth=True)
+        poses2 = torch.cat([poses, poses[-1:]], 0)
+        graphs_before = ba.trainer._graphs
+        ba.global_BA(cur, poses2, n_iters=6, uncert_vol=vol if active else None)
+        assert ba.trainer._graphs is graphs_before, "the ray count did not change: no re-capture"
+    for (n, p), (_, q) in zip(a.trainer.model.named_parameters(), b.trainer.model.named_parameters()):
+        assert torch.equal(p, q), f"parameter {n}: graph replay != eager launches"
+    a.trainer.model.check_asserts(block=True)

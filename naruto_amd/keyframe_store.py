@@ -49,16 +49,27 @@ class KeyFrameStoreHIP:
         self.num_rays_to_save = int(num_rays_to_save)
         self.device = torch.device(device)
         self.rays = torch.zeros(int(num_kf), self.num_rays_to_save, 7, dtype=torch.float32, device=self.device)   # Co-SLAM: self.rays
-        self.frame_ids: Optional[torch.Tensor] = None          # int64 [n_kf] on the device (Co-SLAM keeps it on the host)
+        # int64 ids of the stored keyframes on the device (Co-SLAM keeps them on the host), in a buffer of the store's capacity: its
+        # ADDRESS never changes, so a captured batch-assembly launch stays valid while keyframes are added
+        self._ids = torch.zeros(int(num_kf), dtype=torch.int64, device=self.device)
+        self._n_ids = 0
         self.seed, self.counter = int(seed), 0
 
     def __len__(self):
-        return 0 if self.frame_ids is None else int(self.frame_ids.shape[0])
+        return self._n_ids
+
+    @property
+    def frame_ids(self) -> Optional[torch.Tensor]:
+        return self._ids[:self._n_ids] if self._n_ids else None
 
     def attach_ids(self, frame_ids: torch.Tensor):
         """Co-SLAM KeyFrameDatabase.attach_ids."""
         frame_ids = frame_ids.to(self.device, torch.int64).reshape(-1)
-        self.frame_ids = frame_ids if self.frame_ids is None else torch.cat([self.frame_ids, frame_ids], dim=0)
+        k = int(frame_ids.shape[0])
+        if self._n_ids + k > self._ids.shape[0]:
+            raise RuntimeError(f"keyframe store is full ({self._ids.shape[0]} keyframes): construct it with a larger num_kf")
+        self._ids[self._n_ids:self._n_ids + k] = frame_ids
+        self._n_ids += k
 
     def _distinct(self, n: int, count: int) -> torch.Tensor:
         lib = _lib.load()
@@ -140,10 +151,11 @@ class KeyFrameStoreHIP:
             rays_o, rays_d, target_s = torch.empty(n, 3, **f32), torch.empty(n, 3, **f32), torch.empty(n, 3, **f32)
             target_d = torch.empty(n, 1, **f32)
         ids = torch.empty(n, dtype=torch.int64, device=self.device) if return_ids else None
-        self.counter += 1
+        if rng is None:
+            self.counter += 1                  # the host-keyed draw; with ``rng`` the device-side {seed, counter} keys it and this one rests
         b = _lib.NarutoRayBatch()
         b.store, b.n_kf, b.rays_per_kf = self.rays.data_ptr(), n_kf, self.num_rays_to_save
-        b.frame_ids, b.keyframe_every, b.n_global = self.frame_ids.data_ptr(), int(self.config['mapping']['keyframe_every']), int(sample_num)
+        b.frame_ids, b.keyframe_every, b.n_global = self._ids.data_ptr(), int(self.config['mapping']['keyframe_every']), int(sample_num)
         b.current, b.cur_list = cur.data_ptr(), (cur_list.data_ptr() if cur_list is not None and n_cur_pop > 0 else None)
         b.n_cur_pop, b.n_cur = max(n_cur_pop, 1), n_cur
         b.poses, b.n_poses, b.seed, b.counter = poses.data_ptr(), poses.shape[0], self.seed, self.counter

@@ -563,11 +563,17 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
-    group = parallel.init_from_env("nccl") if (args.gpus > 1 or os.environ.get("NARUTO_FORCE_DIST") == "1") else None
+    # NARUTO_DIST_BACKEND=gloo: a REHEARSAL of the multi-rank launch line on a box with fewer GPUs than ranks (RCCL refuses two ranks on
+    # one device; gloo carries device tensors through the host): ranks share GPU LOCAL_RANK % device_count.  Timings of such a run
+    # mean nothing; the line says so.
+    backend = os.environ.get("NARUTO_DIST_BACKEND", "nccl")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local)
+    group = parallel.init_from_env(backend) if (args.gpus > 1 or os.environ.get("NARUTO_FORCE_DIST") == "1") else None
     world, rank = parallel.world_size(group), parallel.rank(group)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE is {world}"
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
     if args.workload.endswith("_eval") or args.workload == "office0_ba_iter":
@@ -678,6 +684,8 @@ def main():
                        "rays_per_gpu": n_rays, "rays_per_step": n_total, "samples_per_ray": S_tot, "parallelism": f"ray-sharded dp{world}",
                        "optimizer": "torch.optim.Adam" if args.torch_adam else "fused HIP Adam", "hip_graph": bool(use_graph and tr._graphs is not None)},
         }
+        if group is not None and backend != "nccl":
+            out["config"]["rehearsal"] = f"NARUTO_DIST_BACKEND={backend}: {world} ranks over {torch.cuda.device_count()} GPU(s) through the host -- launch-line rehearsal, not a measurement"
         # whole-step roofline figures: per ray S x 3168 B + 44 B and S x 31104 FLOP; per step Adam's 28 B / parameter
         mfma_peak = FP32_MFMA_PEAK_TF if args.mlp == "fp32" else BF16_MFMA_PEAK_TF
         rays_s = n_total * args.steps / dt

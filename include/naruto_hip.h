@@ -189,6 +189,9 @@ typedef struct NarutoExtraPoints {
 #define NARUTO_DECODER_SDF_NET 1
 #define NARUTO_DECODER_COLOR_NET 2
 int naruto_oneblob_fwd(const NarutoField* f, uint32_t M, const float* x, float* out, void* stream);
+/* calc_embedding's channel 0 on its own (scene_rep.py:58-64): out[m] = trilinear sample of uncert_grid at the normalised point x[m]
+ * (grid_sample semantics of the reference's call: align_corners=False, zero padding, x <-> z transposed).  Forward only. */
+int naruto_uncert_sample(const NarutoField* f, uint32_t M, const float* x, const float* uncert_grid, float* out, void* stream);
 int naruto_decoder_fwd(const NarutoField* f, const NarutoParams* p, uint32_t M, int part, const float* a, const float* b, float* out, void* stream);
 size_t naruto_query_bwd_workspace(const NarutoField* f, uint32_t M);
 int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, const NarutoPoints* pts,

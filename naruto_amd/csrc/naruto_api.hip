@@ -232,6 +232,9 @@ int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const f
         }
     }
     if (f->bplan.n_levels != 0 && (d_table != nullptr || adam != nullptr)) {
+        // the binned scatter's counts, prefix sums and item offsets are 32-bit: 8 items per (list point, binned level)
+        if ((uint64_t)M * 8ull * f->bplan.n_levels >= (1ull << 32))
+            return fail(NARUTO_ERR_INVALID, "scatter: %u list points x %u binned levels x 8 items overflow the 32-bit item offsets (split the batch)", M, f->bplan.n_levels);
         static bool attr_set = false;
         if (!attr_set) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_fill), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -472,6 +475,13 @@ int naruto_oneblob_fwd(const NarutoField* f, uint32_t M, const float* x, float* 
     if (M == 0) return NARUTO_OK;
     hipLaunchKernelGGL(k_oneblob_fwd, dim3((M + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, M, x, out);
     return check_launch("oneblob_fwd");
+}
+
+int naruto_uncert_sample(const NarutoField* f, uint32_t M, const float* x, const float* uncert_grid, float* out, void* stream) {
+    if (f == nullptr || x == nullptr || uncert_grid == nullptr || out == nullptr) return fail(NARUTO_ERR_INVALID, "uncert_sample: NULL argument");
+    if (M == 0) return NARUTO_OK;
+    hipLaunchKernelGGL(k_uncert_sample, dim3((M + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, f->ut, M, x, uncert_grid, out);
+    return check_launch("uncert_sample");
 }
 
 int naruto_decoder_fwd(const NarutoField* f, const NarutoParams* p, uint32_t M, int part, const float* a, const float* b, float* out, void* stream) {

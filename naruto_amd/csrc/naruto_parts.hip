@@ -20,6 +20,14 @@ __global__ __launch_bounds__(256) void k_oneblob_fwd(uint32_t M, const float* __
     }
 }
 
+// calc_embedding's uncertainty channel on its own (scene_rep.py:58-64): trilinear sample of the grid, x <-> z quirk included
+__global__ __launch_bounds__(256) void k_uncert_sample(UncertTab ut, uint32_t M, const float* __restrict__ x, const float* __restrict__ grid,
+                                                       float* __restrict__ out) {
+    const uint32_t m = blockIdx.x * 256u + threadIdx.x;
+    if (m >= M) return;
+    out[m] = uncert_sample(ut, grid, x[3 * (size_t)m], x[3 * (size_t)m + 1], x[3 * (size_t)m + 2]);
+}
+
 // mode 0: decoder(embed [M,33], embed_pos [M,48]) -> raw [M,5] = (rgb pre-sigmoid, sdf, uncertainty channel passed through)
 // mode 1: sdf_net(x [M,81] = cat(embed33, pos48))  -> [M,17] = (sdf, geo15, uncertainty channel)        (SDFNetNaruto.forward)
 // mode 2: color_net(x [M,63] = cat(pos48, geo15))  -> [M,3]  (pre-sigmoid)

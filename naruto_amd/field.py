@@ -217,8 +217,7 @@ class NarutoFieldHIP(nn.Module):
         x<->z quirk of the reference's grid_sample call included).  The query functions fuse this; on its own it is two launches
         (differentiable w.r.t. the table through ``embed_fn``; the uncertainty channel comes out detached)."""
         flat = torch.reshape(x, [-1, x.shape[-1]])
-        with torch.no_grad():
-            u = self.query_sdf(flat, return_uncert=True)[..., 1:2]
+        u = ops.uncert_sample(self._handle(), flat, self.uncert_grid)
         return torch.cat([u, self.embed_fn(flat)], dim=1)
 
     def query_color_sdf(self, query_points):

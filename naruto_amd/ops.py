@@ -206,6 +206,18 @@ def oneblob_encode(handle: "FieldHandle", x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def uncert_sample(handle: "FieldHandle", x: torch.Tensor, uncert_grid: torch.Tensor) -> torch.Tensor:
+    """calc_embedding's channel 0 (scene_rep.py:58-64): trilinear sample of the uncertainty grid at normalised points x [M,3] -> [M,1]
+    (forward only; gradients to the grid flow through the fused query operators)."""
+    lib = _lib.load()
+    x = _f32c(x.detach().reshape(-1, 3), "x")
+    g = _f32c(uncert_grid.detach(), "uncert_grid")
+    out = torch.empty(x.shape[0], 1, dtype=torch.float32, device=x.device)
+    with _on_device(x.device):
+        check(lib.naruto_uncert_sample(handle.ptr, x.shape[0], _p(x), _p(g), _p(out), _stream()), "naruto_uncert_sample")
+    return out
+
+
 def decoder_part(handle: "FieldHandle", params: Dict[str, torch.Tensor], part: int, a: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
     """part 0: decoder(embed [M,33], embed_pos [M,48]) -> [M,5]; 1: sdf_net([M,81]) -> [M,17]; 2: color_net([M,63]) -> [M,3]."""
     lib = _lib.load()

@@ -1240,7 +1240,7 @@ def test_train_step_with_large_cotangents(gpu):
     grad_close(ug.reshape(-1), ora.uncert_grid.grad.reshape(-1), "large.grad.uncert_grid")
 
 
-@pytest.mark.parametrize("workload", ["office0_2048x128", "office0_4100x128", "office0_8192x43", "mp3d_2048x256"])
+@pytest.mark.parametrize("workload", ["office0_2048x128", "office0_4100x128", "office0_8192x43", "mp3d_2048x256", "unit1024_T22_16384x43"])
 def test_train_step_full_size_against_oracle(gpu, workload):
     """BASELINE.json's configurations at their full per-GPU sizes -- configs[1] 2048 rays x 128 samples, configs[2] 8192
     rays with the shipped sampling, configs[3]'s per-GPU shard 2048 rays x 256 samples on the MP3D volume; 2^16-entry
@@ -1248,10 +1248,14 @@ def test_train_step_full_size_against_oracle(gpu, workload):
     all CUs) -- against the CPU oracle on the same jitter draw: every loss, the rendered maps and every gradient.  4 100 rays x 128
     samples: more ray groups than the forward has workgroups (a workgroup walks two groups with the loss stage riding along), a
     partly filled last group, and beyond the 4 096 rays up to which the loss tail and the compaction ride in the backward's first
-    launch (so the ordinary tail / compaction launches with the two-level prefix run)."""
+    launch (so the ordinary tail / compaction launches with the two-level prefix run).  unit1024_T22_16384x43: BASELINE configs[4]'s
+    volume and table (unit cube, finest level 1024^3, T = 2^22: 281 MB, HBM resident, counting-sort scatter) at 16 384 rays x 43."""
     from naruto_amd import ops
     from naruto_amd import config as C
-    if workload == "office0_2048x128":
+    depth_range = (0.5, 2.5)
+    if workload == "unit1024_T22_16384x43":
+        cfg, N, depth_range = C.unit_cube_config(1024, 22, perturb=1.0), 16384, (0.15, 0.7)
+    elif workload == "office0_2048x128":
         cfg, N = H.office_cfg(16, perturb=1.0, n_samples_d=117), 2048
     elif workload == "office0_4100x128":
         cfg, N = H.office_cfg(16, perturb=1.0, n_samples_d=117), 4100
@@ -1263,7 +1267,7 @@ def test_train_step_full_size_against_oracle(gpu, workload):
     ora = H.make_oracle(cfg, 0.05, 77)
     m = H.make_hip_from_oracle(cfg, ora, gpu)
     S_tot = tr["n_samples_d"] + tr["n_range_d"]
-    rays = syn.random_rays(N, cfg["mapping"]["bound"], seed=77, zero_depth_frac=0.05)
+    rays = syn.random_rays(N, cfg["mapping"]["bound"], seed=77, zero_depth_frac=0.05, depth_range=depth_range)
     t = {k: torch.from_numpy(v) for k, v in rays.items()}
     r6 = torch.tensor([0.15, 0.8, 0.45, 0.6, 0.05, 0.9])
     rand = torch.rand(N, S_tot, generator=torch.Generator().manual_seed(11))
@@ -2568,3 +2572,83 @@ def test_fused_ba_iteration_equals_its_pieces(gpu, active):
     for (n, p), (_, q) in zip(a.trainer.model.named_parameters(), b.trainer.model.named_parameters()):
         assert torch.equal(p, q), f"parameter {n}: graph replay != eager launches"
     a.trainer.model.check_asserts(block=True)
+
+
+# --------------------------------------------------------------------------------------------- configs[2] at its own size
+def test_configs2_eval_render_at_full_size(gpu):
+    """BASELINE configs[2], planner query path (i): eval-mode render_rays of 8192 rays x (32 + 11) samples with the uncertainty head on,
+    one launch (naruto_render_fwd), against the CPU oracle on the same jitter draw -- every map the reference's dict carries."""
+    cfg = H.office_cfg(16, perturb=1.0)
+    ora = H.make_oracle(cfg, 0.2, 17).eval()
+    m = H.make_hip_from_oracle(cfg, ora, gpu).eval()
+    N, S_tot = 8192, 43
+    rays = syn.random_rays(N, cfg["mapping"]["bound"], seed=17, zero_depth_frac=0.05)
+    ro, rd, td = (torch.from_numpy(rays[k]) for k in ("rays_o", "rays_d", "target_d"))
+    rand = torch.rand(N, S_tot, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        got = m.forward(ro.to(gpu), rd.to(gpu), torch.from_numpy(rays["target_rgb"]).to(gpu), td.to(gpu), rand=rand.to(gpu))     # eval mode: the render dict
+        want = ora.render_rays(ro, rd, target_d=td, rand=rand)
+    assert {'rgb', 'depth', 'disp_map', 'acc_map', 'depth_var', 'z_vals', 'raw', 'uncert_map'} <= set(got)            # scene_rep.py:216-225
+    H.assert_close(got["z_vals"], want["z_vals"], 2e-6, "configs2.z_vals")
+    for k in ("raw", "rgb", "depth", "acc_map", "depth_var", "uncert_map"):
+        H.assert_close(got[k], want[k], TOL_OUT, f"configs2.{k}")
+    H.assert_close(got["disp_map"], want["disp_map"], TOL_OUT, "configs2.disp_map", rel=1e-4)
+    assert float(got["uncert_map"].min()) > 0
+
+
+def test_configs2_map_volumes_on_the_full_lattice(gpu):
+    """BASELINE configs[2], planner query path (ii): get_map_volumes (coslam_utils.py:58-97) on the FULL [49,56,35] lattice of office_0
+    at 0.1 m -- 96 040 points through query_sdf(return_uncert=True) + the post-processing kernel -- against the oracle's restatement
+    driven by the oracle's query_sdf; plus query_sdf itself with every flag the reference's callers use."""
+    from naruto_amd.field import get_map_volumes
+    cfg = H.office_cfg(16)
+    ora = H.make_oracle(cfg, 0.2, 23).eval()
+    m = H.make_hip_from_oracle(cfg, ora, gpu).eval()
+    um, sv = get_map_volumes(m.query_sdf, m.bounding_box, 0.1)
+    with torch.no_grad():
+        oum, osv = S.get_map_volumes(ora.query_sdf, ora.bounding_box, 0.1)
+    assert um.shape == (49, 56, 35) and sv.shape == (49, 56, 35)
+    H.assert_close(sv, osv, TOL_OUT, "configs2.sdf volume")
+    # the uncertainty volume is masked by 0 <= sdf < 0.5: a voxel whose sdf sits within rounding of a mask edge may flip
+    flip = (np.abs(np.asarray(osv)) < 1e-5) | (np.abs(np.asarray(osv) - 0.5) < 1e-5)
+    H.assert_close(np.where(flip, 0.0, um), np.where(flip, 0.0, np.asarray(oum)), TOL_OUT, "configs2.uncertainty volume")
+    assert flip.mean() < 1e-3 and (np.asarray(oum) > 0).mean() > 0.05
+    q = torch.rand(5000, 3, generator=torch.Generator().manual_seed(2)) * 1.2 - 0.1          # some points outside the unit cube
+    with torch.no_grad():
+        a, ga = m.query_sdf(q.to(gpu), return_geo=True, return_uncert=True)
+        b, gb = ora.query_sdf(q, return_geo=True, return_uncert=True)
+        H.assert_close(a, b, TOL_OUT, "configs2.query_sdf(sdf, uncert)")
+        H.assert_close(ga, gb, TOL_OUT, "configs2.query_sdf geo")
+        H.assert_close(m.query_sdf(q.to(gpu), embed=True), ora.query_sdf(q, embed=True), 2e-6, "configs2.query_sdf embed")
+
+
+# --------------------------------------------------------------------------------------------- the driver's multi-GPU launch line
+def test_bench_launch_line_at_two_ranks(gpu):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 ...` --
+    the command the driver runs for the scaling curve -- end to end on whatever this box has: RCCL when two GPUs are visible, otherwise
+    a gloo REHEARSAL with both ranks on the one GPU (NARUTO_DIST_BACKEND=gloo).  Exactly one JSON line from rank 0, the contract's
+    keys, n_gpus = 2, weak scaling = the workload's ray count per rank."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if torch.cuda.device_count() < 2:
+        env["NARUTO_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-kernels", "--no-cpu-baseline", "--workload", "office0_2048x43"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in out, k
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["unit"] == "rays/s"
+    assert out["config"]["rays_per_gpu"] == 2048 and out["config"]["rays_per_step"] == 4096
+    assert abs(out["value"] - 4096 / (out["ms_per_step"] * 1e-3)) <= 1e-3 * out["value"]
+    assert ("rehearsal" in out["config"]) == (torch.cuda.device_count() < 2)

@@ -757,6 +757,34 @@ def main():
             if g_.get("traffic") is not None:
                 g_["traffic_GBps"] = round(g_["traffic"] / g_["kernel_ms"] / 1e6, 1)
                 g_["traffic_frac"] = round(g_["traffic"] / g_["kernel_ms"] / 1e6 / HBM_PEAK_GBS, 4)
+            # Tables no cache holds (T = 2^22: 281 MB): the gather reads RANDOM 64-byte lines, and the memory system's rate for those --
+            # measured here, live, by a launch that does nothing else (naruto_debug_random_lines over this very table) -- is the roof
+            # that actually binds it, far below the streaming figure of `peak`.
+            table_bytes = int(tr.model.embed_fn.params.numel()) * 4
+            if table_bytes > (64 << 20):
+                import ctypes as CT
+                from naruto_amd import _lib, ops
+                lib_ = _lib.load()
+                sink = torch.zeros(1, device=dev)
+                n_lines = CT.c_uint64(0)
+                tb = tr.model.embed_fn.params
+                run = lambda: _lib.check(lib_.naruto_debug_random_lines(tb.data_ptr(), table_bytes, 64, sink.data_ptr(), CT.byref(n_lines), ops._stream()))
+                rl_ms = events_ms(run, 5)
+                rate = n_lines.value / (rl_ms * 1e-3)
+                lt_scale, lt_res, lt_size, lt_off = tr.model._handle().levels()
+                n_big = sum(1 for sz in lt_size if sz * 8 > (4 << 20))                     # levels beyond one XCD's L2
+                lines_model = n_rays * S_tot * n_big * 4                                  # four lines per (sample, level): x-neighbour corners share one
+                g_ = out["roofline_gather"]
+                rr = {"lines_per_s": round(rate, 1), "TBps_of_64B_lines": round(rate * 64 / 1e12, 3),
+                      "measured": "naruto_debug_random_lines over this table (32 random lines per load instruction, 8 loads in flight per wave, 8 waves per SIMD), HIP events",
+                      "levels_beyond_l2": n_big, "lines_per_launch_model": int(lines_model),
+                      "frac_model": round(lines_model / (g_["kernel_ms"] * 1e-3) / rate, 4)}
+                if g_.get("traffic") is not None:
+                    rr["lines_per_launch_pmc"] = int(g_["traffic"] // 64)
+                    rr["frac_pmc"] = round(g_["traffic"] / 64 / (g_["kernel_ms"] * 1e-3) / rate, 4)
+                g_["random_line_roof"] = rr
+                if roof["kernel"].startswith("k_query_fwd"):
+                    roof["random_line_roof"] = rr
             out["roofline"] = roof
             out["kernels"] = rows
             out["kernels_ms_sum"] = round(sum(r["ms"] for r in rows if r["bound"] is not None), 4)

@@ -442,6 +442,12 @@ int naruto_debug_train_query_fwd(const NarutoField* f, const NarutoParams* p, co
  * workspace, in the launch shape of the iteration; writes the scatter's partial tables only (no gradient, no parameter). */
 int naruto_debug_train_scatter(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, void* stream);
 
+/* Measurement aid (bench.py, workloads whose table fits no cache): one launch that reads RANDOM 64-byte lines out of `table`
+ * (table_bytes of it) -- the access pattern of the hash gather on the T = 2^22 levels, without the kernel around it; *n_lines_out
+ * (host) = distinct lines the launch requests.  Timed with HIP events it gives the memory system's random-line rate, the ceiling
+ * `roofline.random_line_roof` prices the gather against (tools/hbm_random_line_bench.hip: the standalone sweep). */
+int naruto_debug_random_lines(const float* table, uint64_t table_bytes, uint32_t iters, float* sink, uint64_t* n_lines_out, void* stream);
+
 /* Hardware self-checks used by the GPU tests: the MFMA / permlane layouts the kernels rely on.
  * out: device buffer of 64*16 floats; returns 0 and fills out (see tests/test_gpu_parity.py: test_mfma_layout, test_permlane32_swap). */
 int naruto_debug_mfma_layout(const float* a, const float* b, float* out, void* stream);

@@ -1420,6 +1420,14 @@ __global__ void k_debug_mfma_bf16(const float* __restrict__ a, const float* __re
     for (int r = 0; r < 16; ++r) out[lane * 16 + r] = c[r];
 }
 
+int naruto_debug_random_lines(const float* table, uint64_t table_bytes, uint32_t iters, float* sink, uint64_t* n_lines_out, void* stream) {
+    if (table == nullptr || sink == nullptr || table_bytes < 64 || iters == 0) return fail(NARUTO_ERR_INVALID, "debug_random_lines: bad argument");
+    const uint32_t blocks = 256u * 8u;
+    hipLaunchKernelGGL(k_debug_random_lines, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float2*>(table), (uint32_t)(table_bytes / 64u), iters, sink);
+    if (n_lines_out != nullptr) *n_lines_out = (uint64_t)blocks * 4u * iters * 8u * 32u;         // waves x iterations x loads x distinct lines per load
+    return check_launch("debug_random_lines");
+}
+
 int naruto_debug_mfma_bf16_layout(const float* a, const float* b, float* out, void* stream) {
     if (a == nullptr || b == nullptr || out == nullptr) return fail(NARUTO_ERR_INVALID, "debug_mfma_bf16_layout: NULL argument");
     hipLaunchKernelGGL(k_debug_mfma_bf16, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, out);

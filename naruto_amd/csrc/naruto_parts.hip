@@ -20,6 +20,26 @@ __global__ __launch_bounds__(256) void k_oneblob_fwd(uint32_t M, const float* __
     }
 }
 
+// measurement aid: the memory system's rate for RANDOM 64-byte lines (the access pattern of the hash gather on a table that fits no
+// cache): each load instruction of a wave fetches 32 random lines, lanes l and l + 32 sharing one (the forward's x-pair layout),
+// eight independent loads in flight per wave.  tools/hbm_random_line_bench.hip is the standalone form with the other patterns.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+__global__ __launch_bounds__(256, 8) void k_debug_random_lines(const float2* __restrict__ table, uint32_t n_lines, uint32_t iters, float* __restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63, gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    float acc = 0.f;
+    for (uint32_t it = 0; it < iters; ++it) {
+        float2 v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const uint32_t line = mix32(gw * 7919u + it * 104729u + (uint32_t)c * 31u + (lane & 31u) * 2654435761u) % n_lines;
+            v[c] = table[(size_t)line * 8u + (lane >> 5)];
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc += v[c].x + v[c].y;
+    }
+    if (acc == 12345.f) out[0] = acc;
+}
+
 // calc_embedding's uncertainty channel on its own (scene_rep.py:58-64): trilinear sample of the grid, x <-> z quirk included
 __global__ __launch_bounds__(256) void k_uncert_sample(UncertTab ut, uint32_t M, const float* __restrict__ x, const float* __restrict__ grid,
                                                        float* __restrict__ out) {

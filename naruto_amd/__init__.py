@@ -12,13 +12,16 @@ from . import config, synthetic  # noqa: F401
 
 def __getattr__(name):
     # torch-dependent modules are imported lazily so that `import naruto_amd` stays cheap
-    if name in ("ops", "field", "parallel", "trainer", "_lib"):
+    if name in ("ops", "field", "parallel", "trainer", "_lib", "dropin", "ba_loop", "keyframe_store", "active_ray_sampler", "planner_aggregation", "mesh"):
         import importlib
         return importlib.import_module("." + name, __name__)
     if name == "NarutoFieldHIP":
         from .field import NarutoFieldHIP
         return NarutoFieldHIP
-    if name == "MappingTrainer":
-        from .trainer import MappingTrainer
-        return MappingTrainer
+    if name in ("MappingTrainer", "FusedAdam"):
+        from . import trainer
+        return getattr(trainer, name)
+    if name == "FusedBA":
+        from .ba_loop import FusedBA
+        return FusedBA
     raise AttributeError(name)

@@ -251,7 +251,12 @@ def kernel_resources(lib_path: str = None):
             cur = {"agpr_count": int(val)}
         elif cur is not None and key == "name":
             name = re.sub(r"^_ZN6naruto\d+", "", val)
-            name = re.sub(r"(ILb([01])E)?E.*$", lambda k: ("<%s>" % ("true" if k.group(2) == "1" else "false")) if k.group(2) else "", name)
+            m2 = re.match(r"(\w+?)(?:I((?:L[bi]\d+E)+)E)?E", name)          # Itanium: name [I <Lb0E | Li128E ...> E] E <signature>
+            if m2:
+                name = m2.group(1)
+                if m2.group(2):
+                    args = re.findall(r"L([bi])(\d+)E", m2.group(2))
+                    name += "<" + ",".join(("true" if v == "1" else "false") if k == "b" else v for k, v in args) + ">"
             out[name] = cur
         elif cur is not None and key in ("vgpr_count", "vgpr_spill_count", "sgpr_spill_count", "sgpr_count", "private_segment_fixed_size",
                                          "group_segment_fixed_size"):

@@ -563,16 +563,21 @@ int naruto_query_fwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
     const PointSrc ps = make_points(pts);
     const EarlyExit none{};
     const bool bf = f->desc.mlp_mode == NARUTO_MLP_BF16;
-    if (color && bf)
-        hipLaunchKernelGGL(k_query_fwd_bf<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, f->lt, f->ut, f->bt, pp, ps, M, raw, sdf_uncert, geo, feat_save, none);
-    else if (color)
-        hipLaunchKernelGGL(k_query_fwd<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, f->lt, f->ut, f->bt, pp, ps, M, raw, sdf_uncert, geo, feat_save, none);
-    else if (bf)
-        hipLaunchKernelGGL(k_query_fwd_bf<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, f->lt, f->ut, f->bt, pp, ps, M, raw, sdf_uncert, geo, feat_save,
-                           none);
-    else
-        hipLaunchKernelGGL(k_query_fwd<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, f->lt, f->ut, f->bt, pp, ps, M, raw, sdf_uncert, geo, feat_save,
-                           none);
+    // between one and two four-wave workgroups per CU: two-wave workgroups instead, so that no CU holds more tiles than it must
+    // (see k_query_fwd).  NARUTO_DEBUG_FWD_SMALL_WG=0: the four-wave form everywhere (A/B timing).
+    static const bool small_wg_on = getenv("NARUTO_DEBUG_FWD_SMALL_WG") == nullptr || atoi(getenv("NARUTO_DEBUG_FWD_SMALL_WG")) != 0;
+    const bool small_wg = small_wg_on && n_tiles > cu_count(f) * 4u && n_tiles < cu_count(f) * 8u;
+    const hipStream_t st = (hipStream_t)stream;
+#define NARUTO_LAUNCH_FWD(KERNEL, COLOR)                                                                                                                      \
+    do {                                                                                                                                                        \
+        if (small_wg) hipLaunchKernelGGL((KERNEL<COLOR, 128>), dim3((n_tiles + 1u) / 2u), dim3(128), 0, st, f->lt, f->ut, f->bt, pp, ps, M, raw, sdf_uncert, geo, feat_save, none); \
+        else hipLaunchKernelGGL((KERNEL<COLOR, 256>), dim3(blocks), dim3(256), 0, st, f->lt, f->ut, f->bt, pp, ps, M, raw, sdf_uncert, geo, feat_save, none);  \
+    } while (0)
+    if (color && bf) NARUTO_LAUNCH_FWD(k_query_fwd_bf, true);
+    else if (color) NARUTO_LAUNCH_FWD(k_query_fwd, true);
+    else if (bf) NARUTO_LAUNCH_FWD(k_query_fwd_bf, false);
+    else NARUTO_LAUNCH_FWD(k_query_fwd, false);
+#undef NARUTO_LAUNCH_FWD
     return check_launch("query_fwd");
 }
 
@@ -805,10 +810,16 @@ int launch_train_query(const NarutoField* f, const NarutoParams* p, const Naruto
         if (fused != nullptr) *fused = true;
         return check_launch("query_fwd_loss");
     }
-    if (f->desc.mlp_mode == NARUTO_MLP_BF16)
-        hipLaunchKernelGGL(k_query_fwd_bf<true>, dim3(blocks), dim3(256), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
-    else
-        hipLaunchKernelGGL(k_query_fwd<true>, dim3(blocks), dim3(256), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
+    // flat tiles, between one and two four-wave workgroups per CU (2 048 rays x 43 samples: 1 376 tiles): two-wave workgroups (see k_query_fwd)
+    static const bool small_wg_on = getenv("NARUTO_DEBUG_FWD_SMALL_WG") == nullptr || atoi(getenv("NARUTO_DEBUG_FWD_SMALL_WG")) != 0;
+    const bool small_wg = small_wg_on && ee.tiles_per_ray == 0u && n_tiles > cu_count(f) * 4u && n_tiles < cu_count(f) * 8u;
+    if (f->desc.mlp_mode == NARUTO_MLP_BF16) {
+        if (small_wg) hipLaunchKernelGGL((k_query_fwd_bf<true, 128>), dim3((n_tiles + 1u) / 2u), dim3(128), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
+        else hipLaunchKernelGGL((k_query_fwd_bf<true, 256>), dim3(blocks), dim3(256), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
+    } else {
+        if (small_wg) hipLaunchKernelGGL((k_query_fwd<true, 128>), dim3((n_tiles + 1u) / 2u), dim3(128), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
+        else hipLaunchKernelGGL((k_query_fwd<true, 256>), dim3(blocks), dim3(256), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
+    }
     return check_launch("query_fwd");
 }
 TvArgs tv_args(const NarutoTrainStep* t) {

@@ -359,20 +359,24 @@ __device__ __forceinline__ void fwd_tile(const FwdLds& L, const LevelTab& lt, co
         }
 }
 
-template <bool COLOR>
-__global__ __launch_bounds__(256, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps,
+// NT = threads per workgroup: 256, or 128 for launches of between one and two 256-thread workgroups per CU -- the time of this kernel
+// grows with the tiles a CU holds (measured: 10 us + 5.8 us per tile and CU), so 1 376 tiles (2 048 rays x 43 samples, the reference's
+// real batch) as 344 workgroups of four put eight tiles on 88 CUs and four on the rest; as 688 workgroups of two no CU holds more than six.
+template <bool COLOR, int NT = 256>
+__global__ __launch_bounds__(NT, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps,
                                                    uint32_t M, float* __restrict__ raw, float* __restrict__ sdf_uncert,
                                                    float* __restrict__ geo, float* __restrict__ feat_save, EarlyExit ee) {
     __shared__ FwdLds L;
-    stage_fwd_weights<256>(L, p, threadIdx.x);
+    stage_fwd_weights<NT>(L, p, threadIdx.x);
     __syncthreads();
+    constexpr uint32_t kW = NT / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hh = lane >> 5, j = lane & 31;
     const uint32_t n_tiles = (M + 63u) / 64u;
     const float2* __restrict__ table = reinterpret_cast<const float2*>(p.table);
     const uint32_t tpr = ee.tiles_per_ray;
     const uint32_t n_tasks = tpr ? n_tiles / tpr : n_tiles;          // rays, or tiles of the flat point list
-    for (uint32_t task = blockIdx.x * 4u + wave; task < n_tasks; task += gridDim.x * 4u) {
+    for (uint32_t task = blockIdx.x * kW + wave; task < n_tasks; task += gridDim.x * kW) {
     EeState ees{false, 0.0f, 0.0f, 0.0f};
     for (uint32_t tq = 0; tq < (tpr ? tpr : 1u); ++tq) {
         const uint32_t tile = tpr ? task * tpr + tq : task;
@@ -576,20 +580,21 @@ __device__ __forceinline__ void fwd_tile_bf(const FwdLdsBf& L, const LevelTab& l
 #ifndef NARUTO_FWD_BF_MINWAVES
 #define NARUTO_FWD_BF_MINWAVES 2
 #endif
-template <bool COLOR>
-__global__ __launch_bounds__(256, NARUTO_FWD_BF_MINWAVES) void k_query_fwd_bf(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps,
+template <bool COLOR, int NT = 256>
+__global__ __launch_bounds__(NT, NARUTO_FWD_BF_MINWAVES) void k_query_fwd_bf(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps,
                                                       uint32_t M, float* __restrict__ raw, float* __restrict__ sdf_uncert,
                                                       float* __restrict__ geo, float* __restrict__ feat_save, EarlyExit ee) {
     __shared__ FwdLdsBf L;
-    stage_fwd_weights_bf<256>(L, p, threadIdx.x);
+    stage_fwd_weights_bf<NT>(L, p, threadIdx.x);
     __syncthreads();
+    constexpr uint32_t kW = NT / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hh = lane >> 5, j = lane & 31;
     const uint32_t n_tiles = (M + 63u) / 64u;
     const float2* __restrict__ table = reinterpret_cast<const float2*>(p.table);
     const uint32_t tpr = ee.tiles_per_ray;
     const uint32_t n_tasks = tpr ? n_tiles / tpr : n_tiles;
-    for (uint32_t task = blockIdx.x * 4u + wave; task < n_tasks; task += gridDim.x * 4u) {
+    for (uint32_t task = blockIdx.x * kW + wave; task < n_tasks; task += gridDim.x * kW) {
     EeState ees{false, 0.0f, 0.0f, 0.0f};
     for (uint32_t tq = 0; tq < (tpr ? tpr : 1u); ++tq) {
         const uint32_t tile = tpr ? task * tpr + tq : task;

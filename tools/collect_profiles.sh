@@ -4,7 +4,7 @@ set -eu
 TAG=${1:-r02}
 cd "$(dirname "$0")/.."
 G=gpurun_out; P=profiles
-for f in bench_default bench_bf16 bench_eval_fp32 bench_eval_bf16 bench_office0_2048x43 bench_office0_8192x43 bench_mp3d_2048x256 bench_unit1024_131072x43 bench_T22_fp32 bench_T22_bf16; do
+for f in bench_default bench_dropin bench_ba_iter bench_ba_iter_active_ray bench_bf16 bench_eval_fp32 bench_eval_bf16 bench_office0_2048x43 bench_office0_8192x43 bench_mp3d_2048x256 bench_unit1024_131072x43 bench_T22_fp32 bench_T22_bf16; do
   [ -s $G/${TAG}_$f.json ] && tail -1 $G/${TAG}_$f.json | python -m json.tool > $P/${TAG}_$f.json
 done
 cp $G/${TAG}_bf16_error_study.txt $P/ 2>/dev/null || true
@@ -16,5 +16,9 @@ done
 cp $G/${TAG}_office0_2048x128_bf16_kernel_trace.txt $P/ 2>/dev/null || true
 python tools/pmc_json.py office0_2048x128 $G/${TAG}_office0_2048x128_pmc_FETCH_SIZE.txt $G/${TAG}_office0_2048x128_pmc_WRITE_SIZE.txt \
        unit1024_T22_131072x43 $G/${TAG}_unit1024_T22_131072x43_pmc_FETCH_SIZE.txt $G/${TAG}_unit1024_T22_131072x43_pmc_WRITE_SIZE.txt > $P/${TAG}_pmc.json
+for f in dropin_kernel_trace dropin_torch_profiler_swap_only dropin_torch_profiler_fused_adam_fused_smoothness hbm_random_line_bench office0_2048x43_kernel_trace office0_ba_iter_kernel_trace; do
+  [ -s $G/${TAG}_$f.txt ] && grep -v "amdgpu.ids\|UserWarning\|_warn_once\|ROCTracer" $G/${TAG}_$f.txt | cut -c1-220 > $P/${TAG}_$f.txt
+done
+for f in sq_counters_sq sq_counters_2048x43_sq; do [ -s $G/${TAG}_$f.txt ] && cp $G/${TAG}_$f.txt $P/${TAG}_${f%_sq}.txt; done
 tail -3 $G/${TAG}_pytest_gpu.log > $P/${TAG}_pytest_gpu_summary.txt
 ls -la $P | tail -30

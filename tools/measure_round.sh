@@ -25,3 +25,17 @@ bash tools/profile_round.sh $TAG unit1024_T22_131072x43 8 > gpurun_out/${TAG}_pr
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/${TAG}_ktbf -o kt -- python $R/bench.py --mlp bf16 --no-cpu-baseline --steps 30 > /dev/null 2> $R/gpurun_out/${TAG}_ktbf.log
 python $R/tools/prof_summary.py $(find $R/gpurun_out/${TAG}_ktbf -name "*.db" | head -1) > $R/gpurun_out/${TAG}_office0_2048x128_bf16_kernel_trace.txt; rm -rf $R/gpurun_out/${TAG}_ktbf
+# round 3: the unchanged caller (bench --path dropin under rocprofv3 + torch.profiler tables), the mapping iteration end to end, the random-line ceiling
+timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/${TAG}_ktdrop -o kt -- python $R/bench.py --path dropin --steps 30 --warmup 10 > $R/gpurun_out/${TAG}_bench_dropin.json 2> $R/gpurun_out/${TAG}_ktdrop.log
+python $R/tools/prof_summary.py $(find $R/gpurun_out/${TAG}_ktdrop -name "*.db" | head -1) > $R/gpurun_out/${TAG}_dropin_kernel_trace.txt; rm -rf $R/gpurun_out/${TAG}_ktdrop
+cd $R
+timeout 300 python tools/prof_dropin.py torch reference 8 > gpurun_out/${TAG}_dropin_torch_profiler_swap_only.txt 2>&1
+timeout 300 python tools/prof_dropin.py fused fused 8 > gpurun_out/${TAG}_dropin_torch_profiler_fused_adam_fused_smoothness.txt 2>&1
+timeout 300 python bench.py --workload office0_ba_iter > gpurun_out/${TAG}_bench_ba_iter.json 2> /dev/null; cut -c1-160 gpurun_out/${TAG}_bench_ba_iter.json; echo
+timeout 300 python bench.py --workload office0_ba_iter --active-ray > gpurun_out/${TAG}_bench_ba_iter_active_ray.json 2> /dev/null; cut -c1-160 gpurun_out/${TAG}_bench_ba_iter_active_ray.json; echo
+[ -x tools/hrl_bench ] && timeout 120 tools/hrl_bench > gpurun_out/${TAG}_hbm_random_line_bench.txt 2>&1
+bash tools/trace_workload.sh $TAG office0_2048x43 > /dev/null 2>&1
+bash tools/trace_workload.sh $TAG office0_ba_iter --active-ray > /dev/null 2>&1
+bash tools/pmc_sq.sh ${TAG}_sq_counters > /dev/null 2>&1
+BENCH_ARGS="--workload office0_2048x43" bash tools/pmc_sq.sh ${TAG}_sq_counters_2048x43 > /dev/null 2>&1
+git -C $R rev-parse HEAD > gpurun_out/${TAG}_commit.txt 2>/dev/null || true

@@ -369,6 +369,8 @@ int naruto_mesh_emit(const uint32_t* dims, const float* sdf_vol, double isolevel
 typedef struct NarutoAdamSeg {
     float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
     uint64_t n; float lr, eps, weight_decay;
+    uint32_t step_lag;     /* this tensor's step number is the launch's minus step_lag (torch.optim.Adam counts steps PER PARAMETER:
+                              one that was added later, or sat a step out without a gradient, lags behind); 0 in the mapping loop */
 } NarutoAdamSeg;
 #define NARUTO_ADAM_ADVANCE 1u   /* step_dev = int32[2] {completed steps, 0}: this launch is step step_dev[0]+1 and stores it back */
 #define NARUTO_ADAM_ZERO_GRAD 2u /* zero every gradient once consumed (the segments' grad buffers are written) */

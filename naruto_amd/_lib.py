@@ -47,7 +47,7 @@ class NarutoExtraPoints(C.Structure):
 
 class NarutoAdamSeg(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
-                ("n", C.c_uint64), ("lr", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float)]
+                ("n", C.c_uint64), ("lr", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("step_lag", C.c_uint32)]
 
 
 MLP_FP32, MLP_BF16 = 0, 1

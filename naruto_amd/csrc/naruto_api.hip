@@ -1388,7 +1388,7 @@ int naruto_adam_multi(const NarutoAdamSeg* segs, uint32_t n_segs, float beta1, f
         if (segs[k].param == nullptr || segs[k].grad == nullptr || segs[k].exp_avg == nullptr || segs[k].exp_avg_sq == nullptr)
             return fail(NARUTO_ERR_INVALID, "adam_multi: NULL pointer in segment %u", k);
         a.p[k] = segs[k].param; a.g[k] = segs[k].grad; a.m[k] = segs[k].exp_avg; a.v[k] = segs[k].exp_avg_sq;
-        a.n[k] = segs[k].n; a.lr[k] = segs[k].lr; a.eps[k] = segs[k].eps; a.wd[k] = segs[k].weight_decay;
+        a.n[k] = segs[k].n; a.lr[k] = segs[k].lr; a.eps[k] = segs[k].eps; a.wd[k] = segs[k].weight_decay; a.lag[k] = segs[k].step_lag;
         a.block_begin[k] = blocks;
         uint64_t nb = (segs[k].n + 1023u) / 1024u;          // >= 4 elements per thread, grid-stride beyond 1024 workgroups
         if (nb < 1) nb = 1;

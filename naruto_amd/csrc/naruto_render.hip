@@ -593,6 +593,7 @@ struct AdamSegs {
     uint64_t n[kAdamMaxSegs];
     uint32_t block_begin[kAdamMaxSegs + 1];   // first block of each segment
     float lr[kAdamMaxSegs], eps[kAdamMaxSegs], wd[kAdamMaxSegs];
+    uint32_t lag[kAdamMaxSegs];               // steps this tensor sat out (torch.optim.Adam counts steps per parameter)
     uint32_t n_segs;
 };
 
@@ -605,7 +606,7 @@ __global__ __launch_bounds__(256) void k_adam_multi(AdamSegs a, float b1, float 
 #pragma unroll
     for (int k = 1; k < kAdamMaxSegs; ++k) sgi += (k < (int)a.n_segs && blockIdx.x >= a.block_begin[k]) ? 1 : 0;
     const int32_t t_int = step_dev != nullptr ? __hip_atomic_load(step_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + ((flags & 1u) ? 1 : 0) : (int32_t)step_host;
-    const float t = (float)t_int;
+    const float t = (float)(t_int - (int32_t)a.lag[sgi]);
     const float bc1 = 1.0f - powf(b1, t), bc2_sqrt = sqrtf(1.0f - powf(b2, t));
     const float step_size = a.lr[sgi] / bc1, eps = a.eps[sgi], wd = a.wd[sgi];
     float* __restrict__ p = a.p[sgi];

@@ -95,6 +95,7 @@ class FusedAdam(optim.Optimizer):
         # int32[1] device word that already holds THIS step's 1-based number when step() runs (MappingTrainer's iteration
         # counter, advanced by the forward): no counting in the optimiser at all
         self.external_step = None
+        self._n_steps = 0                     # host mirror of the launches issued (only DIFFERENCES are used: the per-parameter lag)
         for g in self.param_groups:
             for p in g['params']:
                 self._init_state(p)
@@ -103,6 +104,8 @@ class FusedAdam(optim.Optimizer):
         if 'exp_avg' not in self.state[p]:
             self.state[p]['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
             self.state[p]['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            # torch.optim.Adam counts steps per parameter: one added after k steps, or skipped for want of a gradient, lags by that much
+            self.state[p]['lag'] = getattr(self, '_n_steps', 0)
 
     def add_param_group(self, param_group):
         super().add_param_group(param_group)
@@ -123,8 +126,10 @@ class FusedAdam(optim.Optimizer):
         state_dict = dict(state_dict)
         step = state_dict.pop('naruto_step', None)
         super().load_state_dict(state_dict)
+        self._plan_cache = None                 # the moments are new tensors now
         if step is not None:
             self.step_dev[0] = int(step)
+            self._n_steps = int(step)
 
     def _plan(self):
         """Per (betas) batch of <= 8 tensors: a reusable NarutoAdamSeg array with everything but the gradient pointers filled in."""
@@ -157,12 +162,13 @@ class FusedAdam(optim.Optimizer):
         plan = getattr(self, "_plan_cache", None)
         if plan is None or self._plan_key != tuple(p.data_ptr() for g in self.param_groups for p in g['params']):
             plan = self._plan()
-        launches = []
+        launches, skipped = [], []
         for betas, chunk, segs in plan:
             keep, n = [], 0
             for p, g in chunk:
                 grad = p.grad
                 if grad is None:
+                    skipped.append(p)
                     continue
                 if not grad.is_contiguous() or grad.dtype != torch.float32:
                     grad = grad.contiguous().float()
@@ -172,12 +178,15 @@ class FusedAdam(optim.Optimizer):
                     m, v = self.moments(p)
                     sg.param, sg.exp_avg, sg.exp_avg_sq, sg.n = p.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
                     self._plan_cache = None
-                sg.grad, sg.lr, sg.eps, sg.weight_decay = grad.data_ptr(), g['lr'], g['eps'], g['weight_decay']
+                sg.grad, sg.lr, sg.eps, sg.weight_decay, sg.step_lag = grad.data_ptr(), g['lr'], g['eps'], g['weight_decay'], self.state[p]['lag']
                 n += 1
             if n:
                 launches.append((betas, segs, n, chunk[0][0].device))
         if not launches:
             return loss
+        self._n_steps += 1
+        for p in skipped:
+            self.state[p]['lag'] += 1                      # sat this step out: its own step count does not advance
         if self.external_step is not None:
             for betas, segs, n, dev in launches:
                 ops.adam_multi_segs(segs, n, dev, betas=betas, step_dev=self.external_step, zero_grad=zero_grad)

@@ -2652,3 +2652,53 @@ def test_bench_launch_line_at_two_ranks(gpu):
     assert out["config"]["rays_per_gpu"] == 2048 and out["config"]["rays_per_step"] == 4096
     assert abs(out["value"] - 4096 / (out["ms_per_step"] * 1e-3)) <= 1e-3 * out["value"]
     assert ("rehearsal" in out["config"]) == (torch.cuda.device_count() < 2)
+
+
+def test_fused_adam_is_a_torch_optimizer(gpu):
+    """FusedAdam behind the torch.optim.Optimizer surface the reference's driver and checkpointing use: param groups edited in place
+    (a scheduler's lr change), a parameter without gradient skipped, add_param_group, state_dict -> load_state_dict into a fresh
+    optimiser continuing bit for bit, closure, zero_grad(set_to_none)."""
+    from naruto_amd.trainer import FusedAdam
+    torch.manual_seed(9)
+    mk = lambda: [torch.nn.Parameter(torch.randn(513, device=gpu)), torch.nn.Parameter(torch.randn(7, 33, device=gpu)), torch.nn.Parameter(torch.randn(64, device=gpu))]
+    pa = mk()
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    groups = lambda ps: [{'params': ps[:1], 'weight_decay': 1e-6, 'lr': 0.01}, {'params': ps[1:2], 'eps': 1e-15, 'lr': 0.02}]
+    oa, ob = FusedAdam(groups(pa), betas=(0.9, 0.99)), torch.optim.Adam(groups(pb), betas=(0.9, 0.99))
+    assert isinstance(oa, torch.optim.Optimizer)
+    sched = torch.optim.lr_scheduler.StepLR(oa, step_size=2, gamma=0.5), torch.optim.lr_scheduler.StepLR(ob, step_size=2, gamma=0.5)
+    gen = torch.Generator(gpu).manual_seed(1)
+
+    def feed(ps_a, ps_b, skip=None):
+        for k, (p, q) in enumerate(zip(ps_a, ps_b)):
+            if k == skip:
+                p.grad = q.grad = None
+                continue
+            g = torch.randn(p.shape, device=gpu, generator=gen)
+            p.grad, q.grad = g.clone(), g.clone()
+    for it in range(5):
+        if it == 2:
+            oa.add_param_group({'params': pa[2:], 'lr': 0.005})
+            ob.add_param_group({'params': pb[2:], 'lr': 0.005})
+        feed(pa[:len(oa.state)], pb[:len(oa.state)], skip=1 if it == 3 else None)
+        oa.step()
+        ob.step()
+        for s_ in sched:
+            s_.step()
+    for p, q in zip(pa, pb):
+        H.assert_close(p, q, 2e-6, "FusedAdam vs torch.optim.Adam", rel=1e-5)
+    # checkpoint round trip: a fresh optimiser restored from the state_dict continues exactly like the original
+    import copy
+    sd = copy.deepcopy(oa.state_dict())            # what torch.save / torch.load hands back: load_state_dict itself does not copy tensors
+    pc = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oc = FusedAdam(groups(pc), betas=(0.9, 0.99))
+    oc.add_param_group({'params': pc[2:], 'lr': 0.005})
+    oc.load_state_dict(sd)
+    assert oc.param_groups[0]['lr'] == oa.param_groups[0]['lr']
+    feed(pa, pc)
+    assert oa.step(closure=lambda: torch.tensor(3.0)) == 3.0
+    oc.step()
+    for p, q in zip(pa, pc):
+        assert torch.equal(p, q), "restored optimiser diverges from the original"
+    oa.zero_grad()
+    assert all(p.grad is None for p in pa)

@@ -365,7 +365,10 @@ class NarutoFieldHIP(nn.Module):
         """scene_rep.py:227-287."""
         if not self.training:
             return self.render_rays(rays_o, rays_d, target_d=target_d, rand=rand)
-        if _check:
+        # inside a hipGraph capture (MappingTrainer.capture, dropin.GraphedIteration) nothing may touch the host: the running minimum is
+        # still folded in by the kernels, and whoever replays the graph reads it back (note_min_uncert / check_asserts) outside
+        capturing = rays_o.is_cuda and torch.cuda.is_current_stream_capturing()
+        if _check and not capturing:
             self.check_asserts()
         cfg = self.config
         if self.fused_train and _smooth is None and self.process_group is None and rays_o.is_cuda:
@@ -376,10 +379,11 @@ class NarutoFieldHIP(nn.Module):
             st = self._node_state(rays_o.shape[0], rand is not None)
             rgb, depth, l0, l1, l2, l3, psnr, l5, losses = ops.train_forward_node(st, self._params(), rays_o, rays_d, target_rgb, target_d, rand)
             self._n_fused_forwards += 1
-            if self.strict_assert or self._n_fused_forwards % self.assert_every == 0:
-                self.note_min_uncert(self._min_uncert_run)
-            if self.strict_assert:
-                self.check_asserts(block=True)
+            if not capturing:
+                if self.strict_assert or self._n_fused_forwards % self.assert_every == 0:
+                    self.note_min_uncert(self._min_uncert_run)
+                if self.strict_assert:
+                    self.check_asserts(block=True)
             return {"rgb": rgb, "depth": depth, "rgb_loss": l0, "depth_loss": l1, "sdf_loss": l2, "fs_loss": l3, "psnr": psnr.detach(),
                     "uncert_loss": l5, "_losses": losses, "_smooth_loss": losses[8]}
         z_vals = self._sample_z(rays_o, target_d, rand)

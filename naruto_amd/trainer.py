@@ -113,6 +113,17 @@ class FusedAdam(optim.Optimizer):
             for p in self.param_groups[-1]['params']:
                 self._init_state(p)
 
+    def zero_grad(self, set_to_none: bool = True):
+        """As torch's; while the current stream is CAPTURING (whole-iteration hipGraph capture of a caller's loop body,
+        naruto_amd.dropin.GraphedIteration) gradients are zeroed IN PLACE whatever ``set_to_none`` says: dropping the tensor is a host-side
+        act a replay cannot repeat, and the next backward would then overwrite instead of accumulate."""
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            grads = [p.grad for g in self.param_groups for p in g['params'] if p.grad is not None]
+            if grads:
+                torch._foreach_zero_(grads)
+            return
+        super().zero_grad(set_to_none=set_to_none)
+
     def moments(self, p):
         st = self.state[p]
         return st['exp_avg'], st['exp_avg_sq']

@@ -2702,3 +2702,43 @@ def test_fused_adam_is_a_torch_optimizer(gpu):
         assert torch.equal(p, q), "restored optimiser diverges from the original"
     oa.zero_grad()
     assert all(p.grad is None for p in pa)
+
+
+def test_graphed_caller_iteration_equals_eager(gpu):
+    """naruto_amd.dropin.GraphedIteration: the caller's own loop body (model.forward -> get_loss_from_ret incl. the fused smoothness ->
+    loss.backward(retain_graph=True) -> FusedAdam steps, uncertainty grid every 5th) captured with torch's whole-iteration capture and
+    replayed, against the same body launched eagerly: identical losses per iteration and bit-identical parameters after 12 iterations
+    (two uncertainty-grid steps, its gradient accumulating over five replays in between).  The smoothness lattice is pinned to one
+    placement on both sides (torch's device generator advances differently under replay)."""
+    from naruto_amd import trainer
+    from naruto_amd.dropin import DropInCaller, GraphedIteration
+
+    off, jit = torch.tensor([0.3, 0.6, 0.1], device=gpu), torch.tensor([0.2, 0.9, 0.5], device=gpu)
+
+    class Caller(DropInCaller):
+        def smoothness(self, sample_points=256, voxel_size=0.1, margin=0.05, color=False):
+            return trainer.smoothness(self.model, self.config, sample_points, voxel_size, margin, offset_rand=off, jitter_rand=jit)
+    cfg = H.office_cfg(12, perturb=1.0)
+    ora = H.make_oracle(cfg, 0.1, 13)
+    twins = []
+    for _ in range(2):
+        m = H.make_hip_from_oracle(cfg, ora, gpu).train()
+        twins.append((m, Caller(m, cfg, 0.1, optimizer="fused", smoothness="fused")))
+    (ma, ca), (mb, cb) = twins
+    step = GraphedIteration(cb, 200)
+    ma._node_state(200, False)                          # creates the eager side's {seed, counter}
+    mb._rng_state.copy_(ma._rng_state)                  # same depth jitter on both sides
+    losses = {"eager": [], "graph": []}
+    keys = ("rgb_loss", "depth_loss", "sdf_loss", "fs_loss", "uncert_loss")
+    for i in range(12):
+        rays = syn.random_rays(200, cfg["mapping"]["bound"], seed=300 + i, zero_depth_frac=0.05)
+        t = [torch.from_numpy(rays[k]).to(gpu) for k in ("rays_o", "rays_d", "target_rgb", "target_d")]
+        ret, loss = ca.ba_iteration(i, *t)
+        losses["eager"].append([float(ret[k].detach()) for k in keys] + [float(loss.detach())])
+        ret, loss = step(i, *t)
+        losses["graph"].append([float(ret[k].detach()) for k in keys] + [float(loss.detach())])
+    assert losses["eager"] == losses["graph"], (losses["eager"][-1], losses["graph"][-1])
+    for (n, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert torch.equal(p, q), f"parameter {n}: graph replay != eager launches"
+    ma.check_asserts(block=True)
+    mb.check_asserts(block=True)

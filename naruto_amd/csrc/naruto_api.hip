@@ -1208,7 +1208,8 @@ int naruto_active_ray_select(uint32_t n_total, uint32_t base, uint32_t K, uint32
     hipLaunchKernelGGL(k_ars_lookup, dim3((n_cand + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, n_cand, base, rays_o, rays_d, target_d, uncert_vol,
                        (int)vol_dims[0], (int)vol_dims[1], (int)vol_dims[2], bbox_min[0], bbox_min[1], bbox_min[2], voxel_scale, keys);
     if (int rc = check_launch("ars_lookup")) return rc;
-    hipLaunchKernelGGL(k_ars_select, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_cand, K, keys, sel);
+    if (n_cand <= 1024u * kArsPer) hipLaunchKernelGGL(k_ars_select_small, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_cand, K, keys, sel);
+    else hipLaunchKernelGGL(k_ars_select, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_cand, K, keys, sel);
     if (int rc = check_launch("ars_select")) return rc;
     const uint32_t n_out = base + n_tail;
     hipLaunchKernelGGL(k_ars_gather, dim3((n_out + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, n_out, K, base, n_total, n_tail, sel, rays_o, rays_d,

@@ -104,6 +104,88 @@ __global__ __launch_bounds__(1024) void k_ars_select(uint32_t n_cand, uint32_t K
     }
 }
 
+// The same selection for up to 8 192 candidates (a mapping iteration has 6 444): every thread keeps EIGHT CONSECUTIVE keys in registers,
+// the threshold is found bit by bit -- 32 rounds of "how many of the still-undecided keys have a 0 here", counted with wave
+// reductions and one barrier per round (double-buffered wave counts) -- and the ordered compaction is two block scans over per-thread
+// counts (consecutive keys per thread keep the index order).  No LDS atomics: the histogram form above serialises on them when most
+// keys are equal (a freshly initialised or mostly-zero uncertainty volume puts every candidate in one bin), 31.8 us at 6 444
+// candidates against 20.4 us here (one workgroup = one CU does all of it).  Same result: the K smallest keys, ties at the threshold by lower index, ascending.
+constexpr uint32_t kArsPer = 8;
+__device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t* __restrict__ wave_tot, int lane, int wave, uint32_t& total) {
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const uint32_t t = wave_tot[w]; before += w < wave ? t : 0u; all += t; }
+    total = all;
+    __syncthreads();                    // wave_tot is reused by the next scan
+    return before + incl - v;
+}
+__global__ __launch_bounds__(1024) void k_ars_select_small(uint32_t n_cand, uint32_t K, const uint32_t* __restrict__ keys, uint32_t* __restrict__ sel) {
+    __shared__ uint32_t wave_cnt[2][16];
+    __shared__ uint32_t wave_tot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t j0 = (uint32_t)tid * kArsPer;
+    uint32_t k[kArsPer];
+    uint32_t alive = 0;                                 // bit i: key i exists and is still undecided
+#pragma unroll
+    for (uint32_t i = 0; i < kArsPer; ++i) {
+        const uint32_t j = j0 + i;
+        k[i] = j < n_cand ? keys[j] : 0xFFFFFFFFu;
+        alive |= j < n_cand ? (1u << i) : 0u;
+    }
+    const uint32_t valid = alive;
+    uint32_t prefix = 0, rem = K;                       // the K-th smallest key has these high bits; rem of the undecided keys are still to be taken
+    // (two bits per round with three packed counts: 22.5 us against 20.4 -- the rounds are bound by the one CU's vector issue, not by the barriers)
+    for (int bit = 31; bit >= 0; --bit) {
+        uint32_t zeros = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < kArsPer; ++i) zeros |= (((k[i] >> bit) & 1u) ^ 1u) << i;
+        zeros &= alive;
+        const uint32_t c = wave_sum_u32((uint32_t)__popc(zeros));
+        if (lane == 0) wave_cnt[bit & 1][wave] = c;
+        __syncthreads();
+        uint32_t total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) total += wave_cnt[bit & 1][w];
+        if (rem <= total) {
+            alive = zeros;                              // the K-th key has a 0 here: the ones are out
+        } else {
+            rem -= total;                               // all zeros are taken; the K-th key is among the ones
+            prefix |= 1u << bit;
+            alive &= ~zeros;
+        }
+    }
+    const uint32_t thr = prefix, take_eq = rem;
+    // ordered compaction: every key < thr, plus the first take_eq keys == thr in index order
+    uint32_t eq_mask = 0, lt_mask = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < kArsPer; ++i) {
+        eq_mask |= (k[i] == thr ? 1u : 0u) << i;
+        lt_mask |= (k[i] < thr ? 1u : 0u) << i;
+    }
+    eq_mask &= valid;
+    lt_mask &= valid;
+    uint32_t tot;
+    const uint32_t eq_before = block_exclusive_scan_1024((uint32_t)__popc(eq_mask), wave_tot, lane, wave, tot);
+    uint32_t chosen = lt_mask, eq_rank = eq_before;
+#pragma unroll
+    for (uint32_t i = 0; i < kArsPer; ++i) {
+        if ((eq_mask >> i) & 1u) {
+            if (eq_rank < take_eq) chosen |= 1u << i;
+            ++eq_rank;
+        }
+    }
+    uint32_t out = block_exclusive_scan_1024((uint32_t)__popc(chosen), wave_tot, lane, wave, tot);
+#pragma unroll
+    for (uint32_t i = 0; i < kArsPer; ++i) {
+        if ((chosen >> i) & 1u) sel[out++] = j0 + i;
+    }
+}
+
 // assemble [K selected | first (base-K) rays | last n_tail rays] (active_ray_sampler.py:128-147)
 __global__ __launch_bounds__(256) void k_ars_gather(uint32_t n_out, uint32_t K, uint32_t base, uint32_t n_total, uint32_t n_tail,
                                                     const uint32_t* __restrict__ sel, const float* __restrict__ rays_o, const float* __restrict__ rays_d,

@@ -708,7 +708,8 @@ def main():
                                    f"({n_total} rays per step over {world} GPU), hash L16 F2 T2^{cfg['grid']['hash_size']} ({n_params * 4 / 1e6:.1f} MB of parameters), "
                                    f"MLP 2x32 {args.mlp}, uncert grid; one global_BA mapping iteration incl. smoothness + Adam",
                        "rays_per_gpu": n_rays, "rays_per_step": n_total, "samples_per_ray": S_tot, "parallelism": f"ray-sharded dp{world}",
-                       "optimizer": "torch.optim.Adam" if args.torch_adam else "fused HIP Adam", "hip_graph": bool(use_graph and tr._graphs is not None)},
+                       "optimizer": "torch.optim.Adam" if args.torch_adam else "fused HIP Adam", "hip_graph": bool(use_graph and tr._graphs is not None),
+                       "table_optimizer": "sharded over the ranks (reduce-scatter | Adam on 1/world | all-gather)" if tr.table_shard is not None else "replicated"},
         }
         if group is not None and backend != "nccl":
             out["config"]["rehearsal"] = f"NARUTO_DIST_BACKEND={backend}: {world} ranks over {torch.cuda.device_count()} GPU(s) through the host -- launch-line rehearsal, not a measurement"

@@ -702,7 +702,7 @@ class TrainStep:
                  n_range_d: int, near: float, far: float, range_d: float, depth_trunc: float, rgb_missing: float, perturb: bool,
                  loss_weights: torch.Tensor, smooth: Optional[Tuple[int, float, float]] = None, group=None, n_rays_total: int = 0,
                  device_rng: bool = True, seed: Optional[int] = None, rng_state: Optional[torch.Tensor] = None,
-                 min_uncert_running: Optional[torch.Tensor] = None, own_grads: bool = True):
+                 min_uncert_running: Optional[torch.Tensor] = None, own_grads: bool = True, table_grad_pad: int = 0):
         lib = _lib.load()
         self.handle, self.group = handle, group
         self.fuse_tail = os.environ.get("NARUTO_DEBUG_NO_FUSED_TAIL") is None     # run(): loss tail + compaction inside the backward's first launch
@@ -741,14 +741,18 @@ class TrainStep:
         self.active_idx, self.n_active = torch.empty(M, **i32), torch.zeros(1, **i32)
         self.grads = {n: None for n in PARAM_NAMES}
         if own_grads:
-            self.flat_grad = torch.zeros(sum(self.params[n].numel() for n in self.FLAT_NAMES), **f32)
-            off = 0
-            for n in self.FLAT_NAMES:
+            # table_grad_pad: the table's bucket padded to this many floats (zeros behind the gradient) so that it splits evenly over the
+            # ranks of a sharded optimiser (reduce-scatter; MappingTrainer(shard_table_optimizer=True))
+            n_table = self.params["table"].numel()
+            n_bucket = max(n_table, int(table_grad_pad))
+            self.flat_grad = torch.zeros(n_bucket + sum(self.params[n].numel() for n in self.FLAT_NAMES[1:]), **f32)
+            self.grads["table"] = self.flat_grad[:n_table].view_as(self.params["table"])
+            off = n_bucket
+            for n in self.FLAT_NAMES[1:]:
                 k = self.params[n].numel()
                 self.grads[n] = self.flat_grad[off:off + k].view_as(self.params[n])
                 off += k
-            n_table = self.params["table"].numel()
-            self.grad_bucket_table, self.grad_bucket_mlp = self.flat_grad[:n_table], self.flat_grad[n_table:]      # the two all-reduce buckets
+            self.grad_bucket_table, self.grad_bucket_mlp = self.flat_grad[:n_bucket], self.flat_grad[n_bucket:]      # the two collective buckets
             assert uncert_grad.is_cuda and uncert_grad.dtype == torch.float32 and uncert_grad.is_contiguous()
             self.grads["uncert_grid"] = uncert_grad
         world = 1

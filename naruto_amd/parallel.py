@@ -72,6 +72,35 @@ def all_reduce_sum(t: torch.Tensor, group=None, async_op: bool = False):
     return w if async_op else _Done()
 
 
+def reduce_scatter_sum(src: torch.Tensor, out: torch.Tensor, group=None) -> None:
+    """out = this rank's 1/world slice of the SUM over ranks of ``src`` (src.numel() == world * out.numel()): the first half of a
+    ring all-reduce -- (world-1)/world of src per GPU over the wire.  gloo gets device tensors staged through the host."""
+    if not (dist.is_available() and dist.is_initialized()):
+        out.copy_(src)
+        return
+    assert src.numel() == world_size(group) * out.numel()
+    if src.is_cuda and dist.get_backend(group) == "gloo":
+        h, o = src.detach().cpu(), torch.empty(out.numel(), dtype=out.dtype)
+        dist.reduce_scatter_tensor(o, h, op=dist.ReduceOp.SUM, group=group)
+        out.copy_(o)
+        return
+    dist.reduce_scatter_tensor(out, src, op=dist.ReduceOp.SUM, group=group)
+
+
+def all_gather_into(dst: torch.Tensor, piece: torch.Tensor, group=None) -> None:
+    """dst = concatenation over ranks of ``piece`` (dst.numel() == world * piece.numel()): the second half of a ring all-reduce."""
+    if not (dist.is_available() and dist.is_initialized()):
+        dst.copy_(piece)
+        return
+    assert dst.numel() == world_size(group) * piece.numel()
+    if dst.is_cuda and dist.get_backend(group) == "gloo":
+        h = torch.empty(dst.numel(), dtype=dst.dtype)
+        dist.all_gather_into_tensor(h, piece.detach().cpu(), group=group)
+        dst.copy_(h)
+        return
+    dist.all_gather_into_tensor(dst, piece, group=group)
+
+
 def allreduce_loss_sums(sums: torch.Tensor, group=None) -> torch.Tensor:
     """In-place all-reduce (SUM) of the nine additive loss-sum slots.  Slot 9, min(uncert_map), stays this rank's own
     minimum: it only feeds the reference's ``assert uncert_map.min() > 0``, which every rank can check for its own

@@ -221,7 +221,7 @@ class MappingTrainer:
     (with / without the every-5th-iteration uncertainty-grid step); ``step`` then replays them."""
 
     def __init__(self, config: Dict, bounding_box: torch.Tensor, device, uncert_voxel: float = 0.1, group=None,
-                 fused_adam: bool = False):
+                 fused_adam: bool = False, shard_table_optimizer: Optional[bool] = None):
         self.config = config
         self.device = torch.device(device)
         mp = config.get('mapping', {})
@@ -231,10 +231,33 @@ class MappingTrainer:
             raise NotImplementedError("MappingTrainer steps the mapping optimiser every iteration: mapping.map_accum_step must be 1 and "
                                       "mapping.map_wait_step 0 (drive NarutoFieldHIP from your own loop for gradient accumulation)")
         self.model = NarutoFieldHIP(config, bounding_box.to(self.device)).to(self.device)
+        # Data parallel with a LARGE table (T > 2^17: 281 MB at T = 2^22): the table's optimiser is sharded over the ranks (ZeRO-1 shape) --
+        # reduce-scatter of the table gradient, Adam on this rank's 1/world slice with moments for that slice only, all-gather of the
+        # updated parameters -- instead of all-reduce + the identical full-size Adam on every rank: the same bytes on the wire
+        # (a ring all-reduce IS reduce-scatter + all-gather), 1/world of the optimiser's traffic (1.97 GB per step at T = 2^22) and of
+        # its moments' memory.  None: on when a group is given and the table has more than 2^22 parameters.
+        self.table_shard = None
+        n_table = int(self.model.embed_fn.params.numel())
+        if shard_table_optimizer is None:
+            shard_table_optimizer = bool(group is not None and fused_adam and n_table > (1 << 22))
+        if shard_table_optimizer:
+            assert fused_adam and group is not None, "the sharded table optimiser belongs to the data-parallel fused trainer"
+            world, rank_ = parallel.world_size(group), parallel.rank(group)
+            c = -(-n_table // (4 * world)) * 4                   # floats per rank, a multiple of 4
+            store = torch.zeros(c * world, dtype=torch.float32, device=self.device)
+            with torch.no_grad():
+                store[:n_table].copy_(self.model.embed_fn.params.reshape(-1))
+                self.model.embed_fn.params.data = store[:n_table]          # same Parameter, storage padded to world x c
+            p_slice = store[rank_ * c:(rank_ + 1) * c]
+            p_slice.grad = torch.zeros(c, dtype=torch.float32, device=self.device)       # the reduce-scatter's output
+            self.table_shard = {"c": c, "n_pad": c * world, "store": store, "p_slice": p_slice, "send": torch.empty(c, dtype=torch.float32, device=self.device)}
         if fused_adam:
-            self.map_optimizer = FusedAdam(
-                [{'params': self.model.decoder.parameters(), 'weight_decay': 1e-6, 'lr': config['mapping']['lr_decoder']},
-                 {'params': self.model.embed_fn.parameters(), 'eps': 1e-15, 'lr': config['mapping']['lr_embed']}], betas=(0.9, 0.99))
+            groups = [{'params': self.model.decoder.parameters(), 'weight_decay': 1e-6, 'lr': config['mapping']['lr_decoder']}]
+            if self.table_shard is None:
+                groups.append({'params': self.model.embed_fn.parameters(), 'eps': 1e-15, 'lr': config['mapping']['lr_embed']})
+            self.map_optimizer = FusedAdam(groups, betas=(0.9, 0.99))
+            if self.table_shard is not None:
+                self.table_optimizer = FusedAdam([{'params': [self.table_shard["p_slice"]], 'eps': 1e-15, 'lr': config['mapping']['lr_embed']}], betas=(0.9, 0.99))
             self.uncert_optim = FusedAdam([self.model.get_uncert_grid(uncert_voxel)], lr=1)
         else:
             self.map_optimizer = create_optimizer(self.model, config)
@@ -258,6 +281,8 @@ class MappingTrainer:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             self.iter_state = torch.tensor([seed, 0], dtype=torch.int64, device=self.device)
             self.map_optimizer.external_step = self.iter_state.view(torch.int32)[2:3]
+            if self.table_shard is not None:
+                self.table_optimizer.external_step = self.map_optimizer.external_step
         tr = config['training']
         # get_loss_from_ret's weights laid out like the node's loss vector (slot 8 = smoothness term)
         self._loss_w = torch.tensor([tr['rgb_weight'], tr['depth_weight'], tr['sdf_weight'], tr['fs_weight'], 0.0,
@@ -287,7 +312,8 @@ class MappingTrainer:
                                rgb_missing=tr['rgb_missing'], perturb=tr['perturb'] > 0., loss_weights=self._loss_w,
                                smooth=(tr['smooth_pts'], tr['smooth_vox'], tr['smooth_margin']) if use_smooth else None,
                                group=self.group, n_rays_total=self.model.n_rays_total, rng_state=self.iter_state,
-                               min_uncert_running=self.model.min_uncert_running())
+                               min_uncert_running=self.model.min_uncert_running(),
+                               table_grad_pad=self.table_shard["n_pad"] if self.table_shard is not None else 0)
             if self.fuse_optimizer and self.group is None and ops.handle_supports_overwrite(m._handle()):
                 # optimiser in the backward: the mapping Adam is applied by the launch that finishes the gradients
                 names = {id(p): n for n, p in m._params().items()}
@@ -321,7 +347,10 @@ class MappingTrainer:
                 ts.run_backward(phase=1)
                 pending = parallel.all_reduce_sum(ts.grad_bucket_mlp, self.group, async_op=True)
                 ts.run_backward(phase=2)
-                parallel.all_reduce_sum(ts.grad_bucket_table, self.group)
+                if self.table_shard is not None:
+                    parallel.reduce_scatter_sum(ts.grad_bucket_table, self.table_shard["p_slice"].grad, self.group)
+                else:
+                    parallel.all_reduce_sum(ts.grad_bucket_table, self.group)
                 pending.wait()
                 losses = ts.losses
             else:
@@ -330,6 +359,7 @@ class MappingTrainer:
                 for name, p in model._params().items():
                     p.grad = ts.grads[name]
                 self.map_optimizer.step()
+                self._table_shard_step()
             else:
                 model.uncert_grid.grad = ts.grads["uncert_grid"]          # table / weight gradients are consumed inside the backward
             if uncert_step:
@@ -342,6 +372,18 @@ class MappingTrainer:
         ret = {"rgb": ts.rgb, "depth": ts.depth, "rgb_loss": losses[0], "depth_loss": losses[1], "sdf_loss": losses[2], "fs_loss": losses[3],
                "psnr": losses[4], "uncert_loss": losses[5], "_losses": losses, "_smooth_loss": losses[8]}
         return ret, losses[9]
+
+    def _table_shard_step(self, adam: bool = True, gather: bool = True):
+        """Sharded table optimiser: Adam on this rank's slice (its gradient sits in p_slice.grad after the reduce-scatter), then the
+        all-gather of the updated slices into every rank's table."""
+        sh = self.table_shard
+        if sh is None:
+            return
+        if adam:
+            self.table_optimizer.step()
+        if gather:
+            sh["send"].copy_(sh["p_slice"])
+            parallel.all_gather_into(sh["store"], sh["send"], self.group)
 
     def _iteration(self, rays_o, rays_d, target_rgb, target_d, smooth: bool, uncert_step: bool, check: bool = True):
         if self.direct:
@@ -418,10 +460,15 @@ class MappingTrainer:
                 seg['fwd'].replay()
                 parallel.allreduce_loss_sums(ts.sums, self.group)
                 seg['bwd'].replay()
-                parallel.all_reduce_sum(ts.flat_grad, self.group)
+                if self.table_shard is not None:
+                    parallel.all_reduce_sum(ts.grad_bucket_mlp, self.group)
+                    parallel.reduce_scatter_sum(ts.grad_bucket_table, self.table_shard["p_slice"].grad, self.group)
+                else:
+                    parallel.all_reduce_sum(ts.flat_grad, self.group)
                 if uncert_step:
                     parallel.allreduce_grads([self.model.uncert_grid], self.group)
                 seg['opt'][1 if uncert_step else 0].replay()
+                self._table_shard_step(adam=False)                       # the slice's Adam is part of the opt segment; the all-gather is eager
                 if self.iter % self.assert_every == 0:
                     self.model.note_min_uncert(self.model.min_uncert_running())
                     self.model.check_asserts()
@@ -494,7 +541,8 @@ class MappingTrainer:
         iter_snap = self.iter_state.clone() if self.direct else None
         ugrad_snap = self.model.uncert_grid.grad.detach().clone()
         opt_snap = []
-        for opt in (self.map_optimizer, self.uncert_optim):
+        opts_all = (self.map_optimizer, self.uncert_optim) + ((self.table_optimizer,) if self.table_shard is not None else ())
+        for opt in opts_all:
             if isinstance(opt, FusedAdam):
                 opt_snap.append((opt.step_dev.clone(), [(st_['exp_avg'].clone(), st_['exp_avg_sq'].clone()) for st_ in opt.state.values()]))
             else:
@@ -540,6 +588,7 @@ class MappingTrainer:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool, capture_error_mode=cap_mode), torch.no_grad():
                     self.map_optimizer.step()
+                    self._table_shard_step(gather=False)
                     if variant:
                         self.uncert_optim.step(zero_grad=True)
                 seg['opt'][1 if variant else 0] = g
@@ -571,7 +620,7 @@ class MappingTrainer:
             if iter_snap is not None:
                 self.iter_state.copy_(iter_snap)
             self.model.uncert_grid.grad.copy_(ugrad_snap)
-            for opt, sn in zip((self.map_optimizer, self.uncert_optim), opt_snap):
+            for opt, sn in zip(opts_all, opt_snap):
                 if isinstance(opt, FusedAdam):
                     opt.step_dev.copy_(sn[0])
                     for st_, (m0, v0) in zip(opt.state.values(), sn[1]):

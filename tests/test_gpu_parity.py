@@ -2742,3 +2742,65 @@ def test_graphed_caller_iteration_equals_eager(gpu):
         assert torch.equal(p, q), f"parameter {n}: graph replay != eager launches"
     ma.check_asserts(block=True)
     mb.check_asserts(block=True)
+
+
+# --------------------------------------------------------------------------------------------- sharded table optimiser (large-table data parallelism)
+def _dp_shard_worker(rank, world, port, backend, n_rays, steps, out, shard, graph):
+    import torch.distributed as dist
+    from naruto_amd import trainer, parallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    cfg = H.office_cfg(12, perturb=0.0)
+    torch.manual_seed(5)
+    tr = trainer.MappingTrainer(cfg, torch.tensor(cfg["mapping"]["bound"]), dev, fused_adam=True, group=dist.group.WORLD, shard_table_optimizer=shard)
+    assert (tr.table_shard is not None) == shard
+    lo, hi = parallel.shard_bounds(n_rays, rank, world)
+    if graph:
+        tr.capture(hi - lo, smooth=True, n_rays_total=n_rays)
+    losses = []
+    for it in range(steps):
+        rays = syn.random_rays(n_rays, cfg["mapping"]["bound"], seed=400 + it, zero_depth_frac=0.1)
+        t = [torch.from_numpy(rays[k]) for k in ("rays_o", "rays_d", "target_rgb", "target_d")]
+        shard_rays = [a.to(dev) for a in parallel.shard_rays(t, rank, world)]
+        ret, loss = tr.step(*shard_rays, smooth=True, n_rays_total=n_rays)
+        losses.append(float(loss))
+    torch.cuda.synchronize()
+    # every rank must hold the same table after the all-gather
+    tab = tr.model.embed_fn.params.detach().cpu()
+    gathered = [torch.empty_like(tab) for _ in range(world)]
+    dist.all_gather(gathered, tab)
+    same = all(torch.equal(gathered[0], g) for g in gathered)
+    moments = sum(s_["exp_avg"].numel() for o in ((tr.map_optimizer, tr.table_optimizer) if shard else (tr.map_optimizer,)) for s_ in o.state.values())
+    if rank == 0:
+        torch.save({"params": {n: p.detach().cpu() for n, p in tr.model.named_parameters()}, "losses": losses, "replicas_equal": same, "moments": moments}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_sharded_table_optimizer_equals_replicated(gpu, tmp_path, graph):
+    """MappingTrainer(shard_table_optimizer=True) -- reduce-scatter of the table gradient, Adam on each rank's 1/world slice (moments for
+    that slice only), all-gather of the updated table: the form for tables beyond 2^22 parameters -- against the replicated optimiser
+    (all-reduce + the identical full Adam on every rank) over two ranks: bit-identical parameters and losses after six iterations,
+    eager launches and the three-segment hipGraph form; half the optimiser state per rank."""
+    import socket
+    import torch.multiprocessing as mp
+    n_rays, steps = 160, 6
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    res = {}
+    for shard in (False, True):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        out = str(tmp_path / f"dp_shard{int(shard)}.pt")
+        mp.spawn(_dp_shard_worker, args=(2, port, backend, n_rays, steps, out, shard, graph), nprocs=2, join=True)
+        res[shard] = torch.load(out)
+    a, b = res[False], res[True]
+    assert a["replicas_equal"] and b["replicas_equal"]
+    assert a["losses"] == b["losses"], (a["losses"], b["losses"])
+    for n in a["params"]:
+        assert torch.equal(a["params"][n], b["params"][n]), f"{n}: sharded optimiser != replicated ({backend}, graph={graph})"
+    n_table = a["params"]["embed_fn.params"].numel()
+    assert b["moments"] <= a["moments"] - n_table // 2 + 8, (a["moments"], b["moments"])

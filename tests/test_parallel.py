@@ -116,3 +116,55 @@ def test_two_rank_protocol_equals_single_process(tmp_path):
     for a, b in zip(got["grads"], want):
         scale = float(b.abs().max())
         assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-9
+
+
+def _shard_opt_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(3)
+    n = 1003                                             # not a multiple of the world size: the bucket is padded
+    c = -(-n // (4 * world)) * 4
+    p_full = torch.randn(n)
+    g_local = torch.randn(n, generator=torch.Generator().manual_seed(10 + rank))
+    # replicated: all-reduce, the identical Adam step everywhere
+    g_sum = g_local.clone()
+    parallel.all_reduce_sum(g_sum)
+    pa = torch.nn.Parameter(p_full.clone())
+    oa = torch.optim.Adam([pa], lr=0.01, betas=(0.9, 0.99), eps=1e-15)
+    pa.grad = g_sum
+    oa.step()
+    # sharded: reduce-scatter, Adam on this rank's slice, all-gather
+    store = torch.zeros(c * world)
+    store[:n] = p_full
+    bucket = torch.zeros(c * world)
+    bucket[:n] = g_local
+    sl = torch.nn.Parameter(store[rank * c:(rank + 1) * c].clone())
+    g_slice = torch.empty(c)
+    parallel.reduce_scatter_sum(bucket, g_slice)
+    ob = torch.optim.Adam([sl], lr=0.01, betas=(0.9, 0.99), eps=1e-15)
+    sl.grad = g_slice
+    ob.step()
+    parallel.all_gather_into(store, sl.detach().clone())
+    want_slice = torch.cat([g_sum, torch.zeros(c * world - n)])[rank * c:(rank + 1) * c]
+    if world == 2:           # two operands: one order of summation -> the same bits
+        ok = torch.equal(store[:n], pa.detach()) and torch.equal(g_slice, want_slice)
+    else:                    # three or more: the two collectives may add in different orders
+        ok = torch.allclose(g_slice, want_slice, rtol=1e-6, atol=1e-6) and float((store[:n] - pa.detach()).abs().max()) <= 0.021
+    if rank == 0:
+        torch.save({"ok": bool(ok), "pad_untouched": bool((store[n:] == 0).all())}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_optimizer_protocol(tmp_path, world):
+    """reduce_scatter_sum + Adam on the rank's slice + all_gather_into (the sharded table optimiser of MappingTrainer for large tables)
+    equals all_reduce_sum + the full Adam step on every rank (bit for bit over two ranks; to summation order beyond), over a padded
+    bucket and a world size that does not divide the table."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = str(tmp_path / "shard.pt")
+    mp.spawn(_shard_opt_worker, args=(world, port, out), nprocs=world, join=True)
+    r = torch.load(out)
+    assert r["ok"] and r["pad_untouched"]

@@ -362,8 +362,16 @@ __device__ __forceinline__ HalfCorners hash_level_half_index(const LevelTab& lt,
     for (int c = 0; c < 4; ++c) h.off[c] = idx[c] << 3;
     return h;
 }
-__device__ __forceinline__ void hash_level_half_load(const LevelTab& lt, int T, const float2* __restrict__ table, const HalfCorners& h, float2 (&v)[4]) {
+// live == false: this lane's point is not needed (a sample behind the end of its ray's band, see ee_lane_live): no load is issued for
+// it -- lanes that are switched off ask the memory path for no line, and distinct lines per instruction are what the gather costs --
+// and its features come out as zeros
+__device__ __forceinline__ void hash_level_half_load(const LevelTab& lt, int T, const float2* __restrict__ table, const HalfCorners& h, float2 (&v)[4], bool live = true) {
     const char* __restrict__ tl = reinterpret_cast<const char*>(table + lt.off[T]);
+    if (!live) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = make_float2(0.0f, 0.0f);
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
 #ifdef NARUTO_ABLATE_GATHER

@@ -174,6 +174,10 @@ __device__ __forceinline__ void tv_encode_body(const LevelTab& lt, const BoxTab&
 #define NARUTO_FWD_MINWAVES 2
 #endif
 constexpr int kGatherGroup = NARUTO_GATHER_GROUP;
+#ifndef NARUTO_EE_LANE_SKIP
+#define NARUTO_EE_LANE_SKIP 1
+#endif
+constexpr bool kEeLaneSkip = NARUTO_EE_LANE_SKIP != 0;      // A/B knob: lane-level skip inside evaluated tiles (ee_lane_live)
 
 // Depth-ordered early termination for the TRAINING forward (tiles_per_ray != 0: rays with depth-sorted samples, S a
 // multiple of 64, one wave walks one ray front to back).  What the losses, the compositing and the backward can see of
@@ -228,6 +232,16 @@ __device__ __forceinline__ bool ee_after_tile(EeState& st, const EarlyExit& ee, 
     return false;
 }
 
+// Within a tile that IS evaluated: once the ray's first sign change is known (st.found), a sample beyond
+// max(z_first, measured depth) + truncation can influence nothing -- the criterion by which ee_after_tile skips whole tiles, per lane.
+// Such a lane issues no gathers (fwd_tile's `live`) and its raw entries are written as zeros, exactly as for a skipped tile.  The tile
+// after the one in which the band ends is typically needed for its first few samples only.
+__device__ __forceinline__ bool ee_lane_live(const EeState& st, const EarlyExit& ee, uint32_t task, float z) {
+    if (!st.found) return true;
+    const float lim = fmaxf(st.zfirst, ee.target_d[task]) + ee.trunc_sc;
+    return !(z > lim + 1e-5f * fabsf(lim) + 1e-6f);
+}
+
 // One 64-point tile of the forward: hash gather (lane half hh fetches the corners with x offset hh of points 0..31, then 32..63),
 // OneBlob, both MLPs.  x, y, z: THIS lane's point (lane = point within the tile); mA / mB: feat_save rows of point j / j + 32.
 // Results: out.rgb / out.sdf for this lane's point; geo (optional) [M,15]: the sdf-net's geometric features of both halves.
@@ -238,9 +252,15 @@ struct FwdTileOut {
 
 template <bool COLOR>
 __device__ __forceinline__ void fwd_tile(const FwdLds& L, const LevelTab& lt, const float2* __restrict__ table, float x, float y, float z,
-                                         float* __restrict__ feat_save, float* __restrict__ geo, uint32_t M, uint32_t mA, uint32_t mB, int lane, FwdTileOut& out) {
+                                         float* __restrict__ feat_save, float* __restrict__ geo, uint32_t M, uint32_t mA, uint32_t mB, int lane, FwdTileOut& out,
+                                         bool live = true) {
     const int hh = lane >> 5;
         f32x16 hA = zero16(), hB = zero16(), cA = zero16(), cB = zero16();
+        // live: does anyone need THIS lane's point (ee_lane_live)?  Dead points issue no gathers and save no features; the matrix steps
+        // run over them as over any lane (their outputs are overwritten with zeros by the caller).
+        float la = live ? 1.0f : 0.0f, lb = la;
+        swap32(la, lb);
+        const bool liveA = la != 0.0f, liveB = lb != 0.0f;
         // levels in a real loop (unrolled by kGatherGroup): the gathers of a group are in flight together, the code
         // stays an order of magnitude smaller than the fully unrolled form.
         // Lane layout of the gathers: both halves of the wave work on the same 32 points -- round A on points 0..31,
@@ -261,8 +281,8 @@ __device__ __forceinline__ void fwd_tile(const FwdLds& L, const LevelTab& lt, co
         float2 va[kGatherGroup][4], vb[kGatherGroup][4];
 #pragma unroll
         for (int g = 0; g < kGatherGroup; ++g) {
-            hash_level_half_load(lt, T0 + g, table, ha[g], va[g]);
-            hash_level_half_load(lt, T0 + g, table, hb[g], vb[g]);
+            hash_level_half_load(lt, T0 + g, table, ha[g], va[g], liveA);
+            hash_level_half_load(lt, T0 + g, table, hb[g], vb[g], liveB);
         }
 #pragma unroll
         for (int g = 0; g < kGatherGroup; ++g) {
@@ -276,8 +296,8 @@ __device__ __forceinline__ void fwd_tile(const FwdLds& L, const LevelTab& lt, co
             if (feat_save != nullptr) {
                 // uniform per-level base + 32-bit lane offset (the launcher bounds the point list at 2^29 points)
                 char* __restrict__ fs = reinterpret_cast<char*>(feat_save + (size_t)T * M * 2u);
-                if (mA < M) *reinterpret_cast<float*>(fs + ((mA * 2u + (uint32_t)hh) << 2)) = b0;
-                if (mB < M) *reinterpret_cast<float*>(fs + ((mB * 2u + (uint32_t)hh) << 2)) = b1;
+                if (mA < M && liveA) *reinterpret_cast<float*>(fs + ((mA * 2u + (uint32_t)hh) << 2)) = b0;
+                if (mB < M && liveB) *reinterpret_cast<float*>(fs + ((mB * 2u + (uint32_t)hh) << 2)) = b1;
             }
             const float a = L.s0[T * 64 + lane];
             hA = mfma32(a, b0, hA);
@@ -385,10 +405,12 @@ __global__ __launch_bounds__(NT, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab 
         const uint32_t m = valid ? m_raw : M - 1u;       // padding lanes redo the last point, stores masked
         float x, y, z;
         load_point(ps, bt, m, x, y, z);
-        const float u = uncert_sample(ut, p.uncert_grid, x, y, z);
+        const bool live = (tpr != 0u && tq > 0u && kEeLaneSkip) ? ee_lane_live(ees, ee, task, ps.z_vals[m]) : true;
+        const float u = live ? uncert_sample(ut, p.uncert_grid, x, y, z) : 0.0f;
 
         FwdTileOut to;
-        fwd_tile<COLOR>(L, lt, table, x, y, z, feat_save, geo, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to);
+        fwd_tile<COLOR>(L, lt, table, x, y, z, feat_save, geo, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
+        if (!live) { to.rgb[0] = 0.0f; to.rgb[1] = 0.0f; to.rgb[2] = 0.0f; to.sdf = 0.0f; }
         const float sdf = to.sdf;
         if (sdf_uncert != nullptr && valid) reinterpret_cast<float2*>(sdf_uncert)[m] = make_float2(sdf, u);
         if constexpr (COLOR) {
@@ -470,9 +492,13 @@ __device__ __forceinline__ u32x4_t pack8_acc(const f32x16& a, int r0) {
 
 template <bool COLOR>
 __device__ __forceinline__ void fwd_tile_bf(const FwdLdsBf& L, const LevelTab& lt, const float2* __restrict__ table, float x, float y, float z,
-                                            float* __restrict__ feat_save, float* __restrict__ geo, uint32_t M, uint32_t mA, uint32_t mB, int lane, FwdTileOut& out) {
+                                            float* __restrict__ feat_save, float* __restrict__ geo, uint32_t M, uint32_t mA, uint32_t mB, int lane, FwdTileOut& out,
+                                            bool live = true) {
     const int hh = lane >> 5;
         f32x16 hA = zero16(), hB = zero16(), cA = zero16(), cB = zero16();
+        float la = live ? 1.0f : 0.0f, lb = la;                 // as fwd_tile: dead points issue no gathers and save no features
+        swap32(la, lb);
+        const bool liveA = la != 0.0f, liveB = lb != 0.0f;
         float xa = x, xb = x, ya = y, yb = y, za = z, zb = z;
         swap32(xa, xb); swap32(ya, yb); swap32(za, zb);        // xa = x of points (0..31 | 0..31), xb = (32..63 | 32..63)
         static_assert(8 % kGatherGroup == 0, "a K block of eight levels is gathered in whole groups");
@@ -490,8 +516,8 @@ __device__ __forceinline__ void fwd_tile_bf(const FwdLdsBf& L, const LevelTab& l
             float2 va[kGatherGroup][4], vb[kGatherGroup][4];
 #pragma unroll
             for (int g = 0; g < kGatherGroup; ++g) {
-                hash_level_half_load(lt, 8 * kb + e0 + g, table, ha[g], va[g]);
-                hash_level_half_load(lt, 8 * kb + e0 + g, table, hb[g], vb[g]);
+                hash_level_half_load(lt, 8 * kb + e0 + g, table, ha[g], va[g], liveA);
+                hash_level_half_load(lt, 8 * kb + e0 + g, table, hb[g], vb[g], liveB);
             }
 #pragma unroll
             for (int g = 0; g < kGatherGroup; ++g) {
@@ -506,8 +532,8 @@ __device__ __forceinline__ void fwd_tile_bf(const FwdLdsBf& L, const LevelTab& l
                 fb[e] = ub + wb;
                 if (feat_save != nullptr) {
                     char* __restrict__ fs = reinterpret_cast<char*>(feat_save + (size_t)T * M * 2u);
-                    if (mA < M) *reinterpret_cast<float*>(fs + ((mA * 2u + (uint32_t)hh) << 2)) = fa[e];
-                    if (mB < M) *reinterpret_cast<float*>(fs + ((mB * 2u + (uint32_t)hh) << 2)) = fb[e];
+                    if (mA < M && liveA) *reinterpret_cast<float*>(fs + ((mA * 2u + (uint32_t)hh) << 2)) = fa[e];
+                    if (mB < M && liveB) *reinterpret_cast<float*>(fs + ((mB * 2u + (uint32_t)hh) << 2)) = fb[e];
                 }
             }
             }
@@ -603,10 +629,12 @@ __global__ __launch_bounds__(NT, NARUTO_FWD_BF_MINWAVES) void k_query_fwd_bf(Lev
         const uint32_t m = valid ? m_raw : M - 1u;
         float x, y, z;
         load_point(ps, bt, m, x, y, z);
-        const float u = uncert_sample(ut, p.uncert_grid, x, y, z);
+        const bool live = (tpr != 0u && tq > 0u && kEeLaneSkip) ? ee_lane_live(ees, ee, task, ps.z_vals[m]) : true;
+        const float u = live ? uncert_sample(ut, p.uncert_grid, x, y, z) : 0.0f;
 
         FwdTileOut to;
-        fwd_tile_bf<COLOR>(L, lt, table, x, y, z, feat_save, geo, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to);
+        fwd_tile_bf<COLOR>(L, lt, table, x, y, z, feat_save, geo, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
+        if (!live) { to.rgb[0] = 0.0f; to.rgb[1] = 0.0f; to.rgb[2] = 0.0f; to.sdf = 0.0f; }
         const float sdf = to.sdf;
         if (sdf_uncert != nullptr && valid) reinterpret_cast<float2*>(sdf_uncert)[m] = make_float2(sdf, u);
         if constexpr (COLOR) {

@@ -200,10 +200,12 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
                 const uint32_t m = tile * 64u + (uint32_t)lane;          // M = n_rays * S: no padding lanes
                 float x, y, z;
                 load_point(ps, bt, m, x, y, z);
-                const float u = uncert_sample(ut, p.uncert_grid, x, y, z);
+                const bool live = (tq > 0u && kEeLaneSkip) ? ee_lane_live(ees, ee, task, ps.z_vals[m]) : true;
+                const float u = live ? uncert_sample(ut, p.uncert_grid, x, y, z) : 0.0f;
                 FwdTileOut to;
-                if constexpr (BF) fwd_tile_bf<true>(L, lt, table, x, y, z, feat_save, nullptr, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to);
-                else fwd_tile<true>(L, lt, table, x, y, z, feat_save, nullptr, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to);
+                if constexpr (BF) fwd_tile_bf<true>(L, lt, table, x, y, z, feat_save, nullptr, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
+                else fwd_tile<true>(L, lt, table, x, y, z, feat_save, nullptr, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
+                if (!live) { to.rgb[0] = 0.0f; to.rgb[1] = 0.0f; to.rgb[2] = 0.0f; to.sdf = 0.0f; }
                 float* o = raw + (size_t)m * 5;
                 o[0] = to.rgb[0]; o[1] = to.rgb[1]; o[2] = to.rgb[2]; o[3] = to.sdf; o[4] = u;
                 const uint32_t s = tq * 64u + (uint32_t)lane;

@@ -250,6 +250,46 @@ struct FwdTileOut {
     float sdf;
 };
 
+// the tail of a 64-point tile: sdf of both halves to their lanes, geo features, the colour net's geo part and its 32 -> 3 layer
+template <bool COLOR>
+__device__ __forceinline__ void fwd_epilogue(const FwdLds& L, const f32x16& oA, const f32x16& oB, f32x16& cA, f32x16& cB, float* __restrict__ geo, uint32_t M,
+                                             uint32_t mA, uint32_t mB, int lane, FwdTileOut& out) {
+    const int hh = lane >> 5;
+        float sdf = oA[0], sdf_b = oB[0];
+        swap32(sdf, sdf_b);
+        out.sdf = sdf;
+        if (geo != nullptr) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int row = crow(r, hh);
+                if (row >= 1) {
+                    if (mA < M) geo[(size_t)mA * kGeo + row - 1] = oA[r];
+                    if (mB < M) geo[(size_t)mB * kGeo + row - 1] = oB[r];
+                }
+            }
+        }
+        if constexpr (COLOR) {
+            static_for<0, 8>([&](auto rc) {
+                constexpr int R = decltype(rc)::value;
+                const float a = L.c0g[R * 64 + lane];
+                cA = mfma32(a, oA[R], cA);
+                cB = mfma32(a, oB[R], cB);
+            });
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float pa = 0.0f, pb = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float w = L.c1[(c * 16 + r) * 2 + hh];
+                    pa = fmaf(w, fmaxf(cA[r], 0.0f), pa);
+                    pb = fmaf(w, fmaxf(cB[r], 0.0f), pb);
+                }
+                swap32(pa, pb);                  // lanes<32: (A lo, A hi); lanes>=32: (B lo, B hi)
+                out.rgb[c] = pa + pb;
+            }
+        }
+}
+
 template <bool COLOR>
 __device__ __forceinline__ void fwd_tile(const FwdLds& L, const LevelTab& lt, const float2* __restrict__ table, float x, float y, float z,
                                          float* __restrict__ feat_save, float* __restrict__ geo, uint32_t M, uint32_t mA, uint32_t mB, int lane, FwdTileOut& out,
@@ -344,39 +384,7 @@ __device__ __forceinline__ void fwd_tile(const FwdLds& L, const LevelTab& lt, co
             oA = mfma32(a, fmaxf(hA[T], 0.0f), oA);
             oB = mfma32(a, fmaxf(hB[T], 0.0f), oB);
         });
-        float sdf = oA[0], sdf_b = oB[0];
-        swap32(sdf, sdf_b);
-        out.sdf = sdf;
-        if (geo != nullptr) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int row = crow(r, hh);
-                if (row >= 1) {
-                    if (mA < M) geo[(size_t)mA * kGeo + row - 1] = oA[r];
-                    if (mB < M) geo[(size_t)mB * kGeo + row - 1] = oB[r];
-                }
-            }
-        }
-        if constexpr (COLOR) {
-            static_for<0, 8>([&](auto rc) {
-                constexpr int R = decltype(rc)::value;
-                const float a = L.c0g[R * 64 + lane];
-                cA = mfma32(a, oA[R], cA);
-                cB = mfma32(a, oB[R], cB);
-            });
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float pa = 0.0f, pb = 0.0f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float w = L.c1[(c * 16 + r) * 2 + hh];
-                    pa = fmaf(w, fmaxf(cA[r], 0.0f), pa);
-                    pb = fmaf(w, fmaxf(cB[r], 0.0f), pb);
-                }
-                swap32(pa, pb);                  // lanes<32: (A lo, A hi); lanes>=32: (B lo, B hi)
-                out.rgb[c] = pa + pb;
-            }
-        }
+        fwd_epilogue<COLOR>(L, oA, oB, cA, cB, geo, M, mA, mB, lane, out);
 }
 
 // NT = threads per workgroup: 256, or 128 for launches of between one and two 256-thread workgroups per CU -- the time of this kernel
@@ -409,14 +417,16 @@ __global__ __launch_bounds__(NT, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab 
         const float u = live ? uncert_sample(ut, p.uncert_grid, x, y, z) : 0.0f;
 
         FwdTileOut to;
+        const bool live_out = live;
         fwd_tile<COLOR>(L, lt, table, x, y, z, feat_save, geo, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
-        if (!live) { to.rgb[0] = 0.0f; to.rgb[1] = 0.0f; to.rgb[2] = 0.0f; to.sdf = 0.0f; }
+        if (!live_out) { to.rgb[0] = 0.0f; to.rgb[1] = 0.0f; to.rgb[2] = 0.0f; to.sdf = 0.0f; }
         const float sdf = to.sdf;
-        if (sdf_uncert != nullptr && valid) reinterpret_cast<float2*>(sdf_uncert)[m] = make_float2(sdf, u);
+        const float u_out = live_out ? u : 0.0f;
+        if (sdf_uncert != nullptr && valid) reinterpret_cast<float2*>(sdf_uncert)[m] = make_float2(sdf, u_out);
         if constexpr (COLOR) {
             if (raw != nullptr && valid) {
                 float* o = raw + (size_t)m * 5;
-                o[0] = to.rgb[0]; o[1] = to.rgb[1]; o[2] = to.rgb[2]; o[3] = sdf; o[4] = u;
+                o[0] = to.rgb[0]; o[1] = to.rgb[1]; o[2] = to.rgb[2]; o[3] = sdf; o[4] = u_out;
             }
         }
         if (tpr != 0u && tq + 1u < tpr) {

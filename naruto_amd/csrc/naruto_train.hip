@@ -203,13 +203,15 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
                 const bool live = (tq > 0u && kEeLaneSkip) ? ee_lane_live(ees, ee, task, ps.z_vals[m]) : true;
                 const float u = live ? uncert_sample(ut, p.uncert_grid, x, y, z) : 0.0f;
                 FwdTileOut to;
+                const bool live_out = live;
                 if constexpr (BF) fwd_tile_bf<true>(L, lt, table, x, y, z, feat_save, nullptr, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
                 else fwd_tile<true>(L, lt, table, x, y, z, feat_save, nullptr, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
-                if (!live) { to.rgb[0] = 0.0f; to.rgb[1] = 0.0f; to.rgb[2] = 0.0f; to.sdf = 0.0f; }
+                if (!live_out) { to.rgb[0] = 0.0f; to.rgb[1] = 0.0f; to.rgb[2] = 0.0f; to.sdf = 0.0f; }
+                const float u_out = live_out ? u : 0.0f;
                 float* o = raw + (size_t)m * 5;
-                o[0] = to.rgb[0]; o[1] = to.rgb[1]; o[2] = to.rgb[2]; o[3] = to.sdf; o[4] = u;
+                o[0] = to.rgb[0]; o[1] = to.rgb[1]; o[2] = to.rgb[2]; o[3] = to.sdf; o[4] = u_out;
                 const uint32_t s = tq * 64u + (uint32_t)lane;
-                rs.c0[s] = to.rgb[0]; rs.c1[s] = to.rgb[1]; rs.c2[s] = to.rgb[2]; rs.sdf[s] = to.sdf; rs.u[s] = u;
+                rs.c0[s] = to.rgb[0]; rs.c1[s] = to.rgb[1]; rs.c2[s] = to.rgb[2]; rs.sdf[s] = to.sdf; rs.u[s] = u_out;
                 rs.z[s] = ps.z_vals[m];
                 if (tq + 1u < tpr && ee_after_tile(ees, ee, ps, m, tq, tpr, tile, task, to.sdf, lane, raw)) { ++tq; break; }
             }

@@ -813,11 +813,14 @@ int launch_train_query(const NarutoField* f, const NarutoParams* p, const Naruto
     // flat tiles, between one and two four-wave workgroups per CU (2 048 rays x 43 samples: 1 376 tiles): two-wave workgroups (see k_query_fwd)
     static const bool small_wg_on = getenv("NARUTO_DEBUG_FWD_SMALL_WG") == nullptr || atoi(getenv("NARUTO_DEBUG_FWD_SMALL_WG")) != 0;
     const bool small_wg = small_wg_on && ee.tiles_per_ray == 0u && n_tiles > cu_count(f) * 4u && n_tiles < cu_count(f) * 8u;
+    const bool walk = ee.tiles_per_ray != 0u;          // the depth-ordered walk has its own instantiation: the flat launches carry none of its code
     if (f->desc.mlp_mode == NARUTO_MLP_BF16) {
-        if (small_wg) hipLaunchKernelGGL((k_query_fwd_bf<true, 128>), dim3((n_tiles + 1u) / 2u), dim3(128), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
+        if (walk) hipLaunchKernelGGL((k_query_fwd_bf<true, 256, true>), dim3(blocks), dim3(256), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
+        else if (small_wg) hipLaunchKernelGGL((k_query_fwd_bf<true, 128>), dim3((n_tiles + 1u) / 2u), dim3(128), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
         else hipLaunchKernelGGL((k_query_fwd_bf<true, 256>), dim3(blocks), dim3(256), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
     } else {
-        if (small_wg) hipLaunchKernelGGL((k_query_fwd<true, 128>), dim3((n_tiles + 1u) / 2u), dim3(128), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
+        if (walk) hipLaunchKernelGGL((k_query_fwd<true, 256, true>), dim3(blocks), dim3(256), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
+        else if (small_wg) hipLaunchKernelGGL((k_query_fwd<true, 128>), dim3((n_tiles + 1u) / 2u), dim3(128), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
         else hipLaunchKernelGGL((k_query_fwd<true, 256>), dim3(blocks), dim3(256), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
     }
     return check_launch("query_fwd");

@@ -290,17 +290,18 @@ __device__ __forceinline__ void fwd_epilogue(const FwdLds& L, const f32x16& oA, 
         }
 }
 
-template <bool COLOR>
+template <bool COLOR, bool MASK = false>
 __device__ __forceinline__ void fwd_tile(const FwdLds& L, const LevelTab& lt, const float2* __restrict__ table, float x, float y, float z,
                                          float* __restrict__ feat_save, float* __restrict__ geo, uint32_t M, uint32_t mA, uint32_t mB, int lane, FwdTileOut& out,
                                          bool live = true) {
     const int hh = lane >> 5;
         f32x16 hA = zero16(), hB = zero16(), cA = zero16(), cB = zero16();
-        // live: does anyone need THIS lane's point (ee_lane_live)?  Dead points issue no gathers and save no features; the matrix steps
-        // run over them as over any lane (their outputs are overwritten with zeros by the caller).
+        // MASK (the depth-ordered walks): live = does anyone need THIS lane's point (ee_lane_live)?  Dead points issue no gathers and
+        // save no features; the matrix steps run over them as over any lane (their outputs are overwritten with zeros by the caller).
+        // Without MASK the flags are compile-time true and the predicates fold away (the flat launches pay nothing for them).
         float la = live ? 1.0f : 0.0f, lb = la;
-        swap32(la, lb);
-        const bool liveA = la != 0.0f, liveB = lb != 0.0f;
+        if constexpr (MASK) swap32(la, lb);
+        const bool liveA = MASK ? la != 0.0f : true, liveB = MASK ? lb != 0.0f : true;
         // levels in a real loop (unrolled by kGatherGroup): the gathers of a group are in flight together, the code
         // stays an order of magnitude smaller than the fully unrolled form.
         // Lane layout of the gathers: both halves of the wave work on the same 32 points -- round A on points 0..31,
@@ -390,7 +391,7 @@ __device__ __forceinline__ void fwd_tile(const FwdLds& L, const LevelTab& lt, co
 // NT = threads per workgroup: 256, or 128 for launches of between one and two 256-thread workgroups per CU -- the time of this kernel
 // grows with the tiles a CU holds (measured: 10 us + 5.8 us per tile and CU), so 1 376 tiles (2 048 rays x 43 samples, the reference's
 // real batch) as 344 workgroups of four put eight tiles on 88 CUs and four on the rest; as 688 workgroups of two no CU holds more than six.
-template <bool COLOR, int NT = 256>
+template <bool COLOR, int NT = 256, bool EE = false>
 __global__ __launch_bounds__(NT, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps,
                                                    uint32_t M, float* __restrict__ raw, float* __restrict__ sdf_uncert,
                                                    float* __restrict__ geo, float* __restrict__ feat_save, EarlyExit ee) {
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(NT, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab 
     const int hh = lane >> 5, j = lane & 31;
     const uint32_t n_tiles = (M + 63u) / 64u;
     const float2* __restrict__ table = reinterpret_cast<const float2*>(p.table);
-    const uint32_t tpr = ee.tiles_per_ray;
+    const uint32_t tpr = EE ? ee.tiles_per_ray : 0u;                 // EE: the depth-ordered walk (one wave per ray); otherwise flat tiles, no walk code at all
     const uint32_t n_tasks = tpr ? n_tiles / tpr : n_tiles;          // rays, or tiles of the flat point list
     for (uint32_t task = blockIdx.x * kW + wave; task < n_tasks; task += gridDim.x * kW) {
     EeState ees{false, 0.0f, 0.0f, 0.0f};
@@ -413,12 +414,12 @@ __global__ __launch_bounds__(NT, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab 
         const uint32_t m = valid ? m_raw : M - 1u;       // padding lanes redo the last point, stores masked
         float x, y, z;
         load_point(ps, bt, m, x, y, z);
-        const bool live = (tpr != 0u && tq > 0u && kEeLaneSkip) ? ee_lane_live(ees, ee, task, ps.z_vals[m]) : true;
+        const bool live = (EE && tq > 0u && kEeLaneSkip) ? ee_lane_live(ees, ee, task, ps.z_vals[m]) : true;
         const float u = live ? uncert_sample(ut, p.uncert_grid, x, y, z) : 0.0f;
 
         FwdTileOut to;
         const bool live_out = live;
-        fwd_tile<COLOR>(L, lt, table, x, y, z, feat_save, geo, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
+        fwd_tile<COLOR, EE>(L, lt, table, x, y, z, feat_save, geo, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
         if (!live_out) { to.rgb[0] = 0.0f; to.rgb[1] = 0.0f; to.rgb[2] = 0.0f; to.sdf = 0.0f; }
         const float sdf = to.sdf;
         const float u_out = live_out ? u : 0.0f;
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(NT, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab 
                 o[0] = to.rgb[0]; o[1] = to.rgb[1]; o[2] = to.rgb[2]; o[3] = sdf; o[4] = u_out;
             }
         }
-        if (tpr != 0u && tq + 1u < tpr) {
+        if (EE && tq + 1u < tpr) {
             if (ee_after_tile(ees, ee, ps, m, tq, tpr, tile, task, sdf, lane, raw)) break;
         }
     }
@@ -500,15 +501,15 @@ __device__ __forceinline__ u32x4_t pack8_acc(const f32x16& a, int r0) {
     return pack8(v);
 }
 
-template <bool COLOR>
+template <bool COLOR, bool MASK = false>
 __device__ __forceinline__ void fwd_tile_bf(const FwdLdsBf& L, const LevelTab& lt, const float2* __restrict__ table, float x, float y, float z,
                                             float* __restrict__ feat_save, float* __restrict__ geo, uint32_t M, uint32_t mA, uint32_t mB, int lane, FwdTileOut& out,
                                             bool live = true) {
     const int hh = lane >> 5;
         f32x16 hA = zero16(), hB = zero16(), cA = zero16(), cB = zero16();
-        float la = live ? 1.0f : 0.0f, lb = la;                 // as fwd_tile: dead points issue no gathers and save no features
-        swap32(la, lb);
-        const bool liveA = la != 0.0f, liveB = lb != 0.0f;
+        float la = live ? 1.0f : 0.0f, lb = la;                 // as fwd_tile: with MASK dead points issue no gathers and save no features
+        if constexpr (MASK) swap32(la, lb);
+        const bool liveA = MASK ? la != 0.0f : true, liveB = MASK ? lb != 0.0f : true;
         float xa = x, xb = x, ya = y, yb = y, za = z, zb = z;
         swap32(xa, xb); swap32(ya, yb); swap32(za, zb);        // xa = x of points (0..31 | 0..31), xb = (32..63 | 32..63)
         static_assert(8 % kGatherGroup == 0, "a K block of eight levels is gathered in whole groups");
@@ -616,7 +617,7 @@ __device__ __forceinline__ void fwd_tile_bf(const FwdLdsBf& L, const LevelTab& l
 #ifndef NARUTO_FWD_BF_MINWAVES
 #define NARUTO_FWD_BF_MINWAVES 2
 #endif
-template <bool COLOR, int NT = 256>
+template <bool COLOR, int NT = 256, bool EE = false>
 __global__ __launch_bounds__(NT, NARUTO_FWD_BF_MINWAVES) void k_query_fwd_bf(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps,
                                                       uint32_t M, float* __restrict__ raw, float* __restrict__ sdf_uncert,
                                                       float* __restrict__ geo, float* __restrict__ feat_save, EarlyExit ee) {
@@ -628,7 +629,7 @@ __global__ __launch_bounds__(NT, NARUTO_FWD_BF_MINWAVES) void k_query_fwd_bf(Lev
     const int hh = lane >> 5, j = lane & 31;
     const uint32_t n_tiles = (M + 63u) / 64u;
     const float2* __restrict__ table = reinterpret_cast<const float2*>(p.table);
-    const uint32_t tpr = ee.tiles_per_ray;
+    const uint32_t tpr = EE ? ee.tiles_per_ray : 0u;
     const uint32_t n_tasks = tpr ? n_tiles / tpr : n_tiles;
     for (uint32_t task = blockIdx.x * kW + wave; task < n_tasks; task += gridDim.x * kW) {
     EeState ees{false, 0.0f, 0.0f, 0.0f};
@@ -639,11 +640,11 @@ __global__ __launch_bounds__(NT, NARUTO_FWD_BF_MINWAVES) void k_query_fwd_bf(Lev
         const uint32_t m = valid ? m_raw : M - 1u;
         float x, y, z;
         load_point(ps, bt, m, x, y, z);
-        const bool live = (tpr != 0u && tq > 0u && kEeLaneSkip) ? ee_lane_live(ees, ee, task, ps.z_vals[m]) : true;
+        const bool live = (EE && tq > 0u && kEeLaneSkip) ? ee_lane_live(ees, ee, task, ps.z_vals[m]) : true;
         const float u = live ? uncert_sample(ut, p.uncert_grid, x, y, z) : 0.0f;
 
         FwdTileOut to;
-        fwd_tile_bf<COLOR>(L, lt, table, x, y, z, feat_save, geo, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
+        fwd_tile_bf<COLOR, EE>(L, lt, table, x, y, z, feat_save, geo, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
         if (!live) { to.rgb[0] = 0.0f; to.rgb[1] = 0.0f; to.rgb[2] = 0.0f; to.sdf = 0.0f; }
         const float sdf = to.sdf;
         if (sdf_uncert != nullptr && valid) reinterpret_cast<float2*>(sdf_uncert)[m] = make_float2(sdf, u);
@@ -653,7 +654,7 @@ __global__ __launch_bounds__(NT, NARUTO_FWD_BF_MINWAVES) void k_query_fwd_bf(Lev
                 o[0] = to.rgb[0]; o[1] = to.rgb[1]; o[2] = to.rgb[2]; o[3] = sdf; o[4] = u;
             }
         }
-        if (tpr != 0u && tq + 1u < tpr) {
+        if (EE && tq + 1u < tpr) {
             if (ee_after_tile(ees, ee, ps, m, tq, tpr, tile, task, sdf, lane, raw)) break;
         }
     }

@@ -16,7 +16,7 @@ done
 cp $G/${TAG}_office0_2048x128_bf16_kernel_trace.txt $P/ 2>/dev/null || true
 python tools/pmc_json.py office0_2048x128 $G/${TAG}_office0_2048x128_pmc_FETCH_SIZE.txt $G/${TAG}_office0_2048x128_pmc_WRITE_SIZE.txt \
        unit1024_T22_131072x43 $G/${TAG}_unit1024_T22_131072x43_pmc_FETCH_SIZE.txt $G/${TAG}_unit1024_T22_131072x43_pmc_WRITE_SIZE.txt > $P/${TAG}_pmc.json
-for f in dropin_kernel_trace dropin_torch_profiler_swap_only dropin_torch_profiler_fused_adam_fused_smoothness hbm_random_line_bench office0_2048x43_kernel_trace office0_ba_iter_kernel_trace; do
+for f in dropin_kernel_trace dropin_torch_profiler_swap_only dropin_torch_profiler_fused_adam_fused_smoothness hbm_random_line_bench gather_valu_overlap_bench office0_2048x43_kernel_trace office0_ba_iter_kernel_trace; do
   [ -s $G/${TAG}_$f.txt ] && grep -v "amdgpu.ids\|UserWarning\|_warn_once\|ROCTracer" $G/${TAG}_$f.txt | cut -c1-220 > $P/${TAG}_$f.txt
 done
 for f in sq_counters_sq sq_counters_2048x43_sq; do [ -s $G/${TAG}_$f.txt ] && cp $G/${TAG}_$f.txt $P/${TAG}_${f%_sq}.txt; done

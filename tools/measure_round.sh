@@ -33,7 +33,10 @@ timeout 300 python tools/prof_dropin.py torch reference 8 > gpurun_out/${TAG}_dr
 timeout 300 python tools/prof_dropin.py fused fused 8 > gpurun_out/${TAG}_dropin_torch_profiler_fused_adam_fused_smoothness.txt 2>&1
 timeout 300 python bench.py --workload office0_ba_iter > gpurun_out/${TAG}_bench_ba_iter.json 2> /dev/null; cut -c1-160 gpurun_out/${TAG}_bench_ba_iter.json; echo
 timeout 300 python bench.py --workload office0_ba_iter --active-ray > gpurun_out/${TAG}_bench_ba_iter_active_ray.json 2> /dev/null; cut -c1-160 gpurun_out/${TAG}_bench_ba_iter_active_ray.json; echo
-[ -x tools/hrl_bench ] && timeout 120 tools/hrl_bench > gpurun_out/${TAG}_hbm_random_line_bench.txt 2>&1
+[ -x tools/hrl_bench ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/hbm_random_line_bench.hip -o tools/hrl_bench > /dev/null 2>&1
+[ -x tools/gvo_bench ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/gather_valu_overlap_bench.hip -o tools/gvo_bench > /dev/null 2>&1
+timeout 120 tools/hrl_bench > gpurun_out/${TAG}_hbm_random_line_bench.txt 2>&1
+timeout 120 tools/gvo_bench > gpurun_out/${TAG}_gather_valu_overlap_bench.txt 2>&1
 bash tools/trace_workload.sh $TAG office0_2048x43 > /dev/null 2>&1
 bash tools/trace_workload.sh $TAG office0_ba_iter --active-ray > /dev/null 2>&1
 bash tools/pmc_sq.sh ${TAG}_sq_counters > /dev/null 2>&1

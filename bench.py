@@ -282,12 +282,16 @@ def cpu_baseline(cfg, n_rays: int, device=None, budget_s: float = 30.0):
         return med, ((p90 - p10) / med if med > 0 else 0.0), ((max(ts) - min(ts)) / med if med > 0 else 0.0)
 
     if on_gpu:
+        # the unfused iteration is ~600 small launches: it runs at the speed of the HOST, and with torch's default of one intra-op thread
+        # per core (128 here) its few CPU-side ops stall for milliseconds at a time -- eight threads, as for the drop-in figures
+        torch.set_num_threads(min(8, n_threads_before))
         step = build(cfg)
         for i in range(3):
             step(i)                                      # cold: allocator, kernel selection
         med, ts = timed(step, 5, 25)
         med, idr, full = stats(ts)
-        return {"value": round(n_rays / med, 1), "unit": "rays/s", "kind": "port, unfused torch ops on the same GPU",
+        torch.set_num_threads(n_threads_before)
+        return {"value": round(n_rays / med, 1), "unit": "rays/s", "kind": "port, unfused torch ops on the same GPU", "host_threads": min(8, n_threads_before),
                 "sample": f"median of 25 mapping iterations after 8 warm-ups, {n_rays} rays x {S_tot} samples (oracle/spec_torch.py: forward + losses + smoothness + "
                           f"backward + Adam), {med * 1e3:.1f} ms/iter, spread (p90 - p10) / median {idr * 100:.0f} %, (max - min) / median {full * 100:.0f} %"}
 

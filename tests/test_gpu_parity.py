@@ -2804,3 +2804,38 @@ def test_sharded_table_optimizer_equals_replicated(gpu, tmp_path, graph):
         assert torch.equal(a["params"][n], b["params"][n]), f"{n}: sharded optimiser != replicated ({backend}, graph={graph})"
     n_table = a["params"]["embed_fn.params"].numel()
     assert b["moments"] <= a["moments"] - n_table // 2 + 8, (a["moments"], b["moments"])
+
+
+def test_fused_ba_recaptures_when_the_ray_count_changes(gpu):
+    """FusedBA across keyframes while n_cur = max(sample // n_kf, min_pixels_cur) still moves (the first ~20 keyframes of a run): a
+    new ray count means new static buffers and a new capture; the trajectory stays the eager one, bit for bit."""
+    from naruto_amd import trainer
+    from naruto_amd.ba_loop import FusedBA
+    cfg = H.office_cfg(12, perturb=1.0)
+    cfg["mapping"].update(sample=256, min_pixels_cur=10, filter_depth=True, keyframe_every=5)
+    bound = torch.tensor(cfg["mapping"]["bound"])
+    twins = []
+    for use_graph in (True, False):
+        torch.manual_seed(44)
+        tr = trainer.MappingTrainer(cfg, bound, gpu, fused_adam=True)
+        store, current, poses, _ = _ba_scene(cfg, gpu, n_kf=8)
+        twins.append((FusedBA(tr, store, None, max_poses=64, use_graph=use_graph), current, poses))
+    (a, cur, poses), (b, _, _) = twins
+    b.trainer.model.load_state_dict(a.trainer.model.state_dict())
+    b.trainer.iter_state.copy_(a.trainer.iter_state)
+    counts = []
+    for call in range(2):
+        for ba in (a, b):
+            if call == 1:
+                rs = np.random.RandomState(9)
+                ba.store.add_keyframe({"direction": torch.from_numpy(rs.normal(size=(1, 48, 64, 3)).astype(np.float32)),
+                                       "rgb": torch.from_numpy(rs.uniform(size=(1, 48, 64, 3)).astype(np.float32)),
+                                       "depth": torch.from_numpy(rs.uniform(0.5, 2.0, (1, 48, 64)).astype(np.float32)), "frame_id": torch.tensor([40])}, filter_depth=True)
+            p_all = poses if call == 0 else torch.cat([poses, poses[-1:]], 0)
+            n_cur, n_train = ba.prepare(cur, p_all)
+            for i in range(6):
+                ba.iteration(i)
+        counts.append(n_train)
+    assert counts == [256 + 32, 256 + 28], counts                       # 256 // 8 and 256 // 9
+    for (n, p), (_, q) in zip(a.trainer.model.named_parameters(), b.trainer.model.named_parameters()):
+        assert torch.equal(p, q), f"parameter {n}: graph replay (re-captured) != eager launches"

@@ -431,6 +431,14 @@ def get_map_volumes(query_fn, bounding_box: torch.Tensor, voxel_size: float):
         with torch.cuda.device(su.device):
             _lib.check(_lib.load().naruto_map_volumes(M, su.data_ptr(), out.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
                        "naruto_map_volumes")
-        host = out.cpu().numpy()
+        # one device-to-host copy into a cached PINNED buffer (a pageable destination costs a staging copy and ~0.1 ms more)
+        key = ("pinned", 2 * M)
+        pin = _LATTICE_CACHE.get(key)
+        if pin is None:
+            pin = torch.empty(2, M, dtype=torch.float32, pin_memory=True)
+            _LATTICE_CACHE[key] = pin
+        pin.copy_(out, non_blocking=True)
+        torch.cuda.current_stream(su.device).synchronize()
+        host = pin.numpy()
     shape = tuple(q.shape[:-1])
     return [host[0].reshape(shape).copy(), host[1].reshape(shape).copy()]

@@ -1,4 +1,5 @@
 // extern "C" entry points of libnaruto_hip.so (see include/naruto_hip.h for the contract).
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -568,9 +569,15 @@ int naruto_query_fwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
     static const bool small_wg_on = getenv("NARUTO_DEBUG_FWD_SMALL_WG") == nullptr || atoi(getenv("NARUTO_DEBUG_FWD_SMALL_WG")) != 0;
     const bool small_wg = small_wg_on && n_tiles > cu_count(f) * 4u && n_tiles < cu_count(f) * 8u;
     const hipStream_t st = (hipStream_t)stream;
+    // launch shape (fp32, phase-split tiles; measured in tools/fwd_lab.hip / profiles/r04_fwd_lab.txt): from 8 tiles per CU on, ONE persistent 8-wave
+    // workgroup per CU (one weight image, the waves walk their tiles: 76.5 -> 69.0 us at 4 096 tiles); below that the smaller forms spread the tiles better
+    // (1 376 tiles: 42.2 us as 2-wave workgroups, 45.6 as 8-wave ones).  NARUTO_DEBUG_FWD_SHAPE=0: the old shapes everywhere (A/B timing).
+    static const bool big_wg_on = getenv("NARUTO_DEBUG_FWD_SHAPE") == nullptr || atoi(getenv("NARUTO_DEBUG_FWD_SHAPE")) != 0;
+    const bool big_wg = big_wg_on && kFwdSplit && !bf && n_tiles >= cu_count(f) * 8u;
 #define NARUTO_LAUNCH_FWD(KERNEL, COLOR)                                                                                                                      \
     do {                                                                                                                                                        \
         if (small_wg) hipLaunchKernelGGL((KERNEL<COLOR, 128>), dim3((n_tiles + 1u) / 2u), dim3(128), 0, st, f->lt, f->ut, f->bt, pp, ps, M, raw, sdf_uncert, geo, feat_save, none); \
+        else if (big_wg) hipLaunchKernelGGL((k_query_fwd<COLOR, 512>), dim3(cu_count(f)), dim3(512), 0, st, f->lt, f->ut, f->bt, pp, ps, M, raw, sdf_uncert, geo, feat_save, none); \
         else hipLaunchKernelGGL((KERNEL<COLOR, 256>), dim3(blocks), dim3(256), 0, st, f->lt, f->ut, f->bt, pp, ps, M, raw, sdf_uncert, geo, feat_save, none);  \
     } while (0)
     if (color && bf) NARUTO_LAUNCH_FWD(k_query_fwd_bf, true);
@@ -821,6 +828,7 @@ int launch_train_query(const NarutoField* f, const NarutoParams* p, const Naruto
     } else {
         if (walk) hipLaunchKernelGGL((k_query_fwd<true, 256, true>), dim3(blocks), dim3(256), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
         else if (small_wg) hipLaunchKernelGGL((k_query_fwd<true, 128>), dim3((n_tiles + 1u) / 2u), dim3(128), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
+        else if (kFwdSplit && n_tiles >= cu_count(f) * 8u) hipLaunchKernelGGL((k_query_fwd<true, 512>), dim3(cu_count(f)), dim3(512), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);      // see naruto_query_fwd
         else hipLaunchKernelGGL((k_query_fwd<true, 256>), dim3(blocks), dim3(256), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
     }
     return check_launch("query_fwd");

@@ -388,6 +388,153 @@ __device__ __forceinline__ void fwd_tile(const FwdLds& L, const LevelTab& lt, co
         fwd_epilogue<COLOR>(L, oA, oB, cA, cB, geo, M, mA, mB, lane, out);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Phase-split form of a tile (round 4; measurements: tools/fwd_lab.hip, profiles/r04_fwd_lab.txt).  fwd_tile above keeps gather ->
+// blend -> MFMA of a level in one dependent chain with ONE level of loads in flight.  Here a tile is two phases:
+//   gather  index arithmetic + x-pair gathers + blend of all 16 levels, two levels (16 loads) in flight, at raised wave priority;
+//           the blended features go to the wave's own LDS slab (and to feat_save);
+//   matrix  the chain of ~130 fp32 MFMAs with the B operands of the hash part read from the slab, at normal priority.
+// Why: a wave that issues 64-cycle fp32 MFMAs back to back takes the SIMD's issue port in 64-cycle pieces, and under round-robin issue
+// its partner's 4-cycle address arithmetic crawls -- the partner's gathers are issued late and the memory path (the bound of this
+// kernel: the gather alone takes 51 us, the matrix chain alone 35, tools/fwd_lab.hip) runs dry.  With the gathers in one burst at
+// priority 3 the memory path sees the loads of every gathering wave as early as possible, and matrix phases of one wave fall into the
+// memory waits of another.  Role-split (producer / consumer waves), software-pipelined and token-staggered forms were built and
+// measured in the lab: all land at 69 - 73 us against 76 for the single-chain form; this is the simplest of them.
+// The level loop is fully unrolled with the level index kept a run-time scalar: straight-line code keeps the waitcnt pass's view of
+// the load order exact (it degrades to "wait for everything" at control-flow merges whose paths carry different VMEM operations),
+// while the level constants are fetched when needed instead of all living in SGPRs.  Full tiles only (no exec-masked stores).
+// ------------------------------------------------------------------------------------------------------------------------------
+#ifndef NARUTO_FWD_SPLIT
+#define NARUTO_FWD_SPLIT 1
+#endif
+#ifndef NARUTO_FWD_GATHER_PRIO
+#define NARUTO_FWD_GATHER_PRIO 3
+#endif
+constexpr bool kFwdSplit = NARUTO_FWD_SPLIT != 0;
+struct FwdSlab { float feat[kLevels][2][64]; };          // [level][tile half][lane]: the MFMA B operands of the hash part
+
+// dead lanes (MASK: ee_lane_live) fetch entry 0 of the level -- one shared line per instruction instead of a branch around the loads --
+// and their features come out as zeros
+template <bool MASK>
+__device__ __forceinline__ void hash_level_half_load_sel(const LevelTab& lt, int T, const float2* __restrict__ table, const HalfCorners& h, float2 (&v)[4], bool live) {
+    const char* __restrict__ tl = reinterpret_cast<const char*>(table + lt.off[T]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#ifdef NARUTO_ABLATE_GATHER
+        v[c] = make_float2(__uint_as_float((h.off[c] >> 3) | 0x3f000000u), 0.25f);
+#else
+        v[c] = *reinterpret_cast<const float2*>(tl + ((MASK && !live) ? 0u : h.off[c]));
+#endif
+    }
+}
+
+template <bool MASK>
+__device__ __forceinline__ void fwd_gather_tile(const LevelTab& lt, const float2* __restrict__ table, float x, float y, float z, float* __restrict__ feat_save,
+                                                uint32_t M, uint32_t mA, uint32_t mB, int lane, FwdSlab& sl, bool live) {
+    const uint32_t hh = (uint32_t)lane >> 5;
+    float la = live ? 1.0f : 0.0f, lb = la;
+    if constexpr (MASK) swap32(la, lb);
+    const bool liveA = MASK ? la != 0.0f : true, liveB = MASK ? lb != 0.0f : true;
+    float xa = x, xb = x, ya = y, yb = y, za = z, zb = z;
+    swap32(xa, xb); swap32(ya, yb); swap32(za, zb);
+    HalfCorners ha[2], hb[2];
+    float2 va[2][4], vb[2][4];
+    auto issue = [&](auto tc) {
+        constexpr int T = decltype(tc)::value;
+        int Tr = T;
+        asm volatile("" : "+s"(Tr));
+        ha[T & 1] = hash_level_half_index(lt, Tr, xa, ya, za, hh);
+        hb[T & 1] = hash_level_half_index(lt, Tr, xb, yb, zb, hh);
+        hash_level_half_load_sel<MASK>(lt, Tr, table, ha[T & 1], va[T & 1], liveA);
+        hash_level_half_load_sel<MASK>(lt, Tr, table, hb[T & 1], vb[T & 1], liveB);
+    };
+    issue(std::integral_constant<int, 0>{});
+    static_for<0, kLevels>([&](auto tc) {
+        constexpr int T = decltype(tc)::value;
+        if constexpr (T + 1 < kLevels) issue(std::integral_constant<int, T + 1>{});
+        const float2 pa = hash_level_half_blend(ha[T & 1], va[T & 1]);
+        const float2 pb = hash_level_half_blend(hb[T & 1], vb[T & 1]);
+        float ua = pa.x, wa = pa.y, ub = pb.x, wb = pb.y;
+        swap32(ua, wa);
+        swap32(ub, wb);
+        float b0 = ua + wa, b1 = ub + wb;
+        if constexpr (MASK) { b0 = liveA ? b0 : 0.0f; b1 = liveB ? b1 : 0.0f; }
+        if (feat_save != nullptr) {
+            char* __restrict__ fs = reinterpret_cast<char*>(feat_save + (size_t)T * M * 2u);
+            if constexpr (MASK) {
+                if (liveA) *reinterpret_cast<float*>(fs + ((mA * 2u + hh) << 2)) = b0;
+                if (liveB) *reinterpret_cast<float*>(fs + ((mB * 2u + hh) << 2)) = b1;
+            } else {
+                *reinterpret_cast<float*>(fs + ((mA * 2u + hh) << 2)) = b0;
+                *reinterpret_cast<float*>(fs + ((mB * 2u + hh) << 2)) = b1;
+            }
+        }
+        sl.feat[T][0][lane] = b0;
+        sl.feat[T][1][lane] = b1;
+    });
+}
+
+// the matrix phase: fwd_tile's chain in fwd_tile's order (same accumulation order: same bits), hash-part B operands from the slab
+template <bool COLOR>
+__device__ __forceinline__ void fwd_mlp_tile(const FwdLds& L, const FwdSlab& sl, float x, float y, float z, float* __restrict__ geo, uint32_t M, uint32_t mA, uint32_t mB,
+                                             int lane, FwdTileOut& out) {
+    f32x16 hA = zero16(), hB = zero16(), cA = zero16(), cB = zero16();
+    static_for<0, kLevels>([&](auto tc) {
+        constexpr int T = decltype(tc)::value;
+        const float a = L.s0[T * 64 + lane];
+        hA = mfma32(a, sl.feat[T][0][lane], hA);
+        hB = mfma32(a, sl.feat[T][1][lane], hB);
+    });
+    const bool blob_fast = __all(oneblob_sparse_ok(x) && oneblob_sparse_ok(y) && oneblob_sparse_ok(z));
+    float eb[3][kBins];
+    uint32_t pairs = 0;
+    static_for<0, 3>([&](auto dc) {
+        constexpr int D = decltype(dc)::value;
+        uint32_t pd;
+        oneblob16_auto(D == 0 ? x : (D == 1 ? y : z), blob_fast, eb[D], pd);
+        pairs |= pd << (8 * D);
+    });
+    pairs = blob_fast ? wave_or_u32(pairs) : 0xFFFFFFu;
+    static_for<0, 3>([&](auto dc) {
+        constexpr int D = decltype(dc)::value;
+        static_for<0, 8>([&](auto qc) {
+            constexpr int Q = decltype(qc)::value;
+            constexpr int P = D * 8 + Q;
+            if ((pairs >> P) & 1u) {
+                float b0 = eb[D][2 * Q], b1 = eb[D][2 * Q + 1];
+                swap32(b0, b1);
+                const float as = L.s0[(16 + P) * 64 + lane];
+                hA = mfma32(as, b0, hA);
+                hB = mfma32(as, b1, hB);
+                if constexpr (COLOR) {
+                    const float ac = L.c0p[P * 64 + lane];
+                    cA = mfma32(ac, b0, cA);
+                    cB = mfma32(ac, b1, cB);
+                }
+            }
+        });
+    });
+    f32x16 oA = zero16(), oB = zero16();
+    static_for<0, 16>([&](auto tc) {
+        constexpr int T = decltype(tc)::value;
+        const float a = L.s1[T * 64 + lane];
+        oA = mfma32(a, fmaxf(hA[T], 0.0f), oA);
+        oB = mfma32(a, fmaxf(hB[T], 0.0f), oB);
+    });
+    fwd_epilogue<COLOR>(L, oA, oB, cA, cB, geo, M, mA, mB, lane, out);
+}
+
+// one FULL tile (all 64 points < M), both phases; same results as fwd_tile<COLOR, MASK>
+template <bool COLOR, bool MASK>
+__device__ __forceinline__ void fwd_tile_split(const FwdLds& L, FwdSlab& sl, const LevelTab& lt, const float2* __restrict__ table, float x, float y, float z,
+                                               float* __restrict__ feat_save, float* __restrict__ geo, uint32_t M, uint32_t mA, uint32_t mB, int lane, FwdTileOut& out,
+                                               bool live = true) {
+    if constexpr (NARUTO_FWD_GATHER_PRIO != 0) __builtin_amdgcn_s_setprio(NARUTO_FWD_GATHER_PRIO);
+    fwd_gather_tile<MASK>(lt, table, x, y, z, feat_save, M, mA, mB, lane, sl, live);
+    if constexpr (NARUTO_FWD_GATHER_PRIO != 0) __builtin_amdgcn_s_setprio(0);
+    fwd_mlp_tile<COLOR>(L, sl, x, y, z, geo, M, mA, mB, lane, out);
+}
+
 // NT = threads per workgroup: 256, or 128 for launches of between one and two 256-thread workgroups per CU -- the time of this kernel
 // grows with the tiles a CU holds (measured: 10 us + 5.8 us per tile and CU), so 1 376 tiles (2 048 rays x 43 samples, the reference's
 // real batch) as 344 workgroups of four put eight tiles on 88 CUs and four on the rest; as 688 workgroups of two no CU holds more than six.
@@ -396,10 +543,11 @@ __global__ __launch_bounds__(NT, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab 
                                                    uint32_t M, float* __restrict__ raw, float* __restrict__ sdf_uncert,
                                                    float* __restrict__ geo, float* __restrict__ feat_save, EarlyExit ee) {
     __shared__ FwdLds L;
+    __shared__ FwdSlab slabs[kFwdSplit ? NT / 64 : 1];
     stage_fwd_weights<NT>(L, p, threadIdx.x);
     __syncthreads();
     constexpr uint32_t kW = NT / 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = kFwdSplit ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);
     const int hh = lane >> 5, j = lane & 31;
     const uint32_t n_tiles = (M + 63u) / 64u;
     const float2* __restrict__ table = reinterpret_cast<const float2*>(p.table);
@@ -419,7 +567,10 @@ __global__ __launch_bounds__(NT, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab 
 
         FwdTileOut to;
         const bool live_out = live;
-        fwd_tile<COLOR, EE>(L, lt, table, x, y, z, feat_save, geo, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
+        if (kFwdSplit && tile * 64u + 63u < M)
+            fwd_tile_split<COLOR, EE>(L, slabs[kFwdSplit ? wave : 0], lt, table, x, y, z, feat_save, geo, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
+        else
+            fwd_tile<COLOR, EE>(L, lt, table, x, y, z, feat_save, geo, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
         if (!live_out) { to.rgb[0] = 0.0f; to.rgb[1] = 0.0f; to.rgb[2] = 0.0f; to.sdf = 0.0f; }
         const float sdf = to.sdf;
         const float u_out = live_out ? u : 0.0f;

@@ -339,6 +339,9 @@ def cpu_baseline(cfg, n_rays: int, device=None, budget_s: float = 30.0):
     return out
 
 
+PREWARM_MS = 100.0
+
+
 def timed_chunks(fn, steps: int, chunks: int = 5) -> float:
     """ms per call of fn(i): the MEDIAN over `chunks` consecutive chunks of the loop, each bracketed by device syncs (host-bound eager
     loops on these boxes are disturbed for tens of milliseconds at a time by whatever else the host is doing)."""
@@ -357,13 +360,14 @@ def timed_chunks(fn, steps: int, chunks: int = 5) -> float:
 
 
 def dropin_timing(cfg, n_rays: int, dev, steps: int, warmup: int, which=None):
-    """The UNCHANGED caller: the reference's own global_BA loop body (coslam.py:361-399; restated in naruto_amd/dropin.py) around
+    """The UNCHANGED caller: the reference's own global_BA loop body (coslam.py:361-399; restated in tools/dropin_caller.py) around
     ``NarutoFieldHIP`` -- model.forward (the fused training node), get_loss_from_ret as ten scalar torch ops with Co-SLAM's torch
     smoothness through query_sdf(embed=True) autograd, loss.backward(retain_graph=True), torch.optim.Adam over 1.63 M parameters,
     the uncertainty grid's Adam every 5th iteration: what INTEGRATION.md's two-line swap buys without touching anything else, and
     the optional one-line changes after it.  Eager launches, wall clock with a device sync on both sides (the loop is host bound:
     the caller's own ~60 small torch ops per iteration)."""
-    from naruto_amd.dropin import DropInCaller
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    from dropin_caller import DropInCaller           # the caller's restated loop body: a harness, not product code
     from naruto_amd.field import NarutoFieldHIP
     variants = (("swap_only", "torch", "reference", "the two-line swap at coslam.py:65, nothing else changed"),
                 ("fused_adam", "fused", "reference", "+ optim.Adam -> naruto_amd.FusedAdam in create_optimizer / init_uncert_grid_optim"),
@@ -392,9 +396,9 @@ def dropin_timing(cfg, n_rays: int, dev, steps: int, warmup: int, which=None):
         out[name] = {"ms_per_step": round(ms, 4), "mean_ms_per_step": round(timed_chunks.last_mean, 4), "rays_per_s": round(n_rays / ms * 1e3, 1), "change": what,
                      "host_threads": torch.get_num_threads()}
         if name == "fused_adam_fused_smoothness":
-            # the same loop body, recorded once with torch's whole-iteration capture and replayed (naruto_amd.dropin.GraphedIteration): no
+            # the same loop body, recorded once with torch's whole-iteration capture and replayed (naruto_amd.graphed.GraphedIteration): no
             # host work is left in it after the two one-line changes, so it can be
-            from naruto_amd.dropin import GraphedIteration
+            from naruto_amd.graphed import GraphedIteration
             step = GraphedIteration(caller, n_rays)
             a_ = (rays["rays_o"], rays["rays_d"], rays["target_rgb"], rays["target_d"])
             for i in range(warmup):
@@ -402,7 +406,7 @@ def dropin_timing(cfg, n_rays: int, dev, steps: int, warmup: int, which=None):
             ms = timed_chunks(lambda i: step(warmup + i, *a_), steps)
             m.check_asserts(block=True)
             out["graphed_loop_body"] = {"ms_per_step": round(ms, 4), "mean_ms_per_step": round(timed_chunks.last_mean, 4), "rays_per_s": round(n_rays / ms * 1e3, 1), "host_threads": torch.get_num_threads(),
-                                        "change": "+ the loop body (model.forward ... optimiser steps) wrapped in naruto_amd.dropin.GraphedIteration: hipGraph replay of the caller's own autograd iteration"}
+                                        "change": "+ the loop body (model.forward ... optimiser steps) wrapped in naruto_amd.graphed.GraphedIteration: hipGraph replay of the caller's own autograd iteration"}
             del step
         del caller, m
     torch.set_num_threads(threads_before)
@@ -479,19 +483,15 @@ def run_eval(args, dev):
     return out
 
 
-def run_ba_iter(args, dev):
-    """--workload office0_ba_iter: what ONE iteration of the reference's global_BA loop costs here end to end (coslam.py:310-399):
-    batch draw from the device-resident keyframe store + current frame and the pose transform (naruto_assemble_rays), the active ray
-    selection when mapping.active_ray is on (naruto_active_ray_select over the 4x oversampled batch), and the training iteration
-    (forward, losses incl. smoothness, backward, both Adams) -- one stream, one hipGraph (naruto_amd.ba_loop.FusedBA).  Synthetic
-    Replica-sized inputs: 680 x 1200 frames, 40 keyframes x 5 % of the pixels stored, [49,56,35] planner volume."""
+def ba_scene(mlp: str, active_ray: bool, dev):
+    """The synthetic Replica-sized mapping state of the `office0_ba_iter` workload: trainer, device-resident keyframe store (40 keyframes x
+    5 % of 680 x 1200 pixels), current frame, poses, planner volume, active ray sampler (or None)."""
     from naruto_amd.active_ray_sampler import ActiveRaySamplerHIP
-    from naruto_amd.ba_loop import FusedBA
     from naruto_amd.keyframe_store import KeyFrameStoreHIP
     from naruto_amd.trainer import MappingTrainer
-    cfg, _ = workload(args.workload)
-    cfg["decoder"]["mlp_precision"] = args.mlp
-    cfg["mapping"].update(sample=2048, min_pixels_cur=100, filter_depth=True, keyframe_every=5, active_ray=bool(args.active_ray))
+    cfg, _ = workload("office0_ba_iter")
+    cfg["decoder"]["mlp_precision"] = mlp
+    cfg["mapping"].update(sample=2048, min_pixels_cur=100, filter_depth=True, keyframe_every=5, active_ray=active_ray)
     Hh, Ww, n_kf = 680, 1200, 40
     R = int(Hh * Ww * 0.05)
     torch.manual_seed(0)
@@ -515,7 +515,45 @@ def run_ba_iter(args, dev):
         p_[:3, :3] = q
         p_[:3, 3] = bound[:, 0] + (0.3 + 0.4 * torch.rand(3)) * (bound[:, 1] - bound[:, 0])
     vol = (torch.rand(49, 56, 35) * 3 * (torch.rand(49, 56, 35) < 0.5)).numpy()
-    smp = ActiveRaySamplerHIP(config=cfg, num_uncert_sample=500, oversample_mul=4) if args.active_ray else None
+    smp = ActiveRaySamplerHIP(config=cfg, num_uncert_sample=500, oversample_mul=4) if active_ray else None
+    return cfg, tr, store, smp, current, poses, vol, (Hh, Ww, n_kf, R)
+
+
+def mapping_iter_ms(mlp: str, dev, steps: int, warmup: int):
+    """BASELINE's second metric for the default line: one global_BA iteration END TO END (ray assembly -> [active ray selection] ->
+    training iteration, one hipGraph: naruto_amd.ba_loop.FusedBA), shipped sampling (32 + 11), active rays off and on; ms per iteration,
+    median of five chunks after >= PREWARM_MS of untimed replays.  `--workload office0_ba_iter` gives the long form."""
+    from naruto_amd.ba_loop import FusedBA
+    out = {}
+    for active in (False, True):
+        cfg, tr, store, smp, current, poses, vol, _dims = ba_scene(mlp, active, dev)
+        ba = FusedBA(tr, store, smp, max_poses=256, use_graph=True)
+        n_cur, n_train = ba.prepare(current, poses, vol if active else None)
+        for i in range(warmup):
+            ba.iteration(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        i = 0
+        while time.perf_counter() - t0 < PREWARM_MS * 1e-3:
+            for _ in range(16):
+                ba.iteration(i)
+                i += 1
+            torch.cuda.synchronize()
+        ms = timed_chunks(lambda k: ba.iteration(k), 5 * steps)
+        tr.model.check_asserts(block=True)
+        out["active_ray_on" if active else "active_ray_off"] = {"ms": round(ms, 4), "rays_per_iteration": n_train, "rays_per_s": round(n_train / ms * 1e3, 1)}
+        del ba, tr, store, smp
+    return out
+
+
+def run_ba_iter(args, dev):
+    """--workload office0_ba_iter: what ONE iteration of the reference's global_BA loop costs here end to end (coslam.py:310-399):
+    batch draw from the device-resident keyframe store + current frame and the pose transform (naruto_assemble_rays), the active ray
+    selection when mapping.active_ray is on (naruto_active_ray_select over the 4x oversampled batch), and the training iteration
+    (forward, losses incl. smoothness, backward, both Adams) -- one stream, one hipGraph (naruto_amd.ba_loop.FusedBA).  Synthetic
+    Replica-sized inputs: 680 x 1200 frames, 40 keyframes x 5 % of the pixels stored, [49,56,35] planner volume."""
+    from naruto_amd.ba_loop import FusedBA
+    cfg, tr, store, smp, current, poses, vol, (Hh, Ww, n_kf, R) = ba_scene(args.mlp, bool(args.active_ray), dev)
     res = {}
     for mode in ("graph", "eager"):
         ba = FusedBA(tr, store, smp, max_poses=256, use_graph=(mode == "graph"))
@@ -581,8 +619,22 @@ def main():
                     help="trainer: MappingTrainer's fused iteration (hipGraph replay), the headline; dropin: the reference's unchanged loop body "
                          "(coslam.py:361-399) around NarutoFieldHIP is the timed step (its figures ride in the default line too, as `dropin`)")
     ap.add_argument("--no-dropin", action="store_true")
+    ap.add_argument("--no-mapping-iter", action="store_true", help="skip the mapping-iter ms (office0_ba_iter) figures of the default line")
     ap.add_argument("--active-ray", action="store_true", help="office0_ba_iter: mapping.active_ray on (4x oversampled batch -> active ray selection)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` WITHOUT a launcher (no WORLD_SIZE in the environment): become the documented launch line -- one process per
+    # GPU through torch.distributed.run on 127.0.0.1 -- instead of failing on the world-size check (round-3 review: a scaling run issued like
+    # the 1-GPU command would have wasted its 8-GPU lease).  exec: the launcher inherits stdout, rank 0's one JSON line is this command's.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print("[bench] --gpus %d without a launcher: exec %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+        os.execv(sys.executable, cmd)
 
     # stdout carries exactly ONE line, the JSON result.  RCCL writes its version banner to the C-level stdout (it lands in
     # libc's buffer and would come out after the result); route file descriptor 1 to stderr for the whole run and give it
@@ -679,6 +731,22 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # pre-warm: the timed window of the default run is ~5 ms (20 - 50 steps of ~0.23 ms) -- short enough to be read at ramping clocks right
+    # after the captures and copies above.  Untimed steps for >= PREWARM_MS of wall time first (every rank the same count: the collectives
+    # of a data-parallel step must pair up), stated in the line.
+    torch.cuda.synchronize()
+    t_w = time.perf_counter()
+    for _ in range(8):
+        step()
+    torch.cuda.synchronize()
+    per_step = max((time.perf_counter() - t_w) / 8, 1e-5)
+    n_prewarm = int(min(max(PREWARM_MS * 1e-3 / per_step, 0), 20000))
+    if group is not None:
+        t = torch.tensor([n_prewarm], dtype=torch.int64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
+        n_prewarm = int(t.item())
+    for _ in range(n_prewarm):
+        step()
     tr.model.check_asserts(block=True)
     if group is not None:
         torch.distributed.barrier(group)
@@ -695,6 +763,11 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
         dt = float(t.item())
     tr.model.check_asserts(block=True)
+    # beside the contract's figure (exactly K steps between two syncs, above): the MEDIAN over five further chunks of K steps each, which a
+    # single disturbed chunk cannot move (single process only: the chunks' syncs would need barriers of their own)
+    ms_chunks = None
+    if group is None:
+        ms_chunks = timed_chunks(lambda i: step(), 5 * args.steps)
 
     if rank == 0:
         trc = cfg["training"]
@@ -708,6 +781,10 @@ def main():
             "value": round(n_total * args.steps / dt, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32" if args.mlp == "fp32" else "bf16 (MLP operands; fp32 accumulate, fp32 elsewhere)", "data": "synthetic",
+            "prewarm": {"untimed_steps_before_the_timed_region": args.warmup + 8 + n_prewarm, "target_ms": PREWARM_MS},
+            "ms_per_step_median_of_5_chunks": None if ms_chunks is None else round(ms_chunks, 4),
+            "multi_gpu_note": "no multi-GPU scaling curve has been measured by the builder (one-GPU boxes only): values at n_gpus > 1 come from the driver's runs",
+
             "config": {"workload": f"{args.workload} = BASELINE {WORKLOADS[args.workload][2]}: {volume}, {n_rays} rays x {S_tot} samples per GPU "
                                    f"({n_total} rays per step over {world} GPU), hash L16 F2 T2^{cfg['grid']['hash_size']} ({n_params * 4 / 1e6:.1f} MB of parameters), "
                                    f"MLP 2x32 {args.mlp}, uncert grid; one global_BA mapping iteration incl. smoothness + Adam",
@@ -831,11 +908,21 @@ def main():
                 d = dropin_timing(cfg, n_rays, dev, max(10, min(args.steps, 50)), 10)
                 out["dropin"] = d
                 out["dropin_ms_per_step"] = d["swap_only"]["ms_per_step"]
-                out["dropin_note"] = ("the reference's unchanged loop body around NarutoFieldHIP (bench.py dropin_timing, naruto_amd/dropin.py), eager, wall clock, median (and mean) "
+                out["dropin_note"] = ("the reference's unchanged loop body around NarutoFieldHIP (bench.py dropin_timing, tools/dropin_caller.py), eager, wall clock, median (and mean) "
                                       "over five chunks of the timed loop; "
                                       "ms_per_step / value above are MappingTrainer's fused iteration under hipGraph replay")
             except Exception as e:                               # informational: never fail the bench line over it
                 out["dropin"] = {"error": repr(e)[:300]}
+        if world == 1 and args.workload.startswith("office0") and not args.no_mapping_iter:
+            # BASELINE's metric is "rays/sec (train step) + mapping-iter ms": the second half, measured by the same default run
+            try:
+                mi = mapping_iter_ms(args.mlp, dev, max(10, min(args.steps, 50)), 10)
+                out["mapping_iter_ms"] = mi["active_ray_off"]["ms"]
+                out["mapping_iter"] = dict(mi, note="one global_BA iteration end to end (coslam.py:310-399): ray assembly from the device-resident keyframe store + "
+                                           "current frame (2148 rays) -> [active ray selection over the 4x oversampled batch] -> training iteration at the shipped "
+                                           "32 + 11 samples, one hipGraph (naruto_amd.ba_loop.FusedBA); median of five chunks; long form: --workload office0_ba_iter")
+            except Exception as e:                               # informational: never fail the bench line over it
+                out["mapping_iter"] = {"error": repr(e)[:300]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, n_rays)
             try:

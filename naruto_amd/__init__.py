@@ -12,7 +12,7 @@ from . import config, synthetic  # noqa: F401
 
 def __getattr__(name):
     # torch-dependent modules are imported lazily so that `import naruto_amd` stays cheap
-    if name in ("ops", "field", "parallel", "trainer", "_lib", "dropin", "ba_loop", "keyframe_store", "active_ray_sampler", "planner_aggregation", "mesh"):
+    if name in ("ops", "field", "parallel", "trainer", "_lib", "graphed", "ba_loop", "keyframe_store", "active_ray_sampler", "planner_aggregation", "mesh"):
         import importlib
         return importlib.import_module("." + name, __name__)
     if name == "NarutoFieldHIP":

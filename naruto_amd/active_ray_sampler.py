@@ -49,7 +49,12 @@ class ActiveRaySamplerHIP:
         the reference); ``sample_rays(..., uncert_vol=None, ...)`` then uses this copy.  A volume of the same shape is copied INTO
         the existing device tensor, so a captured launch that reads it (naruto_amd.ba_loop.FusedBA) sees the refresh."""
         src = uncert_vol if torch.is_tensor(uncert_vol) else torch.from_numpy(np.ascontiguousarray(uncert_vol, dtype=np.float32))
-        if self._vol_dev is not None and tuple(self._vol_dev.shape) == tuple(src.shape) and self._vol_dev.device == torch.device(device):
+        want = torch.device(device)
+        # ("cuda" and "cuda:0" name the same device but compare unequal: resolve the index before comparing)
+        want_idx = want.index if want.index is not None else (torch.cuda.current_device() if want.type == "cuda" else None)
+        have = self._vol_dev.device if self._vol_dev is not None else None
+        same_dev = have is not None and have.type == want.type and (have.index if have.index is not None else want_idx) == want_idx
+        if self._vol_dev is not None and tuple(self._vol_dev.shape) == tuple(src.shape) and same_dev:
             self._vol_dev.copy_(src, non_blocking=True)
         else:
             self._vol_dev = _f32c(src.to(device), "uncert_vol")

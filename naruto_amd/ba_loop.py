@@ -45,7 +45,13 @@ class FusedBA:
         self.current = torch.zeros(store.total_pixels, 7, dtype=torch.float32, device=dev)        # the current frame's rays, refreshed per call
         self.poses = torch.zeros(int(max_poses), 4, 4, dtype=torch.float32, device=dev)
         self.dyn = torch.zeros(3, dtype=torch.int64, device=dev)                                   # {n_kf, n_poses, n_cur_pop}
-        self._dyn_host = torch.zeros(3, dtype=torch.int64).pin_memory()
+        # pinned staging for the asynchronous refresh of ``dyn``: TWO buffers used in turn, each guarded by the event recorded behind
+        # its last copy -- a second prepare() must not overwrite a buffer whose host-to-device copy is still queued behind replays
+        self._dyn_host = [torch.zeros(3, dtype=torch.int64).pin_memory() for _ in range(2)]
+        self._dyn_done = [None, None]
+        self._dyn_turn = 0
+        self._n_cur_pop = 1
+        self._vol_ptr = None          # data_ptr of the sampler's volume the graph was captured with
         self._shape = None            # (n_cur, n_train) the graph was captured for
         self._stage = None            # the oversampled batch between assembly and selection (active ray only)
         self._ws = None
@@ -65,7 +71,7 @@ class FusedBA:
         rng = self.trainer.iter_state
 
         def prologue(rays_o, rays_d, target_rgb, target_d):
-            kw = dict(filter_depth=self.filter_depth, rng=rng, dyn=self.dyn, n_cur=n_cur, n_cur_pop=int(self._dyn_host[2]))
+            kw = dict(filter_depth=self.filter_depth, rng=rng, dyn=self.dyn, n_cur=n_cur, n_cur_pop=self._n_cur_pop)
             if not self.active:
                 store.assemble_batch(self.sample_num, self.current, self.poses, self.min_pixels_cur, out=(rays_o, rays_d, target_rgb, target_d), **kw)
                 return
@@ -89,12 +95,24 @@ class FusedBA:
         n_valid = cur.shape[0]
         if self.filter_depth:
             n_valid = int(((cur[:, -1] > 0.0) & (cur[:, -1] <= self.config["cam"]["depth_trunc"])).sum().item())
-        self._dyn_host[0], self._dyn_host[1], self._dyn_host[2] = n_kf, P, max(n_valid, 1)
-        self.dyn.copy_(self._dyn_host, non_blocking=True)
+        turn = self._dyn_turn
+        self._dyn_turn ^= 1
+        if self._dyn_done[turn] is not None:
+            self._dyn_done[turn].synchronize()            # the copy that last read this staging buffer has landed (two calls back: normally long ago)
+        host = self._dyn_host[turn]
+        host[0], host[1], host[2] = n_kf, P, max(n_valid, 1)
+        self._n_cur_pop = max(n_valid, 1)
+        self.dyn.copy_(host, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self._dyn_done[turn] = ev
+        vol_moved = False
         if self.active and uncert_vol is not None:
-            self.sampler.set_volume(uncert_vol, dev)
+            vol = self.sampler.set_volume(uncert_vol, dev)
+            vol_moved = self._vol_ptr is not None and vol.data_ptr() != self._vol_ptr      # a new tensor (other shape): the captured launch reads the old one
+            self._vol_ptr = vol.data_ptr()
         n_cur, n_train = self.sizes(n_kf, n_valid)
-        if self._shape != (n_cur, n_train, smooth):
+        if self._shape != (n_cur, n_train, smooth) or (vol_moved and self.use_graph):
             f32 = dict(dtype=torch.float32, device=dev)
             n_stage = self.sample_num + n_cur
             if self.active:

@@ -365,7 +365,7 @@ class NarutoFieldHIP(nn.Module):
         """scene_rep.py:227-287."""
         if not self.training:
             return self.render_rays(rays_o, rays_d, target_d=target_d, rand=rand)
-        # inside a hipGraph capture (MappingTrainer.capture, dropin.GraphedIteration) nothing may touch the host: the running minimum is
+        # inside a hipGraph capture (MappingTrainer.capture, graphed.GraphedIteration) nothing may touch the host: the running minimum is
         # still folded in by the kernels, and whoever replays the graph reads it back (note_min_uncert / check_asserts) outside
         capturing = rays_o.is_cuda and torch.cuda.is_current_stream_capturing()
         if _check and not capturing:

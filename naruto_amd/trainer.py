@@ -115,7 +115,7 @@ class FusedAdam(optim.Optimizer):
 
     def zero_grad(self, set_to_none: bool = True):
         """As torch's; while the current stream is CAPTURING (whole-iteration hipGraph capture of a caller's loop body,
-        naruto_amd.dropin.GraphedIteration) gradients are zeroed IN PLACE whatever ``set_to_none`` says: dropping the tensor is a host-side
+        naruto_amd.graphed.GraphedIteration) gradients are zeroed IN PLACE whatever ``set_to_none`` says: dropping the tensor is a host-side
         act a replay cannot repeat, and the next backward would then overwrite instead of accumulate."""
         if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
             grads = [p.grad for g in self.param_groups for p in g['params'] if p.grad is not None]
@@ -128,19 +128,49 @@ class FusedAdam(optim.Optimizer):
         st = self.state[p]
         return st['exp_avg'], st['exp_avg_sq']
 
+    def _steps_done(self) -> int:
+        """Optimiser steps taken so far: the device counter, or -- driven by an external iteration counter (MappingTrainer) -- that word."""
+        src = self.external_step if self.external_step is not None else self.step_dev
+        return int(src.reshape(-1)[0].item())
+
     def state_dict(self):
+        """torch.optim.Adam's layout: every parameter's state also carries ``step`` (a float32 scalar tensor, steps taken BY THAT
+        parameter = global count - its lag), so that a ``torch.optim.Adam`` can load this dictionary; ``naruto_step`` is the global count."""
+        done = self._steps_done()
         sd = super().state_dict()
-        sd['naruto_step'] = int(self.step_dev[0].item())
+        sd['state'] = {k: dict(v) for k, v in sd['state'].items()}
+        for st in sd['state'].values():
+            st['step'] = torch.tensor(float(max(done - int(st.get('lag', 0)), 0)), dtype=torch.float32)
+        sd['naruto_step'] = done
         return sd
 
     def load_state_dict(self, state_dict):
+        """Accepts its own dictionaries and ``torch.optim.Adam``'s (no ``naruto_step`` / ``lag``: the global count is the largest
+        per-parameter ``step``, a parameter's lag the difference to it).  With an external step word the count is NOT written there
+        (it is the trainer's iteration counter, restored by the trainer): the lags are set against the count it holds."""
         state_dict = dict(state_dict)
         step = state_dict.pop('naruto_step', None)
         super().load_state_dict(state_dict)
         self._plan_cache = None                 # the moments are new tensors now
-        if step is not None:
-            self.step_dev[0] = int(step)
-            self._n_steps = int(step)
+        per_param = {}
+        for g in self.param_groups:
+            for p in g['params']:
+                st = self.state[p]
+                if 'step' in st:
+                    per_param[p] = int(float(st.pop('step')))
+        if step is None:
+            step = max(per_param.values()) if per_param else 0
+        step = int(step)
+        for g in self.param_groups:
+            for p in g['params']:
+                st = self.state[p]
+                if 'exp_avg' not in st:
+                    self._init_state(p)
+                if 'lag' not in st or p in per_param:
+                    st['lag'] = step - per_param.get(p, step)
+        if self.external_step is None:
+            self.step_dev[0] = step
+        self._n_steps = step
 
     def _plan(self):
         """Per (betas) batch of <= 8 tensors: a reusable NarutoAdamSeg array with everything but the gradient pointers filled in."""

@@ -6,6 +6,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+TOOLS = os.path.join(ROOT, "tools")        # tools/dropin_caller.py: the reference's restated loop body the dropin tests drive
+if TOOLS not in sys.path:
+    sys.path.insert(1, TOOLS)
 
 
 def pytest_configure(config):

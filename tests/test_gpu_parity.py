@@ -2380,11 +2380,11 @@ def test_fused_train_node_autograd_contract(gpu):
 
 @pytest.mark.parametrize("optimizer", ["torch", "fused"])
 def test_dropin_caller_tracks_the_oracle(gpu, optimizer):
-    """The reference's UNCHANGED loop body (naruto_amd/dropin.py = coslam.py:154-174, 361-399 + Co-SLAM's torch smoothness through
+    """The reference's UNCHANGED loop body (tools/dropin_caller.py = coslam.py:154-174, 361-399 + Co-SLAM's torch smoothness through
     query_sdf(embed=True) autograd, loss.backward(retain_graph=True), Adam, the uncertainty grid's Adam every 5th iteration) around
     NarutoFieldHIP against the oracle driven by the same loop with the same host random draws: per-iteration losses and the
     parameters after seven iterations."""
-    from naruto_amd.dropin import DropInCaller
+    from dropin_caller import DropInCaller
     cfg = H.office_cfg(12)
     trc = cfg["training"]
     ora = H.make_oracle(cfg, 0.1, 31).train()
@@ -2431,7 +2431,7 @@ def test_dropin_variants_run_and_agree(gpu):
     """INTEGRATION.md's optional one-line changes after the swap (FusedAdam; the fused smoothness) leave the first iteration's render
     losses untouched and keep training: same rgb / depth / sdf / fs / uncert losses at iteration 0 (the smoothness lattice is drawn
     differently), finite and decreasing total afterwards."""
-    from naruto_amd.dropin import DropInCaller
+    from dropin_caller import DropInCaller
     cfg = H.office_cfg(12)
     ora = H.make_oracle(cfg, 0.1, 3)
     rays = syn.random_rays(300, cfg["mapping"]["bound"], seed=3)
@@ -2552,7 +2552,7 @@ def test_fused_ba_iteration_equals_its_pieces(gpu, active):
     store.seed, store.counter = seed, counter - 1            # assemble_batch pre-increments its host counter
     n_cur = 160 if active else 40
     o, d, s_, t_, _ = store.assemble_batch(b.sample_num, b.current, b.poses[:poses.shape[0]], b.min_pixels_cur, filter_depth=True,
-                                           n_cur=n_cur, n_cur_pop=int(b._dyn_host[2]))
+                                           n_cur=n_cur, n_cur_pop=b._n_cur_pop)
     store.seed, store.counter = saved_seed, saved_counter
     if active:
         o, d, s_, t_ = b.sampler.sample_rays(o, d, s_, t_, n_cur, None, b.bbox)
@@ -2572,6 +2572,57 @@ def test_fused_ba_iteration_equals_its_pieces(gpu, active):
     for (n, p), (_, q) in zip(a.trainer.model.named_parameters(), b.trainer.model.named_parameters()):
         assert torch.equal(p, q), f"parameter {n}: graph replay != eager launches"
     a.trainer.model.check_asserts(block=True)
+
+
+def test_fused_ba_back_to_back_calls_and_volume_refresh(gpu):
+    """Two advisor findings of round 3.  (i) FusedBA.prepare refreshes {n_kf, n_poses, n_cur_pop} through pinned staging with an
+    asynchronous copy: two global_BA calls issued back to back WITHOUT a host sync in between (filter_depth off, so nothing reads back)
+    must each train on the counts of their own call -- the second call's staging write may not overtake the first call's queued copy.
+    (ii) ActiveRaySamplerHIP.set_volume with the device spelled "cuda" (not "cuda:0") must refresh the pinned tensor IN PLACE, the
+    pointer a captured launch reads; a volume of another shape re-captures."""
+    from naruto_amd import trainer
+    from naruto_amd.active_ray_sampler import ActiveRaySamplerHIP
+    from naruto_amd.ba_loop import FusedBA
+    cfg = H.office_cfg(12, perturb=1.0)
+    cfg["mapping"].update(sample=256, min_pixels_cur=40, filter_depth=False, keyframe_every=5)
+    bound = torch.tensor(cfg["mapping"]["bound"])
+
+    def make(use_graph):
+        torch.manual_seed(5)
+        tr = trainer.MappingTrainer(cfg, bound, gpu, fused_adam=True)
+        store, current, poses, vol = _ba_scene(cfg, gpu, n_kf=8)
+        smp = ActiveRaySamplerHIP(config=cfg, num_uncert_sample=48, oversample_mul=4)
+        return FusedBA(tr, store, smp, max_poses=64, use_graph=use_graph), current, poses, vol
+    (a, cur, poses, vol), (b, _, _, _) = make(True), make(False)
+    b.trainer.model.load_state_dict(a.trainer.model.state_dict())
+    b.trainer.iter_state.copy_(a.trainer.iter_state)
+    fr = np.random.RandomState(9)
+    Hh, Ww = 48, 64
+    extra = {"direction": torch.from_numpy(fr.normal(size=(1, Hh, Ww, 3)).astype(np.float32)), "rgb": torch.from_numpy(fr.uniform(size=(1, Hh, Ww, 3)).astype(np.float32)),
+             "depth": torch.from_numpy(fr.uniform(0.5, 2.0, (1, Hh, Ww)).astype(np.float32)), "frame_id": torch.tensor([40])}
+    poses2 = torch.cat([poses, poses[-1:]], 0)
+    vol_gpu = torch.from_numpy(vol)
+    for ba, sync in ((a, False), (b, True)):
+        ba.sampler.set_volume(vol_gpu, "cuda")                         # the spelling without an index
+        ptr = ba.sampler._vol_dev.data_ptr()
+        ba.global_BA(cur, poses, n_iters=4, uncert_vol=vol_gpu * 0.5)  # refresh: same shape -> in place
+        assert ba.sampler._vol_dev.data_ptr() == ptr, "set_volume reallocated a volume of the same shape and device"
+        if sync:
+            torch.cuda.synchronize()
+        ba.store.add_keyframe(extra, filter_depth=False)
+        ba.global_BA(cur, poses2, n_iters=4, uncert_vol=vol_gpu * 0.25)
+        if sync:
+            torch.cuda.synchronize()
+        ba.global_BA(cur, poses2, n_iters=4, uncert_vol=vol_gpu)
+    torch.cuda.synchronize()
+    assert torch.equal(a.sampler._vol_dev, b.sampler._vol_dev)
+    for (n, p), (_, q) in zip(a.trainer.model.named_parameters(), b.trainer.model.named_parameters()):
+        assert torch.equal(p, q), f"parameter {n}: back-to-back graph replays != synchronised eager calls"
+    # another shape: a new tensor, and the graph is captured again
+    graphs = a.trainer._graphs
+    small = torch.from_numpy(vol[:-1].copy())
+    a.global_BA(cur, poses2, n_iters=2, uncert_vol=small)
+    assert a.trainer._graphs is not graphs, "the captured launch still reads the volume of the old shape"
 
 
 # --------------------------------------------------------------------------------------------- configs[2] at its own size
@@ -2654,6 +2705,26 @@ def test_bench_launch_line_at_two_ranks(gpu):
     assert ("rehearsal" in out["config"]) == (torch.cuda.device_count() < 2)
 
 
+def test_bench_self_launches_without_a_launcher(gpu):
+    """`python bench.py --gpus 2 ...` with NO WORLD_SIZE in the environment (how the driver issues its 1-GPU command): bench.py must turn
+    itself into the torch.distributed.run launch line instead of failing on the world-size check, and still print exactly one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    if torch.cuda.device_count() < 2:
+        env["NARUTO_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-kernels", "--no-cpu-baseline", "--workload", "office0_2048x43"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["rays_per_step"] == 4096 and "multi_gpu_note" in out
+
+
 def test_fused_adam_is_a_torch_optimizer(gpu):
     """FusedAdam behind the torch.optim.Optimizer surface the reference's driver and checkpointing use: param groups edited in place
     (a scheduler's lr change), a parameter without gradient skipped, add_param_group, state_dict -> load_state_dict into a fresh
@@ -2702,16 +2773,40 @@ def test_fused_adam_is_a_torch_optimizer(gpu):
         assert torch.equal(p, q), "restored optimiser diverges from the original"
     oa.zero_grad()
     assert all(p.grad is None for p in pa)
+    # interchange with torch.optim.Adam in BOTH directions (advisor, round 3): a torch checkpoint loads into FusedAdam (no 'lag' / 'naruto_step'
+    # in it: the count comes from the per-parameter 'step', a late-added or skipped parameter's lag from the difference) and FusedAdam's loads
+    # into torch (every state carries 'step'); all three then take the same further step
+    sd_t = copy.deepcopy(ob.state_dict())
+    pd = [torch.nn.Parameter(q.detach().clone()) for q in pb]
+    od = FusedAdam(groups(pd), betas=(0.9, 0.99))
+    od.add_param_group({'params': pd[2:], 'lr': 0.005})
+    od.load_state_dict(sd_t)
+    sd_f = copy.deepcopy(od.state_dict())
+    assert all('step' in st for st in sd_f['state'].values())
+    pe = [torch.nn.Parameter(q.detach().clone()) for q in pb]
+    oe = torch.optim.Adam(groups(pe), betas=(0.9, 0.99))
+    oe.add_param_group({'params': pe[2:], 'lr': 0.005})
+    oe.load_state_dict(sd_f)
+    for k in range(3):
+        g = [torch.randn(q.shape, device=gpu, generator=gen) for q in pb]
+        for ps in (pb, pd, pe):
+            for q, gg in zip(ps, g):
+                q.grad = gg.clone()
+        ob.step(); od.step(); oe.step()
+    for q, r, t in zip(pb, pd, pe):
+        assert torch.equal(q, t), "torch.optim.Adam restored from FusedAdam's state_dict diverges from the original torch optimiser"
+        H.assert_close(r, q, 2e-6, "FusedAdam restored from a torch.optim.Adam state_dict", rel=1e-5)
 
 
 def test_graphed_caller_iteration_equals_eager(gpu):
-    """naruto_amd.dropin.GraphedIteration: the caller's own loop body (model.forward -> get_loss_from_ret incl. the fused smoothness ->
+    """naruto_amd.graphed.GraphedIteration: the caller's own loop body (model.forward -> get_loss_from_ret incl. the fused smoothness ->
     loss.backward(retain_graph=True) -> FusedAdam steps, uncertainty grid every 5th) captured with torch's whole-iteration capture and
     replayed, against the same body launched eagerly: identical losses per iteration and bit-identical parameters after 12 iterations
     (two uncertainty-grid steps, its gradient accumulating over five replays in between).  The smoothness lattice is pinned to one
     placement on both sides (torch's device generator advances differently under replay)."""
     from naruto_amd import trainer
-    from naruto_amd.dropin import DropInCaller, GraphedIteration
+    from dropin_caller import DropInCaller
+    from naruto_amd.graphed import GraphedIteration
 
     off, jit = torch.tensor([0.3, 0.6, 0.1], device=gpu), torch.tensor([0.2, 0.9, 0.5], device=gpu)
 

@@ -9,7 +9,7 @@ cat gpurun_out/q_pytest.txt
 cd /tmp && export TMPDIR=/tmp
 for wl in office0_2048x128 office0_2048x43; do
   rm -rf $R/gpurun_out/q_kt
-  timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/q_kt -o kt -- python $R/bench.py --workload $wl --no-cpu-baseline --no-dropin --steps 50 > $R/gpurun_out/q_bench_$wl.json 2> $R/gpurun_out/q_kt.log
+  timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/q_kt -o kt -- python $R/bench.py --workload $wl --no-cpu-baseline --no-dropin --no-mapping-iter --steps 50 > $R/gpurun_out/q_bench_$wl.json 2> $R/gpurun_out/q_kt.log
   python $R/tools/prof_summary.py $(find $R/gpurun_out/q_kt -name "*.db" | head -1) > $R/gpurun_out/q_trace_$wl.txt; rm -rf $R/gpurun_out/q_kt
   echo "== $wl: $(grep -o '"ms_per_step": [0-9.]*' $R/gpurun_out/q_bench_$wl.json | head -1)"
   head -9 $R/gpurun_out/q_trace_$wl.txt | cut -c1-60,96-160

@@ -5,7 +5,7 @@ import torch
 from torch.profiler import profile, ProfilerActivity
 from naruto_amd import config as C, synthetic as syn
 from naruto_amd.field import NarutoFieldHIP
-from naruto_amd.dropin import DropInCaller
+from dropin_caller import DropInCaller
 
 dev = torch.device("cuda:0")
 cfg = C.office0_config(perturb=1.0, n_samples_d=117)

@@ -1,11 +1,11 @@
-"""Where the unchanged caller's iteration goes (naruto_amd/dropin.py = coslam.py:361-399): wall time of each piece with a device sync
+"""Where the unchanged caller's iteration goes (tools/dropin_caller.py = coslam.py:361-399): wall time of each piece with a device sync
 around it, and the same pieces without syncs (host-side issue time)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from naruto_amd import config as C, synthetic as syn
 from naruto_amd.field import NarutoFieldHIP
-from naruto_amd.dropin import DropInCaller
+from dropin_caller import DropInCaller
 
 dev = torch.device("cuda:0")
 cfg = C.office0_config(perturb=1.0, n_samples_d=117)

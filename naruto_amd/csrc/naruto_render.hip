@@ -242,6 +242,9 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_composite_fwd(uint32_t n
 //  7 sum_valid 1/(2(u+1e-9))      8 sum_valid log(u+1e-9)     9 min u (all rays)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool depth_valid(float d, float depth_trunc) { return d > 0.0f && d < depth_trunc; }
+// A NaN measured depth is a MISSING measurement: the loss code reads the depth through this, so that the masked products
+// (mask * td with mask = 0) are 0 and not NaN -- the reference lets the NaN poison every loss of the batch.
+__device__ __forceinline__ float measured_depth(float d) { return d == d ? d : 0.0f; }
 // scene_rep.py:249-250 writes rgb_missing into a BOOL tensor: invalid-depth rays keep weight 1 unless rgb_missing == 0
 __device__ __forceinline__ float rgb_weight(bool valid, float rgb_missing) { return valid ? 1.0f : (rgb_missing != 0.0f ? 1.0f : 0.0f); }
 
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_terms(uint32_t n_ra
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t n = blockIdx.x * kRaysPerBlock + wave;
     if (n >= n_rays) return;
-    const float td = target_d[n];
+    const float td = measured_depth(target_d[n]);
     const bool valid = depth_valid(td, depth_trunc);
     const float dm = td > 0.0f ? 1.0f : 0.0f;
     float fs = 0.0f, nfs = 0.0f, sl = 0.0f, nsdf = 0.0f;
@@ -409,7 +412,7 @@ __device__ __forceinline__ void composite_bwd_ray(float* ray_lds, uint32_t n, in
     float td = 0.0f, dm = 0.0f, c_fs = 0.0f, c_sdf = 0.0f;
     if constexpr (LOSS) {
         const LossScalars k = loss_scalars(la.sums, la.n_total, S);
-        td = la.target_d[n];
+        td = measured_depth(la.target_d[n]);
         const bool valid = depth_valid(td, la.depth_trunc);
         dm = td > 0.0f ? 1.0f : 0.0f;
         const float w = rgb_weight(valid, la.rgb_missing);

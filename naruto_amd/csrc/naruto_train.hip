@@ -75,7 +75,7 @@ __device__ __forceinline__ void loss_stage_ray(const LossStageArgs& a, const Ray
     const uint32_t S = a.S;
     const RayWeights rw = ray_weights(rs, S, a.trunc, a.sc_factor, lane);
     const RayOut o = ray_composite(rs, rw, n, S, a.white_bkgd, nullptr, lane);
-    const float td = a.target_d[n];
+    const float td = measured_depth(a.target_d[n]);
     const bool valid = depth_valid(td, a.depth_trunc);
     const float dm = td > 0.0f ? 1.0f : 0.0f;
     float fs = 0.0f, nfs = 0.0f, sl = 0.0f, nsdf = 0.0f;

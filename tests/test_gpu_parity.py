@@ -277,18 +277,14 @@ def test_render_fused_equals_the_three_operators(gpu, mode, n_samples_d, with_de
 
 
 # --------------------------------------------------------------------------------------------- bf16 MLP mode
+from oracle import spec_bf16 as BF          # the bf16 mode's arithmetic restated (rounding points cited against the kernels) + its bound to the exact network
+
+
 def _bf16_emulated_raw(ora, x):
-    """What the bf16 mode computes, restated with torch: operands of the three matrix layers rounded to bf16 (nearest even),
-    products and sums in fp32; encodings, the 32 -> 3 colour layer and the uncertainty sample untouched."""
-    bf = lambda t: t.bfloat16().float()
+    """raw and the sdf net's outputs of the bf16 mode: oracle/spec_bf16.py (pinned to the exact network by tests/test_oracle.py)."""
     with torch.no_grad():
-        feats, pos = S.hash_encode(x, ora.table, ora.meta), S.oneblob_encode(x, 16)
-        h = bf(torch.cat([feats, pos], -1)).double() @ bf(ora.sdf_w0).double().T
-        out = bf(torch.relu(h.float())).double() @ bf(ora.sdf_w1).double().T
-        c = bf(torch.cat([pos, out.float()[:, 1:]], -1)).double() @ bf(ora.col_w0).double().T
-        rgb = torch.relu(c.float()) @ ora.col_w1.T
-        unc = ora.query_color_sdf(x)[:, 4:5]
-        return torch.cat([rgb, out.float()[:, :1], unc], -1), out.float()
+        raw, out = BF.query_color_sdf_bf16(ora, x)
+    return raw, out
 
 
 @pytest.mark.parametrize("hash_size", [12, 16])
@@ -328,26 +324,6 @@ def test_bf16_mode_matches_its_restatement(gpu, hash_size):
     assert float(err[4]) <= 4e-6                              # the uncertainty channel does not pass through the MLPs
 
 
-class _BfLinear(torch.autograd.Function):
-    """y = bf16(x) . bf16(W)^T with fp32 accumulation; backward the way k_query_bwd_bf computes it: dx = bf16(g) . bf16(W),
-    dW = bf16(g)^T . bf16(x).  ``exact_dx``: the 32 -> 3 colour layer, whose forward and input gradient are fp32 VALU code."""
-
-    @staticmethod
-    def forward(ctx, x, W, exact):
-        bf = lambda t: t.bfloat16().float()
-        ctx.save_for_backward(x, W)
-        ctx.exact = exact
-        return (x.double() @ W.double().T).float() if exact else (bf(x).double() @ bf(W).double().T).float()
-
-    @staticmethod
-    def backward(ctx, g):
-        bf = lambda t: t.bfloat16().float()
-        x, W = ctx.saved_tensors
-        dx = (g.double() @ W.double()).float() if ctx.exact else (bf(g).double() @ bf(W).double()).float()
-        dW = (bf(g).double().T @ bf(x).double()).float()
-        return dx, dW, None
-
-
 def test_bf16_mode_backward_matches_its_restatement(gpu):
     """k_query_bwd_bf (everything in registers, transposes on the matrix core) against a torch restatement of its arithmetic:
     every matrix product with bf16-rounded operands and fp32 accumulation, ReLU masks from the bf16 forward.  All six gradients,
@@ -362,13 +338,7 @@ def test_bf16_mode_backward_matches_its_restatement(gpu):
     x = torch.from_numpy(np.concatenate([rs.uniform(0, 1, (2049, 3)), rs.uniform(-0.3, 1.3, (40, 3))]).astype(np.float32))
     cot = torch.from_numpy(rs.normal(size=(n, 5)).astype(np.float32))
     cot[rs.uniform(size=n) < 0.1] = 0.0
-    feats, pos = S.hash_encode(x, ora.table, ora.meta), S.oneblob_encode(x, 16)
-    h = _BfLinear.apply(torch.cat([feats, pos], -1), ora.sdf_w0, False)
-    out = _BfLinear.apply(torch.relu(h), ora.sdf_w1, False)
-    c = _BfLinear.apply(torch.cat([pos, out[:, 1:]], -1), ora.col_w0, False)
-    rgb = _BfLinear.apply(torch.relu(c), ora.col_w1, True)
-    unc = ora.query_color_sdf(x)[:, 4:5]
-    raw_o = torch.cat([rgb, out[:, :1], unc], -1)
+    raw_o, _ = BF.query_color_sdf_bf16(ora, x)
     (raw_o * cot).sum().backward()
     raw_h = m.query_color_sdf(x.to(gpu))
     (raw_h * cot.to(gpu)).sum().backward()

@@ -368,3 +368,34 @@ def test_oracle_extract_mesh_golden():
             assert (np.abs(o["colors"] - g["uncert_colors"]).max(-1) > 1e-6).mean() < 0.01       # a bin edge may flip with 1-ulp noise
     v, f = MN.marching_cubes(g["vol"], float(g["isolevel"]), 3.0, table)
     assert np.array_equal(v, g["verts_index"]) and np.array_equal(f, g["faces"])
+
+
+def test_bf16_restatement_is_pinned_to_the_exact_network():
+    """oracle/spec_bf16.py (what the GPU tests hold the bf16-MFMA kernels to) against an fp64 evaluation of the EXACT network (the reference's
+    decoder, decoder.py:29-41,99-116): the distance stays inside the bound derived from the half-ulp rounding of every bf16 operand
+    (bf16_forward_bound: absolute-value propagation, no cancellation assumed), elementwise -- and is, as random signs make it, an order of
+    magnitude inside; the uncertainty channel, which does not pass through the MLPs, is untouched.  The restatement's gradients are finite
+    and close to the exact network's (bounded relative distance: the weight gradients see rounded cotangents and rounded inputs)."""
+    from oracle import spec_bf16 as BF
+    cfg = H.office_cfg(12)
+    ora = H.make_oracle(cfg, 0.3, 61)
+    rs = np.random.RandomState(61)
+    x = torch.from_numpy(np.concatenate([rs.uniform(0, 1, (1500, 3)), rs.uniform(-0.4, 1.4, (250, 3))]).astype(np.float32))
+    raw, out = BF.query_color_sdf_bf16(ora, x)
+    bound, exact = BF.bf16_forward_bound(ora, x)
+    err = (raw[:, :4].detach().double() - exact).abs()
+    slack = 1e-6 * exact.abs() + 1e-7                                     # fp32 accumulation of the restatement against the fp64 evaluation
+    assert bool((err <= bound + slack).all()), f"outside the derived bound: worst ratio {float((err / (bound + slack)).max()):.3f}"
+    assert float((err / (bound + slack)).max()) < 0.5, "the worst-case bound should be loose by the cancellation of ~80 random-sign terms"
+    assert float(err.max()) <= 1e-2 * float(exact.abs().max())
+    assert torch.equal(raw[:, 4], ora.query_color_sdf(x)[:, 4]), "the uncertainty channel does not pass through the MLPs"
+    cot = torch.from_numpy(rs.normal(size=(x.shape[0], 5)).astype(np.float32))
+    (raw * cot).sum().backward()
+    g_bf = {k: v.grad.clone() for k, v in (("sdf_w0", ora.sdf_w0), ("sdf_w1", ora.sdf_w1), ("col_w0", ora.col_w0), ("col_w1", ora.col_w1), ("table", ora.table))}
+    ora.zero_grad()
+    (ora.query_color_sdf(x) * cot).sum().backward()
+    for k, p_ in (("sdf_w0", ora.sdf_w0), ("sdf_w1", ora.sdf_w1), ("col_w0", ora.col_w0), ("col_w1", ora.col_w1), ("table", ora.table)):
+        a, b = g_bf[k].double(), p_.grad.double()
+        assert bool(torch.isfinite(a).all())
+        rel = float((a - b).norm() / b.norm())
+        assert rel < 0.1, f"bf16 restatement, gradient {k}: relative distance {rel:.3e} to the exact network"      # measured 0.5 - 5 % (ReLU masks of the bf16 forward, rounded cotangents)

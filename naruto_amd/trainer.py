@@ -489,12 +489,15 @@ class MappingTrainer:
                 seg, ts = st['segments'], st['ts']
                 seg['fwd'].replay()
                 parallel.allreduce_loss_sums(ts.sums, self.group)
-                seg['bwd'].replay()
+                seg['bwd_mlp'].replay()
+                pending = parallel.all_reduce_sum(ts.grad_bucket_mlp, self.group, async_op=True)      # under the scatter
+                seg['bwd_table'].replay()
                 if self.table_shard is not None:
-                    parallel.all_reduce_sum(ts.grad_bucket_mlp, self.group)
                     parallel.reduce_scatter_sum(ts.grad_bucket_table, self.table_shard["p_slice"].grad, self.group)
                 else:
-                    parallel.all_reduce_sum(ts.flat_grad, self.group)
+                    parallel.all_reduce_sum(ts.grad_bucket_table, self.group)
+                if pending is not None:
+                    pending.wait()
                 if uncert_step:
                     parallel.allreduce_grads([self.model.uncert_grid], self.group)
                 seg['opt'][1 if uncert_step else 0].replay()
@@ -608,10 +611,18 @@ class MappingTrainer:
                 ts.run_forward(*args)
             pool = g.pool()
             seg['fwd'] = g
+            # the backward as TWO segments split at the MLP / table boundary (as the eager path does): the 20 KB bucket of MLP weight
+            # gradients is complete after the first and is all-reduced asynchronously WHILE the second -- the table scatter, the longest
+            # kernel of the step -- replays; the table bucket follows it.  Same kernels in the same order as the one-piece backward:
+            # same bits (tests/test_gpu_parity.py::test_two_rank_data_parallel_training compares against the single-process trajectory).
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool, capture_error_mode=cap_mode), torch.no_grad():
-                ts.run_backward()
-            seg['bwd'] = g
+                ts.run_backward(phase=1)
+            seg['bwd_mlp'] = g
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, capture_error_mode=cap_mode), torch.no_grad():
+                ts.run_backward(phase=2)
+            seg['bwd_table'] = g
             for name, p in self.model._params().items():
                 p.grad = ts.grads[name]
             for variant in (False, True):

@@ -10,7 +10,7 @@ i=0
 while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
-  timeout 150 rocprofv3 --kernel-trace --pmc $line -d $R/gpurun_out/${TAG}_sq_$i -o pmc -- python $R/bench.py --no-graph --no-cpu-baseline --no-kernels --no-dropin --steps 10 --warmup 3 ${BENCH_ARGS:-} > /dev/null 2> $R/gpurun_out/${TAG}_sq_$i.log
+  timeout 150 rocprofv3 --kernel-trace --pmc $line -d $R/gpurun_out/${TAG}_sq_$i -o pmc -- python $R/bench.py --no-graph --no-cpu-baseline --no-kernels --no-dropin --no-mapping-iter --steps 10 --warmup 3 ${BENCH_ARGS:-} > /dev/null 2> $R/gpurun_out/${TAG}_sq_$i.log
   python $R/tools/prof_summary.py $(find $R/gpurun_out/${TAG}_sq_$i -name "*.db" | head -1) | grep "k_query_fwd\|k_query_bwd\|k_hash_scatter" | grep -v "calls" >> $R/gpurun_out/${TAG}_sq.txt
   rm -rf $R/gpurun_out/${TAG}_sq_$i
 done <<'LIST'

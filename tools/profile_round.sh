@@ -13,11 +13,11 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $R/gpurun_out
 P=$R/gpurun_out/${TAG}_${W}
-timeout 900 rocprofv3 --kernel-trace -d ${P}_kt -o kt -- python $R/bench.py --workload $W --steps $STEPS --warmup 5 --no-cpu-baseline --no-dropin > ${P}_bench_under_rocprof.json 2> ${P}_kt.log
+timeout 900 rocprofv3 --kernel-trace -d ${P}_kt -o kt -- python $R/bench.py --workload $W --steps $STEPS --warmup 5 --no-cpu-baseline --no-dropin --no-mapping-iter > ${P}_bench_under_rocprof.json 2> ${P}_kt.log
 python $R/tools/prof_summary.py $(find ${P}_kt -name "*.db" | head -1) > ${P}_kernel_trace.txt
 rm -rf ${P}_kt
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --kernel-trace --pmc $c -d ${P}_pmc_$c -o pmc -- python $R/bench.py --workload $W --no-graph --no-cpu-baseline --no-dropin --steps 6 --warmup 2 > /dev/null 2> ${P}_pmc_$c.log
+  timeout 900 rocprofv3 --kernel-trace --pmc $c -d ${P}_pmc_$c -o pmc -- python $R/bench.py --workload $W --no-graph --no-cpu-baseline --no-dropin --no-mapping-iter --steps 6 --warmup 2 > /dev/null 2> ${P}_pmc_$c.log
   python $R/tools/prof_summary.py $(find ${P}_pmc_$c -name "*.db" | head -1) > ${P}_pmc_$c.txt
   rm -rf ${P}_pmc_$c
 done

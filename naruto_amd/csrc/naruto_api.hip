@@ -573,11 +573,11 @@ int naruto_query_fwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
     // workgroup per CU (one weight image, the waves walk their tiles: 76.5 -> 69.0 us at 4 096 tiles); below that the smaller forms spread the tiles better
     // (1 376 tiles: 42.2 us as 2-wave workgroups, 45.6 as 8-wave ones).  NARUTO_DEBUG_FWD_SHAPE=0: the old shapes everywhere (A/B timing).
     static const bool big_wg_on = getenv("NARUTO_DEBUG_FWD_SHAPE") == nullptr || atoi(getenv("NARUTO_DEBUG_FWD_SHAPE")) != 0;
-    const bool big_wg = big_wg_on && kFwdSplit && !bf && n_tiles >= cu_count(f) * 8u;
+    const bool big_wg = big_wg_on && kFwdSplit && n_tiles >= cu_count(f) * 8u;
 #define NARUTO_LAUNCH_FWD(KERNEL, COLOR)                                                                                                                      \
     do {                                                                                                                                                        \
         if (small_wg) hipLaunchKernelGGL((KERNEL<COLOR, 128>), dim3((n_tiles + 1u) / 2u), dim3(128), 0, st, f->lt, f->ut, f->bt, pp, ps, M, raw, sdf_uncert, geo, feat_save, none); \
-        else if (big_wg) hipLaunchKernelGGL((k_query_fwd<COLOR, 512>), dim3(cu_count(f)), dim3(512), 0, st, f->lt, f->ut, f->bt, pp, ps, M, raw, sdf_uncert, geo, feat_save, none); \
+        else if (big_wg) hipLaunchKernelGGL((KERNEL<COLOR, 512>), dim3(cu_count(f)), dim3(512), 0, st, f->lt, f->ut, f->bt, pp, ps, M, raw, sdf_uncert, geo, feat_save, none); \
         else hipLaunchKernelGGL((KERNEL<COLOR, 256>), dim3(blocks), dim3(256), 0, st, f->lt, f->ut, f->bt, pp, ps, M, raw, sdf_uncert, geo, feat_save, none);  \
     } while (0)
     if (color && bf) NARUTO_LAUNCH_FWD(k_query_fwd_bf, true);
@@ -824,6 +824,7 @@ int launch_train_query(const NarutoField* f, const NarutoParams* p, const Naruto
     if (f->desc.mlp_mode == NARUTO_MLP_BF16) {
         if (walk) hipLaunchKernelGGL((k_query_fwd_bf<true, 256, true>), dim3(blocks), dim3(256), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
         else if (small_wg) hipLaunchKernelGGL((k_query_fwd_bf<true, 128>), dim3((n_tiles + 1u) / 2u), dim3(128), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
+        else if (kFwdSplit && n_tiles >= cu_count(f) * 8u) hipLaunchKernelGGL((k_query_fwd_bf<true, 512>), dim3(cu_count(f)), dim3(512), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
         else hipLaunchKernelGGL((k_query_fwd_bf<true, 256>), dim3(blocks), dim3(256), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
     } else {
         if (walk) hipLaunchKernelGGL((k_query_fwd<true, 256, true>), dim3(blocks), dim3(256), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);

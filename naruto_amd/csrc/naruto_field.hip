@@ -652,57 +652,11 @@ __device__ __forceinline__ u32x4_t pack8_acc(const f32x16& a, int r0) {
     return pack8(v);
 }
 
-template <bool COLOR, bool MASK = false>
-__device__ __forceinline__ void fwd_tile_bf(const FwdLdsBf& L, const LevelTab& lt, const float2* __restrict__ table, float x, float y, float z,
-                                            float* __restrict__ feat_save, float* __restrict__ geo, uint32_t M, uint32_t mA, uint32_t mB, int lane, FwdTileOut& out,
-                                            bool live = true) {
+// the rest of a bf16 tile once the hash part of sdf layer 0 sits in hA / hB: OneBlob K blocks, sdf layer 1, the colour net
+template <bool COLOR>
+__device__ __forceinline__ void fwd_tail_bf(const FwdLdsBf& L, f32x16& hA, f32x16& hB, f32x16& cA, f32x16& cB, float x, float y, float z, float* __restrict__ geo, uint32_t M,
+                                            uint32_t mA, uint32_t mB, int lane, FwdTileOut& out) {
     const int hh = lane >> 5;
-        f32x16 hA = zero16(), hB = zero16(), cA = zero16(), cB = zero16();
-        float la = live ? 1.0f : 0.0f, lb = la;                 // as fwd_tile: with MASK dead points issue no gathers and save no features
-        if constexpr (MASK) swap32(la, lb);
-        const bool liveA = MASK ? la != 0.0f : true, liveB = MASK ? lb != 0.0f : true;
-        float xa = x, xb = x, ya = y, yb = y, za = z, zb = z;
-        swap32(xa, xb); swap32(ya, yb); swap32(za, zb);        // xa = x of points (0..31 | 0..31), xb = (32..63 | 32..63)
-        static_assert(8 % kGatherGroup == 0, "a K block of eight levels is gathered in whole groups");
-#pragma unroll 1
-        for (int kb = 0; kb < 2; ++kb) {
-            float fa[8], fb[8];
-#pragma unroll
-            for (int e0 = 0; e0 < 8; e0 += kGatherGroup) {
-            HalfCorners ha[kGatherGroup], hb[kGatherGroup];
-#pragma unroll
-            for (int g = 0; g < kGatherGroup; ++g) {
-                ha[g] = hash_level_half_index(lt, 8 * kb + e0 + g, xa, ya, za, (uint32_t)hh);
-                hb[g] = hash_level_half_index(lt, 8 * kb + e0 + g, xb, yb, zb, (uint32_t)hh);
-            }
-            float2 va[kGatherGroup][4], vb[kGatherGroup][4];
-#pragma unroll
-            for (int g = 0; g < kGatherGroup; ++g) {
-                hash_level_half_load(lt, 8 * kb + e0 + g, table, ha[g], va[g], liveA);
-                hash_level_half_load(lt, 8 * kb + e0 + g, table, hb[g], vb[g], liveB);
-            }
-#pragma unroll
-            for (int g = 0; g < kGatherGroup; ++g) {
-                const int e = e0 + g;
-                const int T = 8 * kb + e;
-                const float2 pa = hash_level_half_blend(ha[g], va[g]);
-                const float2 pb = hash_level_half_blend(hb[g], vb[g]);
-                float ua = pa.x, wa = pa.y, ub = pb.x, wb = pb.y;
-                swap32(ua, wa);
-                swap32(ub, wb);
-                fa[e] = ua + wa;                      // feature hh of level T of point j (tile A) / j + 32 (tile B), fp32
-                fb[e] = ub + wb;
-                if (feat_save != nullptr) {
-                    char* __restrict__ fs = reinterpret_cast<char*>(feat_save + (size_t)T * M * 2u);
-                    if (mA < M && liveA) *reinterpret_cast<float*>(fs + ((mA * 2u + (uint32_t)hh) << 2)) = fa[e];
-                    if (mB < M && liveB) *reinterpret_cast<float*>(fs + ((mB * 2u + (uint32_t)hh) << 2)) = fb[e];
-                }
-            }
-            }
-            const u32x4_t w = L.s0[kb * 64 + lane];
-            hA = mfma16(w, pack8(fa), hA);
-            hB = mfma16(w, pack8(fb), hB);
-        }
         const bool blob_fast = __all(oneblob_sparse_ok(x) && oneblob_sparse_ok(y) && oneblob_sparse_ok(z));
         static_for<0, 3>([&](auto dc) {
             constexpr int D = decltype(dc)::value;
@@ -764,6 +718,81 @@ __device__ __forceinline__ void fwd_tile_bf(const FwdLdsBf& L, const LevelTab& l
         }
 }
 
+template <bool COLOR, bool MASK = false>
+__device__ __forceinline__ void fwd_tile_bf(const FwdLdsBf& L, const LevelTab& lt, const float2* __restrict__ table, float x, float y, float z,
+                                            float* __restrict__ feat_save, float* __restrict__ geo, uint32_t M, uint32_t mA, uint32_t mB, int lane, FwdTileOut& out,
+                                            bool live = true) {
+    const int hh = lane >> 5;
+        f32x16 hA = zero16(), hB = zero16(), cA = zero16(), cB = zero16();
+        float la = live ? 1.0f : 0.0f, lb = la;                 // as fwd_tile: with MASK dead points issue no gathers and save no features
+        if constexpr (MASK) swap32(la, lb);
+        const bool liveA = MASK ? la != 0.0f : true, liveB = MASK ? lb != 0.0f : true;
+        float xa = x, xb = x, ya = y, yb = y, za = z, zb = z;
+        swap32(xa, xb); swap32(ya, yb); swap32(za, zb);        // xa = x of points (0..31 | 0..31), xb = (32..63 | 32..63)
+        static_assert(8 % kGatherGroup == 0, "a K block of eight levels is gathered in whole groups");
+#pragma unroll 1
+        for (int kb = 0; kb < 2; ++kb) {
+            float fa[8], fb[8];
+#pragma unroll
+            for (int e0 = 0; e0 < 8; e0 += kGatherGroup) {
+            HalfCorners ha[kGatherGroup], hb[kGatherGroup];
+#pragma unroll
+            for (int g = 0; g < kGatherGroup; ++g) {
+                ha[g] = hash_level_half_index(lt, 8 * kb + e0 + g, xa, ya, za, (uint32_t)hh);
+                hb[g] = hash_level_half_index(lt, 8 * kb + e0 + g, xb, yb, zb, (uint32_t)hh);
+            }
+            float2 va[kGatherGroup][4], vb[kGatherGroup][4];
+#pragma unroll
+            for (int g = 0; g < kGatherGroup; ++g) {
+                hash_level_half_load(lt, 8 * kb + e0 + g, table, ha[g], va[g], liveA);
+                hash_level_half_load(lt, 8 * kb + e0 + g, table, hb[g], vb[g], liveB);
+            }
+#pragma unroll
+            for (int g = 0; g < kGatherGroup; ++g) {
+                const int e = e0 + g;
+                const int T = 8 * kb + e;
+                const float2 pa = hash_level_half_blend(ha[g], va[g]);
+                const float2 pb = hash_level_half_blend(hb[g], vb[g]);
+                float ua = pa.x, wa = pa.y, ub = pb.x, wb = pb.y;
+                swap32(ua, wa);
+                swap32(ub, wb);
+                fa[e] = ua + wa;                      // feature hh of level T of point j (tile A) / j + 32 (tile B), fp32
+                fb[e] = ub + wb;
+                if (feat_save != nullptr) {
+                    char* __restrict__ fs = reinterpret_cast<char*>(feat_save + (size_t)T * M * 2u);
+                    if (mA < M && liveA) *reinterpret_cast<float*>(fs + ((mA * 2u + (uint32_t)hh) << 2)) = fa[e];
+                    if (mB < M && liveB) *reinterpret_cast<float*>(fs + ((mB * 2u + (uint32_t)hh) << 2)) = fb[e];
+                }
+            }
+            }
+            const u32x4_t w = L.s0[kb * 64 + lane];
+            hA = mfma16(w, pack8(fa), hA);
+            hB = mfma16(w, pack8(fb), hB);
+        }
+        fwd_tail_bf<COLOR>(L, hA, hB, cA, cB, x, y, z, geo, M, mA, mB, lane, out);
+}
+
+// phase-split form of a FULL bf16 tile (see fwd_tile_split): the same gather phase, then the two hash K blocks from the slab
+template <bool COLOR, bool MASK>
+__device__ __forceinline__ void fwd_tile_split_bf(const FwdLdsBf& L, FwdSlab& sl, const LevelTab& lt, const float2* __restrict__ table, float x, float y, float z,
+                                                  float* __restrict__ feat_save, float* __restrict__ geo, uint32_t M, uint32_t mA, uint32_t mB, int lane, FwdTileOut& out,
+                                                  bool live = true) {
+    if constexpr (NARUTO_FWD_GATHER_PRIO != 0) __builtin_amdgcn_s_setprio(NARUTO_FWD_GATHER_PRIO);
+    fwd_gather_tile<MASK>(lt, table, x, y, z, feat_save, M, mA, mB, lane, sl, live);
+    if constexpr (NARUTO_FWD_GATHER_PRIO != 0) __builtin_amdgcn_s_setprio(0);
+    f32x16 hA = zero16(), hB = zero16(), cA = zero16(), cB = zero16();
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        float fa[8], fb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { fa[e] = sl.feat[8 * kb + e][0][lane]; fb[e] = sl.feat[8 * kb + e][1][lane]; }
+        const u32x4_t w = L.s0[kb * 64 + lane];
+        hA = mfma16(w, pack8(fa), hA);
+        hB = mfma16(w, pack8(fb), hB);
+    }
+    fwd_tail_bf<COLOR>(L, hA, hB, cA, cB, x, y, z, geo, M, mA, mB, lane, out);
+}
+
 // 2, not 3, waves per SIMD: at 3 (<= 168 registers) the kernel spills 65 registers and the forward takes 65 us instead of 51
 #ifndef NARUTO_FWD_BF_MINWAVES
 #define NARUTO_FWD_BF_MINWAVES 2
@@ -773,10 +802,11 @@ __global__ __launch_bounds__(NT, NARUTO_FWD_BF_MINWAVES) void k_query_fwd_bf(Lev
                                                       uint32_t M, float* __restrict__ raw, float* __restrict__ sdf_uncert,
                                                       float* __restrict__ geo, float* __restrict__ feat_save, EarlyExit ee) {
     __shared__ FwdLdsBf L;
+    __shared__ FwdSlab slabs[kFwdSplit ? NT / 64 : 1];
     stage_fwd_weights_bf<NT>(L, p, threadIdx.x);
     __syncthreads();
     constexpr uint32_t kW = NT / 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = kFwdSplit ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);
     const int hh = lane >> 5, j = lane & 31;
     const uint32_t n_tiles = (M + 63u) / 64u;
     const float2* __restrict__ table = reinterpret_cast<const float2*>(p.table);
@@ -795,7 +825,10 @@ __global__ __launch_bounds__(NT, NARUTO_FWD_BF_MINWAVES) void k_query_fwd_bf(Lev
         const float u = live ? uncert_sample(ut, p.uncert_grid, x, y, z) : 0.0f;
 
         FwdTileOut to;
-        fwd_tile_bf<COLOR, EE>(L, lt, table, x, y, z, feat_save, geo, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
+        if (kFwdSplit && tile * 64u + 63u < M)
+            fwd_tile_split_bf<COLOR, EE>(L, slabs[kFwdSplit ? wave : 0], lt, table, x, y, z, feat_save, geo, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
+        else
+            fwd_tile_bf<COLOR, EE>(L, lt, table, x, y, z, feat_save, geo, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
         if (!live) { to.rgb[0] = 0.0f; to.rgb[1] = 0.0f; to.rgb[2] = 0.0f; to.sdf = 0.0f; }
         const float sdf = to.sdf;
         if (sdf_uncert != nullptr && valid) reinterpret_cast<float2*>(sdf_uncert)[m] = make_float2(sdf, u);

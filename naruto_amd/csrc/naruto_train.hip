@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
                                                            float* __restrict__ feat_save, EarlyExit ee, LossStageArgs a, uint32_t n_fwd_blocks) {
     using Lds = std::conditional_t<BF, FwdLdsBf, FwdLds>;
     __shared__ Lds L;
-    __shared__ FwdSlab slabs[(kFwdSplit && !BF) ? kRaysPerBlock : 1];
+    __shared__ FwdSlab slabs[kFwdSplit ? kRaysPerBlock : 1];
     __shared__ double red[4];
     __shared__ float terms[kRaysPerBlock][10];
     extern __shared__ float ray_lds[];
@@ -205,7 +205,8 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
                 const float u = live ? uncert_sample(ut, p.uncert_grid, x, y, z) : 0.0f;
                 FwdTileOut to;
                 const bool live_out = live;
-                if constexpr (BF) fwd_tile_bf<true, true>(L, lt, table, x, y, z, feat_save, nullptr, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
+                if constexpr (BF && kFwdSplit) fwd_tile_split_bf<true, true>(L, slabs[wave], lt, table, x, y, z, feat_save, nullptr, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
+                else if constexpr (BF) fwd_tile_bf<true, true>(L, lt, table, x, y, z, feat_save, nullptr, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
                 else if constexpr (kFwdSplit) fwd_tile_split<true, true>(L, slabs[wave], lt, table, x, y, z, feat_save, nullptr, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);      // M = n_rays * 64 tpr: every tile is full
                 else fwd_tile<true, true>(L, lt, table, x, y, z, feat_save, nullptr, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
                 if (!live_out) { to.rgb[0] = 0.0f; to.rgb[1] = 0.0f; to.rgb[2] = 0.0f; to.sdf = 0.0f; }

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256, 2) void k_render_fwd(LevelTab lt, UncertTab ut
     if constexpr (BF) stage_fwd_weights_bf<256>(L, p, threadIdx.x);
     else stage_fwd_weights<256>(L, p, threadIdx.x);
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t S = a.nu + a.nr;
     const float2* __restrict__ table = reinterpret_cast<const float2*>(p.table);
     const RayScratch rs = ray_scratch(ray_lds, wave, S);
@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256, 2) void k_render_fwd(LevelTab lt, UncertTab ut
             const float z = __fdiv_rn(__fsub_rn(pz, bt.bmin[2]), bt.bext[2]);
             const float u = uncert_sample(ut, p.uncert_grid, x, y, z);
             FwdTileOut to;
+            // (the single-chain tile: this kernel's rays may take up to 128 KB of dynamic LDS at 1 024 samples, which leaves no room for feature slabs)
             if constexpr (BF) fwd_tile_bf<true>(L, lt, table, x, y, z, nullptr, nullptr, 0u, 0u, 0u, lane, to);
             else fwd_tile<true>(L, lt, table, x, y, z, nullptr, nullptr, 0u, 0u, 0u, lane, to);
             if (valid) {
@@ -130,6 +131,7 @@ template <bool BF>
 __global__ __launch_bounds__(256, NARUTO_RENDER_PACKED_MINWAVES) void k_render_fwd_packed(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, RenderArgs a) {
     using Lds = std::conditional_t<BF, FwdLdsBf, FwdLds>;
     __shared__ Lds L;
+    __shared__ FwdSlab slabs[kFwdSplit ? 4 : 1];
     extern __shared__ float ray_lds[];
     if constexpr (BF) stage_fwd_weights_bf<256>(L, p, threadIdx.x);
     else stage_fwd_weights<256>(L, p, threadIdx.x);
@@ -166,7 +168,10 @@ __global__ __launch_bounds__(256, NARUTO_RENDER_PACKED_MINWAVES) void k_render_f
             const float z = __fdiv_rn(__fsub_rn(pz, bt.bmin[2]), bt.bext[2]);
             const float u = uncert_sample(ut, p.uncert_grid, x, y, z);
             FwdTileOut to;
-            if constexpr (BF) fwd_tile_bf<true>(L, lt, table, x, y, z, nullptr, nullptr, 0u, 0u, 0u, lane, to);
+            // (nothing is saved here, so the phase-split form also takes tiles whose tail lanes are padding)
+            if constexpr (BF && kFwdSplit) fwd_tile_split_bf<true, false>(L, slabs[wave], lt, table, x, y, z, nullptr, nullptr, 0u, 0u, 0u, lane, to);
+            else if constexpr (BF) fwd_tile_bf<true>(L, lt, table, x, y, z, nullptr, nullptr, 0u, 0u, 0u, lane, to);
+            else if constexpr (kFwdSplit) fwd_tile_split<true, false>(L, slabs[wave], lt, table, x, y, z, nullptr, nullptr, 0u, 0u, 0u, lane, to);
             else fwd_tile<true>(L, lt, table, x, y, z, nullptr, nullptr, 0u, 0u, 0u, lane, to);
             if (valid) {
                 rs.c0[s] = to.rgb[0]; rs.c1[s] = to.rgb[1]; rs.c2[s] = to.rgb[2];

@@ -440,6 +440,9 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
  * with early termination when S % 64 == 0 -- and then with the loss stage riding in the same launch, k_query_fwd_loss); t->z_vals
  * must hold a previous forward's depths. */
 int naruto_debug_train_query_fwd(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, void* stream);
+/* profiling: a device buffer of 16 x (ray workgroups) uint64 into which the packed training forward (k_query_fwd_loss_packed) stamps the
+ * shader clock at the start and behind each step of every workgroup's first chunk (tools/fwd_timeline.py); NULL switches it off. */
+int naruto_debug_fwd_timeline(void* device_buffer);
 /* profiling (bench.py's roofline): k_hash_scatter_lds alone, over the point list the preceding naruto_train_backward left in the
  * workspace, in the launch shape of the iteration; writes the scatter's partial tables only (no gradient, no parameter). */
 int naruto_debug_train_scatter(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, void* stream);

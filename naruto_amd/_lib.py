@@ -176,6 +176,7 @@ SIGNATURES = {
     "naruto_debug_random_lines": (_I, [_V, C.c_uint64, C.c_uint32, _V, C.POINTER(C.c_uint64), _V]),
     "naruto_decoder_fwd": (_I, [_V, C.POINTER(NarutoParams), C.c_uint32, C.c_int, _V, _V, _V, _V]),
     "naruto_debug_train_query_fwd": (_I, [_V, C.POINTER(NarutoParams), C.POINTER(NarutoTrainStep), _V]),
+    "naruto_debug_fwd_timeline": (_I, [_V]),
     "naruto_debug_train_scatter": (_I, [_V, C.POINTER(NarutoParams), C.POINTER(NarutoTrainStep), _V]),
     "naruto_render_fwd": (_I, [_V, C.POINTER(NarutoParams), C.POINTER(NarutoRender), _V]),
     "naruto_train_backward": (_I, [_V, C.POINTER(NarutoParams), C.POINTER(NarutoTrainStep), C.POINTER(NarutoGrads), _U32,

@@ -35,6 +35,7 @@ struct NarutoField {
 namespace {
 
 thread_local char g_err[512] = "";
+unsigned long long* g_fwd_timeline = nullptr;       // profiling: naruto_debug_fwd_timeline
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -806,6 +807,44 @@ int launch_train_query(const NarutoField* f, const NarutoParams* p, const Naruto
         if (blocks > cu_count(f) * 4u) blocks = cu_count(f) * 4u;
     }
     static const bool no_fuse = getenv("NARUTO_DEBUG_NO_FUSED_LOSS_STAGE") != nullptr;      // A/B knob: the two launches instead
+    // the packed forward (k_query_fwd_loss_packed: only the samples a consumer can see, packed across rays; any samples-per-ray count).
+    // NARUTO_FWD_PACKED=0: the depth-ordered walk / the flat launch + k_loss_stage instead (A/B timing; losses and gradients agree to the
+    // distance between OneBlob's closed and dense forms, ~1e-6: which form a point gets depends on the tile it shares)
+    // Where: rays the depth-ordered walk cannot take (S not a multiple of 64, or a single tile: the shipped 32 + 11 sampling) -- there it replaces the
+    // flat launch over ALL samples + k_loss_stage (2 048 x 43: 41.7 + 8.0 us -> 44.5 us).  For S = 64 k the walk stays: it overlaps one wave's
+    // gathers with another's matrix chain, while the packed workgroup's steps are separated by barriers (2 048 x 128: walk 64.6 us, packed 66.7;
+    // per-step timeline: tools/fwd_timeline.py, profiles/r04_fwd_timeline.txt).  NARUTO_FWD_PACKED=2 forces it everywhere.
+    static const int packed_mode = getenv("NARUTO_FWD_PACKED") == nullptr ? 1 : atoi(getenv("NARUTO_FWD_PACKED"));
+    const bool packed_on = packed_mode == 2 || (packed_mode == 1 && (S % 64u != 0u || S <= 64u));
+    if (loss != nullptr && packed_on && !no_fuse && kFwdSplit && S <= 4095u && N >= 1u) {
+        // rows (of four rays) a workgroup holds at a time: as many as the LDS next to the weights and the eight feature slabs takes, at most three
+        const size_t lds_free = (size_t)160u * 1024u - sizeof(FwdLds) - (size_t)kPackTiles * sizeof(FwdSlab) - sizeof(PackPts) - 2048u;
+        uint32_t rows = kPackMaxRows;
+        while (rows > 0u && packed_lds_bytes(rows, S) > lds_free) --rows;
+        if (rows > 0u) {
+            static size_t attr_bytes = 0;
+            const size_t need = packed_lds_bytes(rows, S);
+            if (need > attr_bytes) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_fwd_loss_packed<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_free) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_fwd_loss_packed<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_free) != hipSuccess)
+                    return fail(NARUTO_ERR_LAUNCH, "query_fwd_loss_packed: cannot reserve %zu bytes of LDS: %s", lds_free, hipGetErrorString(hipGetLastError()));
+                attr_bytes = lds_free;
+            }
+            const uint32_t n_rows = (N + (uint32_t)kRaysPerBlock - 1u) / (uint32_t)kRaysPerBlock;
+            const uint32_t pblocks = n_rows < cu_count(f) ? n_rows : cu_count(f);            // one 8-wave workgroup per CU, rows spread evenly over them
+            EarlyExit pe{};
+            pe.target_d = t->target_d;
+            pe.trunc_sc = f->desc.trunc * f->desc.sc_factor;
+            if (f->desc.mlp_mode == NARUTO_MLP_BF16)
+                hipLaunchKernelGGL(k_query_fwd_loss_packed<true>, dim3(pblocks + loss->n_tv_blocks), dim3(64 * kPackWaves), need, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw,
+                                   t->feat_save, pe, *loss, pblocks, rows, g_fwd_timeline);
+            else
+                hipLaunchKernelGGL(k_query_fwd_loss_packed<false>, dim3(pblocks + loss->n_tv_blocks), dim3(64 * kPackWaves), need, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw,
+                                   t->feat_save, pe, *loss, pblocks, rows, g_fwd_timeline);
+            if (fused != nullptr) *fused = true;
+            return check_launch("query_fwd_loss_packed");
+        }
+    }
     if (loss != nullptr && ee.tiles_per_ray != 0u && ray_scratch_bytes(S) <= kFwdLossMaxRayLds && !no_fuse) {
         if (int rc = ray_lds_attr()) return rc;
         if (f->desc.mlp_mode == NARUTO_MLP_BF16)
@@ -937,6 +976,13 @@ int naruto_train_finalize(const NarutoField* f, const NarutoTrainStep* t, void* 
     hipLaunchKernelGGL(k_loss_finalize_total, dim3(1), dim3(64), 0, (hipStream_t)stream, t->sums, t->n_rays_total ? t->n_rays_total : t->n_rays, S, t->losses,
                        t->loss_weights, t->min_uncert_running);
     return check_launch("loss_finalize_total");
+}
+
+// profiling: device buffer of 16 x (workgroups) uint64 the packed training forward stamps s_memtime into (NULL: off) -- the per-step timeline of
+// k_query_fwd_loss_packed's first chunk, see its header
+int naruto_debug_fwd_timeline(void* device_buffer) {
+    g_fwd_timeline = static_cast<unsigned long long*>(device_buffer);
+    return NARUTO_OK;
 }
 
 int naruto_debug_train_query_fwd(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, void* stream) {

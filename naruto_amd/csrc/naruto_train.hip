@@ -236,6 +236,301 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
 template __global__ void k_query_fwd_loss<false>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t);
 template __global__ void k_query_fwd_loss<true>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t);
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// PACKED training forward (round 4): field query + loss stage for rays of ANY sample count, evaluating only the samples some consumer
+// can see, packed across rays into full 64-sample tiles.
+//
+// What a consumer can see of a ray ends at max(first sign change of the sdf, measured depth) + truncation (EarlyExit above).  The
+// depth-ordered walk (k_query_fwd_loss) finds that limit tile by tile, one wave per ray: it needs S = 64 k, evaluates whole tiles (the
+// matrix chain runs over dead lanes too) and leaves rays shorter than a tile -- the shipped 32 + 11 sampling -- without any early
+// termination.  Here the part of the limit that is known BEFORE any network output is used first: every sample with z <= depth +
+// truncation is needed whatever the sdf turns out to be (the limit is at least that).  A workgroup takes up to three loss rows
+// (12 rays), lists those samples of all its rays back to back, evaluates the list as 64-sample tiles over its eight waves (phase 1),
+// then looks for each ray's first sign change among what was evaluated: a ray whose limit reaches further (sign change behind the
+// measured depth, or none yet, or no depth at all) lists the samples up to its limit (all remaining ones when there is no sign change
+// to go by) for phase 2.  Unevaluated samples get raw = 0, as in the walk: same losses, same gradients (tests: every train_step test
+// runs through this kernel).  Per tile the phase-split form (fwd_tile_split): the tile's points may come from several rays, so feat_save
+// rows are per lane.  The loss stage then runs from the rays' LDS images as in k_query_fwd_loss, rows of four rays in the same order.
+// The workgroup works on its tiles TOGETHER -- points, then all (tile, level) gather units spread over the eight waves with two units'
+// loads in flight each, then the matrix chains -- because with three to eight tiles per CU a tile's latency (16 gather round trips + the
+// matrix chain), not throughput, is what the launch costs.  Measured on the benchmark's random-initialised network (2 048 rays): S = 43
+// 44.5 us against 41.7 (flat field query over all samples) + 8.0 (k_loss_stage); S = 128 66.7 us against the walk's 64.6 -- the steps are
+// separated by barriers, so a workgroup's gathers never overlap its own matrix chains (tools/fwd_timeline.py): the launcher uses it
+// where the walk cannot run.
+// ------------------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kPackWaves = 8;
+constexpr uint32_t kPackMaxRows = 3;                         // loss rows (kRaysPerBlock rays each) a workgroup holds at a time
+constexpr uint32_t kPackMaxRays = kPackMaxRows * kRaysPerBlock;
+constexpr uint32_t kPackTiles = 8;                           // tiles a workgroup evaluates together (one feature slab each)
+inline size_t packed_lds_bytes(uint32_t rows, uint32_t S) { return (size_t)rows * kRaysPerBlock * S * (kRayFields * sizeof(float) + sizeof(uint16_t)) + 16u; }
+
+// the points of the tiles in flight: what every wave of the workgroup needs of a tile (position for the gathers and OneBlob, feat_save row,
+// uncertainty sample, where the results go)
+struct PackPts {
+    float x[kPackTiles][64], y[kPackTiles][64], z[kPackTiles][64], u[kPackTiles][64];
+    uint32_t m[kPackTiles][64];          // sample index n * S + s (feat_save / raw row); padding lanes repeat the tile's last entry
+    uint16_t code[kPackTiles][64];       // (ray << 12) | sample, 0xFFFF = padding lane
+};
+
+// one (tile, level) gather unit, in two steps so that a wave keeps TWO units' loads in flight
+struct PackUnit {
+    HalfCorners ha, hb;
+    float2 va[4], vb[4];
+    uint32_t mA, mB, tile, T;
+};
+__device__ __forceinline__ void pack_unit_issue(PackUnit& q, const PackPts& P, const LevelTab& lt, const float2* __restrict__ table, uint32_t tile, uint32_t T, int lane) {
+    const uint32_t hh = (uint32_t)lane >> 5, j = (uint32_t)lane & 31u;
+    q.tile = tile; q.T = T;
+    q.mA = P.m[tile][j]; q.mB = P.m[tile][j + 32u];
+    q.ha = hash_level_half_index(lt, (int)T, P.x[tile][j], P.y[tile][j], P.z[tile][j], hh);
+    q.hb = hash_level_half_index(lt, (int)T, P.x[tile][j + 32u], P.y[tile][j + 32u], P.z[tile][j + 32u], hh);
+    hash_level_half_load(lt, (int)T, table, q.ha, q.va);
+    hash_level_half_load(lt, (int)T, table, q.hb, q.vb);
+}
+__device__ __forceinline__ void pack_unit_retire(const PackUnit& q, FwdSlab* __restrict__ slabs, float* __restrict__ feat_save, uint32_t M, int lane) {
+    const uint32_t hh = (uint32_t)lane >> 5;
+    const float2 pa = hash_level_half_blend(q.ha, q.va);
+    const float2 pb = hash_level_half_blend(q.hb, q.vb);
+    float ua = pa.x, wa = pa.y, ub = pb.x, wb = pb.y;
+    swap32(ua, wa);
+    swap32(ub, wb);
+    const float b0 = ua + wa, b1 = ub + wb;
+    // (no branch around the stores: the stand-in unit behind a wave's last one repeats that unit and rewrites the same values)
+    char* __restrict__ fs = reinterpret_cast<char*>(feat_save + (size_t)q.T * M * 2u);
+    *reinterpret_cast<float*>(fs + ((q.mA * 2u + hh) << 2)) = b0;
+    *reinterpret_cast<float*>(fs + ((q.mB * 2u + hh) << 2)) = b1;
+    slabs[q.tile].feat[q.T][0][lane] = b0;
+    slabs[q.tile].feat[q.T][1][lane] = b1;
+}
+
+template <bool BF>
+__global__ __launch_bounds__(64 * kPackWaves, 2) void k_query_fwd_loss_packed(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps, uint32_t M, float* __restrict__ raw,
+                                                                             float* __restrict__ feat_save, EarlyExit ee, LossStageArgs a, uint32_t n_fwd_blocks,
+                                                                             uint32_t rows_per_chunk, unsigned long long* __restrict__ timeline) {
+    using Lds = std::conditional_t<BF, FwdLdsBf, FwdLds>;
+    // timeline (profiling, NULL otherwise; naruto_debug_fwd_timeline): thread 0 of every ray workgroup stamps s_memtime at the start and behind each
+    // step of its FIRST chunk: [16] per workgroup
+    int tl_k = 0;
+    auto stamp = [&]() {
+        if (timeline != nullptr && threadIdx.x == 0 && tl_k < 16) timeline[(size_t)blockIdx.x * 16u + (size_t)tl_k] = (unsigned long long)clock64();
+        ++tl_k;
+    };
+    stamp();                                        // 0: start
+    __shared__ Lds L;
+    __shared__ FwdSlab slabs[kPackTiles];
+    __shared__ PackPts P;
+    __shared__ double red[4];
+    __shared__ float terms[kPackMaxRays][10];
+    __shared__ uint32_t cnt[kPackMaxRays];          // samples of ray r the coming phase evaluates
+    __shared__ uint32_t done[kPackMaxRays];         // samples of ray r evaluated so far (a prefix: depths are sorted)
+    extern __shared__ float ray_lds[];
+    if (blockIdx.x >= n_fwd_blocks) {               // the smoothness term's workgroups (written for 256 threads: the upper half only meets the barrier)
+        if (threadIdx.x < 256u) tv_loss_list_body(a.tv, a.tv_feat, a.tv_d_list, a.tv_scale_dev, a.tv_scale_host, a.tv_partial, blockIdx.x - n_fwd_blocks, a.n_tv_blocks, red);
+        else __syncthreads();
+        return;
+    }
+    if constexpr (BF) stage_fwd_weights_bf<64 * kPackWaves>(L, p, threadIdx.x);
+    else stage_fwd_weights<64 * kPackWaves>(L, p, threadIdx.x);
+    __syncthreads();
+    stamp();                                        // 1: weights staged
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const float2* __restrict__ table = reinterpret_cast<const float2*>(p.table);
+    const uint32_t S = a.S, N = a.n_rays;
+    const uint32_t n_rows = (N + (uint32_t)kRaysPerBlock - 1u) / (uint32_t)kRaysPerBlock;
+    const uint32_t row_lo = (uint32_t)(((uint64_t)blockIdx.x * n_rows) / n_fwd_blocks), row_hi = (uint32_t)(((uint64_t)(blockIdx.x + 1u) * n_rows) / n_fwd_blocks);
+    const uint32_t r_cap = rows_per_chunk * (uint32_t)kRaysPerBlock;
+    uint16_t* __restrict__ list = reinterpret_cast<uint16_t*>(ray_lds + (size_t)r_cap * kRayFields * S);
+    auto image = [&](uint32_t r) { return ray_scratch(ray_lds, (int)r, S); };
+    const float margin_rel = 1e-5f, margin_abs = 1e-6f;                       // ee_after_tile's conservative margin
+    for (uint32_t row0 = row_lo; row0 < row_hi; row0 += rows_per_chunk) {      // uniform over the workgroup: barriers inside
+        const uint32_t n_row = row_hi - row0 < rows_per_chunk ? row_hi - row0 : rows_per_chunk, R = n_row * (uint32_t)kRaysPerBlock;
+        const uint32_t n0 = row0 * (uint32_t)kRaysPerBlock;
+        // ---- the rays' depths into their images; phase 1 = the samples up to measured depth + truncation
+        for (uint32_t r = (uint32_t)wave; r < R; r += kPackWaves) {
+            const uint32_t n = n0 + r;
+            uint32_t c = 0;
+            if (n < N) {
+                const RayScratch rs = image(r);
+                const float td = ee.target_d[n];
+                const float lim = td + ee.trunc_sc;
+                // no (or NaN) depth: the limit is the first sign change + truncation, wherever that is -- the whole ray goes into phase 1 (a second
+                // phase costs the workgroup another chain of gather round trips + a matrix chain: with 5 % of the rays lacking a depth a third
+                // of the workgroups would pay it for a handful of samples)
+                const bool has = td > 0.0f;
+                for (uint32_t s2 = lane; s2 < S; s2 += 64u) {
+                    const float zz = ps.z_vals[(size_t)n * S + s2];
+                    rs.z[s2] = zz;
+                    c += (!has || !(zz > lim + margin_rel * fabsf(lim) + margin_abs)) ? 1u : 0u;
+                }
+                c = wave_sum_u32(c);
+                if (c == 0u) c = S;                        // not one sample inside depth + truncation: nothing to look for a sign change in -- the whole ray
+            }
+            if (lane == 0) { cnt[r] = c; done[r] = 0u; }
+        }
+        __syncthreads();
+        stamp();                                    // 2: depths loaded, phase-1 counts
+        for (int phase = 0; phase < 2; ++phase) {
+            // ---- list the phase's samples ray after ray: entry = (ray << 12) | sample
+            uint32_t total = 0;
+            for (uint32_t r = 0; r < R; ++r) {
+                const uint32_t c = cnt[r], d0 = done[r];
+                if (r % kPackWaves == (uint32_t)wave) {
+                    for (uint32_t k = lane; k < c; k += 64u) list[total + k] = (uint16_t)((r << 12) | (d0 + k));
+                }
+                total += c;
+            }
+            if (total == 0u) continue;                     // (uniform: cnt is the same for every thread) nothing left to evaluate: typically all of phase 2
+            __syncthreads();
+            stamp();                                // 3 / 8: list built
+            // ---- the listed samples as 64-point tiles, kPackTiles at a time, the WORKGROUP working on them together: the latency of a
+            // tile is a chain of 16 gather round trips + the matrix chain, and a workgroup has only a handful of tiles
+            const uint32_t n_t = (total + 63u) / 64u;
+            for (uint32_t t0 = 0; t0 < n_t; t0 += kPackTiles) {
+                const uint32_t nt = n_t - t0 < kPackTiles ? n_t - t0 : kPackTiles;
+                // (P) the tiles' points: position, uncertainty sample, output rows -- tile by tile over the waves
+                for (uint32_t t = (uint32_t)wave; t < nt; t += kPackWaves) {
+                    const uint32_t e_raw = (t0 + t) * 64u + (uint32_t)lane;
+                    const bool valid = e_raw < total;
+                    const uint32_t code = list[valid ? e_raw : total - 1u];      // padding lanes redo the last entry (their stores repeat its values)
+                    const uint32_t r = code >> 12, s2 = code & 4095u, n = n0 + r;
+                    const float tz = image(r).z[s2];
+                    // load_point's arithmetic: p = o + d t (separately rounded), then the box normalisation
+                    const float px = __fadd_rn(ps.rays_o[3 * n + 0], __fmul_rn(ps.rays_d[3 * n + 0], tz));
+                    const float py = __fadd_rn(ps.rays_o[3 * n + 1], __fmul_rn(ps.rays_d[3 * n + 1], tz));
+                    const float pz = __fadd_rn(ps.rays_o[3 * n + 2], __fmul_rn(ps.rays_d[3 * n + 2], tz));
+                    const float x = __fdiv_rn(__fsub_rn(px, bt.bmin[0]), bt.bext[0]);
+                    const float y = __fdiv_rn(__fsub_rn(py, bt.bmin[1]), bt.bext[1]);
+                    const float z = __fdiv_rn(__fsub_rn(pz, bt.bmin[2]), bt.bext[2]);
+                    P.x[t][lane] = x; P.y[t][lane] = y; P.z[t][lane] = z;
+                    P.u[t][lane] = uncert_sample(ut, p.uncert_grid, x, y, z);
+                    P.m[t][lane] = n * S + s2;
+                    P.code[t][lane] = valid ? (uint16_t)code : (uint16_t)0xFFFFu;
+                }
+                __syncthreads();
+                stamp();                            // 4 / 9: points
+                // (G) the (tile, level) gather units over the waves, level-major (the waves work on the same levels at the same time), two
+                // units' loads in flight per wave
+                {
+                    if constexpr (NARUTO_FWD_GATHER_PRIO != 0) __builtin_amdgcn_s_setprio(NARUTO_FWD_GATHER_PRIO);
+                    const uint32_t n_units = nt * (uint32_t)kLevels;
+                    const uint32_t mine = n_units > (uint32_t)wave ? (n_units - (uint32_t)wave + kPackWaves - 1u) / kPackWaves : 0u;       // units wave, wave + 8, ...
+                    auto unit_of = [&](uint32_t i, uint32_t& tile, uint32_t& T) {
+                        const uint32_t q = (uint32_t)wave + (i < mine ? i : mine - 1u) * kPackWaves;       // behind the last unit: a stand-in that repeats it
+                        T = q / nt; tile = q - T * nt;
+                    };
+                    if (mine > 0u) {
+                        PackUnit q0, q1;
+                        uint32_t tile, T;
+                        unit_of(0u, tile, T);
+                        pack_unit_issue(q0, P, lt, table, tile, T, lane);
+                        for (uint32_t i = 0; i < mine; i += 2u) {
+                            unit_of(i + 1u, tile, T);
+                            pack_unit_issue(q1, P, lt, table, tile, T, lane);
+                            pack_unit_retire(q0, slabs, feat_save, M, lane);
+                            unit_of(i + 2u, tile, T);
+                            pack_unit_issue(q0, P, lt, table, tile, T, lane);
+                            pack_unit_retire(q1, slabs, feat_save, M, lane);
+                        }
+                        pack_unit_retire(q0, slabs, feat_save, M, lane);               // the stand-in behind the last unit
+                    }
+                    if constexpr (NARUTO_FWD_GATHER_PRIO != 0) __builtin_amdgcn_s_setprio(0);
+                }
+                __syncthreads();
+                stamp();                            // 5 / 10: gathers
+                // (M) the matrix chains, tile by tile over the waves
+                for (uint32_t t = (uint32_t)wave; t < nt; t += kPackWaves) {
+                    const float x = P.x[t][lane], y = P.y[t][lane], z = P.z[t][lane];
+                    FwdTileOut to;
+                    if constexpr (BF) {
+                        f32x16 hA = zero16(), hB = zero16(), cA = zero16(), cB = zero16();
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb) {
+                            float fa[8], fb[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { fa[e] = slabs[t].feat[8 * kb + e][0][lane]; fb[e] = slabs[t].feat[8 * kb + e][1][lane]; }
+                            const u32x4_t w = L.s0[kb * 64 + lane];
+                            hA = mfma16(w, pack8(fa), hA);
+                            hB = mfma16(w, pack8(fb), hB);
+                        }
+                        fwd_tail_bf<true>(L, hA, hB, cA, cB, x, y, z, nullptr, M, 0u, 0u, lane, to);
+                    } else {
+                        fwd_mlp_tile<true>(L, slabs[t], x, y, z, nullptr, M, 0u, 0u, lane, to);
+                    }
+                    const uint32_t code = P.code[t][lane];
+                    if (code != 0xFFFFu) {
+                        const uint32_t r = code >> 12, s2 = code & 4095u;
+                        const RayScratch rs = image(r);
+                        const float u = P.u[t][lane];
+                        float* o = raw + (size_t)P.m[t][lane] * 5;
+                        o[0] = to.rgb[0]; o[1] = to.rgb[1]; o[2] = to.rgb[2]; o[3] = to.sdf; o[4] = u;
+                        rs.c0[s2] = to.rgb[0]; rs.c1[s2] = to.rgb[1]; rs.c2[s2] = to.rgb[2]; rs.sdf[s2] = to.sdf; rs.u[s2] = u;
+                    }
+                }
+                __syncthreads();
+                stamp();                            // 6 / 11: matrix chains
+            }
+            // ---- what each ray still needs
+            for (uint32_t r = (uint32_t)wave; r < R; r += kPackWaves) {
+                const uint32_t n = n0 + r;
+                const uint32_t n_e = done[r] + cnt[r];
+                uint32_t more = 0;
+                if (n < N && phase == 0 && n_e < S) {
+                    const RayScratch rs = image(r);
+                    uint32_t first = 0xFFFFFFFFu;
+                    for (uint32_t s2 = lane; s2 + 1u < n_e; s2 += 64u) {
+                        if (rs.sdf[s2] * rs.sdf[s2 + 1u] < 0.0f) { first = s2; break; }
+                    }
+                    first = wave_min_u32(first);
+                    if (first == 0xFFFFFFFFu) {
+                        more = S - n_e;                                           // no sign change to go by yet: the rest of the ray
+                    } else {
+                        const float lim = fmaxf(rs.z[first], ee.target_d[n]) + ee.trunc_sc;
+                        uint32_t need = 0;
+                        for (uint32_t s2 = lane; s2 < S; s2 += 64u) need += !(rs.z[s2] > lim + margin_rel * fabsf(lim) + margin_abs) ? 1u : 0u;
+                        need = wave_sum_u32(need);
+                        more = need > n_e ? need - n_e : 0u;
+                    }
+                }
+                if (lane == 0) { done[r] = n_e; cnt[r] = more; }
+            }
+            __syncthreads();
+            stamp();                                // 7 / 12: what the rays still need
+        }
+        // ---- samples nobody can see: raw = 0 (memory and image); then the loss stage's ray work from the images
+        for (uint32_t r = (uint32_t)wave; r < R; r += kPackWaves) {
+            const uint32_t n = n0 + r;
+            if (n < N) {
+                const RayScratch rs = image(r);
+                for (uint32_t s2 = done[r] + (uint32_t)lane; s2 < S; s2 += 64u) {
+                    rs.c0[s2] = 0.0f; rs.c1[s2] = 0.0f; rs.c2[s2] = 0.0f; rs.sdf[s2] = 0.0f; rs.u[s2] = 0.0f;
+                    float* o = raw + ((size_t)n * S + s2) * 5;
+                    o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f; o[3] = 0.0f; o[4] = 0.0f;
+                }
+                wave_lds_sync();
+                loss_stage_ray(a, rs, n, lane, terms[r]);
+            } else {
+                loss_stage_no_ray(lane, terms[r]);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 10u * n_row) {                       // rows of four rays, summed in ray order: k_loss_stage's rows
+            const uint32_t k = threadIdx.x % 10u, rr = threadIdx.x / 10u;
+            double v = (double)terms[rr * 4u][k];
+#pragma unroll
+            for (uint32_t w = 1; w < (uint32_t)kRaysPerBlock; ++w) {
+                const double uu = (double)terms[rr * 4u + w][k];
+                v = k == 9u ? ((uu < v || uu != uu) ? uu : v) : v + uu;
+            }
+            a.partials[(size_t)(row0 + rr) * 16 + k] = v;
+        }
+        __syncthreads();
+        if (timeline != nullptr && threadIdx.x == 0 && row0 == row_lo) timeline[(size_t)blockIdx.x * 16u + 15u] = (unsigned long long)clock64();     // 15: first chunk done
+        tl_k = 16;
+    }
+}
+template __global__ void k_query_fwd_loss_packed<false>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t, uint32_t, unsigned long long*);
+template __global__ void k_query_fwd_loss_packed<true>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t, uint32_t, unsigned long long*);
+
 // A1 | the smoothness lattice's points + hash features, one launch: workgroups [0, n_ray_blocks) sample the depths of four
 // rays each (one per wave, 2 S floats of dynamic LDS per wave), the rest are k_tv_encode's workgroups
 struct SampleArgs {

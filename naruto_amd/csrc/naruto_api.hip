@@ -817,30 +817,49 @@ int launch_train_query(const NarutoField* f, const NarutoParams* p, const Naruto
     static const int packed_mode = getenv("NARUTO_FWD_PACKED") == nullptr ? 1 : atoi(getenv("NARUTO_FWD_PACKED"));
     const bool packed_on = packed_mode == 2 || (packed_mode == 1 && (S % 64u != 0u || S <= 64u));
     if (loss != nullptr && packed_on && !no_fuse && kFwdSplit && S <= 4095u && N >= 1u) {
-        // rows (of four rays) a workgroup holds at a time: as many as the LDS next to the weights and the eight feature slabs takes, at most three
-        const size_t lds_free = (size_t)160u * 1024u - sizeof(FwdLds) - (size_t)kPackTiles * sizeof(FwdSlab) - sizeof(PackPts) - 2048u;
+        // workgroup shape: 8 waves x 1 per CU, or 4 waves x 2 per CU (NARUTO_PACK_WAVES); rows (of four rays) a workgroup holds at a time: as many as
+        // the LDS next to the weights, the feature slabs and the tiles' points takes, at most three
+        static const int pack_waves = getenv("NARUTO_PACK_WAVES") ? atoi(getenv("NARUTO_PACK_WAVES")) : 8;
+        const uint32_t W = pack_waves == 4 ? 4u : 8u, per_cu = W == 4u ? 2u : 1u;
+        static size_t static_lds[2] = {0, 0};                                    // the kernel's own static LDS, fp32 form (the larger), from the code object
+        if (static_lds[W == 4u] == 0u) {
+            hipFuncAttributes fa{};
+            const void* fn = W == 4u ? reinterpret_cast<const void*>(k_query_fwd_loss_packed<false, 4>) : reinterpret_cast<const void*>(k_query_fwd_loss_packed<false, 8>);
+            if (hipFuncGetAttributes(&fa, fn) != hipSuccess) return fail(NARUTO_ERR_LAUNCH, "query_fwd_loss_packed: hipFuncGetAttributes: %s", hipGetErrorString(hipGetLastError()));
+            static_lds[W == 4u] = fa.sharedSizeBytes;
+        }
+        const size_t fixed = static_lds[W == 4u] + 256u;
+        const size_t lds_free = (size_t)160u * 1024u / per_cu > fixed ? (size_t)160u * 1024u / per_cu - fixed : 0u;
         uint32_t rows = kPackMaxRows;
         while (rows > 0u && packed_lds_bytes(rows, S) > lds_free) --rows;
         if (rows > 0u) {
-            static size_t attr_bytes = 0;
+            static size_t attr_bytes[2] = {0, 0};
             const size_t need = packed_lds_bytes(rows, S);
-            if (need > attr_bytes) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_fwd_loss_packed<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_free) != hipSuccess ||
-                    hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_fwd_loss_packed<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_free) != hipSuccess)
+            if (need > attr_bytes[W == 4u]) {
+                hipError_t e1, e2;
+                if (W == 4u) {
+                    e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_fwd_loss_packed<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_free);
+                    e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_fwd_loss_packed<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_free);
+                } else {
+                    e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_fwd_loss_packed<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_free);
+                    e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_fwd_loss_packed<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_free);
+                }
+                if (e1 != hipSuccess || e2 != hipSuccess)
                     return fail(NARUTO_ERR_LAUNCH, "query_fwd_loss_packed: cannot reserve %zu bytes of LDS: %s", lds_free, hipGetErrorString(hipGetLastError()));
-                attr_bytes = lds_free;
+                attr_bytes[W == 4u] = lds_free;
             }
             const uint32_t n_rows = (N + (uint32_t)kRaysPerBlock - 1u) / (uint32_t)kRaysPerBlock;
-            const uint32_t pblocks = n_rows < cu_count(f) ? n_rows : cu_count(f);            // one 8-wave workgroup per CU, rows spread evenly over them
+            const uint32_t slots = cu_count(f) * per_cu;
+            const uint32_t pblocks = n_rows < slots ? n_rows : slots;            // every workgroup resident at once, the rows spread evenly over them
             EarlyExit pe{};
             pe.target_d = t->target_d;
             pe.trunc_sc = f->desc.trunc * f->desc.sc_factor;
-            if (f->desc.mlp_mode == NARUTO_MLP_BF16)
-                hipLaunchKernelGGL(k_query_fwd_loss_packed<true>, dim3(pblocks + loss->n_tv_blocks), dim3(64 * kPackWaves), need, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw,
-                                   t->feat_save, pe, *loss, pblocks, rows, g_fwd_timeline);
-            else
-                hipLaunchKernelGGL(k_query_fwd_loss_packed<false>, dim3(pblocks + loss->n_tv_blocks), dim3(64 * kPackWaves), need, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw,
-                                   t->feat_save, pe, *loss, pblocks, rows, g_fwd_timeline);
+            const bool bfm = f->desc.mlp_mode == NARUTO_MLP_BF16;
+#define NARUTO_LAUNCH_PACKED(BFV, WV) hipLaunchKernelGGL((k_query_fwd_loss_packed<BFV, WV>), dim3(pblocks + loss->n_tv_blocks), dim3(64 * WV), need, st, f->lt, f->ut, f->bt, *p, ps, M, \
+                                                         t->raw, t->feat_save, pe, *loss, pblocks, rows, g_fwd_timeline)
+            if (W == 4u) { if (bfm) NARUTO_LAUNCH_PACKED(true, 4); else NARUTO_LAUNCH_PACKED(false, 4); }
+            else { if (bfm) NARUTO_LAUNCH_PACKED(true, 8); else NARUTO_LAUNCH_PACKED(false, 8); }
+#undef NARUTO_LAUNCH_PACKED
             if (fused != nullptr) *fused = true;
             return check_launch("query_fwd_loss_packed");
         }

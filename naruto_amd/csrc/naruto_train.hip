@@ -258,18 +258,19 @@ template __global__ void k_query_fwd_loss<true>(LevelTab, UncertTab, BoxTab, Nar
 // separated by barriers, so a workgroup's gathers never overlap its own matrix chains (tools/fwd_timeline.py): the launcher uses it
 // where the walk cannot run.
 // ------------------------------------------------------------------------------------------------------------------------------
-constexpr uint32_t kPackWaves = 8;
 constexpr uint32_t kPackMaxRows = 3;                         // loss rows (kRaysPerBlock rays each) a workgroup holds at a time
 constexpr uint32_t kPackMaxRays = kPackMaxRows * kRaysPerBlock;
-constexpr uint32_t kPackTiles = 8;                           // tiles a workgroup evaluates together (one feature slab each)
+// WAVES = waves per workgroup = tiles it evaluates together (one feature slab each): 8 (one workgroup per CU) or 4 (two per CU, which then
+// drift apart so that one's gathers meet the other's matrix chains)
 inline size_t packed_lds_bytes(uint32_t rows, uint32_t S) { return (size_t)rows * kRaysPerBlock * S * (kRayFields * sizeof(float) + sizeof(uint16_t)) + 16u; }
 
 // the points of the tiles in flight: what every wave of the workgroup needs of a tile (position for the gathers and OneBlob, feat_save row,
 // uncertainty sample, where the results go)
+template <int TILES>
 struct PackPts {
-    float x[kPackTiles][64], y[kPackTiles][64], z[kPackTiles][64], u[kPackTiles][64];
-    uint32_t m[kPackTiles][64];          // sample index n * S + s (feat_save / raw row); padding lanes repeat the tile's last entry
-    uint16_t code[kPackTiles][64];       // (ray << 12) | sample, 0xFFFF = padding lane
+    float x[TILES][64], y[TILES][64], z[TILES][64], u[TILES][64];
+    uint32_t m[TILES][64];          // sample index n * S + s (feat_save / raw row); padding lanes repeat the tile's last entry
+    uint16_t code[TILES][64];       // (ray << 12) | sample, 0xFFFF = padding lane
 };
 
 // one (tile, level) gather unit, in two steps so that a wave keeps TWO units' loads in flight
@@ -278,7 +279,8 @@ struct PackUnit {
     float2 va[4], vb[4];
     uint32_t mA, mB, tile, T;
 };
-__device__ __forceinline__ void pack_unit_issue(PackUnit& q, const PackPts& P, const LevelTab& lt, const float2* __restrict__ table, uint32_t tile, uint32_t T, int lane) {
+template <int TILES>
+__device__ __forceinline__ void pack_unit_issue(PackUnit& q, const PackPts<TILES>& P, const LevelTab& lt, const float2* __restrict__ table, uint32_t tile, uint32_t T, int lane) {
     const uint32_t hh = (uint32_t)lane >> 5, j = (uint32_t)lane & 31u;
     q.tile = tile; q.T = T;
     q.mA = P.m[tile][j]; q.mB = P.m[tile][j + 32u];
@@ -303,11 +305,12 @@ __device__ __forceinline__ void pack_unit_retire(const PackUnit& q, FwdSlab* __r
     slabs[q.tile].feat[q.T][1][lane] = b1;
 }
 
-template <bool BF>
-__global__ __launch_bounds__(64 * kPackWaves, 2) void k_query_fwd_loss_packed(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps, uint32_t M, float* __restrict__ raw,
+template <bool BF, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void k_query_fwd_loss_packed(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps, uint32_t M, float* __restrict__ raw,
                                                                              float* __restrict__ feat_save, EarlyExit ee, LossStageArgs a, uint32_t n_fwd_blocks,
                                                                              uint32_t rows_per_chunk, unsigned long long* __restrict__ timeline) {
     using Lds = std::conditional_t<BF, FwdLdsBf, FwdLds>;
+    constexpr uint32_t kPackWaves = WAVES, kPackTiles = WAVES;
     // timeline (profiling, NULL otherwise; naruto_debug_fwd_timeline): thread 0 of every ray workgroup stamps s_memtime at the start and behind each
     // step of its FIRST chunk: [16] per workgroup
     int tl_k = 0;
@@ -318,19 +321,19 @@ __global__ __launch_bounds__(64 * kPackWaves, 2) void k_query_fwd_loss_packed(Le
     stamp();                                        // 0: start
     __shared__ Lds L;
     __shared__ FwdSlab slabs[kPackTiles];
-    __shared__ PackPts P;
+    __shared__ PackPts<WAVES> P;
     __shared__ double red[4];
     __shared__ float terms[kPackMaxRays][10];
     __shared__ uint32_t cnt[kPackMaxRays];          // samples of ray r the coming phase evaluates
     __shared__ uint32_t done[kPackMaxRays];         // samples of ray r evaluated so far (a prefix: depths are sorted)
     extern __shared__ float ray_lds[];
     if (blockIdx.x >= n_fwd_blocks) {               // the smoothness term's workgroups (written for 256 threads: the upper half only meets the barrier)
-        if (threadIdx.x < 256u) tv_loss_list_body(a.tv, a.tv_feat, a.tv_d_list, a.tv_scale_dev, a.tv_scale_host, a.tv_partial, blockIdx.x - n_fwd_blocks, a.n_tv_blocks, red);
+        if (WAVES == 4 || threadIdx.x < 256u) tv_loss_list_body(a.tv, a.tv_feat, a.tv_d_list, a.tv_scale_dev, a.tv_scale_host, a.tv_partial, blockIdx.x - n_fwd_blocks, a.n_tv_blocks, red);
         else __syncthreads();
         return;
     }
-    if constexpr (BF) stage_fwd_weights_bf<64 * kPackWaves>(L, p, threadIdx.x);
-    else stage_fwd_weights<64 * kPackWaves>(L, p, threadIdx.x);
+    if constexpr (BF) stage_fwd_weights_bf<64 * WAVES>(L, p, threadIdx.x);
+    else stage_fwd_weights<64 * WAVES>(L, p, threadIdx.x);
     __syncthreads();
     stamp();                                        // 1: weights staged
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -528,8 +531,10 @@ __global__ __launch_bounds__(64 * kPackWaves, 2) void k_query_fwd_loss_packed(Le
         tl_k = 16;
     }
 }
-template __global__ void k_query_fwd_loss_packed<false>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t, uint32_t, unsigned long long*);
-template __global__ void k_query_fwd_loss_packed<true>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t, uint32_t, unsigned long long*);
+template __global__ void k_query_fwd_loss_packed<false, 8>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t, uint32_t, unsigned long long*);
+template __global__ void k_query_fwd_loss_packed<true, 8>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t, uint32_t, unsigned long long*);
+template __global__ void k_query_fwd_loss_packed<false, 4>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t, uint32_t, unsigned long long*);
+template __global__ void k_query_fwd_loss_packed<true, 4>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t, uint32_t, unsigned long long*);
 
 // A1 | the smoothness lattice's points + hash features, one launch: workgroups [0, n_ray_blocks) sample the depths of four
 // rays each (one per wave, 2 S floats of dynamic LDS per wave), the rest are k_tv_encode's workgroups

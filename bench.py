@@ -186,7 +186,7 @@ def kernel_table(tr, rays, cfg, iters: int):
         sc_it_ms = events_ms(lambda: _lib.check(lib.naruto_debug_train_scatter(h.ptr, CT.byref(ts.ps), CT.byref(t), st())), iters)
         sc_it_bytes = (n_act + n_lat) * (2 * 16 * 8 * 8 + 128 + 16) + n_act * 2 * 32
         rows.append({"kernel": "k_hash_scatter_lds as launched by the iteration", "ms": round(sc_it_ms, 5), "alg_bytes": int(sc_it_bytes), "alg_flops": 0,
-                     "GBps": round(sc_it_bytes / sc_it_ms / 1e6, 1), "TFLOPs": 0.0, "bound": None, "list_points": n_act + n_lat,
+                     "GBps": round(sc_it_bytes / sc_it_ms / 1e6, 1), "TFLOPs": 0.0, "bound": None, "list_points": n_act + n_lat, "active_samples": n_act,
                      "alg_bytes_all_samples": int((M + n_lat) * (2 * 16 * 8 * 8 + 128 + 16) + M * 2 * 32)})
     for name, ms in (("naruto_train_forward (eager)", fwd_ms), ("naruto_train_backward (eager)", bwd_ms),
                      ("k_query_fwd<color> as launched by the iteration (with the loss stage in the same launch when S % 64 == 0)", qit_ms)):
@@ -901,6 +901,15 @@ def main():
             except Exception as e:                               # informational: never fail the bench line over it
                 out["roofline_gather"]["random_line_roof"] = {"error": repr(e)[:200]}
             out["roofline"] = roof
+            if sc_it is not None and "active_samples" in sc_it:
+                # the same figure with the backward's share (3168 B minus the forward's 1056 B per sample) charged only for the samples the
+                # backward actually processes (the compacted list: non-zero loss gradient), not for every sample of the batch: the honest
+                # denominator for "how close is the whole step to the HBM roof"
+                fwd_b = next(r for r in rows if r["kernel"].startswith("k_query_fwd<color>") and "launch" in r)["alg_bytes"] / (n_rays * S_tot)
+                act_bytes = n_rays * (S_tot * fwd_b + 44) + sc_it["active_samples"] * (3168 - fwd_b) + n_params * 28
+                out["step_roofline"].update({"alg_bytes_active_samples": int(act_bytes), "active_samples": int(sc_it["active_samples"]),
+                                             "samples": int(n_rays * S_tot), "achieved_GBps_active_samples": round(act_bytes / (ms * 1e-3) / 1e9, 1),
+                                             "hbm_frac_active_samples": round(act_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
             out["kernels"] = rows
             out["kernels_ms_sum"] = round(sum(r["ms"] for r in rows if r["bound"] is not None), 4)
         if not args.no_dropin and world == 1:
@@ -926,7 +935,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, n_rays)
             try:
-                out["torch_gpu_baseline"] = cpu_baseline(cfg, n_rays, device=dev)
+                out["torch_gpu_baseline"] = dict(cpu_baseline(cfg, n_rays, device=dev),
+                                                 what="the ORACLE's unfused torch ops (oracle/spec.py) run on the MI355X -- NOT tiny-cuda-nn / the reference's CUDA "
+                                                      "path, which has no ROCm build; a floor for 'any GPU code', not a competitor")
             except Exception as e:                               # informational: never fail the bench line over it
                 out["torch_gpu_baseline"] = {"error": repr(e)[:200]}
         sys.stdout.flush()

@@ -20,5 +20,10 @@ for f in dropin_kernel_trace dropin_torch_profiler_swap_only dropin_torch_profil
   [ -s $G/${TAG}_$f.txt ] && grep -v "amdgpu.ids\|UserWarning\|_warn_once\|ROCTracer" $G/${TAG}_$f.txt | cut -c1-220 > $P/${TAG}_$f.txt
 done
 for f in sq_counters_sq sq_counters_2048x43_sq; do [ -s $G/${TAG}_$f.txt ] && cp $G/${TAG}_$f.txt $P/${TAG}_${f%_sq}.txt; done
+for f in fwd_timeline_2048x43 fwd_timeline_2048x128_packed_everywhere trained_step accuracy_study; do
+  [ -s $G/${TAG}_$f.txt ] && grep -v "amdgpu.ids\|UserWarning\|_warn_once\|ROCTracer" $G/${TAG}_$f.txt | cut -c1-260 > $P/${TAG}_$f.txt
+done
+[ -s $G/${TAG}_accuracy_study.json ] && cp $G/${TAG}_accuracy_study.json $P/
+git rev-parse HEAD > $P/${TAG}_commit.txt   # the tree the measurement ran on: commit before measuring, collect before the next commit
 tail -3 $G/${TAG}_pytest_gpu.log > $P/${TAG}_pytest_gpu_summary.txt
 ls -la $P | tail -30

@@ -14,9 +14,9 @@ echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest_gpu.log
 tail -4 gpurun_out/${TAG}_pytest_gpu.log | cut -c1-300
 timeout 900 python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err; cut -c1-200 gpurun_out/${TAG}_bench_default.json
 timeout 600 python bench.py --mlp bf16 --no-cpu-baseline > gpurun_out/${TAG}_bench_bf16.json 2> /dev/null; cut -c1-200 gpurun_out/${TAG}_bench_bf16.json
-for m in fp32 bf16; do timeout 600 python bench.py --workload office0_8192x43_eval --mlp $m --no-cpu-baseline > gpurun_out/${TAG}_bench_eval_$m.json 2> /dev/null; cut -c1-200 gpurun_out/${TAG}_bench_eval_$m.json; done
+for m in fp32 bf16; do timeout 600 python bench.py --workload office0_8192x43_eval --mlp $m --no-cpu-baseline --no-mapping-iter > gpurun_out/${TAG}_bench_eval_$m.json 2> /dev/null; cut -c1-200 gpurun_out/${TAG}_bench_eval_$m.json; done
 for w in office0_2048x43 office0_8192x43 mp3d_2048x256 unit1024_131072x43; do
-  timeout 600 python bench.py --workload $w --no-cpu-baseline --steps 20 > gpurun_out/${TAG}_bench_$w.json 2> /dev/null; cut -c1-160 gpurun_out/${TAG}_bench_$w.json; echo
+  timeout 600 python bench.py --workload $w --no-cpu-baseline --no-mapping-iter --steps 20 > gpurun_out/${TAG}_bench_$w.json 2> /dev/null; cut -c1-160 gpurun_out/${TAG}_bench_$w.json; echo
 done
 for m in fp32 bf16; do timeout 900 python bench.py --workload unit1024_T22_131072x43 --mlp $m --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${TAG}_bench_T22_$m.json 2> /dev/null; cut -c1-160 gpurun_out/${TAG}_bench_T22_$m.json; echo; done
 timeout 600 python tools/bf16_error_study.py > gpurun_out/${TAG}_bf16_error_study.txt 2>&1
@@ -41,4 +41,11 @@ bash tools/trace_workload.sh $TAG office0_2048x43 > /dev/null 2>&1
 bash tools/trace_workload.sh $TAG office0_ba_iter --active-ray > /dev/null 2>&1
 bash tools/pmc_sq.sh ${TAG}_sq_counters > /dev/null 2>&1
 BENCH_ARGS="--workload office0_2048x43" bash tools/pmc_sq.sh ${TAG}_sq_counters_2048x43 > /dev/null 2>&1
+# round 4: per-step timeline of the packed training forward, the iteration on a trained map, the reconstruction-accuracy study (HIP fp32 / bf16 /
+# NaN depths against the CPU oracle on the analytic room: ~2 min of CPU for the oracle's 390 iterations)
+cd $R
+timeout 300 python tools/fwd_timeline.py office0_2048x43 > gpurun_out/${TAG}_fwd_timeline_2048x43.txt 2>&1
+NARUTO_FWD_PACKED=2 timeout 300 python tools/fwd_timeline.py office0_2048x128 > gpurun_out/${TAG}_fwd_timeline_2048x128_packed_everywhere.txt 2>&1
+timeout 600 python tools/time_trained_step.py > gpurun_out/${TAG}_trained_step.txt 2>&1
+timeout 1500 python tests/accuracy_study.py --out gpurun_out/${TAG}_accuracy_study.json > gpurun_out/${TAG}_accuracy_study.txt 2>&1
 git -C $R rev-parse HEAD > gpurun_out/${TAG}_commit.txt 2>/dev/null || true

@@ -87,8 +87,10 @@ int ray_lds_attr() {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_composite_bwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_loss_stage), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_loss_bwd_fused), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_fwd_loss<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLossMaxRayLds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_fwd_loss<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLossMaxRayLds) != hipSuccess)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_fwd_loss<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLossMaxRayLds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_fwd_loss<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLossMaxRayLds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_fwd_loss<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLossMaxRayLds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_fwd_loss<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLossMaxRayLds) != hipSuccess)
         return fail(NARUTO_ERR_LAUNCH, "per-ray kernels: cannot reserve %d bytes of LDS: %s", bytes, hipGetErrorString(hipGetLastError()));
     done = true;
     return NARUTO_OK;
@@ -183,7 +185,7 @@ ScatterWs scatter_ws(const NarutoField* f, void* base, uint32_t M) {
         w.counts = reinterpret_cast<uint32_t*>(b + off); off += al256((size_t)bin_rows(M) * f->bplan.n_bins * sizeof(uint32_t));
         w.totals = reinterpret_cast<uint32_t*>(b + off); off += al256((size_t)f->bplan.n_bins * sizeof(uint32_t));
         w.starts = reinterpret_cast<uint32_t*>(b + off); off += al256(((size_t)f->bplan.n_bins + 1u) * sizeof(uint32_t));
-        w.items = reinterpret_cast<BinItem*>(b + off);   off += al256((size_t)M * f->bplan.n_levels * 8u * sizeof(BinItem));
+        w.items = reinterpret_cast<BinItem*>(b + off);   off += al256((size_t)M * f->bplan.n_levels * kBinItemsPerPoint * sizeof(BinItem));
     }
     w.total = off;
     return w;
@@ -235,12 +237,16 @@ int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const f
     }
     if (f->bplan.n_levels != 0 && (d_table != nullptr || adam != nullptr)) {
         // the binned scatter's counts, prefix sums and item offsets are 32-bit: 8 items per (list point, binned level)
-        if ((uint64_t)M * 8ull * f->bplan.n_levels >= (1ull << 32))
+        if ((uint64_t)M * kBinItemsPerPoint * f->bplan.n_levels >= (1ull << 32))
             return fail(NARUTO_ERR_INVALID, "scatter: %u list points x %u binned levels x 8 items overflow the 32-bit item offsets (split the batch)", M, f->bplan.n_levels);
+        uint32_t nb_max = 0;
+        for (uint32_t k = 0; k < f->bplan.n_levels; ++k) nb_max = f->bplan.bin0[k + 1] - f->bplan.bin0[k] > nb_max ? f->bplan.bin0[k + 1] - f->bplan.bin0[k] : nb_max;
+        const bool round_1024 = bin_fill_lds_bytes(1024u, nb_max) <= (size_t)160u * 1024u;            // else 512-point rounds (T = 2^24)
         static bool attr_set = false;
         if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_fill), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)bin_fill_lds_bytes((uint32_t)kMaxBinsPerLevel)) != hipSuccess ||
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_fill<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_fill<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)bin_fill_lds_bytes(512u, (uint32_t)kMaxBinsPerLevel)) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_apply), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(2u * kBinEntries * sizeof(unsigned long long))) != hipSuccess)
                 return fail(NARUTO_ERR_LAUNCH, "binned scatter: cannot reserve LDS: %s", hipGetErrorString(hipGetLastError()));
@@ -254,10 +260,12 @@ int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const f
         if (int rc = check_launch("bin_colscan")) return rc;
         hipLaunchKernelGGL(k_bin_start, dim3(1), dim3(1024), 0, st, w.totals, bp.n_bins, w.starts);
         if (int rc = check_launch("bin_start")) return rc;
-        uint32_t nb_max = 0;
-        for (uint32_t k = 0; k < bp.n_levels; ++k) nb_max = bp.bin0[k + 1] - bp.bin0[k] > nb_max ? bp.bin0[k + 1] - bp.bin0[k] : nb_max;
-        hipLaunchKernelGGL(k_bin_fill, dim3(rows, bp.n_levels), dim3(kBinFillThreads), bin_fill_lds_bytes(nb_max), st, f->lt, f->bt, ps, M, d_feat, stride_m, stride_l,
-                           bp, nb_max, w.counts, w.starts, w.items, m_dev);
+        if (round_1024)
+            hipLaunchKernelGGL(k_bin_fill<1024>, dim3(rows, bp.n_levels), dim3(1024), bin_fill_lds_bytes(1024u, nb_max), st, f->lt, f->bt, ps, M, d_feat, stride_m, stride_l,
+                               bp, nb_max, w.counts, w.starts, w.items, m_dev);
+        else
+            hipLaunchKernelGGL(k_bin_fill<512>, dim3(rows, bp.n_levels), dim3(512), bin_fill_lds_bytes(512u, nb_max), st, f->lt, f->bt, ps, M, d_feat, stride_m, stride_l,
+                               bp, nb_max, w.counts, w.starts, w.items, m_dev);
         if (int rc = check_launch("bin_fill")) return rc;
         AdamFuse none{};
         hipLaunchKernelGGL(k_bin_apply, dim3(bp.n_bins), dim3(kBinApplyThreads), 2u * kBinEntries * sizeof(unsigned long long), st, f->lt, bp, w.starts, w.items,
@@ -814,8 +822,20 @@ int launch_train_query(const NarutoField* f, const NarutoParams* p, const Naruto
     // flat launch over ALL samples + k_loss_stage (2 048 x 43: 41.7 + 8.0 us -> 44.5 us).  For S = 64 k the walk stays: it overlaps one wave's
     // gathers with another's matrix chain, while the packed workgroup's steps are separated by barriers (2 048 x 128: walk 64.6 us, packed 66.7;
     // per-step timeline: tools/fwd_timeline.py, profiles/r04_fwd_timeline.txt).  NARUTO_FWD_PACKED=2 forces it everywhere.
+    // ... and only where its rows (of four rays) fall evenly on the workgroups and a workgroup has few of them: a row is the unit of
+    // distribution, so 537 rows (the BA batch: 2 148 rays) leave 25 of 256 workgroups with three rows and the launch with their time (0.211
+    // against 0.1875 ms per BA iteration; 512 rows: 0.164 against 0.1715), and from dozens of rows per workgroup on the flat launch's overlap
+    // of gathers and matrix chains across its waves wins (131 072 x 43, T = 2^16: 5.92 against 4.87 ms per step) -- tools/ba_ab.sh.  =3: as 1, without this test.
     static const int packed_mode = getenv("NARUTO_FWD_PACKED") == nullptr ? 1 : atoi(getenv("NARUTO_FWD_PACKED"));
-    const bool packed_on = packed_mode == 2 || (packed_mode == 1 && (S % 64u != 0u || S <= 64u));
+    bool packed_on = packed_mode == 2 || ((packed_mode == 1 || packed_mode == 3) && (S % 64u != 0u || S <= 64u));
+    if (packed_on && packed_mode == 1) {
+        const uint32_t n_rows_ = (N + (uint32_t)kRaysPerBlock - 1u) / (uint32_t)kRaysPerBlock, slots_ = cu_count(f);
+        const uint32_t wgs = n_rows_ < slots_ ? n_rows_ : slots_, per = (n_rows_ + wgs - 1u) / (wgs > 0u ? wgs : 1u);
+        // tables no cache holds (T = 2^22: 281 MB): the gathers are HBM random-line bound, every sample NOT evaluated is time saved, and the packed
+        // form wins at any batch size (131 072 x 43: 8.09 against 9.41 ms per step)
+        const bool hbm_resident = (size_t)f->n_entries * 2u * sizeof(float) > ((size_t)64u << 20);
+        packed_on = hbm_resident || (n_rows_ <= 8u * slots_ && (uint64_t)per * wgs * 100u <= (uint64_t)n_rows_ * 115u);
+    }
     if (loss != nullptr && packed_on && !no_fuse && kFwdSplit && S <= 4095u && N >= 1u) {
         // workgroup shape: 8 waves x 1 per CU, or 4 waves x 2 per CU (NARUTO_PACK_WAVES); rows (of four rays) a workgroup holds at a time: as many as
         // the LDS next to the weights, the feature slabs and the tiles' points takes, at most three
@@ -866,12 +886,14 @@ int launch_train_query(const NarutoField* f, const NarutoParams* p, const Naruto
     }
     if (loss != nullptr && ee.tiles_per_ray != 0u && ray_scratch_bytes(S) <= kFwdLossMaxRayLds && !no_fuse) {
         if (int rc = ray_lds_attr()) return rc;
-        if (f->desc.mlp_mode == NARUTO_MLP_BF16)
-            hipLaunchKernelGGL(k_query_fwd_loss<true>, dim3(blocks + loss->n_tv_blocks), dim3(256), ray_scratch_bytes(S), st, f->lt, f->ut, f->bt, *p, ps, M, t->raw,
-                               t->feat_save, ee, *loss, blocks);
-        else
-            hipLaunchKernelGGL(k_query_fwd_loss<false>, dim3(blocks + loss->n_tv_blocks), dim3(256), ray_scratch_bytes(S), st, f->lt, f->ut, f->bt, *p, ps, M, t->raw,
-                               t->feat_save, ee, *loss, blocks);
+        // the two-phase tile costs 32 KB of slabs per workgroup: only while two workgroups still share a CU (S <= 192), see k_query_fwd_loss
+        const bool split = kFwdSplit && sizeof(FwdLds) + (size_t)kRaysPerBlock * sizeof(FwdSlab) + ray_scratch_bytes(S) + 512u <= (size_t)80u * 1024u;
+        const bool bfm = f->desc.mlp_mode == NARUTO_MLP_BF16;
+#define NARUTO_LAUNCH_WALK(BFV, SPV) hipLaunchKernelGGL((k_query_fwd_loss<BFV, SPV>), dim3(blocks + loss->n_tv_blocks), dim3(256), ray_scratch_bytes(S), st, f->lt, f->ut, f->bt, *p, ps, M, \
+                                                        t->raw, t->feat_save, ee, *loss, blocks)
+        if (split) { if (bfm) NARUTO_LAUNCH_WALK(true, true); else NARUTO_LAUNCH_WALK(false, true); }
+        else { if (bfm) NARUTO_LAUNCH_WALK(true, false); else NARUTO_LAUNCH_WALK(false, false); }
+#undef NARUTO_LAUNCH_WALK
         if (fused != nullptr) *fused = true;
         return check_launch("query_fwd_loss");
     }

@@ -11,12 +11,16 @@
 //
 //   k_bin_count   (row, level): items per bin of this row's share of the point list            -> counts[row][bin]
 //   k_bin_colscan / k_bin_start: exclusive prefix over rows per bin, exclusive prefix over bins  -> item run of (row, bin)
-//   k_bin_fill    (row, level): recompute the items, sort each 512-point round by bin in LDS, write the runs coalesced
+//   k_bin_fill    (row, level): recompute the items, sort each 1 024-point round by bin in LDS, write the runs coalesced
 //   k_bin_apply   (bin)       : accumulate the bin's items in a 128 KB LDS image (both features of 8 192 entries), then
 //                               either write / add the gradient slice or apply the fused Adam step to it in place
 //
-// HBM traffic per (point, level): 96 B of items written + 96 B read (12 B per corner: entry-in-bin, two contributions),
-// against the 2 x 64 B read-modify-write of the 8 corners that the algorithm asks for; the point list is read twice.
+// An ITEM is an x-PAIR of corners (round 4; round 2 - 3: one 12-byte item per corner).  The two corners of a point that differ in x only
+// have indices that differ in their low bits (hashed: (gx ^ h) vs ((gx + 1) ^ h); dense: consecutive), so they fall into the same
+// 8 192-entry bin unless gx + 1 carries across bit 13 (one pair in 8 192): one 16-byte item {both entries within the bin, wy wz g of the
+// two features, wx} carries both, and k_bin_apply forms the four contributions (a_f (1 - wx), a_f wx) in fp64 on the way into the image.
+// A pair that straddles two bins becomes two items with one corner each.  HBM traffic per (point, level): 64 B of items written + 64 B
+// read (was 96 + 96), against the 2 x 64 B read-modify-write of the 8 corners that the algorithm asks for; the point list is read twice.
 //
 // Reference behaviour replaced: the backward of tcnn's HashGrid encoding (atomicAdd into the gradient table) behind
 // JointEncodingNaruto.embed_fn (reference src/slam/coslam/model/scene_rep.py:59,110) and, with the fused optimiser,
@@ -45,7 +49,32 @@ struct BinPlan {
     uint32_t n_bins;
 };
 
-struct BinItem { uint32_t rel; float v0, v1; };          // entry within the bin, contribution * 2^8 per feature
+// code: bits 0..12 the x0 corner's entry within the bin, bits 13..25 the x1 corner's, bit 26 / 27: the x0 / x1 corner is present;
+// a0, a1 = (wy wz) g_f with the pair's y / z weights; wx = the point's x fraction (the x0 corner weighs 1 - wx, the x1 corner wx)
+struct __attribute__((aligned(16))) BinItem { uint32_t code; float a0, a1, wx; };
+constexpr uint32_t kBinHas0 = 1u << 26, kBinHas1 = 1u << 27;
+constexpr uint32_t kBinItemsPerPoint = 8;                // capacity per (list point, level): four pairs, each split in the worst case
+
+// the level's corner indices (hash_corners_rt's order: corner c = dx + 2 dy + 4 dz, so pair q = dy + 2 dz is corners 2q, 2q + 1), the
+// pairs' y / z weights and the x fraction -- the same arithmetic in k_bin_count and k_bin_fill, so that both see the same items
+__device__ __forceinline__ void bin_pairs(const LevelTab& lt, int level, float x, float y, float z, uint32_t (&idx)[8], float (&wyz)[4], float& wx) {
+    float w_unused[8];
+    hash_corners_rt(lt, level, x, y, z, idx, w_unused);
+    const float scale = lt.scale[level];
+    const float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
+    wx = px - floorf(px);
+    const float wy = py - floorf(py), wz = pz - floorf(pz);
+    const float uy = 1.0f - wy, uz = 1.0f - wz;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wyz[q] = ((q & 1) ? wy : uy) * ((q & 2) ? wz : uz);
+}
+
+// a contribution a * w (|w| <= 1) onto the 2^-40 lattice: the product is exact in fp64 and the fma with the magic number rounds it
+// once (naruto_field.hip, "through the fp64 pipe"); beyond the magic number's range the fp32 split (reaches 2^22, drops NaN / Inf)
+__device__ __forceinline__ unsigned long long fix40_prod(float a, float w) {
+    if (fabsf(a) < kFixMagicRange) return fix40_bits(fma((double)a, (double)w, kFixMagic));
+    return to_fix40(a * w);
+}
 
 // this (row)'s share of the point list: multiples of kBinRound so that count and fill walk the same rounds
 __device__ __forceinline__ void bin_row_range(uint32_t M, uint32_t rows, uint32_t row, uint32_t& m_lo, uint32_t& m_hi) {
@@ -72,10 +101,14 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_count(LevelTab lt, BoxTab b
         float x, y, z;
         load_point(ps, bt, m, x, y, z);
         uint32_t idx[8];
-        float w[8];
-        hash_corners_rt(lt, (int)level, x, y, z, idx, w);
+        float wyz[4], wx;
+        bin_pairs(lt, (int)level, x, y, z, idx, wyz, wx);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) atomicAdd(&hist[idx[c] >> kBinLog2], 1u);
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t b0 = idx[2 * q] >> kBinLog2, b1 = idx[2 * q + 1] >> kBinLog2;
+            atomicAdd(&hist[b0], 1u);
+            if (b1 != b0) atomicAdd(&hist[b1], 1u);
+        }
     }
     __syncthreads();
     uint32_t* __restrict__ out = counts + (size_t)row * plan.n_bins + plan.bin0[k];
@@ -136,21 +169,25 @@ __global__ __launch_bounds__(1024) void k_bin_start(const uint32_t* __restrict__
     if (threadIdx.x == 0) starts[n_bins] = carry;
 }
 
-// k_bin_fill: kBinRound threads, one point per thread and round.  Dynamic LDS: | items[kBinRound * 8] | hist[nb_max] | off[nb_max] |
-// base[nb_max] | wave_tot[16] | -- 102 KB at 1 024 points per round and 512 bins per level (T = 2^22): one 16-wave workgroup per CU.
-// (Rounds of 512 points, two workgroups per CU: a (round, bin) run is 8 items = 96 B on average and ends in partly written lines --
-// 5.0 GB written for 3.6 GB of items; 1 024-point rounds: 2.08 -> 1.77 ms at T = 2^22.)  While an
-// item sits in LDS its first word carries the bin next to the entry (rel | bin << 13); the bin is stripped on the way out.
-constexpr int kBinFillThreads = kBinRound;
-inline size_t bin_fill_lds_bytes(uint32_t nb_max) { return (size_t)kBinRound * 8u * sizeof(BinItem) + 3u * (size_t)nb_max * sizeof(uint32_t) + 64u; }
+// k_bin_fill<ROUND>: ROUND threads, one point per thread and round.  Dynamic LDS: | items[ROUND * 8] | bin of each item (u16) | hist[nb_max] |
+// off[nb_max] | base[nb_max] | wave_tot[16] | -- sized for the worst case of every pair straddling two bins: 150 KB at 1 024 points per
+// round and 512 bins per level (T = 2^22), one 16-wave workgroup per CU; levels of more than 1 024 bins (T = 2^24) take 512-point rounds.
+// (Rounds of 512 points: a (round, bin) run is 4 items = 64 B on average and ends in partly written lines; 1 024-point rounds with
+// 12-byte items: 2.08 -> 1.77 ms at T = 2^22.)
+inline size_t bin_fill_lds_bytes(uint32_t round, uint32_t nb_max) {
+    return (size_t)round * kBinItemsPerPoint * (sizeof(BinItem) + sizeof(uint16_t)) + 3u * (size_t)nb_max * sizeof(uint32_t) + 64u;
+}
 
-__global__ __launch_bounds__(kBinFillThreads) void k_bin_fill(LevelTab lt, BoxTab bt, PointSrc ps, uint32_t M, const float* __restrict__ d_feat,
-                                                              size_t stride_m, size_t stride_l, BinPlan plan, uint32_t nb_max,
-                                                              const uint32_t* __restrict__ counts, const uint32_t* __restrict__ starts,
-                                                              BinItem* __restrict__ items_out, const uint32_t* __restrict__ m_dev) {
+template <int ROUND>
+__global__ __launch_bounds__(ROUND) void k_bin_fill(LevelTab lt, BoxTab bt, PointSrc ps, uint32_t M, const float* __restrict__ d_feat,
+                                                    size_t stride_m, size_t stride_l, BinPlan plan, uint32_t nb_max,
+                                                    const uint32_t* __restrict__ counts, const uint32_t* __restrict__ starts,
+                                                    BinItem* __restrict__ items_out, const uint32_t* __restrict__ m_dev) {
+    constexpr int kBinFillThreads = ROUND;
     extern __shared__ __attribute__((aligned(16))) char bin_smem[];
     BinItem* __restrict__ l_items = reinterpret_cast<BinItem*>(bin_smem);
-    uint32_t* __restrict__ l_hist = reinterpret_cast<uint32_t*>(bin_smem + (size_t)kBinRound * 8u * sizeof(BinItem));
+    uint16_t* __restrict__ l_bin = reinterpret_cast<uint16_t*>(bin_smem + (size_t)ROUND * kBinItemsPerPoint * sizeof(BinItem));
+    uint32_t* __restrict__ l_hist = reinterpret_cast<uint32_t*>(bin_smem + (size_t)ROUND * kBinItemsPerPoint * (sizeof(BinItem) + sizeof(uint16_t)));
     uint32_t* __restrict__ l_off = l_hist + nb_max;
     uint32_t* __restrict__ l_base = l_off + nb_max;
     uint32_t* __restrict__ l_wave_tot = l_base + nb_max;
@@ -182,20 +219,24 @@ __global__ __launch_bounds__(kBinFillThreads) void k_bin_fill(LevelTab lt, BoxTa
     float2 g_nxt = make_float2(0.0f, 0.0f);
     PointRaw p_nxt{};
     if (m_lo < m_hi) load_in(m_lo, g_nxt, p_nxt);
-    for (uint32_t r0 = m_lo; r0 < m_hi; r0 += (uint32_t)kBinRound) {
+    for (uint32_t r0 = m_lo; r0 < m_hi; r0 += (uint32_t)ROUND) {
         const float2 g = g_nxt;
         const PointRaw pr = p_nxt;
-        if (r0 + (uint32_t)kBinRound < m_hi) load_in(r0 + (uint32_t)kBinRound, g_nxt, p_nxt);
-        // 1. this thread's point -> 8 items in registers, rank of each item within (round, bin)
+        if (r0 + (uint32_t)ROUND < m_hi) load_in(r0 + (uint32_t)ROUND, g_nxt, p_nxt);
+        // 1. this thread's point -> its pair items in registers, rank of each item within (round, bin)
         uint32_t e_idx[8], e_rank[8];
-        float e_w[8];
+        float e_wyz[4], e_wx = 0.0f;
         const bool live = !(g.x == 0.0f && g.y == 0.0f);
         if (live) {
             float x, y, z;
             finish_point(ps, bt, pr, x, y, z);
-            hash_corners_rt(lt, (int)level, x, y, z, e_idx, e_w);
+            bin_pairs(lt, (int)level, x, y, z, e_idx, e_wyz, e_wx);
 #pragma unroll
-            for (int c = 0; c < 8; ++c) e_rank[c] = atomicAdd(&l_hist[e_idx[c] >> kBinLog2], 1u);
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t b0 = e_idx[2 * q] >> kBinLog2, b1 = e_idx[2 * q + 1] >> kBinLog2;
+                e_rank[2 * q] = atomicAdd(&l_hist[b0], 1u);
+                e_rank[2 * q + 1] = b1 != b0 ? atomicAdd(&l_hist[b1], 1u) : 0u;
+            }
         }
         __syncthreads();
         // 2. exclusive prefix of the round's histogram (thread t: bins [t * per_thread, (t + 1) * per_thread))
@@ -228,20 +269,26 @@ __global__ __launch_bounds__(kBinFillThreads) void k_bin_fill(LevelTab lt, BoxTa
         const uint32_t n_items = l_off[nb - 1u] + l_hist[nb - 1u];
         // 3. place
         if (live) {
-            const float g0 = g.x * 256.0f, g1 = g.y * 256.0f;       // the 2^8 of to_fix40 folded in once per point
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const uint32_t b = e_idx[c] >> kBinLog2;
-                l_items[l_off[b] + e_rank[c]] = BinItem{(e_idx[c] & (kBinEntries - 1u)) | (b << kBinLog2), e_w[c] * g0, e_w[c] * g1};
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t b0 = e_idx[2 * q] >> kBinLog2, b1 = e_idx[2 * q + 1] >> kBinLog2;
+                const uint32_t r0 = e_idx[2 * q] & (kBinEntries - 1u), r1 = (e_idx[2 * q + 1] & (kBinEntries - 1u)) << kBinLog2;
+                const float a0 = e_wyz[q] * g.x, a1 = e_wyz[q] * g.y;
+                const uint32_t at0 = l_off[b0] + e_rank[2 * q];
+                l_items[at0] = BinItem{b0 == b1 ? (r0 | r1 | kBinHas0 | kBinHas1) : (r0 | kBinHas0), a0, a1, e_wx};
+                l_bin[at0] = (uint16_t)b0;
+                if (b1 != b0) {
+                    const uint32_t at1 = l_off[b1] + e_rank[2 * q + 1];
+                    l_items[at1] = BinItem{r1 | kBinHas1, a0, a1, e_wx};
+                    l_bin[at1] = (uint16_t)b1;
+                }
             }
         }
         __syncthreads();
-        // 4. write the runs: consecutive sorted positions of a bin go to consecutive addresses
+        // 4. write the runs: consecutive sorted positions of a bin go to consecutive addresses (16-byte stores)
         for (uint32_t i = threadIdx.x; i < n_items; i += kBinFillThreads) {
-            BinItem it = l_items[i];
-            const uint32_t b = it.rel >> kBinLog2;
-            it.rel &= kBinEntries - 1u;
-            items_out[(size_t)l_base[b] + (i - l_off[b])] = it;
+            const uint32_t b = l_bin[i];
+            items_out[(size_t)l_base[b] + (i - l_off[b])] = l_items[i];
         }
         __syncthreads();
         for (uint32_t b = threadIdx.x; b < nb; b += kBinFillThreads) {
@@ -280,8 +327,18 @@ __global__ __launch_bounds__(kBinApplyThreads) void k_bin_apply(LevelTab lt, Bin
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (i0 + (uint32_t)u * kBinApplyThreads >= i_hi) break;
-                atomicAdd(bin_acc + 2u * it[u].rel, to_fix40_scaled(it[u].v0));            // ds_add_u64
-                atomicAdd(bin_acc + 2u * it[u].rel + 1u, to_fix40_scaled(it[u].v1));
+                const uint32_t code = it[u].code;
+                const float wx = it[u].wx, ux = 1.0f - wx;
+                if (code & kBinHas0) {
+                    const uint32_t r = code & (kBinEntries - 1u);
+                    atomicAdd(bin_acc + 2u * r, fix40_prod(it[u].a0, ux));                    // ds_add_u64
+                    atomicAdd(bin_acc + 2u * r + 1u, fix40_prod(it[u].a1, ux));
+                }
+                if (code & kBinHas1) {
+                    const uint32_t r = (code >> kBinLog2) & (kBinEntries - 1u);
+                    atomicAdd(bin_acc + 2u * r, fix40_prod(it[u].a0, wx));
+                    atomicAdd(bin_acc + 2u * r + 1u, fix40_prod(it[u].a1, wx));
+                }
             }
         }
         __syncthreads();

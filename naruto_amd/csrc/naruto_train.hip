@@ -167,12 +167,14 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_stage(LossStageArgs
 // runs the loss stage's ray work from there when the ray is done -- the loss stage's launch, its reload of raw and its trip through
 // the launch queue go away; the smoothness term's workgroups ride behind the ray workgroups (they start as soon as workgroups of
 // early-terminated rays retire).  Same arithmetic in the same order as k_query_fwd<true> | k_loss_stage: same bits.
-template <bool BF>
+// SPLIT: the tile in two phases through a per-wave LDS slab (fwd_tile_split) -- 32 KB per workgroup, so the launcher uses it only while two
+// workgroups still fit a CU next to the rays' images (up to 192 samples per ray); longer rays keep the register form (fwd_tile).
+template <bool BF, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps, uint32_t M, float* __restrict__ raw,
                                                            float* __restrict__ feat_save, EarlyExit ee, LossStageArgs a, uint32_t n_fwd_blocks) {
     using Lds = std::conditional_t<BF, FwdLdsBf, FwdLds>;
     __shared__ Lds L;
-    __shared__ FwdSlab slabs[kFwdSplit ? kRaysPerBlock : 1];
+    __shared__ FwdSlab slabs[SPLIT ? kRaysPerBlock : 1];
     __shared__ double red[4];
     __shared__ float terms[kRaysPerBlock][10];
     extern __shared__ float ray_lds[];
@@ -205,9 +207,9 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
                 const float u = live ? uncert_sample(ut, p.uncert_grid, x, y, z) : 0.0f;
                 FwdTileOut to;
                 const bool live_out = live;
-                if constexpr (BF && kFwdSplit) fwd_tile_split_bf<true, true>(L, slabs[wave], lt, table, x, y, z, feat_save, nullptr, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
+                if constexpr (BF && SPLIT) fwd_tile_split_bf<true, true>(L, slabs[wave], lt, table, x, y, z, feat_save, nullptr, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
                 else if constexpr (BF) fwd_tile_bf<true, true>(L, lt, table, x, y, z, feat_save, nullptr, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
-                else if constexpr (kFwdSplit) fwd_tile_split<true, true>(L, slabs[wave], lt, table, x, y, z, feat_save, nullptr, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);      // M = n_rays * 64 tpr: every tile is full
+                else if constexpr (SPLIT) fwd_tile_split<true, true>(L, slabs[wave], lt, table, x, y, z, feat_save, nullptr, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);      // M = n_rays * 64 tpr: every tile is full
                 else fwd_tile<true, true>(L, lt, table, x, y, z, feat_save, nullptr, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
                 if (!live_out) { to.rgb[0] = 0.0f; to.rgb[1] = 0.0f; to.rgb[2] = 0.0f; to.sdf = 0.0f; }
                 const float u_out = live_out ? u : 0.0f;
@@ -233,8 +235,10 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
         __syncthreads();                                   // terms are rewritten by the next group
     }
 }
-template __global__ void k_query_fwd_loss<false>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t);
-template __global__ void k_query_fwd_loss<true>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t);
+template __global__ void k_query_fwd_loss<false, false>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t);
+template __global__ void k_query_fwd_loss<true, false>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t);
+template __global__ void k_query_fwd_loss<false, true>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t);
+template __global__ void k_query_fwd_loss<true, true>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t);
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // PACKED training forward (round 4): field query + loss stage for rays of ANY sample count, evaluating only the samples some consumer

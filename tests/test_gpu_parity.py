@@ -1581,13 +1581,14 @@ def test_launch_variants_give_the_same_bits(gpu, tmp_path):
 
 def test_packed_forward_equals_the_flat_one(gpu, tmp_path):
     """The shipped 32 + 11 sampling goes through k_query_fwd_loss_packed (only the samples a consumer can see, packed across rays, loss stage
-    from LDS); NARUTO_FWD_PACKED=0 runs the flat field query over every sample + k_loss_stage instead.  Same losses, rendered maps, sums and
+    from LDS) when its rows fall evenly on the workgroups (NARUTO_FWD_PACKED=3: whatever the row count); NARUTO_FWD_PACKED=0 runs the flat
+    field query over every sample + k_loss_stage instead.  Same losses, rendered maps, sums and
     gradients -- not bit for bit: a point's OneBlob takes the closed form or the dense one depending on the tile it shares (both forms of
     the same function, 1.2e-6 apart), so the comparison is at that distance.  NARUTO_FWD_PACKED=2 (the packed kernel for S = 128 too)
     against the depth-ordered walk likewise."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for tag, n_samples_d, env_a, env_b in (("43", 32, {"NARUTO_FWD_PACKED": "1"}, {"NARUTO_FWD_PACKED": "0"}), ("128", 117, {"NARUTO_FWD_PACKED": "2"}, {"NARUTO_FWD_PACKED": "0"})):
+    for tag, n_samples_d, env_a, env_b in (("43", 32, {"NARUTO_FWD_PACKED": "3"}, {"NARUTO_FWD_PACKED": "0"}), ("128", 117, {"NARUTO_FWD_PACKED": "2"}, {"NARUTO_FWD_PACKED": "0"})):
         script = tmp_path / f"iteration_{tag}.py"
         script.write_text(_KNOB_SCRIPT.replace("n_samples_d=117", f"n_samples_d={n_samples_d}"))
         res = []

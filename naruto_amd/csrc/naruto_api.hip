@@ -1302,6 +1302,19 @@ int naruto_active_ray_select(uint32_t n_total, uint32_t base, uint32_t K, uint32
         return fail(NARUTO_ERR_INVALID, "active_ray_select: need 0 < K <= base, n_tail > 0, base + n_tail < n_total");
     const uint32_t n_cand = n_total - n_tail - base;
     if (n_cand <= K) return fail(NARUTO_ERR_INVALID, "active_ray_select: %u candidates for K = %u (numpy argpartition needs K < n)", n_cand, K);
+    static const bool fused_on = getenv("NARUTO_DEBUG_ARS_FUSED") == nullptr || atoi(getenv("NARUTO_DEBUG_ARS_FUSED")) != 0;
+    if (fused_on && n_cand <= kArsFusedMax) {
+        // lookup, selection and gather in one launch (k_ars_fused); NARUTO_DEBUG_ARS_FUSED=0: the three launches below (same result)
+        ArsArgs a{};
+        a.n_total = n_total; a.base = base; a.K = K; a.n_tail = n_tail; a.n_cand = n_cand;
+        a.rays_o = rays_o; a.rays_d = rays_d; a.target_s = target_s; a.target_d = target_d; a.vol = uncert_vol;
+        a.X = (int)vol_dims[0]; a.Y = (int)vol_dims[1]; a.Z = (int)vol_dims[2];
+        a.bx = bbox_min[0]; a.by = bbox_min[1]; a.bz = bbox_min[2]; a.voxel_scale = voxel_scale;
+        a.o_out = out_o; a.d_out = out_d; a.s_out = out_s; a.t_out = out_t;
+        const uint32_t n_copy = base + n_tail - K;
+        hipLaunchKernelGGL(k_ars_fused, dim3(1u + (n_copy + kArsFusedThreads - 1u) / kArsFusedThreads), dim3(kArsFusedThreads), 0, (hipStream_t)stream, a);
+        return check_launch("ars_fused");
+    }
     uint32_t* keys = reinterpret_cast<uint32_t*>(workspace);
     uint32_t* sel = keys + n_cand;
     hipLaunchKernelGGL(k_ars_lookup, dim3((n_cand + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, n_cand, base, rays_o, rays_d, target_d, uncert_vol,

@@ -186,6 +186,168 @@ __global__ __launch_bounds__(1024) void k_ars_select_small(uint32_t n_cand, uint
     }
 }
 
+// N1 in ONE launch (round 4; up to 8 192 candidates, a mapping iteration has 6 444): workgroup 0 looks the keys up, selects and gathers the K
+// selected rays; the other workgroups copy the rows that do not depend on the selection ([K, base): the first base - K rays, [base, n_out): the
+// tail).  Replaces k_ars_lookup | k_ars_select_small | k_ars_gather (4.6 + 20.5 + 4.6 us and two launch gaps inside every mapping iteration).
+// The selection is the bit-by-bit threshold search of k_ars_select_small on BIT-SLICED keys: a thread holds 32 consecutive keys, transposed
+// once (32 x 32 bit matrix in registers) into B[b] = "bit b of my 32 keys", so that a round is one and-not + popcount per thread instead of
+// three instructions per key, and four waves (one per SIMD) instead of sixteen share the per-round reduction and barrier.  Same result: the K
+// smallest keys, ties at the threshold by lower index, ascending.
+struct ArsArgs {
+    uint32_t n_total, base, K, n_tail, n_cand;
+    const float *rays_o, *rays_d, *target_s, *target_d, *vol;
+    int X, Y, Z;
+    float bx, by, bz, voxel_scale;
+    float *o_out, *d_out, *s_out, *t_out;
+};
+constexpr uint32_t kArsFusedThreads = 1024, kArsSelThreads = 256, kArsFusedPer = 32, kArsFusedMax = kArsSelThreads * kArsFusedPer;
+
+__device__ __forceinline__ uint32_t ars_key(const ArsArgs& a, uint32_t j) {
+    const size_t r = (size_t)a.base + j;
+    const float t = a.target_d[r];
+    const float px = __fadd_rn(a.rays_o[3 * r + 0], __fmul_rn(a.rays_d[3 * r + 0], t));
+    const float py = __fadd_rn(a.rays_o[3 * r + 1], __fmul_rn(a.rays_d[3 * r + 1], t));
+    const float pz = __fadd_rn(a.rays_o[3 * r + 2], __fmul_rn(a.rays_d[3 * r + 2], t));
+    // numpy: ((pts - bbox_min) * 10).round().astype(int), then np.clip -- rintf is round-half-to-even like np.round
+    const float fx = rintf(__fmul_rn(__fsub_rn(px, a.bx), a.voxel_scale));
+    const float fy = rintf(__fmul_rn(__fsub_rn(py, a.by), a.voxel_scale));
+    const float fz = rintf(__fmul_rn(__fsub_rn(pz, a.bz), a.voxel_scale));
+    const int ix = (int)fminf(fmaxf(fx, 0.0f), (float)(a.X - 1));
+    const int iy = (int)fminf(fmaxf(fy, 0.0f), (float)(a.Y - 1));
+    const int iz = (int)fminf(fmaxf(fz, 0.0f), (float)(a.Z - 1));
+    return sortable_key(a.vol[((size_t)ix * a.Y + iy) * a.Z + iz]);
+}
+__device__ __forceinline__ void ars_copy_row(const ArsArgs& a, size_t src, size_t r) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        a.o_out[3 * r + c] = a.rays_o[3 * src + c];
+        a.d_out[3 * r + c] = a.rays_d[3 * src + c];
+        a.s_out[3 * r + c] = a.target_s[3 * src + c];
+    }
+    a.t_out[r] = a.target_d[src];
+}
+// exclusive scan over the values of the selecting waves (0 .. 3); called by ALL waves of the workgroup (the barriers are the workgroup's),
+// the others pass 0; every thread gets the total too
+__device__ __forceinline__ uint32_t sel_exclusive_scan(uint32_t v, uint32_t* __restrict__ wave_tot, int lane, int wave, uint32_t& total) {
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
+    if (lane == 63 && wave < 4) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const uint32_t t = wave_tot[w]; before += w < wave ? t : 0u; all += t; }
+    total = all;
+    __syncthreads();                    // wave_tot is reused by the next scan
+    return before + incl - v;
+}
+
+// Workgroup 0: all sixteen waves look the keys up (eight independent lookups in flight per thread: the lookup is two dependent trips to
+// memory, ray -> voxel), the first four then select -- one wave per SIMD, the other twelve only keep the workgroup's barriers company --
+// and all sixteen gather the selected rows.
+__global__ __launch_bounds__(kArsFusedThreads) void k_ars_fused(ArsArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t n_out = a.base + a.n_tail;
+    if (blockIdx.x > 0) {                               // rows that do not depend on the selection
+        const uint32_t r = a.K + (blockIdx.x - 1u) * kArsFusedThreads + (uint32_t)tid;
+        if (r < n_out) ars_copy_row(a, r < a.base ? (size_t)(r - a.K) : (size_t)a.n_total - a.n_tail + (r - a.base), r);
+        return;
+    }
+    __shared__ uint32_t l_keys[kArsFusedMax + kArsSelThreads];            // key j at j + (j >> 5): a thread's 32 consecutive keys without bank conflicts; later: sel
+    __shared__ uint32_t wave_cnt[2][4];
+    __shared__ uint32_t wave_tot[4];
+    {
+        uint32_t kk[kArsFusedMax / kArsFusedThreads];
+#pragma unroll
+        for (uint32_t i = 0; i < kArsFusedMax / kArsFusedThreads; ++i) {
+            const uint32_t j = i * kArsFusedThreads + (uint32_t)tid;
+            kk[i] = ars_key(a, j < a.n_cand ? j : a.n_cand - 1u);
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < kArsFusedMax / kArsFusedThreads; ++i) {
+            const uint32_t j = i * kArsFusedThreads + (uint32_t)tid;
+            l_keys[j + (j >> 5)] = j < a.n_cand ? kk[i] : 0xFFFFFFFFu;
+        }
+    }
+    __syncthreads();
+    const bool selects = wave < 4;                      // wave-uniform
+    const uint32_t j0 = (uint32_t)tid * kArsFusedPer;
+    // bit-sliced keys: A[r] = key 31 - r in, B[b] = A[31 - b] out (the transpose below mirrors both axes)
+    uint32_t A[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) A[r] = 0u;
+    uint32_t valid = 0u;
+    if (selects) {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) A[r] = l_keys[33u * (uint32_t)tid + (uint32_t)(31 - r)];
+        uint32_t m = 0x0000FFFFu;
+#pragma unroll
+        for (int jj = 16; jj != 0; jj >>= 1, m ^= (m << jj)) {
+#pragma unroll
+            for (int k = 0; k < 32; k = (k + jj + 1) & ~jj) {
+                const uint32_t t = (A[k] ^ (A[k + jj] >> jj)) & m;
+                A[k] ^= t;
+                A[k + jj] ^= (t << jj);
+            }
+        }
+        valid = j0 >= a.n_cand ? 0u : (a.n_cand - j0 >= 32u ? 0xFFFFFFFFu : ((1u << (a.n_cand - j0)) - 1u));
+    }
+    uint32_t alive = valid, prefix = 0, rem = a.K;      // the K-th smallest key has these high bits; rem of the undecided keys are still to be taken
+#pragma unroll
+    for (int bit = 31; bit >= 0; --bit) {
+        uint32_t zeros = 0u;
+        if (selects) {
+            zeros = ~A[31 - bit] & alive;
+            const uint32_t c = wave_sum_u32((uint32_t)__popc(zeros));
+            if (lane == 0) wave_cnt[bit & 1][wave] = c;
+        }
+        __syncthreads();
+        if (selects) {
+            const uint32_t total = wave_cnt[bit & 1][0] + wave_cnt[bit & 1][1] + wave_cnt[bit & 1][2] + wave_cnt[bit & 1][3];
+            if (rem <= total) {
+                alive = zeros;                          // the K-th key has a 0 here: the ones are out
+            } else {
+                rem -= total;                           // all zeros are taken; the K-th key is among the ones
+                prefix |= 1u << bit;
+                alive &= ~zeros;
+            }
+        }
+    }
+    // keys < threshold / == threshold, bit-sliced
+    uint32_t eq_mask = valid, lt_mask = 0;
+    if (selects) {
+#pragma unroll
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t b = A[31 - bit];
+            if ((prefix >> bit) & 1u) { lt_mask |= eq_mask & ~b; eq_mask &= b; }
+            else eq_mask &= ~b;
+        }
+    }
+    uint32_t tot;
+    const uint32_t eq_before = sel_exclusive_scan((uint32_t)__popc(eq_mask), wave_tot, lane, wave, tot);
+    // the first `rem` keys == threshold in index order: this thread takes its lowest (rem - eq_before) of them
+    uint32_t take = (selects && eq_before < rem) ? rem - eq_before : 0u;
+    uint32_t chosen = lt_mask, e = eq_mask;
+#pragma unroll 1
+    while (take != 0u && e != 0u) {
+        const uint32_t low = e & (0u - e);
+        chosen |= low;
+        e ^= low;
+        --take;
+    }
+    uint32_t out = sel_exclusive_scan((uint32_t)__popc(chosen), wave_tot, lane, wave, tot);
+    // (the scans' barriers are behind every thread's last read of its keys: l_keys becomes the selection list)
+    uint32_t c2 = chosen;
+#pragma unroll 1
+    while (c2 != 0u) {
+        const uint32_t i = (uint32_t)__ffs((int)c2) - 1u;
+        l_keys[out++] = j0 + i;
+        c2 &= c2 - 1u;
+    }
+    __syncthreads();
+    for (uint32_t r = (uint32_t)tid; r < a.K; r += kArsFusedThreads) ars_copy_row(a, (size_t)l_keys[r] + a.base, r);
+}
+
 // assemble [K selected | first (base-K) rays | last n_tail rays] (active_ray_sampler.py:128-147)
 __global__ __launch_bounds__(256) void k_ars_gather(uint32_t n_out, uint32_t K, uint32_t base, uint32_t n_total, uint32_t n_tail,
                                                     const uint32_t* __restrict__ sel, const float* __restrict__ rays_o, const float* __restrict__ rays_d,

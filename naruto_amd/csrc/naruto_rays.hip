@@ -205,9 +205,12 @@ constexpr uint32_t kArsFusedThreads = 1024, kArsSelThreads = 256, kArsFusedPer =
 __device__ __forceinline__ uint32_t ars_key(const ArsArgs& a, uint32_t j) {
     const size_t r = (size_t)a.base + j;
     const float t = a.target_d[r];
-    const float px = __fadd_rn(a.rays_o[3 * r + 0], __fmul_rn(a.rays_d[3 * r + 0], t));
-    const float py = __fadd_rn(a.rays_o[3 * r + 1], __fmul_rn(a.rays_d[3 * r + 1], t));
-    const float pz = __fadd_rn(a.rays_o[3 * r + 2], __fmul_rn(a.rays_d[3 * r + 2], t));
+    // a ray's three floats as ONE 12-byte load (one instruction over 12 consecutive lines per wave instead of three strided ones: the
+    // one CU that runs this workgroup issues every load of the 8 192 lookups)
+    const float3 o = *reinterpret_cast<const float3*>(a.rays_o + 3 * r), d = *reinterpret_cast<const float3*>(a.rays_d + 3 * r);
+    const float px = __fadd_rn(o.x, __fmul_rn(d.x, t));
+    const float py = __fadd_rn(o.y, __fmul_rn(d.y, t));
+    const float pz = __fadd_rn(o.z, __fmul_rn(d.z, t));
     // numpy: ((pts - bbox_min) * 10).round().astype(int), then np.clip -- rintf is round-half-to-even like np.round
     const float fx = rintf(__fmul_rn(__fsub_rn(px, a.bx), a.voxel_scale));
     const float fy = rintf(__fmul_rn(__fsub_rn(py, a.by), a.voxel_scale));
@@ -218,13 +221,13 @@ __device__ __forceinline__ uint32_t ars_key(const ArsArgs& a, uint32_t j) {
     return sortable_key(a.vol[((size_t)ix * a.Y + iy) * a.Z + iz]);
 }
 __device__ __forceinline__ void ars_copy_row(const ArsArgs& a, size_t src, size_t r) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        a.o_out[3 * r + c] = a.rays_o[3 * src + c];
-        a.d_out[3 * r + c] = a.rays_d[3 * src + c];
-        a.s_out[3 * r + c] = a.target_s[3 * src + c];
-    }
-    a.t_out[r] = a.target_d[src];
+    const float3 o = *reinterpret_cast<const float3*>(a.rays_o + 3 * src), d = *reinterpret_cast<const float3*>(a.rays_d + 3 * src),
+                 c = *reinterpret_cast<const float3*>(a.target_s + 3 * src);
+    const float t = a.target_d[src];
+    *reinterpret_cast<float3*>(a.o_out + 3 * r) = o;
+    *reinterpret_cast<float3*>(a.d_out + 3 * r) = d;
+    *reinterpret_cast<float3*>(a.s_out + 3 * r) = c;
+    a.t_out[r] = t;
 }
 // exclusive scan over the values of the selecting waves (0 .. 3); called by ALL waves of the workgroup (the barriers are the workgroup's),
 // the others pass 0; every thread gets the total too
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(kArsFusedThreads) void k_ars_fused(ArsArgs a) {
         return;
     }
     __shared__ uint32_t l_keys[kArsFusedMax + kArsSelThreads];            // key j at j + (j >> 5): a thread's 32 consecutive keys without bank conflicts; later: sel
-    __shared__ uint32_t wave_cnt[2][4];
+    __shared__ uint32_t wave_cnt[2][4][2];
     __shared__ uint32_t wave_tot[4];
     {
         uint32_t kk[kArsFusedMax / kArsFusedThreads];
@@ -293,23 +296,31 @@ __global__ __launch_bounds__(kArsFusedThreads) void k_ars_fused(ArsArgs a) {
         valid = j0 >= a.n_cand ? 0u : (a.n_cand - j0 >= 32u ? 0xFFFFFFFFu : ((1u << (a.n_cand - j0)) - 1u));
     }
     uint32_t alive = valid, prefix = 0, rem = a.K;      // the K-th smallest key has these high bits; rem of the undecided keys are still to be taken
+    // two bits per round: how many undecided keys continue with 00 / 01 / 10 (11 is the rest), the first two counts packed into one word
+    // (a wave's count is at most 2 048, the workgroup's 8 192) -- sixteen barrier rounds instead of thirty-two
 #pragma unroll
-    for (int bit = 31; bit >= 0; --bit) {
-        uint32_t zeros = 0u;
+    for (int bit = 31; bit >= 1; bit -= 2) {
+        uint32_t z00 = 0u, z01 = 0u, z10 = 0u;
         if (selects) {
-            zeros = ~A[31 - bit] & alive;
-            const uint32_t c = wave_sum_u32((uint32_t)__popc(zeros));
-            if (lane == 0) wave_cnt[bit & 1][wave] = c;
+            const uint32_t hi = A[31 - bit], lo = A[32 - bit];
+            z00 = ~hi & ~lo & alive; z01 = ~hi & lo & alive; z10 = hi & ~lo & alive;
+            const uint32_t p = wave_sum_u32((uint32_t)__popc(z00) | ((uint32_t)__popc(z01) << 16));
+            const uint32_t q = wave_sum_u32((uint32_t)__popc(z10));
+            if (lane == 0) { wave_cnt[(bit >> 1) & 1][wave][0] = p; wave_cnt[(bit >> 1) & 1][wave][1] = q; }
         }
         __syncthreads();
         if (selects) {
-            const uint32_t total = wave_cnt[bit & 1][0] + wave_cnt[bit & 1][1] + wave_cnt[bit & 1][2] + wave_cnt[bit & 1][3];
-            if (rem <= total) {
-                alive = zeros;                          // the K-th key has a 0 here: the ones are out
+            const uint32_t (*wc)[2] = wave_cnt[(bit >> 1) & 1];
+            const uint32_t P = wc[0][0] + wc[1][0] + wc[2][0] + wc[3][0], t10 = wc[0][1] + wc[1][1] + wc[2][1] + wc[3][1];
+            const uint32_t t00 = P & 0xFFFFu, t01 = P >> 16;
+            if (rem <= t00) {
+                alive = z00;
+            } else if (rem <= t00 + t01) {
+                rem -= t00; alive = z01; prefix |= 1u << (bit - 1);
+            } else if (rem <= t00 + t01 + t10) {
+                rem -= t00 + t01; alive = z10; prefix |= 1u << bit;
             } else {
-                rem -= total;                           // all zeros are taken; the K-th key is among the ones
-                prefix |= 1u << bit;
-                alive &= ~zeros;
+                rem -= t00 + t01 + t10; alive &= ~(z00 | z01 | z10); prefix |= 3u << (bit - 1);
             }
         }
     }

@@ -241,7 +241,8 @@ int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const f
             return fail(NARUTO_ERR_INVALID, "scatter: %u list points x %u binned levels x 8 items overflow the 32-bit item offsets (split the batch)", M, f->bplan.n_levels);
         uint32_t nb_max = 0;
         for (uint32_t k = 0; k < f->bplan.n_levels; ++k) nb_max = f->bplan.bin0[k + 1] - f->bplan.bin0[k] > nb_max ? f->bplan.bin0[k + 1] - f->bplan.bin0[k] : nb_max;
-        const bool round_1024 = bin_fill_lds_bytes(1024u, nb_max) <= (size_t)160u * 1024u;            // else 512-point rounds (T = 2^24)
+        static const bool force_512 = getenv("NARUTO_DEBUG_BIN_ROUND") != nullptr && atoi(getenv("NARUTO_DEBUG_BIN_ROUND")) == 512;      // same bits: fixed-point sums
+        const bool round_1024 = !force_512 && bin_fill_lds_bytes(1024u, nb_max) <= (size_t)160u * 1024u;            // else 512-point rounds (T = 2^24)
         static bool attr_set = false;
         if (!attr_set) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_fill<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||

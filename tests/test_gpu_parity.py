@@ -1579,6 +1579,27 @@ def test_launch_variants_give_the_same_bits(gpu, tmp_path):
             assert np.array_equal(v, r[k], equal_nan=True), f"split multiplier: {k} differs"
 
 
+def test_binned_scatter_round_size_changes_no_bit(gpu, tmp_path):
+    """Levels of more than 2^17 entries go through the counting-sort scatter (naruto_binned.hip): 1 024-point sorting rounds, or 512-point
+    ones where a level has more than 1 024 bins (T = 2^24) -- forced here by NARUTO_DEBUG_BIN_ROUND=512 on a T = 2^18 field.  The sums are
+    fixed point, so how the items are cut into rounds and runs must not change a bit of any gradient."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "iteration_T18.py"
+    script.write_text(_KNOB_SCRIPT.replace("H.office_cfg(12,", "H.office_cfg(18,"))
+    res = []
+    for k, env in enumerate(({}, {"NARUTO_DEBUG_BIN_ROUND": "512"})):
+        out = tmp_path / f"T18_{k}.npz"
+        e = dict(os.environ)
+        e.update(env)
+        subprocess.run([sys.executable, str(script), root, str(out)], check=True, env=e, timeout=900)
+        res.append(dict(np.load(out)))
+    a, b = res
+    assert float(np.abs(a["g_table"]).max()) > 0
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), f"{k} differs between 1 024- and 512-point rounds"
+
+
 def test_packed_forward_equals_the_flat_one(gpu, tmp_path):
     """The shipped 32 + 11 sampling goes through k_query_fwd_loss_packed (only the samples a consumer can see, packed across rays, loss stage
     from LDS) when its rows fall evenly on the workgroups (NARUTO_FWD_PACKED=3: whatever the row count); NARUTO_FWD_PACKED=0 runs the flat

@@ -812,31 +812,27 @@ int launch_train_query(const NarutoField* f, const NarutoParams* p, const Naruto
         ee.target_d = t->target_d;
         ee.trunc_sc = f->desc.trunc * f->desc.sc_factor;
         ee.tiles_per_ray = S / 64u;
+        static const uint32_t stagger = getenv("NARUTO_DEBUG_WALK_STAGGER") ? (uint32_t)atoi(getenv("NARUTO_DEBUG_WALK_STAGGER")) : 0u;
+        ee.stagger = stagger;
         blocks = (N + 3u) / 4u;
         if (blocks > cu_count(f) * 4u) blocks = cu_count(f) * 4u;
     }
     static const bool no_fuse = getenv("NARUTO_DEBUG_NO_FUSED_LOSS_STAGE") != nullptr;      // A/B knob: the two launches instead
-    // the packed forward (k_query_fwd_loss_packed: only the samples a consumer can see, packed across rays; any samples-per-ray count).
-    // NARUTO_FWD_PACKED=0: the depth-ordered walk / the flat launch + k_loss_stage instead (A/B timing; losses and gradients agree to the
-    // distance between OneBlob's closed and dense forms, ~1e-6: which form a point gets depends on the tile it shares)
-    // Where: rays the depth-ordered walk cannot take (S not a multiple of 64, or a single tile: the shipped 32 + 11 sampling) -- there it replaces the
-    // flat launch over ALL samples + k_loss_stage (2 048 x 43: 41.7 + 8.0 us -> 44.5 us).  For S = 64 k the walk stays: it overlaps one wave's
-    // gathers with another's matrix chain, while the packed workgroup's steps are separated by barriers (2 048 x 128: walk 64.6 us, packed 66.7;
-    // per-step timeline: tools/fwd_timeline.py, profiles/r04_fwd_timeline.txt).  NARUTO_FWD_PACKED=2 forces it everywhere.
-    // ... and only where its rows (of four rays) fall evenly on the workgroups and a workgroup has few of them: a row is the unit of
-    // distribution, so 537 rows (the BA batch: 2 148 rays) leave 25 of 256 workgroups with three rows and the launch with their time (0.211
-    // against 0.1875 ms per BA iteration; 512 rows: 0.164 against 0.1715), and from dozens of rows per workgroup on the flat launch's overlap
-    // of gathers and matrix chains across its waves wins (131 072 x 43, T = 2^16: 5.92 against 4.87 ms per step) -- tools/ba_ab.sh.  =3: as 1, without this test.
+    // the packed forward (k_query_fwd_loss_packed: only the samples a consumer can see, packed across rays, loss stage from LDS; any
+    // samples-per-ray count).  Its workgroup works in barrier-separated steps -- all gathers of a pass, then all matrix chains -- so what it
+    // gains is the samples it does NOT evaluate, and what it loses is the flat launch's overlap of one wave's gathers with another's matrix
+    // chain.  Measured (tools/ba_ab*.sh, tools/fwd_timeline_ba.py):
+    //   * tables no cache holds (T = 2^22, 281 MB): every gather is an HBM line -- 131 072 x 43: 8.09 against 9.41 ms per step: ON;
+    //   * cache-resident tables: scene dependent.  2 048 random benchmark rays x 43: 0.166 against 0.1715 ms per step; the BA batch (2 148
+    //     rays from the keyframe store, random-initialised network: nearly every sample ends up evaluated, in two passes): ray workgroups
+    //     55 us + the smoothness tail against 42.7 + 8.6 us flat, 0.206 against 0.188 ms per iteration; 131 072 x 43: 5.92 against 4.87 ms.
+    //     Nothing known at launch time tells these apart: OFF (S = 64 k keeps the depth-ordered walk, everything else the flat launch).
+    // NARUTO_FWD_PACKED: 0 never, 1 (default) as above, 2 everywhere incl. S = 64 k, 3 wherever the walk cannot run.  Losses and gradients
+    // agree with the other launch shapes to the distance between OneBlob's closed and dense forms, ~1e-6 (which form a point gets depends on
+    // the tile it shares).  NARUTO_PACK_ONE_PASS=1: every sample in the first pass (measured: 0.200 / 0.180 ms at the two batches above).
     static const int packed_mode = getenv("NARUTO_FWD_PACKED") == nullptr ? 1 : atoi(getenv("NARUTO_FWD_PACKED"));
     bool packed_on = packed_mode == 2 || ((packed_mode == 1 || packed_mode == 3) && (S % 64u != 0u || S <= 64u));
-    if (packed_on && packed_mode == 1) {
-        const uint32_t n_rows_ = (N + (uint32_t)kRaysPerBlock - 1u) / (uint32_t)kRaysPerBlock, slots_ = cu_count(f);
-        const uint32_t wgs = n_rows_ < slots_ ? n_rows_ : slots_, per = (n_rows_ + wgs - 1u) / (wgs > 0u ? wgs : 1u);
-        // tables no cache holds (T = 2^22: 281 MB): the gathers are HBM random-line bound, every sample NOT evaluated is time saved, and the packed
-        // form wins at any batch size (131 072 x 43: 8.09 against 9.41 ms per step)
-        const bool hbm_resident = (size_t)f->n_entries * 2u * sizeof(float) > ((size_t)64u << 20);
-        packed_on = hbm_resident || (n_rows_ <= 8u * slots_ && (uint64_t)per * wgs * 100u <= (uint64_t)n_rows_ * 115u);
-    }
+    if (packed_on && packed_mode == 1) packed_on = (size_t)f->n_entries * 2u * sizeof(float) > ((size_t)64u << 20);
     if (loss != nullptr && packed_on && !no_fuse && kFwdSplit && S <= 4095u && N >= 1u) {
         // workgroup shape: 8 waves x 1 per CU, or 4 waves x 2 per CU (NARUTO_PACK_WAVES); rows (of four rays) a workgroup holds at a time: as many as
         // the LDS next to the weights, the feature slabs and the tiles' points takes, at most three
@@ -876,8 +872,13 @@ int launch_train_query(const NarutoField* f, const NarutoParams* p, const Naruto
             pe.target_d = t->target_d;
             pe.trunc_sc = f->desc.trunc * f->desc.sc_factor;
             const bool bfm = f->desc.mlp_mode == NARUTO_MLP_BF16;
+            static const int one_pass_env = getenv("NARUTO_PACK_ONE_PASS") ? atoi(getenv("NARUTO_PACK_ONE_PASS")) : -1;
+            const bool one_pass = one_pass_env == 1;
+            uint32_t rays_cap = rows * (uint32_t)kRaysPerBlock;
+            if (one_pass && rays_cap * S > 64u * W && 64u * W / S >= 1u) rays_cap = 64u * W / S;           // one pass: all of a chunk's samples in one group of tiles
+            const uint32_t rows_arg = rays_cap | (one_pass ? 0x100u : 0u);
 #define NARUTO_LAUNCH_PACKED(BFV, WV) hipLaunchKernelGGL((k_query_fwd_loss_packed<BFV, WV>), dim3(pblocks + loss->n_tv_blocks), dim3(64 * WV), need, st, f->lt, f->ut, f->bt, *p, ps, M, \
-                                                         t->raw, t->feat_save, pe, *loss, pblocks, rows, g_fwd_timeline)
+                                                         t->raw, t->feat_save, pe, *loss, pblocks, rows_arg, g_fwd_timeline)
             if (W == 4u) { if (bfm) NARUTO_LAUNCH_PACKED(true, 4); else NARUTO_LAUNCH_PACKED(false, 4); }
             else { if (bfm) NARUTO_LAUNCH_PACKED(true, 8); else NARUTO_LAUNCH_PACKED(false, 8); }
 #undef NARUTO_LAUNCH_PACKED

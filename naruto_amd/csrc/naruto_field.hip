@@ -190,6 +190,7 @@ struct EarlyExit {
     const float* target_d;
     float trunc_sc;
     uint32_t tiles_per_ray;
+    uint32_t stagger;            // experiment (NARUTO_DEBUG_WALK_STAGGER): low 8 bits = s_sleep(127) loops half of the walk's workgroups wait before their first tile; bit 8: which half
 };
 
 // state of one ray's front-to-back walk (wave-uniform): first sign change seen, its depth, the last sample so far

@@ -205,12 +205,11 @@ constexpr uint32_t kArsFusedThreads = 1024, kArsSelThreads = 256, kArsFusedPer =
 __device__ __forceinline__ uint32_t ars_key(const ArsArgs& a, uint32_t j) {
     const size_t r = (size_t)a.base + j;
     const float t = a.target_d[r];
-    // a ray's three floats as ONE 12-byte load (one instruction over 12 consecutive lines per wave instead of three strided ones: the
-    // one CU that runs this workgroup issues every load of the 8 192 lookups)
-    const float3 o = *reinterpret_cast<const float3*>(a.rays_o + 3 * r), d = *reinterpret_cast<const float3*>(a.rays_d + 3 * r);
-    const float px = __fadd_rn(o.x, __fmul_rn(d.x, t));
-    const float py = __fadd_rn(o.y, __fmul_rn(d.y, t));
-    const float pz = __fadd_rn(o.z, __fmul_rn(d.z, t));
+    const float ox = a.rays_o[3 * r + 0], oy = a.rays_o[3 * r + 1], oz = a.rays_o[3 * r + 2];
+    const float dx = a.rays_d[3 * r + 0], dy = a.rays_d[3 * r + 1], dz = a.rays_d[3 * r + 2];
+    const float px = __fadd_rn(ox, __fmul_rn(dx, t));
+    const float py = __fadd_rn(oy, __fmul_rn(dy, t));
+    const float pz = __fadd_rn(oz, __fmul_rn(dz, t));
     // numpy: ((pts - bbox_min) * 10).round().astype(int), then np.clip -- rintf is round-half-to-even like np.round
     const float fx = rintf(__fmul_rn(__fsub_rn(px, a.bx), a.voxel_scale));
     const float fy = rintf(__fmul_rn(__fsub_rn(py, a.by), a.voxel_scale));
@@ -221,13 +220,13 @@ __device__ __forceinline__ uint32_t ars_key(const ArsArgs& a, uint32_t j) {
     return sortable_key(a.vol[((size_t)ix * a.Y + iy) * a.Z + iz]);
 }
 __device__ __forceinline__ void ars_copy_row(const ArsArgs& a, size_t src, size_t r) {
-    const float3 o = *reinterpret_cast<const float3*>(a.rays_o + 3 * src), d = *reinterpret_cast<const float3*>(a.rays_d + 3 * src),
-                 c = *reinterpret_cast<const float3*>(a.target_s + 3 * src);
-    const float t = a.target_d[src];
-    *reinterpret_cast<float3*>(a.o_out + 3 * r) = o;
-    *reinterpret_cast<float3*>(a.d_out + 3 * r) = d;
-    *reinterpret_cast<float3*>(a.s_out + 3 * r) = c;
-    a.t_out[r] = t;
+    float v[10];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { v[c] = a.rays_o[3 * src + c]; v[3 + c] = a.rays_d[3 * src + c]; v[6 + c] = a.target_s[3 * src + c]; }
+    v[9] = a.target_d[src];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { a.o_out[3 * r + c] = v[c]; a.d_out[3 * r + c] = v[3 + c]; a.s_out[3 * r + c] = v[6 + c]; }
+    a.t_out[r] = v[9];
 }
 // exclusive scan over the values of the selecting waves (0 .. 3); called by ALL waves of the workgroup (the barriers are the workgroup's),
 // the others pass 0; every thread gets the total too

@@ -185,6 +185,10 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
     if constexpr (BF) stage_fwd_weights_bf<256>(L, p, threadIdx.x);
     else stage_fwd_weights<256>(L, p, threadIdx.x);
     __syncthreads();
+    if (ee.stagger != 0u) {
+        const bool late = (ee.stagger & 256u) ? (blockIdx.x & 1u) != 0u : blockIdx.x >= n_fwd_blocks / 2u;
+        if (late) for (uint32_t i = 0; i < (ee.stagger & 255u); ++i) __builtin_amdgcn_s_sleep(127);
+    }
     // the wave index as a SCALAR: everything derived from it (the ray, its tiles, the wave's LDS image) then lives in SGPRs instead of
     // vector registers -- what took this kernel from 9 spilled registers (40 bytes of scratch, reloaded inside the tile loop) to none
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_query_fwd_loss_packed(LevelTa
     // step of its FIRST chunk: [16] per workgroup
     int tl_k = 0;
     auto stamp = [&]() {
-        if (timeline != nullptr && threadIdx.x == 0 && tl_k < 16) timeline[(size_t)blockIdx.x * 16u + (size_t)tl_k] = (unsigned long long)clock64();
+        if (timeline != nullptr && threadIdx.x == 0 && tl_k < 16 && blockIdx.x < n_fwd_blocks) timeline[(size_t)blockIdx.x * 16u + (size_t)tl_k] = (unsigned long long)wall_clock64();      // (the smoothness workgroups stamp nothing: the buffer has a row per ray workgroup)
         ++tl_k;
     };
     stamp();                                        // 0: start
@@ -328,6 +332,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_query_fwd_loss_packed(LevelTa
     __shared__ PackPts<WAVES> P;
     __shared__ double red[4];
     __shared__ float terms[kPackMaxRays][10];
+    __shared__ double row_acc[10];                  // the workgroup's running loss sums (its rays in order)
     __shared__ uint32_t cnt[kPackMaxRays];          // samples of ray r the coming phase evaluates
     __shared__ uint32_t done[kPackMaxRays];         // samples of ray r evaluated so far (a prefix: depths are sorted)
     extern __shared__ float ray_lds[];
@@ -345,13 +350,17 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_query_fwd_loss_packed(LevelTa
     const uint32_t S = a.S, N = a.n_rays;
     const uint32_t n_rows = (N + (uint32_t)kRaysPerBlock - 1u) / (uint32_t)kRaysPerBlock;
     const uint32_t row_lo = (uint32_t)(((uint64_t)blockIdx.x * n_rows) / n_fwd_blocks), row_hi = (uint32_t)(((uint64_t)(blockIdx.x + 1u) * n_rows) / n_fwd_blocks);
-    const uint32_t r_cap = rows_per_chunk * (uint32_t)kRaysPerBlock;
+    const uint32_t r_cap = rows_per_chunk & 0xFFu;             // rays a chunk holds (low byte); bit 8: one pass
     uint16_t* __restrict__ list = reinterpret_cast<uint16_t*>(ray_lds + (size_t)r_cap * kRayFields * S);
     auto image = [&](uint32_t r) { return ray_scratch(ray_lds, (int)r, S); };
     const float margin_rel = 1e-5f, margin_abs = 1e-6f;                       // ee_after_tile's conservative margin
-    for (uint32_t row0 = row_lo; row0 < row_hi; row0 += rows_per_chunk) {      // uniform over the workgroup: barriers inside
-        const uint32_t n_row = row_hi - row0 < rows_per_chunk ? row_hi - row0 : rows_per_chunk, R = n_row * (uint32_t)kRaysPerBlock;
-        const uint32_t n0 = row0 * (uint32_t)kRaysPerBlock;
+    // The RAYS are spread evenly over the workgroups (2 148 rays on 256 workgroups: eight or nine each -- spreading whole loss rows of four
+    // rays would leave 25 workgroups with twelve); the loss rows stay a partition of the sums: this workgroup adds the terms of all its rays,
+    // in ray order, into the first of the row slots it owns (rows row_lo .. row_hi - 1: at least one) and leaves neutral rows in the others.
+    const uint32_t n_lo = (uint32_t)(((uint64_t)blockIdx.x * N) / n_fwd_blocks), n_hi = (uint32_t)(((uint64_t)(blockIdx.x + 1u) * N) / n_fwd_blocks);
+    if (threadIdx.x < 10u) row_acc[threadIdx.x] = threadIdx.x == 9u ? (double)__builtin_huge_valf() : 0.0;
+    for (uint32_t n0 = n_lo; n0 < n_hi; n0 += r_cap) {                         // uniform over the workgroup: barriers inside
+        const uint32_t R = n_hi - n0 < r_cap ? n_hi - n0 : r_cap;
         // ---- the rays' depths into their images; phase 1 = the samples up to measured depth + truncation
         for (uint32_t r = (uint32_t)wave; r < R; r += kPackWaves) {
             const uint32_t n = n0 + r;
@@ -370,7 +379,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_query_fwd_loss_packed(LevelTa
                     c += (!has || !(zz > lim + margin_rel * fabsf(lim) + margin_abs)) ? 1u : 0u;
                 }
                 c = wave_sum_u32(c);
-                if (c == 0u) c = S;                        // not one sample inside depth + truncation: nothing to look for a sign change in -- the whole ray
+                if (c == 0u || (rows_per_chunk & 0x100u)) c = S;   // not one sample inside depth + truncation: nothing to look for a sign change in -- the whole ray; bit 8: ONE pass over everything
             }
             if (lane == 0) { cnt[r] = c; done[r] = 0u; }
         }
@@ -520,19 +529,23 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_query_fwd_loss_packed(LevelTa
             }
         }
         __syncthreads();
-        if (threadIdx.x < 10u * n_row) {                       // rows of four rays, summed in ray order: k_loss_stage's rows
-            const uint32_t k = threadIdx.x % 10u, rr = threadIdx.x / 10u;
-            double v = (double)terms[rr * 4u][k];
-#pragma unroll
-            for (uint32_t w = 1; w < (uint32_t)kRaysPerBlock; ++w) {
-                const double uu = (double)terms[rr * 4u + w][k];
+        if (threadIdx.x < 10u) {                               // the chunk's rays, in ray order, onto the workgroup's running sums (slot 9: a minimum, NaN sticks)
+            const uint32_t k = threadIdx.x;
+            double v = row_acc[k];
+            for (uint32_t r = 0; r < R; ++r) {
+                const double uu = (double)terms[r][k];
                 v = k == 9u ? ((uu < v || uu != uu) ? uu : v) : v + uu;
             }
-            a.partials[(size_t)(row0 + rr) * 16 + k] = v;
+            row_acc[k] = v;
         }
         __syncthreads();
-        if (timeline != nullptr && threadIdx.x == 0 && row0 == row_lo) timeline[(size_t)blockIdx.x * 16u + 15u] = (unsigned long long)clock64();     // 15: first chunk done
+        if (timeline != nullptr && threadIdx.x == 0 && n0 == n_lo) timeline[(size_t)blockIdx.x * 16u + 15u] = (unsigned long long)wall_clock64();     // 15: first chunk done
         tl_k = 16;
+    }
+    if (threadIdx.x < 10u) {
+        const uint32_t k = threadIdx.x;
+        a.partials[(size_t)row_lo * 16 + k] = row_acc[k];
+        for (uint32_t row = row_lo + 1u; row < row_hi; ++row) a.partials[(size_t)row * 16 + k] = k == 9u ? (double)__builtin_huge_valf() : 0.0;
     }
 }
 template __global__ void k_query_fwd_loss_packed<false, 8>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t, uint32_t, unsigned long long*);

@@ -1,6 +1,6 @@
 """Per-step timeline of the packed training forward (k_query_fwd_loss_packed): thread 0 of every ray workgroup stamps the shader clock
-(s_memtime) at the start and behind each step of its first chunk; printed: mean / p10 / p90 over the workgroups of the time each step
-takes, in microseconds at the measured clock.   python tools/fwd_timeline.py [workload] [mlp]"""
+(the constant-rate global counter, wall_clock64: 100 MHz) at the start and behind each step of its first chunk; printed: mean / p10 / p90
+over the workgroups of the time each step takes, in microseconds.   python tools/fwd_timeline.py [workload] [mlp]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -33,7 +33,7 @@ names = ["weights staged", "depths + counts", "list 1", "points 1", "gathers 1",
 t0 = t[:, 0]
 end = t[:, 15]
 tot = float(np.mean(end - t0))
-print(f"{wl} {mlp}: {n_wg} ray workgroups; shader-clock ticks x 0.01 (s_memtime; divide a step's share by the kernel's duration in the rocprofv3 trace for microseconds); "
+print(f"{wl} {mlp}: {n_wg} ray workgroups; microseconds (100 MHz global counter); "
       f"first chunk end - start: mean {tot / 100:.1f}, max {np.max(end - t0) / 100:.1f}")
 prev = t0
 for k, nm in enumerate(names, start=1):

@@ -35,7 +35,7 @@ for rep in range(3):
     t = buf.cpu().numpy().reshape(n_wg, 16).astype(np.float64)
     t0, end = t[:, 0], t[:, 15]
     tot = float(np.mean(end - t0))
-    print(f"iteration {20 + rep}: {n_train} rays; chunk end - start: mean {tot / 100:.1f}, max {np.max(end - t0) / 100:.1f} (ticks x 0.01); "
+    print(f"iteration {20 + rep}: {n_train} rays; chunk end - start: mean {tot / 100:.1f}, max {np.max(end - t0) / 100:.1f} us; "
           f"starts spread over {(t0.max() - t0.min()) / 100:.1f}, last end - first start {(end.max() - t0.min()) / 100:.1f}; "
           f"start by workgroup id (every 32nd, relative): {[round((x - t0.min()) / 100) for x in t0[::32]]}")
     prev = t0

@@ -44,8 +44,10 @@ BENCH_ARGS="--workload office0_2048x43" bash tools/pmc_sq.sh ${TAG}_sq_counters_
 # round 4: per-step timeline of the packed training forward, the iteration on a trained map, the reconstruction-accuracy study (HIP fp32 / bf16 /
 # NaN depths against the CPU oracle on the analytic room: ~2 min of CPU for the oracle's 390 iterations)
 cd $R
-timeout 300 python tools/fwd_timeline.py office0_2048x43 > gpurun_out/${TAG}_fwd_timeline_2048x43.txt 2>&1
+NARUTO_FWD_PACKED=3 timeout 300 python tools/fwd_timeline.py office0_2048x43 > gpurun_out/${TAG}_fwd_timeline_2048x43.txt 2>&1
+TIMELINE_GRAPH=1 NARUTO_FWD_PACKED=3 timeout 300 python tools/fwd_timeline_ba.py > gpurun_out/${TAG}_fwd_timeline_ba.txt 2>&1
 NARUTO_FWD_PACKED=2 timeout 300 python tools/fwd_timeline.py office0_2048x128 > gpurun_out/${TAG}_fwd_timeline_2048x128_packed_everywhere.txt 2>&1
-timeout 600 python tools/time_trained_step.py > gpurun_out/${TAG}_trained_step.txt 2>&1
+NARUTO_FWD_PACKED=3 timeout 600 python tools/time_trained_step.py > gpurun_out/${TAG}_trained_step.txt 2>&1
+timeout 600 python tools/time_trained_step.py > gpurun_out/${TAG}_trained_step_flat.txt 2>&1
 timeout 1500 python tests/accuracy_study.py --out gpurun_out/${TAG}_accuracy_study.json > gpurun_out/${TAG}_accuracy_study.txt 2>&1
 git -C $R rev-parse HEAD > gpurun_out/${TAG}_commit.txt 2>/dev/null || true

@@ -1606,12 +1606,16 @@ def test_packed_forward_equals_the_flat_one(gpu, tmp_path):
     field query over every sample + k_loss_stage instead.  Same losses, rendered maps, sums and
     gradients -- not bit for bit: a point's OneBlob takes the closed form or the dense one depending on the tile it shares (both forms of
     the same function, 1.2e-6 apart), so the comparison is at that distance.  NARUTO_FWD_PACKED=2 (the packed kernel for S = 128 too)
-    against the depth-ordered walk likewise."""
+    against the depth-ordered walk likewise; a three-ray batch (fewer rays than a loss row), and a batch of several chunks per workgroup
+    with every sample in one pass (NARUTO_PACK_ONE_PASS)."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for tag, n_samples_d, env_a, env_b in (("43", 32, {"NARUTO_FWD_PACKED": "3"}, {"NARUTO_FWD_PACKED": "0"}), ("128", 117, {"NARUTO_FWD_PACKED": "2"}, {"NARUTO_FWD_PACKED": "0"})):
+    for tag, n_samples_d, n_rays, env_a, env_b in (("43", 32, 333, {"NARUTO_FWD_PACKED": "3"}, {"NARUTO_FWD_PACKED": "0"}),
+                                                   ("43_three_rays", 32, 3, {"NARUTO_FWD_PACKED": "3"}, {"NARUTO_FWD_PACKED": "0"}),
+                                                   ("43_one_pass", 32, 4100, {"NARUTO_FWD_PACKED": "3", "NARUTO_PACK_ONE_PASS": "1"}, {"NARUTO_FWD_PACKED": "0"}),
+                                                   ("128", 117, 333, {"NARUTO_FWD_PACKED": "2"}, {"NARUTO_FWD_PACKED": "0"})):
         script = tmp_path / f"iteration_{tag}.py"
-        script.write_text(_KNOB_SCRIPT.replace("n_samples_d=117", f"n_samples_d={n_samples_d}"))
+        script.write_text(_KNOB_SCRIPT.replace("n_samples_d=117", f"n_samples_d={n_samples_d}").replace("N = 333", f"N = {n_rays}"))
         res = []
         for k, env in enumerate((env_a, env_b)):
             out = tmp_path / f"{tag}_{k}.npz"

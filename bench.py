@@ -698,11 +698,12 @@ def main():
     torch.manual_seed(0)                                     # identical replicas on every rank
     tr = MappingTrainer(cfg, torch.tensor(cfg["mapping"]["bound"], dtype=torch.float32), dev, 0.1, group=group,
                         fused_adam=not args.torch_adam)
-    # Single process: the whole iteration replays from one hipGraph.  Data parallel: three graph segments (forward | backward |
-    # optimiser) with the two collectives as ordinary eager RCCL calls in between -- no collective is captured, and the host issues
-    # 3 replays + 2 collectives per step instead of ~14 launches (world size 1 with NARUTO_FORCE_DIST=1: 0.30 ms segmented, 0.41 ms
-    # eager: the eager step is bound by the host).  NARUTO_GRAPH_DIST=eager|whole selects the other forms.
-    use_graph = (not args.no_graph) and (group is None or os.environ.get("NARUTO_GRAPH_DIST", "segmented") in ("segmented", "whole"))
+    # Single process: the whole iteration replays from one hipGraph.  Data parallel: EAGER launches by default (round 4) -- measured at world
+    # size 1 with real RCCL calls (NARUTO_FORCE_DIST=1, tools/dp_world1.sh): eager 0.274 ms, four graph segments with the collectives
+    # eager in between 0.297 (a hipGraph launch costs more than the three or four kernel launches it replaces), everything incl. the
+    # collectives in ONE graph 0.235 -- the fastest, but a captured RCCL collective over several ranks cannot be exercised on the one-GPU
+    # build boxes, so it stays opt-in.  NARUTO_GRAPH_DIST=segmented|whole selects the graph forms.
+    use_graph = (not args.no_graph) and (group is None or os.environ.get("NARUTO_GRAPH_DIST", "eager") in ("segmented", "whole"))
     if use_graph:
         try:
             tr.capture(n_rays, smooth=True, n_rays_total=n_total)

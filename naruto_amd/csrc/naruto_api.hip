@@ -821,7 +821,7 @@ int launch_train_query(const NarutoField* f, const NarutoParams* p, const Naruto
     // the packed forward (k_query_fwd_loss_packed: only the samples a consumer can see, packed across rays, loss stage from LDS; any
     // samples-per-ray count).  Its workgroup works in barrier-separated steps -- all gathers of a pass, then all matrix chains -- so what it
     // gains is the samples it does NOT evaluate, and what it loses is the flat launch's overlap of one wave's gathers with another's matrix
-    // chain.  Measured (tools/ba_ab*.sh, tools/fwd_timeline_ba.py):
+    // chain.  Measured (tools/ba_ab.sh, tools/fwd_timeline_ba.py):
     //   * tables no cache holds (T = 2^22, 281 MB): every gather is an HBM line -- 131 072 x 43: 8.09 against 9.41 ms per step: ON;
     //   * cache-resident tables: scene dependent.  2 048 random benchmark rays x 43: 0.166 against 0.1715 ms per step; the BA batch (2 148
     //     rays from the keyframe store, random-initialised network: nearly every sample ends up evaluated, in two passes): ray workgroups

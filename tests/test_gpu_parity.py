@@ -1996,6 +1996,50 @@ def test_active_ray_sampler_ties(gpu):
         assert torch.equal(a.cpu(), b)
 
 
+@pytest.mark.parametrize("n_cand,K", [(33, 1), (33, 32), (1000, 999), (4097, 500), (8191, 2048), (8192, 1), (8192, 8191), (8192, 3000)])
+def test_active_ray_select_edges_through_the_c_abi(gpu, n_cand, K):
+    """naruto_active_ray_select (k_ars_fused: lookup, bit-sliced threshold search, gather in one launch) at the edges of its range: candidate
+    counts that are not multiples of a thread's 32 keys, the largest count it takes (8 192), K = 1 and K = n - 1, and a volume full of ties,
+    negative values, +-0 and NaNs (a NaN sorts last).  The rays are placed ON voxel centres (direction 0), so the expected keys are the volume's
+    values at known voxels and the expected batch is [the K smallest by (value, index), ascending index | the first base - K rays | the tail]."""
+    import ctypes as C
+    from naruto_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(n_cand * 7 + K)
+    X, Y, Z = 49, 56, 35
+    vol = rs.choice(np.array([0.0, -0.0, 0.5, 0.5, 1.25, -3.0, 7.0, np.nan, 2.0 ** -130], np.float32), size=(X, Y, Z)).astype(np.float32)
+    vol[rs.rand(X, Y, Z) < 0.3] = np.float32(rs.uniform(-1, 4))                                        # one more heavily tied value
+    base, n_tail = max(K, 64), 25
+    n_total = base + n_cand + n_tail
+    bmin = np.array([-1.5, 0.25, -2.0], np.float32)
+    vox = np.stack([rs.randint(0, X, n_total), rs.randint(0, Y, n_total), rs.randint(0, Z, n_total)], 1)
+    rays_o = (bmin + vox.astype(np.float32) / np.float32(10.0)).astype(np.float32)                    # (o - bmin) * 10 rounds back to the voxel
+    assert np.array_equal(np.rint((rays_o - bmin) * np.float32(10.0)).astype(int), vox)
+    rays_d = np.zeros((n_total, 3), np.float32)
+    target_s = rs.rand(n_total, 3).astype(np.float32)
+    target_d = rs.uniform(0.5, 3.0, n_total).astype(np.float32)
+    cand_vals = vol[vox[base:base + n_cand, 0], vox[base:base + n_cand, 1], vox[base:base + n_cand, 2]]
+    # order: float order with -0 < +0 as the sortable key has it (sign bit), NaN last; ties by index
+    bits = cand_vals.view(np.uint32).astype(np.uint64)
+    keys = np.where(bits & 0x80000000, (~bits) & 0xFFFFFFFF, bits | 0x80000000)
+    order = np.lexsort((np.arange(n_cand), keys))
+    sel = np.sort(order[:K])
+    src = np.concatenate([base + sel, np.arange(0, base - K), np.arange(n_total - n_tail, n_total)])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+    o, d, c, td, v = t(rays_o), t(rays_d), t(target_s), t(target_d), t(vol)
+    n_out = base + n_tail
+    outs = [torch.full((n_out, 3), -7.0, device=gpu) for _ in range(3)] + [torch.full((n_out,), -7.0, device=gpu)]
+    ws = torch.empty(lib.naruto_active_ray_workspace(n_total, K) // 4 + 4, dtype=torch.int32, device=gpu)
+    dims = (C.c_uint32 * 3)(X, Y, Z)
+    bm = (C.c_float * 3)(*[float(b) for b in bmin])
+    p = lambda a: C.c_void_p(a.data_ptr())
+    _lib.check(lib.naruto_active_ray_select(n_total, base, K, n_tail, p(o), p(d), p(c), p(td), p(v), dims, bm, 10.0, p(outs[0]), p(outs[1]), p(outs[2]),
+                                            p(outs[3]), p(ws), None), "naruto_active_ray_select")
+    torch.cuda.synchronize()
+    for got, want, name in ((outs[0], rays_o[src], "rays_o"), (outs[1], rays_d[src], "rays_d"), (outs[2], target_s[src], "target_s"), (outs[3], target_d[src], "target_d")):
+        assert np.array_equal(got.cpu().numpy(), want), f"{name}: selected batch differs (n_cand {n_cand}, K {K})"
+
+
 # --------------------------------------------------------------------------------------------- N2, store side
 def test_keyframe_store_batch_assembly(gpu):
     """KeyFrameStoreHIP: add_keyframe keeps distinct (valid) pixels and tiles short frames; assemble_batch draws distinct

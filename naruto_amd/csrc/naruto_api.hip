@@ -627,7 +627,7 @@ BwdWs bwd_ws(const NarutoField* f, void* workspace, uint32_t cap) {
 int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, const NarutoPoints* pts, const float* feat_save,
                    const float* d_raw, const float* d_geo, const uint32_t* active_idx, const uint32_t* n_active, const NarutoExtraPoints* extra,
                    uint32_t flags, const NarutoGrads* g, void* workspace, void* stream, uint32_t n_front, const uint32_t* n_list_dev,
-                   const AdamFuse* adam = nullptr, const void* w_img = nullptr) {
+                   const AdamFuse* adam = nullptr, const void* w_img = nullptr, const TvLate* tv_late = nullptr) {
     if ((active_idx == nullptr) != (n_active == nullptr)) return fail(NARUTO_ERR_INVALID, "query_bwd: active_idx and n_active go together");
     if (n_front > 0 && (extra != nullptr || n_list_dev == nullptr)) return fail(NARUTO_ERR_INVALID, "query_bwd: front list excludes extra points");
     const uint32_t E = n_front > 0 ? n_front : ((extra != nullptr && g != nullptr && g->table != nullptr) ? extra->n : 0u);
@@ -697,9 +697,10 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
             ur.voxels_pad = uncert_pad(f);
         }
         const uint32_t n_unc_blocks = unc_scatter ? (ur.n_voxels + 255u) / 256u : 0u;
-        hipLaunchKernelGGL(k_bwd_finish, dim3(n_table_blocks + kAccFloats / 32 + n_unc_blocks), dim3(256), 0, (hipStream_t)stream, f->lt, scatter_ws,
+        const TvLate tvl = tv_late != nullptr ? *tv_late : TvLate{};
+        hipLaunchKernelGGL(k_bwd_finish, dim3(n_table_blocks + kAccFloats / 32 + n_unc_blocks + (tvl.n_tv_blocks != 0u ? 1u : 0u)), dim3(256), 0, (hipStream_t)stream, f->lt, scatter_ws,
                            level_splits(f, cnt != nullptr ? cap : M),
-                           n_params, partial_plane(f), partials, blocks, *g, *adam, n_table_blocks, ur);
+                           n_params, partial_plane(f), partials, blocks, *g, *adam, n_table_blocks, ur, tvl, n_unc_blocks);
         return check_launch("bwd_finish");
     }
     const bool want_w = g->sdf_w0 || g->sdf_w1 || g->col_w0 || g->col_w1;
@@ -797,8 +798,21 @@ int train_check(const NarutoField* f, const NarutoParams* p, const NarutoTrainSt
 // A2..A5 of the training forward: k_query_fwd over the batch's samples, one wave per ray with depth-ordered early termination
 // when the samples per ray are a multiple of 64 (otherwise flat 64-sample tiles)
 // loss != NULL: the loss stage may ride in the field query's launch (k_query_fwd_loss: the depth-ordered walk only); *fused tells
+// The five-launch iteration (round 4, see WalkExtra in naruto_train.hip): where the training forward is the depth-ordered walk in its
+// two-phase form and forward + backward are issued as one iteration (deferred tail), the walk samples its own depths, its tail workgroups
+// encode the smoothness lattice, the term itself is evaluated by workgroups of the backward's first launch and its value lands in the
+// losses with the backward's last launch -- k_sample_encode has no launch of its own.  NARUTO_TV_MOVE=0: the six-launch form (same bits).
+inline bool tv_moved(const NarutoTrainStep* t, bool deferred) {
+    static const bool on = getenv("NARUTO_TV_MOVE") == nullptr || atoi(getenv("NARUTO_TV_MOVE")) != 0;
+    static const bool no_fuse = getenv("NARUTO_DEBUG_NO_FUSED_LOSS_STAGE") != nullptr, no_ee = getenv("NARUTO_DEBUG_NO_EARLY_EXIT") != nullptr;
+    static const int packed_mode = getenv("NARUTO_FWD_PACKED") == nullptr ? 1 : atoi(getenv("NARUTO_FWD_PACKED"));
+    const uint32_t S = t->n_samples_d + t->n_range_d;
+    const bool walk = S % 64u == 0u && S > 64u && !no_ee && !no_fuse && packed_mode != 2 && ray_scratch_bytes(S) <= kFwdLossMaxRayLds;
+    const bool split = kFwdSplit && sizeof(FwdLds) + (size_t)kRaysPerBlock * sizeof(FwdSlab) + ray_scratch_bytes(S) + 512u <= (size_t)80u * 1024u;
+    return on && deferred && t->smooth_points != 0 && walk && split;
+}
 int launch_train_query(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, hipStream_t st, const LossStageArgs* loss = nullptr,
-                       bool* fused = nullptr) {
+                       bool* fused = nullptr, const WalkExtra* walk_extra = nullptr) {
     if (fused != nullptr) *fused = false;
     const uint32_t N = t->n_rays, S = t->n_samples_d + t->n_range_d, M = N * S;
     PointSrc ps{};
@@ -891,8 +905,10 @@ int launch_train_query(const NarutoField* f, const NarutoParams* p, const Naruto
         // the two-phase tile costs 32 KB of slabs per workgroup: only while two workgroups still share a CU (S <= 192), see k_query_fwd_loss
         const bool split = kFwdSplit && sizeof(FwdLds) + (size_t)kRaysPerBlock * sizeof(FwdSlab) + ray_scratch_bytes(S) + 512u <= (size_t)80u * 1024u;
         const bool bfm = f->desc.mlp_mode == NARUTO_MLP_BF16;
-#define NARUTO_LAUNCH_WALK(BFV, SPV) hipLaunchKernelGGL((k_query_fwd_loss<BFV, SPV>), dim3(blocks + loss->n_tv_blocks), dim3(256), ray_scratch_bytes(S), st, f->lt, f->ut, f->bt, *p, ps, M, \
-                                                        t->raw, t->feat_save, ee, *loss, blocks)
+        const WalkExtra wxa = walk_extra != nullptr ? *walk_extra : WalkExtra{};
+        const uint32_t tail_blocks = wxa.on ? tv_encode_blocks(loss->tv.n * loss->tv.n * loss->tv.n) : loss->n_tv_blocks;
+#define NARUTO_LAUNCH_WALK(BFV, SPV) hipLaunchKernelGGL((k_query_fwd_loss<BFV, SPV>), dim3(blocks + tail_blocks), dim3(256), ray_scratch_bytes(S), st, f->lt, f->ut, f->bt, *p, ps, M, \
+                                                        t->raw, t->feat_save, ee, *loss, blocks, wxa)
         if (split) { if (bfm) NARUTO_LAUNCH_WALK(true, true); else NARUTO_LAUNCH_WALK(false, true); }
         else { if (bfm) NARUTO_LAUNCH_WALK(true, false); else NARUTO_LAUNCH_WALK(false, false); }
 #undef NARUTO_LAUNCH_WALK
@@ -977,7 +993,13 @@ int naruto_train_forward(const NarutoField* f, const NarutoParams* p, const Naru
     TvArgs tva = tv_args(t);
     tva.cap = list_cap(M + w.n3);
     const BwdWs bw = bwd_ws(f, w.bwd, list_cap(M + w.n3));
-    if (t->smooth_points != 0) {
+    const bool deferred_ = finalize == NARUTO_TRAIN_FWD_DEFER_TAIL && tail_rides_in_backward(t);
+    WalkExtra wx{};
+    if (tv_moved(t, deferred_)) {
+        wx.on = 1u;
+        wx.sa = SampleArgs{N, t->target_d, t->near_, t->far_, t->n_samples_d, t->n_range_d, t->range_d, jitter, jitter_rng, t->z_vals, (N + 3u) / 4u};
+        wx.rand6 = t->rand6; wx.rng = t->rng; wx.x_out = bw.x_soa;
+    } else if (t->smooth_points != 0) {
         SampleArgs sa{N, t->target_d, t->near_, t->far_, t->n_samples_d, t->n_range_d, t->range_d, jitter, jitter_rng, t->z_vals, (N + 3u) / 4u};
         static const int dbg_roles = getenv("NARUTO_DEBUG_SAMPLE_ROLES") ? atoi(getenv("NARUTO_DEBUG_SAMPLE_ROLES")) : 3;   // profiling knob: 1 rays, 2 lattice
         if (dbg_roles == 2) sa.n_rays = 0;
@@ -994,7 +1016,7 @@ int naruto_train_forward(const NarutoField* f, const NarutoParams* p, const Naru
     const bool deferred = finalize == NARUTO_TRAIN_FWD_DEFER_TAIL && tail_rides_in_backward(t);
     if (int rc = ray_lds_attr()) return rc;
     bool loss_done = false;
-    if (int rc = launch_train_query(f, p, t, st, &a, &loss_done)) return rc;
+    if (int rc = launch_train_query(f, p, t, st, &a, &loss_done, &wx)) return rc;
     if (!loss_done) {
         static const int dbg_ls_roles = getenv("NARUTO_DEBUG_LOSS_STAGE_ROLES") ? atoi(getenv("NARUTO_DEBUG_LOSS_STAGE_ROLES")) : 3;     // profiling knob: 1 rays, 2 lattice
         if (dbg_ls_roles == 1) a.n_tv_blocks = 0;
@@ -1125,11 +1147,20 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
         fa.partials = reinterpret_cast<const double*>(w.terms); fa.n_ray_blocks = (N + kRaysPerBlock - 1) / kRaysPerBlock;
         fa.ray_count = t->ray_count; fa.ray_off = t->ray_offset; fa.active_idx = t->active_idx; fa.n_active = t->n_active;
         fa.n_front = smooth_d ? w.n3 : 0u; fa.n_list = bwd.n_total;
-        fa.tail = loss_tail_args(t, w, fa.n_ray_blocks, t->smooth_points != 0 ? w.n_tv_blocks : 0u, tv_args(t).inv_p3, 1);
+        // (the term moved into this launch: the tail cannot see its partial sums -- the last launch of the backward adds the value, TvLate)
+        fa.tail = loss_tail_args(t, w, fa.n_ray_blocks, (t->smooth_points != 0 && !tv_moved(t, true)) ? w.n_tv_blocks : 0u, tv_args(t).inv_p3, 1);
         fa.sums_given = sums_given ? 1 : 0;
         // one more workgroup prepares the MLP backward's weight images (the parameters do not change before k_query_bwd reads them)
         fa.w_img = w.w_img; fa.w_bf = f->desc.mlp_mode == NARUTO_MLP_BF16 ? 1 : 0; fa.params = *p;
-        hipLaunchKernelGGL(k_loss_bwd_fused, dim3(fa.n_ray_blocks + 2u), dim3(64 * kRaysPerBlock), ray_scratch_bytes(S), st, fa);
+        if (tv_moved(t, true)) {
+            TvArgs tva = tv_args(t);
+            tva.cap = list_cap(M + w.n3);
+            fa.tv = tva; fa.tv_feat = w.tv_feat; fa.tv_d_list = bwd.d_feat; fa.tv_partial = w.tv_partial;
+            fa.tv_scale_dev = t->loss_weights != nullptr ? t->loss_weights + 8 : nullptr;
+            fa.tv_scale_host = t->smooth_grad_scale != 0.0f ? t->smooth_grad_scale : 1.0f;
+            fa.tv_n_blocks = w.n_tv_blocks;
+        }
+        hipLaunchKernelGGL(k_loss_bwd_fused, dim3(fa.n_ray_blocks + 2u + fa.tv_n_blocks), dim3(64 * kRaysPerBlock), ray_scratch_bytes(S), st, fa);
         if (int rc = check_launch("loss_bwd_fused")) return rc;
     }
     if (!table_only && !deferred) {
@@ -1155,10 +1186,21 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
     pts.rays_o = t->rays_o; pts.rays_d = t->rays_d; pts.z_vals = t->z_vals; pts.n_samples = S;
     const AdamFuse* ad = opt != nullptr ? &adam : nullptr;
     const void* w_img = deferred ? w.w_img : nullptr;            // prepared by k_loss_bwd_fused just above
+    TvLate tvl{};
+    const bool late = deferred && tv_moved(t, true);
+    if (late) { tvl.tv_partial = w.tv_partial; tvl.n_tv_blocks = w.n_tv_blocks; tvl.inv_p3 = tv_args(t).inv_p3; tvl.losses = t->losses; tvl.loss_weights = t->loss_weights; }
+    int rc;
     if (n_front > 0)
-        return query_bwd_impl(f, p, M, &pts, t->feat_save, t->d_raw, nullptr, t->active_idx, t->n_active, nullptr, flags, g, w.bwd, stream, n_front, bw.n_total, ad, w_img);
-    // no smoothness term: the workspace was sized for cap = M + n3 with n3 = 0
-    return query_bwd_impl(f, p, M, &pts, t->feat_save, t->d_raw, nullptr, t->active_idx, t->n_active, nullptr, flags, g, w.bwd, stream, 0u, nullptr, ad, w_img);
+        rc = query_bwd_impl(f, p, M, &pts, t->feat_save, t->d_raw, nullptr, t->active_idx, t->n_active, nullptr, flags, g, w.bwd, stream, n_front, bw.n_total, ad, w_img,
+                            (late && ad != nullptr) ? &tvl : nullptr);
+    else        // no smoothness term: the workspace was sized for cap = M + n3 with n3 = 0
+        rc = query_bwd_impl(f, p, M, &pts, t->feat_save, t->d_raw, nullptr, t->active_idx, t->n_active, nullptr, flags, g, w.bwd, stream, 0u, nullptr, ad, w_img);
+    if (rc != NARUTO_OK) return rc;
+    if (late && ad == nullptr) {                                 // no optimiser in the backward: the value gets a (tiny) launch of its own
+        hipLaunchKernelGGL(k_tv_late, dim3(1), dim3(256), 0, st, tvl);
+        return check_launch("tv_late");
+    }
+    return NARUTO_OK;
 }
 
 int naruto_render_fwd(const NarutoField* f, const NarutoParams* p, const NarutoRender* r, void* stream) {

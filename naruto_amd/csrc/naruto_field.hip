@@ -2449,9 +2449,38 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 // tables; MLP weights: sum of the per-workgroup dW partials) applies the Adam step in place -- the gradients need not be
 // written (g pointers may be NULL), k_adam_multi and one more pass over parameters + moments disappear.
 // Single process only: data parallelism needs the gradients all-reduced first.
+// The smoothness term's VALUE, finished late (round 4): when the term is evaluated by workgroups of the backward's first launch (next to the
+// loss tail, which therefore cannot see their partial sums), the LAST launch of the backward adds it to the losses -- the tail's own
+// arithmetic: the partials summed by 256 threads in the same pattern, losses[8] = sum / P^3, and the total's last addend w[8] losses[8]
+// (loss_total adds the slots in order, the smoothness slot last, and the tail added + 0 for it).
+struct TvLate {
+    const double* tv_partial; uint32_t n_tv_blocks; float inv_p3;      // n_tv_blocks == 0: nothing to do
+    float* losses; const float* loss_weights;
+};
+__device__ __forceinline__ void tv_late_body(const TvLate& a) {
+    __shared__ double tv_red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double tv = 0.0;
+    for (uint32_t i = threadIdx.x; i < a.n_tv_blocks; i += 256) tv += a.tv_partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tv += __shfl_xor(tv, o, 64);
+    if (lane == 0) tv_red[wave] = tv;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float l8 = (float)((tv_red[0] + tv_red[1] + tv_red[2] + tv_red[3]) * (double)a.inv_p3);
+        a.losses[8] = l8;
+        if (a.loss_weights != nullptr) {
+            const float w8 = a.loss_weights[8];
+            a.losses[9] += w8 != 0.0f ? w8 * l8 : 0.0f;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_tv_late(TvLate a) { tv_late_body(a); }
+
 __global__ __launch_bounds__(256) void k_bwd_finish(LevelTab lt, const float* __restrict__ partial, LevelSplits ls, size_t n_params,
                                                     size_t n_plane, const float* __restrict__ wpartials, uint32_t n_wblocks, NarutoGrads g, AdamFuse adam,
-                                                    uint32_t n_table_blocks, UncertReduce unc) {
+                                                    uint32_t n_table_blocks, UncertReduce unc, TvLate tvl, uint32_t n_unc_blocks) {
+    if (blockIdx.x >= n_table_blocks + kAccFloats / 32 + n_unc_blocks) { tv_late_body(tvl); return; }
     if (blockIdx.x >= n_table_blocks + kAccFloats / 32) { uncert_reduce_body(unc, blockIdx.x - n_table_blocks - kAccFloats / 32); return; }
     if (blockIdx.x >= n_table_blocks) {
         wgrad_reduce_body(wpartials, n_wblocks, g, 1, blockIdx.x - n_table_blocks, &adam);

@@ -167,11 +167,26 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_stage(LossStageArgs
 // runs the loss stage's ray work from there when the ray is done -- the loss stage's launch, its reload of raw and its trip through
 // the launch queue go away; the smoothness term's workgroups ride behind the ray workgroups (they start as soon as workgroups of
 // early-terminated rays retire).  Same arithmetic in the same order as k_query_fwd<true> | k_loss_stage: same bits.
+struct SampleArgs {
+    uint32_t n_rays; const float* target_d; float near_, far_; uint32_t nu, nr; float range_d;
+    const float* rand; const uint64_t* rng; float* z_vals;
+    uint32_t n_ray_blocks;
+};
+// The five-launch iteration (round 4; SPLIT instantiations only): the walk samples its rays' depths itself (sample_z_ray in front of each
+// ray's first tile, through the wave's LDS image) and its tail workgroups ENCODE the smoothness lattice instead of evaluating the term, which
+// moves to workgroups of the backward's first launch (k_loss_bwd_fused: the encoded features are complete there by the launch boundary) --
+// k_sample_encode's launch (14 us + a gap, in front of the forward with nothing to overlap it) disappears; the forward grows by 5 us, the
+// backward's first launch by 1: 0.2219 -> 0.2135 ms per iteration.  Same bits as the six-launch form: same routines on the same data.
+struct WalkExtra {
+    uint32_t on;
+    SampleArgs sa;
+    const float* rand6; const uint64_t* rng; float* x_out;
+};
 // SPLIT: the tile in two phases through a per-wave LDS slab (fwd_tile_split) -- 32 KB per workgroup, so the launcher uses it only while two
 // workgroups still fit a CU next to the rays' images (up to 192 samples per ray); longer rays keep the register form (fwd_tile).
 template <bool BF, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps, uint32_t M, float* __restrict__ raw,
-                                                           float* __restrict__ feat_save, EarlyExit ee, LossStageArgs a, uint32_t n_fwd_blocks) {
+                                                           float* __restrict__ feat_save, EarlyExit ee, LossStageArgs a, uint32_t n_fwd_blocks, WalkExtra wx) {
     using Lds = std::conditional_t<BF, FwdLdsBf, FwdLds>;
     __shared__ Lds L;
     __shared__ FwdSlab slabs[SPLIT ? kRaysPerBlock : 1];
@@ -179,7 +194,10 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
     __shared__ float terms[kRaysPerBlock][10];
     extern __shared__ float ray_lds[];
     if (blockIdx.x >= n_fwd_blocks) {
-        tv_loss_list_body(a.tv, a.tv_feat, a.tv_d_list, a.tv_scale_dev, a.tv_scale_host, a.tv_partial, blockIdx.x - n_fwd_blocks, a.n_tv_blocks, red);
+        bool encode = false;
+        if constexpr (SPLIT) encode = wx.on != 0u;
+        if (encode) tv_encode_body(lt, bt, a.tv, wx.rand6, wx.rng, reinterpret_cast<const float2*>(p.table), wx.x_out, const_cast<float*>(a.tv_feat), blockIdx.x - n_fwd_blocks);
+        else tv_loss_list_body(a.tv, a.tv_feat, a.tv_d_list, a.tv_scale_dev, a.tv_scale_host, a.tv_partial, blockIdx.x - n_fwd_blocks, a.n_tv_blocks, red);
         return;
     }
     if constexpr (BF) stage_fwd_weights_bf<256>(L, p, threadIdx.x);
@@ -200,6 +218,10 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
     for (uint32_t group = blockIdx.x; group < n_groups; group += n_fwd_blocks) {          // uniform over the workgroup: barriers inside
         const uint32_t task = group * (uint32_t)kRaysPerBlock + (uint32_t)wave;
         if (task < a.n_rays) {
+            if constexpr (SPLIT) if (wx.on) {
+                sample_z_ray(task, wx.sa.target_d, wx.sa.near_, wx.sa.far_, wx.sa.nu, wx.sa.nr, wx.sa.range_d, wx.sa.rand, wx.sa.rng, wx.sa.z_vals, rs.c0, rs.c1, lane);
+                __threadfence_block();
+            }
             EeState ees{false, 0.0f, 0.0f, 0.0f};
             uint32_t tq = 0;
             for (; tq < tpr; ++tq) {
@@ -239,10 +261,10 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
         __syncthreads();                                   // terms are rewritten by the next group
     }
 }
-template __global__ void k_query_fwd_loss<false, false>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t);
-template __global__ void k_query_fwd_loss<true, false>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t);
-template __global__ void k_query_fwd_loss<false, true>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t);
-template __global__ void k_query_fwd_loss<true, true>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t);
+template __global__ void k_query_fwd_loss<false, false>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t, WalkExtra);
+template __global__ void k_query_fwd_loss<true, false>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t, WalkExtra);
+template __global__ void k_query_fwd_loss<false, true>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t, WalkExtra);
+template __global__ void k_query_fwd_loss<true, true>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t, WalkExtra);
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // PACKED training forward (round 4): field query + loss stage for rays of ANY sample count, evaluating only the samples some consumer
@@ -555,11 +577,6 @@ template __global__ void k_query_fwd_loss_packed<true, 4>(LevelTab, UncertTab, B
 
 // A1 | the smoothness lattice's points + hash features, one launch: workgroups [0, n_ray_blocks) sample the depths of four
 // rays each (one per wave, 2 S floats of dynamic LDS per wave), the rest are k_tv_encode's workgroups
-struct SampleArgs {
-    uint32_t n_rays; const float* target_d; float near_, far_; uint32_t nu, nr; float range_d;
-    const float* rand; const uint64_t* rng; float* z_vals;
-    uint32_t n_ray_blocks;
-};
 __global__ __launch_bounds__(256) void k_sample_encode(SampleArgs sa, LevelTab lt, BoxTab bt, TvArgs a, const float* __restrict__ rand6,
                                                        const uint64_t* __restrict__ rng, const float2* __restrict__ table, float* __restrict__ x_out,
                                                        float* __restrict__ feat) {
@@ -717,6 +734,8 @@ struct FusedBwdArgs {
     void* w_img; int w_bf; NarutoParams params;       // w_img != NULL: workgroup n_ray_blocks + 1 prepares the MLP backward's weight images there
     int sums_given;               // data parallel: la.sums holds the ALL-REDUCED sums (the forward ran its tail with finalize = 0); the extra
                                   // workgroup then only turns them into losses[0..7] and the total
+    // the five-launch iteration (WalkExtra): workgroups n_ray_blocks + 2 ... evaluate the smoothness term (tv_n_blocks of them; 0: off)
+    TvArgs tv; const float* tv_feat; float* tv_d_list; const float* tv_scale_dev; float tv_scale_host; double* tv_partial; uint32_t tv_n_blocks;
 };
 __global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_bwd_fused(FusedBwdArgs a) {
     extern __shared__ float ray_lds[];
@@ -725,6 +744,10 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_bwd_fused(FusedBwdA
     __shared__ double s_sums[16];
     __shared__ uint32_t pre[kRaysPerBlock], cnt[kRaysPerBlock];
     static_assert(kRaysPerBlock == 4, "the reductions below are written for four waves");
+    if (blockIdx.x >= a.n_ray_blocks + 2u) {
+        tv_loss_list_body(a.tv, a.tv_feat, a.tv_d_list, a.tv_scale_dev, a.tv_scale_host, a.tv_partial, blockIdx.x - a.n_ray_blocks - 2u, a.tv_n_blocks, red);
+        return;
+    }
     if (blockIdx.x == a.n_ray_blocks + 1u) { prepare_bwd_weight_image(a.w_img, a.w_bf, a.params, threadIdx.x); return; }
     if (blockIdx.x == a.n_ray_blocks) {
         if (!a.sums_given) loss_tail_body(a.tail, red, part, s_sums);

@@ -1059,7 +1059,17 @@ int naruto_debug_train_query_fwd(const NarutoField* f, const NarutoParams* p, co
     tva.cap = list_cap(M + w.n3);
     const BwdWs bw = bwd_ws(f, w.bwd, list_cap(M + w.n3));
     const LossStageArgs a = loss_stage_args(f, t, w, bw, tva);
-    return launch_train_query(f, p, t, (hipStream_t)stream, &a, nullptr);
+    // (the five-launch iteration's form of it -- depth sampling in the walk, the lattice encode in its tail workgroups -- where the trainer's
+    // iteration takes that form; the jitter is whatever the step's generator state gives: timing only)
+    WalkExtra wx{};
+    if (tv_moved(t, tail_rides_in_backward(t))) {
+        const float* jitter = t->perturb ? t->rand : nullptr;
+        const uint64_t* jitter_rng = (t->perturb && t->rand == nullptr) ? t->rng : nullptr;
+        wx.on = 1u;
+        wx.sa = SampleArgs{t->n_rays, t->target_d, t->near_, t->far_, t->n_samples_d, t->n_range_d, t->range_d, jitter, jitter_rng, t->z_vals, (t->n_rays + 3u) / 4u};
+        wx.rand6 = t->rand6; wx.rng = t->rng; wx.x_out = bw.x_soa;
+    }
+    return launch_train_query(f, p, t, (hipStream_t)stream, &a, nullptr, &wx);
 }
 
 // profiling: k_hash_scatter_lds ALONE over the point list the last naruto_train_backward left in the workspace, in the launch shape

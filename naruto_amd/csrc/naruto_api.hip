@@ -90,7 +90,9 @@ int ray_lds_attr() {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_fwd_loss<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLossMaxRayLds) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_fwd_loss<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLossMaxRayLds) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_fwd_loss<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLossMaxRayLds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_fwd_loss<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLossMaxRayLds) != hipSuccess)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_fwd_loss<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFwdLossMaxRayLds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_fwd_loss_short<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_query_fwd_loss_short<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 1024) != hipSuccess)
         return fail(NARUTO_ERR_LAUNCH, "per-ray kernels: cannot reserve %d bytes of LDS: %s", bytes, hipGetErrorString(hipGetLastError()));
     done = true;
     return NARUTO_OK;
@@ -802,36 +804,105 @@ int train_check(const NarutoField* f, const NarutoParams* p, const NarutoTrainSt
 // two-phase form and forward + backward are issued as one iteration (deferred tail), the walk samples its own depths, its tail workgroups
 // encode the smoothness lattice, the term itself is evaluated by workgroups of the backward's first launch and its value lands in the
 // losses with the backward's last launch -- k_sample_encode has no launch of its own.  NARUTO_TV_MOVE=0: the six-launch form (same bits).
-inline bool tv_moved(const NarutoTrainStep* t, bool deferred) {
-    static const bool on = getenv("NARUTO_TV_MOVE") == nullptr || atoi(getenv("NARUTO_TV_MOVE")) != 0;
+// ONE decision, used by everyone who has to know which launch form the training forward takes (the forward itself, the backward's
+// moved smoothness term, the debug re-launches): the round-4 form re-derived the walk's conditions by hand in tv_moved().
+//   Flat    64-sample tiles over the flat point list (k_query_fwd), loss stage and depth sampling in launches of their own
+//   Walk    one wave per ray, front to back (k_query_fwd_loss when the loss stage rides along, k_query_fwd<EE> otherwise); since round 5
+//           also for sample counts that are not a multiple of 64 -- the ray's last tile is partly filled, its dead lanes issue no loads --
+//           so that the shipped 32 + 11 sampling gets the five-launch iteration too (fused form only; NARUTO_WALK_PARTIAL: 0 never,
+//           1 (default) up to NARUTO_WALK_PARTIAL_MAX tiles per CU, 2 always)
+//   Packed  k_query_fwd_loss_packed (see launch_train_query)
+//   Short   S <= 64 (round 5): a workgroup packs 256 / S rays into its four waves' tiles (k_query_fwd_loss_short), loss stage inside, one row
+//           of loss partials per workgroup -- the shipped 32 + 11 sampling in five launches without a second round of workgroups
+enum class FwdForm { Flat, Walk, Packed, Short };
+struct TrainFwdPlan {
+    FwdForm form;
+    bool fused;         // the loss stage rides in the field query's launch
+    bool split;         // Walk: the two-phase tile (k_query_fwd_loss<*, true>)
+    bool tv_moved;      // the walk samples its own depths and encodes the lattice; the term is evaluated in the backward's first launch
+    uint32_t tpr;       // Walk: tiles per ray
+    uint32_t rays_per_row;      // rays per row of the loss stage's partial sums (kRaysPerBlock, or Short's rays per workgroup)
+};
+TrainFwdPlan train_fwd_plan(const NarutoField* f, const NarutoTrainStep* t, bool with_loss, bool deferred) {
+    static const bool tv_on = getenv("NARUTO_TV_MOVE") == nullptr || atoi(getenv("NARUTO_TV_MOVE")) != 0;
     static const bool no_fuse = getenv("NARUTO_DEBUG_NO_FUSED_LOSS_STAGE") != nullptr, no_ee = getenv("NARUTO_DEBUG_NO_EARLY_EXIT") != nullptr;
     static const int packed_mode = getenv("NARUTO_FWD_PACKED") == nullptr ? 1 : atoi(getenv("NARUTO_FWD_PACKED"));
-    const uint32_t S = t->n_samples_d + t->n_range_d;
-    const bool walk = S % 64u == 0u && S > 64u && !no_ee && !no_fuse && packed_mode != 2 && ray_scratch_bytes(S) <= kFwdLossMaxRayLds;
-    const bool split = kFwdSplit && sizeof(FwdLds) + (size_t)kRaysPerBlock * sizeof(FwdSlab) + ray_scratch_bytes(S) + 512u <= (size_t)80u * 1024u;
-    return on && deferred && t->smooth_points != 0 && walk && split;
+    static const int partial_mode = getenv("NARUTO_WALK_PARTIAL") == nullptr ? 1 : atoi(getenv("NARUTO_WALK_PARTIAL"));
+    // measured (tools/walk_ab.sh, profiles/r05_walk_ab.txt): Short wins while its workgroups are ONE round (two per CU: 8 tiles) -- 2 048 x 43
+    // 0.171 -> 0.159 ms, the BA batch 0.1875 -> 0.1795 -- and loses beyond (8 192 x 43: 0.391 -> 0.408, 131 072 x 43: 4.86 -> 4.92)
+    static const uint32_t partial_max = getenv("NARUTO_WALK_PARTIAL_MAX") ? (uint32_t)atoi(getenv("NARUTO_WALK_PARTIAL_MAX")) : 8u;
+    const uint32_t N = t->n_rays, S = t->n_samples_d + t->n_range_d;
+    TrainFwdPlan pl{FwdForm::Flat, false, false, false, 0u, (uint32_t)kRaysPerBlock};
+    const bool exact = S % 64u == 0u && S > 64u;
+    const bool can_fuse = with_loss && !no_fuse && ray_scratch_bytes(S) <= kFwdLossMaxRayLds;
+    bool packed_on = packed_mode == 2 || ((packed_mode == 1 || packed_mode == 3) && !exact);
+    if (packed_on && packed_mode == 1) packed_on = (size_t)f->n_entries * 2u * sizeof(float) > ((size_t)64u << 20);
+    if (packed_on && with_loss && !no_fuse && kFwdSplit && S <= 4095u && N >= 1u) {
+        pl.form = FwdForm::Packed;          // (falls back to the flat launch inside launch_train_query if not even one row fits the LDS)
+        pl.fused = true;
+        return pl;
+    }
+    if (S <= 64u && can_fuse && kFwdSplit && partial_mode != 0) {
+        const uint32_t R = short_rays_per_block(S);
+        if (partial_mode == 2 || (uint64_t)((N + R - 1u) / R) * 4u <= (uint64_t)cu_count(f) * partial_max) {
+            pl.form = FwdForm::Short;
+            pl.fused = true;
+            pl.split = true;
+            pl.rays_per_row = R;
+            pl.tv_moved = tv_on && deferred && t->smooth_points != 0;
+            return pl;
+        }
+    }
+    const uint32_t tpr = (S + 63u) / 64u;
+    bool walk = exact && !no_ee;
+    if (!walk && !exact && !no_ee && can_fuse && partial_mode != 0)
+        walk = partial_mode == 2 || (uint64_t)N * tpr <= (uint64_t)cu_count(f) * partial_max * 2u;
+    if (!walk) return pl;
+    pl.form = FwdForm::Walk;
+    pl.tpr = tpr;
+    pl.fused = can_fuse;
+    pl.split = pl.fused && kFwdSplit && sizeof(FwdLds) + (size_t)kRaysPerBlock * sizeof(FwdSlab) + ray_scratch_bytes(S) + 512u <= (size_t)80u * 1024u;
+    pl.tv_moved = tv_on && deferred && t->smooth_points != 0 && pl.fused && pl.split;
+    return pl;
+}
+// The five-launch iteration (round 4, see WalkExtra in naruto_train.hip): where the training forward is the depth-ordered walk in its
+// two-phase form and forward + backward are issued as one iteration (deferred tail), the walk samples its own depths, its tail workgroups
+// encode the smoothness lattice, the term itself is evaluated by workgroups of the backward's first launch and its value lands in the
+// losses with the backward's last launch -- k_sample_encode has no launch of its own.  NARUTO_TV_MOVE=0: the six-launch form (same bits).
+// level groups per lattice-encode workgroup where the encode rides as tail role of the training forward (NARUTO_TV_TAIL_GROUPS: 1, 2, 4)
+inline uint32_t tv_tail_groups() {
+    static const uint32_t g = getenv("NARUTO_TV_TAIL_GROUPS") ? (uint32_t)atoi(getenv("NARUTO_TV_TAIL_GROUPS")) : 1u;
+    return g;
+}
+inline bool tv_moved(const NarutoField* f, const NarutoTrainStep* t, bool deferred) { return train_fwd_plan(f, t, true, deferred).tv_moved; }
+// rows of per-workgroup partial sums the FUSED loss stage of the plan's form leaves (the stand-alone k_loss_stage: one per kRaysPerBlock rays)
+inline uint32_t loss_rows(const NarutoField* f, const NarutoTrainStep* t, bool deferred) {
+    const uint32_t R = train_fwd_plan(f, t, true, deferred).rays_per_row;
+    return (t->n_rays + R - 1u) / R;
 }
 int launch_train_query(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, hipStream_t st, const LossStageArgs* loss = nullptr,
-                       bool* fused = nullptr, const WalkExtra* walk_extra = nullptr) {
+                       bool* fused = nullptr, const WalkExtra* walk_extra = nullptr, bool deferred = false) {
     if (fused != nullptr) *fused = false;
     const uint32_t N = t->n_rays, S = t->n_samples_d + t->n_range_d, M = N * S;
+    const TrainFwdPlan pl = train_fwd_plan(f, t, loss != nullptr, deferred);
+    const bool wx_on = walk_extra != nullptr && walk_extra->on != 0u;
+    // the caller skipped k_sample_encode because the plan said the walk samples its own depths: any other form here would read stale depths
+    if (wx_on != pl.tv_moved) return fail(NARUTO_ERR_INVALID, "train query: the caller's launch plan (depth sampling in the walk: %d) is not the launcher's (%d)", (int)wx_on, (int)pl.tv_moved);
     PointSrc ps{};
     ps.rays_o = t->rays_o; ps.rays_d = t->rays_d; ps.z_vals = t->z_vals; ps.S = S;
     const uint32_t n_tiles = (M + 63u) / 64u;
     uint32_t blocks = (n_tiles + 3u) / 4u;
     if (blocks > cu_count(f) * 4u) blocks = cu_count(f) * 4u;
     EarlyExit ee{};
-    static const bool no_ee = getenv("NARUTO_DEBUG_NO_EARLY_EXIT") != nullptr;             // profiling knob
-    if (S % 64u == 0u && S > 64u && !no_ee) {      // depth-ordered early termination: one wave per ray, front to back
+    if (pl.form == FwdForm::Walk) {      // depth-ordered early termination: one wave per ray, front to back
         ee.target_d = t->target_d;
         ee.trunc_sc = f->desc.trunc * f->desc.sc_factor;
-        ee.tiles_per_ray = S / 64u;
+        ee.tiles_per_ray = pl.tpr;
         static const uint32_t stagger = getenv("NARUTO_DEBUG_WALK_STAGGER") ? (uint32_t)atoi(getenv("NARUTO_DEBUG_WALK_STAGGER")) : 0u;
         ee.stagger = stagger;
         blocks = (N + 3u) / 4u;
         if (blocks > cu_count(f) * 4u) blocks = cu_count(f) * 4u;
     }
-    static const bool no_fuse = getenv("NARUTO_DEBUG_NO_FUSED_LOSS_STAGE") != nullptr;      // A/B knob: the two launches instead
     // the packed forward (k_query_fwd_loss_packed: only the samples a consumer can see, packed across rays, loss stage from LDS; any
     // samples-per-ray count).  Its workgroup works in barrier-separated steps -- all gathers of a pass, then all matrix chains -- so what it
     // gains is the samples it does NOT evaluate, and what it loses is the flat launch's overlap of one wave's gathers with another's matrix
@@ -844,10 +915,7 @@ int launch_train_query(const NarutoField* f, const NarutoParams* p, const Naruto
     // NARUTO_FWD_PACKED: 0 never, 1 (default) as above, 2 everywhere incl. S = 64 k, 3 wherever the walk cannot run.  Losses and gradients
     // agree with the other launch shapes to the distance between OneBlob's closed and dense forms, ~1e-6 (which form a point gets depends on
     // the tile it shares).  NARUTO_PACK_ONE_PASS=1: every sample in the first pass (measured: 0.200 / 0.180 ms at the two batches above).
-    static const int packed_mode = getenv("NARUTO_FWD_PACKED") == nullptr ? 1 : atoi(getenv("NARUTO_FWD_PACKED"));
-    bool packed_on = packed_mode == 2 || ((packed_mode == 1 || packed_mode == 3) && (S % 64u != 0u || S <= 64u));
-    if (packed_on && packed_mode == 1) packed_on = (size_t)f->n_entries * 2u * sizeof(float) > ((size_t)64u << 20);
-    if (loss != nullptr && packed_on && !no_fuse && kFwdSplit && S <= 4095u && N >= 1u) {
+    if (pl.form == FwdForm::Packed) {
         // workgroup shape: 8 waves x 1 per CU, or 4 waves x 2 per CU (NARUTO_PACK_WAVES); rows (of four rays) a workgroup holds at a time: as many as
         // the LDS next to the weights, the feature slabs and the tiles' points takes, at most three
         static const int pack_waves = getenv("NARUTO_PACK_WAVES") ? atoi(getenv("NARUTO_PACK_WAVES")) : 8;
@@ -900,16 +968,28 @@ int launch_train_query(const NarutoField* f, const NarutoParams* p, const Naruto
             return check_launch("query_fwd_loss_packed");
         }
     }
-    if (loss != nullptr && ee.tiles_per_ray != 0u && ray_scratch_bytes(S) <= kFwdLossMaxRayLds && !no_fuse) {
+    if (pl.form == FwdForm::Short) {
         if (int rc = ray_lds_attr()) return rc;
-        // the two-phase tile costs 32 KB of slabs per workgroup: only while two workgroups still share a CU (S <= 192), see k_query_fwd_loss
-        const bool split = kFwdSplit && sizeof(FwdLds) + (size_t)kRaysPerBlock * sizeof(FwdSlab) + ray_scratch_bytes(S) + 512u <= (size_t)80u * 1024u;
         const bool bfm = f->desc.mlp_mode == NARUTO_MLP_BF16;
         const WalkExtra wxa = walk_extra != nullptr ? *walk_extra : WalkExtra{};
-        const uint32_t tail_blocks = wxa.on ? tv_encode_blocks(loss->tv.n * loss->tv.n * loss->tv.n) : loss->n_tv_blocks;
+        const uint32_t tail_blocks = wxa.on ? tv_encode_blocks(loss->tv.n * loss->tv.n * loss->tv.n, wxa.tv_groups) : loss->n_tv_blocks;
+        const uint32_t R = pl.rays_per_row;
+        uint32_t sblocks = (N + R - 1u) / R;
+        if (sblocks > cu_count(f) * 4u) sblocks = cu_count(f) * 4u;
+        if (bfm) hipLaunchKernelGGL(k_query_fwd_loss_short<true>, dim3(sblocks + tail_blocks), dim3(256), short_lds_bytes(S), st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, t->feat_save, *loss, sblocks, wxa, R, g_fwd_timeline);
+        else hipLaunchKernelGGL(k_query_fwd_loss_short<false>, dim3(sblocks + tail_blocks), dim3(256), short_lds_bytes(S), st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, t->feat_save, *loss, sblocks, wxa, R, g_fwd_timeline);
+        if (fused != nullptr) *fused = true;
+        return check_launch("query_fwd_loss_short");
+    }
+    if (pl.form == FwdForm::Walk && pl.fused) {
+        if (int rc = ray_lds_attr()) return rc;
+        // the two-phase tile costs 32 KB of slabs per workgroup: only while two workgroups still share a CU (S <= 192), see k_query_fwd_loss
+        const bool bfm = f->desc.mlp_mode == NARUTO_MLP_BF16;
+        const WalkExtra wxa = walk_extra != nullptr ? *walk_extra : WalkExtra{};
+        const uint32_t tail_blocks = wxa.on ? tv_encode_blocks(loss->tv.n * loss->tv.n * loss->tv.n, wxa.tv_groups) : loss->n_tv_blocks;
 #define NARUTO_LAUNCH_WALK(BFV, SPV) hipLaunchKernelGGL((k_query_fwd_loss<BFV, SPV>), dim3(blocks + tail_blocks), dim3(256), ray_scratch_bytes(S), st, f->lt, f->ut, f->bt, *p, ps, M, \
                                                         t->raw, t->feat_save, ee, *loss, blocks, wxa)
-        if (split) { if (bfm) NARUTO_LAUNCH_WALK(true, true); else NARUTO_LAUNCH_WALK(false, true); }
+        if (pl.split) { if (bfm) NARUTO_LAUNCH_WALK(true, true); else NARUTO_LAUNCH_WALK(false, true); }
         else { if (bfm) NARUTO_LAUNCH_WALK(true, false); else NARUTO_LAUNCH_WALK(false, false); }
 #undef NARUTO_LAUNCH_WALK
         if (fused != nullptr) *fused = true;
@@ -918,7 +998,7 @@ int launch_train_query(const NarutoField* f, const NarutoParams* p, const Naruto
     // flat tiles, between one and two four-wave workgroups per CU (2 048 rays x 43 samples: 1 376 tiles): two-wave workgroups (see k_query_fwd)
     static const bool small_wg_on = getenv("NARUTO_DEBUG_FWD_SMALL_WG") == nullptr || atoi(getenv("NARUTO_DEBUG_FWD_SMALL_WG")) != 0;
     const bool small_wg = small_wg_on && ee.tiles_per_ray == 0u && n_tiles > cu_count(f) * 4u && n_tiles < cu_count(f) * 8u;
-    const bool walk = ee.tiles_per_ray != 0u;          // the depth-ordered walk has its own instantiation: the flat launches carry none of its code
+    const bool walk = ee.tiles_per_ray != 0u;          // the depth-ordered walk has its own instantiation: the flat launches carry none of its code (full tiles only: S = 64 k)
     if (f->desc.mlp_mode == NARUTO_MLP_BF16) {
         if (walk) hipLaunchKernelGGL((k_query_fwd_bf<true, 256, true>), dim3(blocks), dim3(256), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
         else if (small_wg) hipLaunchKernelGGL((k_query_fwd_bf<true, 128>), dim3((n_tiles + 1u) / 2u), dim3(128), 0, st, f->lt, f->ut, f->bt, *p, ps, M, t->raw, nullptr, nullptr, t->feat_save, ee);
@@ -995,8 +1075,9 @@ int naruto_train_forward(const NarutoField* f, const NarutoParams* p, const Naru
     const BwdWs bw = bwd_ws(f, w.bwd, list_cap(M + w.n3));
     const bool deferred_ = finalize == NARUTO_TRAIN_FWD_DEFER_TAIL && tail_rides_in_backward(t);
     WalkExtra wx{};
-    if (tv_moved(t, deferred_)) {
+    if (tv_moved(f, t, deferred_)) {
         wx.on = 1u;
+        wx.tv_groups = tv_tail_groups();
         wx.sa = SampleArgs{N, t->target_d, t->near_, t->far_, t->n_samples_d, t->n_range_d, t->range_d, jitter, jitter_rng, t->z_vals, (N + 3u) / 4u};
         wx.rand6 = t->rand6; wx.rng = t->rng; wx.x_out = bw.x_soa;
     } else if (t->smooth_points != 0) {
@@ -1016,7 +1097,7 @@ int naruto_train_forward(const NarutoField* f, const NarutoParams* p, const Naru
     const bool deferred = finalize == NARUTO_TRAIN_FWD_DEFER_TAIL && tail_rides_in_backward(t);
     if (int rc = ray_lds_attr()) return rc;
     bool loss_done = false;
-    if (int rc = launch_train_query(f, p, t, st, &a, &loss_done, &wx)) return rc;
+    if (int rc = launch_train_query(f, p, t, st, &a, &loss_done, &wx, deferred)) return rc;
     if (!loss_done) {
         static const int dbg_ls_roles = getenv("NARUTO_DEBUG_LOSS_STAGE_ROLES") ? atoi(getenv("NARUTO_DEBUG_LOSS_STAGE_ROLES")) : 3;     // profiling knob: 1 rays, 2 lattice
         if (dbg_ls_roles == 1) a.n_tv_blocks = 0;
@@ -1025,9 +1106,10 @@ int naruto_train_forward(const NarutoField* f, const NarutoParams* p, const Naru
         if (int rc = check_launch("loss_stage")) return rc;
     }
     if (deferred) return NARUTO_OK;                          // the tail is a workgroup of the backward's first launch
-    LossTailArgs tl = loss_tail_args(t, w, a.n_ray_blocks, a.n_tv_blocks, tva.inv_p3, finalize != 0);
-    if (a.n_ray_blocks > 4u * kTailRows) {          // large batch: fold the per-workgroup rows first
-        hipLaunchKernelGGL(k_loss_fold, dim3(kTailRows), dim3(64), 0, st, tl.partials, a.n_ray_blocks, w.fold);
+    const uint32_t n_rows = loss_done ? loss_rows(f, t, deferred) : a.n_ray_blocks;      // rows of partial sums the loss stage left
+    LossTailArgs tl = loss_tail_args(t, w, n_rows, a.n_tv_blocks, tva.inv_p3, finalize != 0);
+    if (n_rows > 4u * kTailRows) {          // large batch: fold the per-workgroup rows first
+        hipLaunchKernelGGL(k_loss_fold, dim3(kTailRows), dim3(64), 0, st, tl.partials, n_rows, w.fold);
         if (int rc = check_launch("loss_fold")) return rc;
         tl.partials = w.fold; tl.n_ray_blocks = kTailRows;
     }
@@ -1062,14 +1144,16 @@ int naruto_debug_train_query_fwd(const NarutoField* f, const NarutoParams* p, co
     // (the five-launch iteration's form of it -- depth sampling in the walk, the lattice encode in its tail workgroups -- where the trainer's
     // iteration takes that form; the jitter is whatever the step's generator state gives: timing only)
     WalkExtra wx{};
-    if (tv_moved(t, tail_rides_in_backward(t))) {
+    const bool deferred = tail_rides_in_backward(t);
+    if (tv_moved(f, t, deferred)) {
         const float* jitter = t->perturb ? t->rand : nullptr;
         const uint64_t* jitter_rng = (t->perturb && t->rand == nullptr) ? t->rng : nullptr;
         wx.on = 1u;
+        wx.tv_groups = tv_tail_groups();
         wx.sa = SampleArgs{t->n_rays, t->target_d, t->near_, t->far_, t->n_samples_d, t->n_range_d, t->range_d, jitter, jitter_rng, t->z_vals, (t->n_rays + 3u) / 4u};
         wx.rand6 = t->rand6; wx.rng = t->rng; wx.x_out = bw.x_soa;
     }
-    return launch_train_query(f, p, t, (hipStream_t)stream, &a, nullptr, &wx);
+    return launch_train_query(f, p, t, (hipStream_t)stream, &a, nullptr, &wx, deferred);
 }
 
 // profiling: k_hash_scatter_lds ALONE over the point list the last naruto_train_backward left in the workspace, in the launch shape
@@ -1148,6 +1232,10 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
         if (int rc = naruto_train_finalize(f, t, stream)) return rc;
     }
     if (int rc = ray_lds_attr()) return rc;
+    // the smoothness term moved into this backward only where the FORWARD was told to defer its tail (NARUTO_TRAIN_BWD_DEFERRED_TAIL): with
+    // NARUTO_TRAIN_BWD_SUMS_GIVEN (data parallel, the autograd node) the forward ran k_sample_encode, evaluated the term itself and its
+    // value is already in losses[8] -- evaluating it here again would count it twice in the total (round-4 advisor finding)
+    const bool moved = (flags & NARUTO_TRAIN_BWD_DEFERRED_TAIL) != 0u && deferred && tv_moved(f, t, true);
     if (deferred) {
         const bool smooth_d = t->smooth_points != 0 && (g->table != nullptr || opt != nullptr);
         const BwdWs bwd = bwd_ws(f, w.bwd, list_cap(M + w.n3));
@@ -1158,11 +1246,13 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
         fa.ray_count = t->ray_count; fa.ray_off = t->ray_offset; fa.active_idx = t->active_idx; fa.n_active = t->n_active;
         fa.n_front = smooth_d ? w.n3 : 0u; fa.n_list = bwd.n_total;
         // (the term moved into this launch: the tail cannot see its partial sums -- the last launch of the backward adds the value, TvLate)
-        fa.tail = loss_tail_args(t, w, fa.n_ray_blocks, (t->smooth_points != 0 && !tv_moved(t, true)) ? w.n_tv_blocks : 0u, tv_args(t).inv_p3, 1);
+        // rows the forward's loss stage left: the plan's, when this backward belongs to a forward that deferred its tail (sums_given: unused)
+        fa.n_rows = (flags & NARUTO_TRAIN_BWD_DEFERRED_TAIL) != 0u ? loss_rows(f, t, true) : fa.n_ray_blocks;
+        fa.tail = loss_tail_args(t, w, fa.n_rows, (t->smooth_points != 0 && !moved) ? w.n_tv_blocks : 0u, tv_args(t).inv_p3, 1);
         fa.sums_given = sums_given ? 1 : 0;
         // one more workgroup prepares the MLP backward's weight images (the parameters do not change before k_query_bwd reads them)
         fa.w_img = w.w_img; fa.w_bf = f->desc.mlp_mode == NARUTO_MLP_BF16 ? 1 : 0; fa.params = *p;
-        if (tv_moved(t, true)) {
+        if (moved) {
             TvArgs tva = tv_args(t);
             tva.cap = list_cap(M + w.n3);
             fa.tv = tva; fa.tv_feat = w.tv_feat; fa.tv_d_list = bwd.d_feat; fa.tv_partial = w.tv_partial;
@@ -1197,7 +1287,7 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
     const AdamFuse* ad = opt != nullptr ? &adam : nullptr;
     const void* w_img = deferred ? w.w_img : nullptr;            // prepared by k_loss_bwd_fused just above
     TvLate tvl{};
-    const bool late = deferred && tv_moved(t, true);
+    const bool late = moved;
     if (late) { tvl.tv_partial = w.tv_partial; tvl.n_tv_blocks = w.n_tv_blocks; tvl.inv_p3 = tv_args(t).inv_p3; tvl.losses = t->losses; tvl.loss_weights = t->loss_weights; }
     int rc;
     if (n_front > 0)

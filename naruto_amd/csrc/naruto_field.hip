@@ -52,8 +52,53 @@ struct FwdLds {
 // NT (threads per workgroup) is a compile-time constant so that the loops unroll completely and all of a thread's loads
 // (strided reads of the row-major weights: one cache line per lane) are in flight together; with a runtime stride the
 // 22 (forward) / 62 (backward) loads per thread were issued one L2 round trip after the other
+// Where the staging reads the nn.Linear weights from: the parameters themselves (one 64-byte line per lane and load -- the rows are 320 /
+// 252 bytes apart --, which is what a workgroup's staging costs: ~2 500 line requests through the CU's L1, 4.4 us measured in
+// k_query_fwd_loss_short, tools/short_timeline.py), or a raw copy in LDS that the workgroup fetched with COALESCED loads first (344 lines)
+// and reads back transposed, conflict-free thanks to odd row strides (stage_fwd_weights_via_lds below).
+struct WSrcGlobal {
+    const NarutoParams& p;
+    __device__ __forceinline__ float sdf_w0(int i, int c) const { return p.sdf_w0[i * kInSdf + c]; }
+    __device__ __forceinline__ float col_w0(int i, int c) const { return p.col_w0[i * kInCol + c]; }
+    __device__ __forceinline__ float sdf_w1(int i, int u) const { return p.sdf_w1[i * kHidden + u]; }
+    __device__ __forceinline__ float col_w1(int e) const { return p.col_w1[e]; }
+};
+constexpr int kRawS0Ld = kInSdf + 1, kRawC0Ld = kInCol, kRawS1Ld = kHidden + 1;      // 81, 63, 33: odd => a column read (32 rows) hits 32 banks
+constexpr int kRawC0 = kHidden * kRawS0Ld, kRawS1 = kRawC0 + kHidden * kRawC0Ld;
+constexpr int kFwdRawFloats = kRawS1 + kOut * kRawS1Ld;                              // 5 136 floats = 20.1 KB
+struct WSrcLds {
+    const float* raw; const NarutoParams& p;
+    __device__ __forceinline__ float sdf_w0(int i, int c) const { return raw[i * kRawS0Ld + c]; }
+    __device__ __forceinline__ float col_w0(int i, int c) const { return raw[kRawC0 + i * kRawC0Ld + c]; }
+    __device__ __forceinline__ float sdf_w1(int i, int u) const { return raw[kRawS1 + i * kRawS1Ld + u]; }
+    __device__ __forceinline__ float col_w1(int e) const { return p.col_w1[e]; }
+};
+// hop 1: the three weight matrices, coalesced, into the raw area (all of a thread's loads in flight together); ends with a barrier
 template <int NT>
-__device__ __forceinline__ void stage_fwd_weights(FwdLds& L, const NarutoParams& p, int tid) {
+__device__ __forceinline__ void fetch_raw_weights(float* __restrict__ raw, const NarutoParams& p, int tid) {
+    constexpr int n0 = kHidden * kInSdf, n1 = kHidden * kInCol, n2 = kOut * kHidden;
+    constexpr int q0 = (n0 + NT - 1) / NT, q1 = (n1 + NT - 1) / NT, q2 = (n2 + NT - 1) / NT;
+    float v0[q0], v1[q1], v2[q2];
+#pragma unroll
+    for (int q = 0; q < q0; ++q) { const int g = q * NT + tid; v0[q] = g < n0 ? p.sdf_w0[g] : 0.0f; }
+#pragma unroll
+    for (int q = 0; q < q1; ++q) { const int g = q * NT + tid; v1[q] = g < n1 ? p.col_w0[g] : 0.0f; }
+#pragma unroll
+    for (int q = 0; q < q2; ++q) { const int g = q * NT + tid; v2[q] = g < n2 ? p.sdf_w1[g] : 0.0f; }
+#pragma unroll
+    for (int q = 0; q < q0; ++q) { const int g = q * NT + tid; if (g < n0) raw[g + g / kInSdf] = v0[q]; }           // row i starts at i * 81
+#pragma unroll
+    for (int q = 0; q < q1; ++q) { const int g = q * NT + tid; if (g < n1) raw[kRawC0 + g] = v1[q]; }
+#pragma unroll
+    for (int q = 0; q < q2; ++q) { const int g = q * NT + tid; if (g < n2) raw[kRawS1 + g + g / kHidden] = v2[q]; }
+    __syncthreads();
+}
+
+// NT (threads per workgroup) is a compile-time constant so that the loops unroll completely and all of a thread's loads
+// (strided reads of the row-major weights: one cache line per lane) are in flight together; with a runtime stride the
+// 22 (forward) / 62 (backward) loads per thread were issued one L2 round trip after the other
+template <int NT, typename SRC>
+__device__ __forceinline__ void stage_fwd_weights_from(FwdLds& L, const SRC& w, int tid) {
     constexpr int nthreads = NT;
 #pragma unroll
     for (int e0 = 0; e0 < 40 * 64; e0 += NT) {
@@ -61,21 +106,21 @@ __device__ __forceinline__ void stage_fwd_weights(FwdLds& L, const NarutoParams&
         if (e >= 40 * 64) continue;
         const int t = e >> 6, l = e & 63, i = l & 31, kk = l >> 5;
         const int col = t < 16 ? 2 * t + kk : kFeat + 2 * (t - 16) + kk;
-        L.s0[e] = p.sdf_w0[i * kInSdf + col];
+        L.s0[e] = w.sdf_w0(i, col);
     }
 #pragma unroll
     for (int e0 = 0; e0 < 24 * 64; e0 += nthreads) {
         const int e = e0 + tid;
         if (e >= 24 * 64) continue;
         const int t = e >> 6, l = e & 63, i = l & 31, kk = l >> 5;
-        L.c0p[e] = p.col_w0[i * kInCol + 2 * t + kk];
+        L.c0p[e] = w.col_w0(i, 2 * t + kk);
     }
 #pragma unroll
     for (int e0 = 0; e0 < 16 * 64; e0 += nthreads) {
         const int e = e0 + tid;
         if (e >= 16 * 64) continue;
         const int t = e >> 6, l = e & 63, i = l & 31, kk = l >> 5;
-        L.s1[e] = i < kOut ? p.sdf_w1[i * kHidden + crow(t, kk)] : 0.0f;
+        L.s1[e] = i < kOut ? w.sdf_w1(i, crow(t, kk)) : 0.0f;
     }
 #pragma unroll
     for (int e0 = 0; e0 < 8 * 64; e0 += nthreads) {
@@ -83,15 +128,24 @@ __device__ __forceinline__ void stage_fwd_weights(FwdLds& L, const NarutoParams&
         if (e >= 8 * 64) continue;
         const int r = e >> 6, l = e & 63, i = l & 31, kk = l >> 5;
         const int row = crow(r, kk);                      // sdf-net output row 0..15; row 0 is the sdf
-        L.c0g[e] = row >= 1 ? p.col_w0[i * kInCol + kPos + row - 1] : 0.0f;
+        L.c0g[e] = row >= 1 ? w.col_w0(i, kPos + row - 1) : 0.0f;
     }
 #pragma unroll
     for (int e0 = 0; e0 < 3 * 16 * 2; e0 += nthreads) {
         const int e = e0 + tid;
         if (e >= 3 * 16 * 2) continue;
         const int c = e / 32, r = (e >> 1) & 15, hh = e & 1;
-        L.c1[e] = p.col_w1[c * kHidden + crow(r, hh)];
+        L.c1[e] = w.col_w1(c * kHidden + crow(r, hh));
     }
+}
+template <int NT>
+__device__ __forceinline__ void stage_fwd_weights(FwdLds& L, const NarutoParams& p, int tid) { stage_fwd_weights_from<NT>(L, WSrcGlobal{p}, tid); }
+// through the raw area (>= kFwdRawFloats floats of LDS the caller does not need yet -- the feature slabs); the caller's barrier behind the
+// staging also releases the raw area
+template <int NT>
+__device__ __forceinline__ void stage_fwd_weights_via_lds(FwdLds& L, float* __restrict__ raw, const NarutoParams& p, int tid) {
+    fetch_raw_weights<NT>(raw, p, tid);
+    stage_fwd_weights_from<NT>(L, WSrcLds{raw, p}, tid);
 }
 
 // ---- smoothness lattice (see the comment block at k_tv_encode below) ----
@@ -113,14 +167,22 @@ struct TvArgs {
 constexpr int kTvLevels = NARUTO_TV_LEVELS;
 static_assert(kLevels % kTvLevels == 0, "the lattice encode handles whole groups of levels");
 constexpr uint32_t kTvPointsPerBlock = 128;          // 256 threads = 4 waves x 32 points x 2 x-halves
-inline uint32_t tv_encode_blocks(uint32_t n3) { return (uint32_t)(kLevels / kTvLevels) * ((n3 + kTvPointsPerBlock - 1u) / kTvPointsPerBlock); }
+// groups: level groups (of kTvLevels levels) ONE workgroup walks for its 128 points -- 1 = as many short workgroups as possible (the encode
+// alone on the chip: k_sample_encode, k_tv_encode); more = fewer, longer workgroups, for the encode as tail role of the training forward,
+// where it runs in the few slots the ray workgroups leave free and what counts is that it is DONE when they are (round 5)
+inline uint32_t tv_encode_blocks(uint32_t n3, uint32_t groups = 1u) {
+    const uint32_t ng = (uint32_t)(kLevels / kTvLevels), g = groups < 1u ? 1u : (groups > ng ? ng : groups);
+    return ((ng + g - 1u) / g) * ((n3 + kTvPointsPerBlock - 1u) / kTvPointsPerBlock);
+}
 
 __device__ __forceinline__ void tv_encode_body(const LevelTab& lt, const BoxTab& bt, const TvArgs& a, const float* __restrict__ rand6,
                                                const uint64_t* __restrict__ rng, const float2* __restrict__ table, float* __restrict__ x_out,
-                                               float* __restrict__ feat, uint32_t block) {
+                                               float* __restrict__ feat, uint32_t block, uint32_t groups = 1u) {
     const uint32_t n3 = a.n * a.n * a.n;
     const uint32_t per_group = (n3 + kTvPointsPerBlock - 1u) / kTvPointsPerBlock;
-    const uint32_t group = block / per_group;
+    constexpr uint32_t kNg = (uint32_t)(kLevels / kTvLevels);
+    const uint32_t gpb = groups < 1u ? 1u : (groups > kNg ? kNg : groups);
+    const uint32_t group0 = (block / per_group) * gpb;
     const uint32_t lane = threadIdx.x & 63u, xh = lane >> 5;
     const uint32_t m_raw = (block % per_group) * kTvPointsPerBlock + (threadIdx.x >> 6) * 32u + (lane & 31u);
     const bool valid = m_raw < n3;
@@ -139,12 +201,13 @@ __device__ __forceinline__ void tv_encode_body(const LevelTab& lt, const BoxTab&
         const float offset = r_off * offset_max + a.margin;
         const float p = ((float)ijk[d] + r_jit) * a.voxel + bt.bmin[d] + offset;
         xn[d] = __fdiv_rn(p - bt.bmin[d], bt.bext[d]);
-        if (group == 0 && xh == 0u && valid) {
+        if (group0 == 0 && xh == 0u && valid) {
             if (a.cap != 0) x_out[(size_t)d * a.cap + m] = xn[d];
             else x_out[3 * (size_t)m + d] = xn[d];
         }
-        if (group == 0 && xh == 0u && valid && d == 0 && a.cap != 0) x_out[3 * (size_t)a.cap + m] = 0.0f;   // row 3: no raw[...,4] cotangent at lattice points
+        if (group0 == 0 && xh == 0u && valid && d == 0 && a.cap != 0) x_out[3 * (size_t)a.cap + m] = 0.0f;   // row 3: no raw[...,4] cotangent at lattice points
     }
+    for (uint32_t group = group0; group < group0 + gpb && group < kNg; ++group) {
     HalfCorners h[kTvLevels];
 #pragma unroll
     for (int g = 0; g < kTvLevels; ++g) h[g] = hash_level_half_index(lt, (int)group * kTvLevels + g, xn[0], xn[1], xn[2], xh);
@@ -164,6 +227,7 @@ __device__ __forceinline__ void tv_encode_body(const LevelTab& lt, const BoxTab&
             if (a.cap != 0) reinterpret_cast<float2*>(feat)[(size_t)level * n3 + m] = f;
             else reinterpret_cast<float2*>(feat + (size_t)m * kFeat)[level] = f;
         }
+    }
     }
 }
 
@@ -201,7 +265,9 @@ struct EeState {
 
 // after tile tq of ray `task`: update the state from the tile's sdf values (lane = sample) and decide whether the ray's remaining
 // tiles can be skipped (their raw entries are then written as zeros).  Returns true = stop.
-__device__ __forceinline__ bool ee_after_tile(EeState& st, const EarlyExit& ee, const PointSrc& ps, uint32_t m, uint32_t tq, uint32_t tpr, uint32_t tile,
+// (the tile is a FULL one: a partly filled tile is its ray's last and nothing follows it; next_begin / ray_end: the sample indices at which
+// the ray's next tile starts and the ray ends -- what is written as zeros when the walk stops here)
+__device__ __forceinline__ bool ee_after_tile(EeState& st, const EarlyExit& ee, const PointSrc& ps, uint32_t m, uint32_t tq, uint32_t next_begin, uint32_t ray_end,
                                               uint32_t task, float sdf, int lane, float* __restrict__ raw) {
     const float zs = ps.z_vals[m];
     if (!st.found) {
@@ -225,7 +291,7 @@ __device__ __forceinline__ bool ee_after_tile(EeState& st, const EarlyExit& ee, 
         const float lim = fmaxf(st.zfirst, ee.target_d[task]) + ee.trunc_sc;
         if (z_last > lim + 1e-5f * fabsf(lim) + 1e-6f) {
             if (raw != nullptr) {
-                for (uint32_t k = (tile + 1u) * 64u * 5u + lane; k < (task + 1u) * tpr * 64u * 5u; k += 64u) raw[k] = 0.0f;
+                for (uint32_t k = next_begin * 5u + lane; k < ray_end * 5u; k += 64u) raw[k] = 0.0f;
             }
             return true;
         }
@@ -545,7 +611,8 @@ __global__ __launch_bounds__(NT, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab 
                                                    float* __restrict__ geo, float* __restrict__ feat_save, EarlyExit ee) {
     __shared__ FwdLds L;
     __shared__ FwdSlab slabs[kFwdSplit ? NT / 64 : 1];
-    stage_fwd_weights<NT>(L, p, threadIdx.x);
+    if constexpr (sizeof(slabs) >= kFwdRawFloats * sizeof(float)) stage_fwd_weights_via_lds<NT>(L, reinterpret_cast<float*>(slabs), p, threadIdx.x);
+    else stage_fwd_weights<NT>(L, p, threadIdx.x);
     __syncthreads();
     constexpr uint32_t kW = NT / 64;
     const int lane = threadIdx.x & 63, wave = kFwdSplit ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);
@@ -583,7 +650,7 @@ __global__ __launch_bounds__(NT, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab 
             }
         }
         if (EE && tq + 1u < tpr) {
-            if (ee_after_tile(ees, ee, ps, m, tq, tpr, tile, task, sdf, lane, raw)) break;
+            if (ee_after_tile(ees, ee, ps, m, tq, (tile + 1u) * 64u, (task + 1u) * tpr * 64u, task, sdf, lane, raw)) break;
         }
     }
     }
@@ -611,8 +678,8 @@ struct FwdLdsBf {
     float c1[3 * 16 * 2];  // colour layer 1 (fp32 VALU), as FwdLds::c1
 };
 
-template <int NT>
-__device__ __forceinline__ void stage_fwd_weights_bf(FwdLdsBf& L, const NarutoParams& p, int tid) {
+template <int NT, typename SRC>
+__device__ __forceinline__ void stage_fwd_weights_bf_from(FwdLdsBf& L, const SRC& w, int tid) {
 #pragma unroll
     for (int e0 = 0; e0 < 11 * 64; e0 += NT) {
         const int e = e0 + tid;
@@ -621,11 +688,11 @@ __device__ __forceinline__ void stage_fwd_weights_bf(FwdLdsBf& L, const NarutoPa
         float v[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            if (t < 2) v[q] = p.sdf_w0[i * kInSdf + 2 * (8 * t + q) + hh];
-            else if (t < 5) v[q] = p.sdf_w0[i * kInSdf + kFeat + 16 * (t - 2) + 8 * hh + q];
-            else if (t < 8) v[q] = p.col_w0[i * kInCol + 16 * (t - 5) + 8 * hh + q];
-            else if (t == 8) { const int row = crow(q, hh); v[q] = row >= 1 ? p.col_w0[i * kInCol + kPos + row - 1] : 0.0f; }
-            else v[q] = i < kOut ? p.sdf_w1[i * kHidden + crow(8 * (t - 9) + q, hh)] : 0.0f;
+            if (t < 2) v[q] = w.sdf_w0(i, 2 * (8 * t + q) + hh);
+            else if (t < 5) v[q] = w.sdf_w0(i, kFeat + 16 * (t - 2) + 8 * hh + q);
+            else if (t < 8) v[q] = w.col_w0(i, 16 * (t - 5) + 8 * hh + q);
+            else if (t == 8) { const int row = crow(q, hh); v[q] = row >= 1 ? w.col_w0(i, kPos + row - 1) : 0.0f; }
+            else v[q] = i < kOut ? w.sdf_w1(i, crow(8 * (t - 9) + q, hh)) : 0.0f;
         }
         const u32x4_t w = {pk_bf16(v[0], v[1]), pk_bf16(v[2], v[3]), pk_bf16(v[4], v[5]), pk_bf16(v[6], v[7])};
         if (t < 5) L.s0[t * 64 + l] = w;
@@ -637,8 +704,15 @@ __device__ __forceinline__ void stage_fwd_weights_bf(FwdLdsBf& L, const NarutoPa
         const int e = e0 + tid;
         if (e >= 3 * 16 * 2) continue;
         const int c = e / 32, r = (e >> 1) & 15, hh = e & 1;
-        L.c1[e] = p.col_w1[c * kHidden + crow(r, hh)];
+        L.c1[e] = w.col_w1(c * kHidden + crow(r, hh));
     }
+}
+template <int NT>
+__device__ __forceinline__ void stage_fwd_weights_bf(FwdLdsBf& L, const NarutoParams& p, int tid) { stage_fwd_weights_bf_from<NT>(L, WSrcGlobal{p}, tid); }
+template <int NT>
+__device__ __forceinline__ void stage_fwd_weights_bf_via_lds(FwdLdsBf& L, float* __restrict__ raw, const NarutoParams& p, int tid) {
+    fetch_raw_weights<NT>(raw, p, tid);
+    stage_fwd_weights_bf_from<NT>(L, WSrcLds{raw, p}, tid);
 }
 
 __device__ __forceinline__ u32x4_t pack8(const float (&v)[8]) {
@@ -804,7 +878,8 @@ __global__ __launch_bounds__(NT, NARUTO_FWD_BF_MINWAVES) void k_query_fwd_bf(Lev
                                                       float* __restrict__ geo, float* __restrict__ feat_save, EarlyExit ee) {
     __shared__ FwdLdsBf L;
     __shared__ FwdSlab slabs[kFwdSplit ? NT / 64 : 1];
-    stage_fwd_weights_bf<NT>(L, p, threadIdx.x);
+    if constexpr (sizeof(slabs) >= kFwdRawFloats * sizeof(float)) stage_fwd_weights_bf_via_lds<NT>(L, reinterpret_cast<float*>(slabs), p, threadIdx.x);
+    else stage_fwd_weights_bf<NT>(L, p, threadIdx.x);
     __syncthreads();
     constexpr uint32_t kW = NT / 64;
     const int lane = threadIdx.x & 63, wave = kFwdSplit ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);
@@ -840,7 +915,7 @@ __global__ __launch_bounds__(NT, NARUTO_FWD_BF_MINWAVES) void k_query_fwd_bf(Lev
             }
         }
         if (EE && tq + 1u < tpr) {
-            if (ee_after_tile(ees, ee, ps, m, tq, tpr, tile, task, sdf, lane, raw)) break;
+            if (ee_after_tile(ees, ee, ps, m, tq, (tile + 1u) * 64u, (task + 1u) * tpr * 64u, task, sdf, lane, raw)) break;
         }
     }
     }

@@ -29,70 +29,90 @@ __device__ __forceinline__ float linspace_at(float start, float end, uint32_t st
 // one wave = one ray; zs / us: this wave's LDS, S floats each (merged list; the two sorted input lists: uniform [0, nu) then
 // near-surface [nu, nu+nr))
 // z_vals (global [n_rays,S]) and z_keep (this wave's LDS, S floats, distinct from zs / us) are both optional destinations
+// The three per-sample steps of the sampling (between them: every sample of the ray must have finished the step before).  sample_z_ray_core
+// runs them one wave per ray (wave_lds_sync between the steps), k_query_fwd_loss_short one THREAD per sample for several rays at once
+// (__syncthreads between the steps): same functions, same bits.
+// step A -- the two sorted input lists side by side in us: uniform [0, nu), near-surface [nu, nu + nr)   (has_depth only)
+__device__ __forceinline__ float sample_z_input(uint32_t s, float d, float near_, float far_, uint32_t nu, uint32_t nr, float range_d) {
+    const bool use_near_far = !(d > 0.0f);           // rows with target_d <= 0 (NaN also lands here)
+    if (s < nu) return linspace_at(near_, far_, nu, s);
+    return use_near_far ? linspace_at(near_, far_, nr, s - nu) : __fadd_rn(linspace_at(-range_d, range_d, nr, s - nu), d);
+}
+// step B -- element s of us goes to its place in the merged list zs
+// Both lists are arithmetic progressions (non-decreasing), so "how many of the other list lie below v" is a division away;
+// the estimate is then walked to the exact count by comparing the ACTUAL list values (the comparisons decide, as in a
+// merge: ties keep the uniform element first), one or two LDS reads instead of a 32-step scan / 7-step binary search.
+__device__ __forceinline__ void sample_z_merge(uint32_t s, uint32_t nu, uint32_t nr, const float* __restrict__ us, float* __restrict__ zs) {
+    const float u0 = nu ? us[0] : 0.0f, u_step = nu > 1 ? (us[nu - 1] - us[0]) / (float)(nu - 1) : 0.0f;
+    const float r0 = nr ? us[nu] : 0.0f, r_step = nr > 1 ? (us[nu + nr - 1] - us[nu]) / (float)(nr - 1) : 0.0f;
+    const float v = us[s];
+    uint32_t rank;
+    if (u_step < 0.0f || r_step < 0.0f) {         // far < near or range_d < 0 (no shipped config): the plain scans
+        if (s < nu) {
+            rank = s;
+            for (uint32_t k = 0; k < nr; ++k) rank += us[nu + k] < v ? 1u : 0u;
+        } else {
+            uint32_t lo = 0, hi = nu;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (us[mid] <= v) lo = mid + 1; else hi = mid;
+            }
+            rank = (s - nu) + lo;
+        }
+    } else if (s < nu) {                          // uniform element: rank = i + #{R < U[i]}
+        const float e = (v - r0) / r_step;        // R[k] < v  <=>  k < e (up to rounding)
+        uint32_t c = !(e > 0.0f) ? 0u : (e >= (float)nr ? nr : (uint32_t)e);         // NaN (zero step) -> 0, then walked up
+        while (c < nr && us[nu + c] < v) ++c;
+        while (c > 0u && !(us[nu + c - 1u] < v)) --c;
+        rank = s + c;
+    } else {                                      // near-surface element: rank = k + #{U <= R[k]}
+        const float e = (v - u0) / u_step + 1.0f; // U[i] <= v  <=>  i + 1 <= e (up to rounding)
+        uint32_t c = !(e > 0.0f) ? 0u : (e >= (float)nu ? nu : (uint32_t)e);
+        while (c < nu && us[c] <= v) ++c;
+        while (c > 0u && !(us[c - 1u] <= v)) --c;
+        rank = (s - nu) + c;
+    }
+    zs[rank] = v;
+}
+// step C -- the stratified jitter of sample s of ray n
+__device__ __forceinline__ float sample_z_jitter(uint32_t n, uint32_t s, uint32_t S, const float* __restrict__ zs, const float* __restrict__ rand, bool use_rng, uint64_t key) {
+    float v = zs[s];
+    if (rand != nullptr || use_rng) {
+        const float lo = s == 0 ? zs[0] : 0.5f * (zs[s] + zs[s - 1]);
+        const float up = s == S - 1 ? zs[S - 1] : 0.5f * (zs[s + 1] + zs[s]);
+        const float r = rand != nullptr ? rand[(size_t)n * S + s] : rng_uniform(key, (uint64_t)n * S + s);
+        v = __fadd_rn(lo, __fmul_rn(__fsub_rn(up, lo), r));
+    }
+    return v;
+}
+// (the core takes the ray's measured depth and the jitter key already LOADED -- has_depth: is there a target_d at all; use_rng: draw the
+// jitter from `key`)
+__device__ __forceinline__ void sample_z_ray_core(uint32_t n, bool has_depth, float d, float near_, float far_, uint32_t nu, uint32_t nr,
+                                                  float range_d, const float* __restrict__ rand, bool use_rng, uint64_t key,
+                                                  float* __restrict__ z_vals, float* __restrict__ zs, float* __restrict__ us, int lane,
+                                                  float* __restrict__ z_keep = nullptr) {
+    const uint32_t S = nu + nr;
+    if (!has_depth) {
+        for (uint32_t s = lane; s < S; s += 64) zs[s] = linspace_at(near_, far_, S, s);     // S == n_samples, nr == 0
+    } else {
+        for (uint32_t s = lane; s < S; s += 64) us[s] = sample_z_input(s, d, near_, far_, nu, nr, range_d);
+        wave_lds_sync();
+        for (uint32_t s = lane; s < S; s += 64) sample_z_merge(s, nu, nr, us, zs);
+    }
+    wave_lds_sync();
+    for (uint32_t s = lane; s < S; s += 64) {
+        const float v = sample_z_jitter(n, s, S, zs, rand, use_rng, key);
+        if (z_vals != nullptr) z_vals[(size_t)n * S + s] = v;
+        if (z_keep != nullptr) z_keep[s] = v;
+    }
+}
 __device__ __forceinline__ void sample_z_ray(uint32_t n, const float* __restrict__ target_d, float near_, float far_, uint32_t nu, uint32_t nr,
                                              float range_d, const float* __restrict__ rand, const uint64_t* __restrict__ rng,
                                              float* __restrict__ z_vals, float* __restrict__ zs, float* __restrict__ us, int lane,
                                              float* __restrict__ z_keep = nullptr) {
-    const uint32_t S = nu + nr;
-    if (target_d == nullptr) {
-        for (uint32_t s = lane; s < S; s += 64) zs[s] = linspace_at(near_, far_, S, s);     // S == n_samples, nr == 0
-    } else {
-        const float d = target_d[n];
-        const bool use_near_far = !(d > 0.0f);           // rows with target_d <= 0 (NaN also lands here)
-        for (uint32_t s = lane; s < S; s += 64) {
-            if (s < nu) us[s] = linspace_at(near_, far_, nu, s);
-            else us[s] = use_near_far ? linspace_at(near_, far_, nr, s - nu) : __fadd_rn(linspace_at(-range_d, range_d, nr, s - nu), d);
-        }
-        wave_lds_sync();
-        // Both lists are arithmetic progressions (non-decreasing), so "how many of the other list lie below v" is a division away;
-        // the estimate is then walked to the exact count by comparing the ACTUAL list values (the comparisons decide, as in a
-        // merge: ties keep the uniform element first), one or two LDS reads instead of a 32-step scan / 7-step binary search.
-        const float u0 = nu ? us[0] : 0.0f, u_step = nu > 1 ? (us[nu - 1] - us[0]) / (float)(nu - 1) : 0.0f;
-        const float r0 = nr ? us[nu] : 0.0f, r_step = nr > 1 ? (us[nu + nr - 1] - us[nu]) / (float)(nr - 1) : 0.0f;
-        for (uint32_t s = lane; s < S; s += 64) {
-            const float v = us[s];
-            uint32_t rank;
-            if (u_step < 0.0f || r_step < 0.0f) {         // far < near or range_d < 0 (no shipped config): the plain scans
-                if (s < nu) {
-                    rank = s;
-                    for (uint32_t k = 0; k < nr; ++k) rank += us[nu + k] < v ? 1u : 0u;
-                } else {
-                    uint32_t lo = 0, hi = nu;
-                    while (lo < hi) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if (us[mid] <= v) lo = mid + 1; else hi = mid;
-                    }
-                    rank = (s - nu) + lo;
-                }
-            } else if (s < nu) {                          // uniform element: rank = i + #{R < U[i]}
-                const float e = (v - r0) / r_step;        // R[k] < v  <=>  k < e (up to rounding)
-                uint32_t c = !(e > 0.0f) ? 0u : (e >= (float)nr ? nr : (uint32_t)e);         // NaN (zero step) -> 0, then walked up
-                while (c < nr && us[nu + c] < v) ++c;
-                while (c > 0u && !(us[nu + c - 1u] < v)) --c;
-                rank = s + c;
-            } else {                                      // near-surface element: rank = k + #{U <= R[k]}
-                const float e = (v - u0) / u_step + 1.0f; // U[i] <= v  <=>  i + 1 <= e (up to rounding)
-                uint32_t c = !(e > 0.0f) ? 0u : (e >= (float)nu ? nu : (uint32_t)e);
-                while (c < nu && us[c] <= v) ++c;
-                while (c > 0u && !(us[c - 1u] <= v)) --c;
-                rank = (s - nu) + c;
-            }
-            zs[rank] = v;
-        }
-    }
-    wave_lds_sync();
-    const uint64_t key = rng != nullptr ? rng_key(rng) : 0ull;
-    for (uint32_t s = lane; s < S; s += 64) {
-        float v = zs[s];
-        if (rand != nullptr || rng != nullptr) {
-            const float lo = s == 0 ? zs[0] : 0.5f * (zs[s] + zs[s - 1]);
-            const float up = s == S - 1 ? zs[S - 1] : 0.5f * (zs[s + 1] + zs[s]);
-            const float r = rand != nullptr ? rand[(size_t)n * S + s] : rng_uniform(key, (uint64_t)n * S + s);
-            v = __fadd_rn(lo, __fmul_rn(__fsub_rn(up, lo), r));
-        }
-        if (z_vals != nullptr) z_vals[(size_t)n * S + s] = v;
-        if (z_keep != nullptr) z_keep[s] = v;
-    }
+    const float d = target_d != nullptr ? target_d[n] : 0.0f;
+    const uint64_t key = (rand == nullptr && rng != nullptr) ? rng_key(rng) : 0ull;
+    sample_z_ray_core(n, target_d != nullptr, d, near_, far_, nu, nr, range_d, rand, rand == nullptr && rng != nullptr, key, z_vals, zs, us, lane, z_keep);
 }
 
 

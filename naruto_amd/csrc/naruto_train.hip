@@ -71,11 +71,12 @@ __device__ __forceinline__ void loss_total(float* __restrict__ losses, const flo
 
 // the loss stage's work on one ray whose raw values / depths sit in the wave's LDS image rs (load_ray's layout): compositing, per-ray
 // loss terms -> t[10], the rendered outputs, the ray's list length for the backward
-__device__ __forceinline__ void loss_stage_ray(const LossStageArgs& a, const RayScratch& rs, uint32_t n, int lane, float* __restrict__ t) {
+// (tg: the ray's target colour and measured depth {r, g, b, d} if the caller already holds them, e.g. in LDS; NULL: read here)
+__device__ __forceinline__ void loss_stage_ray(const LossStageArgs& a, const RayScratch& rs, uint32_t n, int lane, float* __restrict__ t, const float* tg = nullptr) {
     const uint32_t S = a.S;
     const RayWeights rw = ray_weights(rs, S, a.trunc, a.sc_factor, lane);
     const RayOut o = ray_composite(rs, rw, n, S, a.white_bkgd, nullptr, lane);
-    const float td = measured_depth(a.target_d[n]);
+    const float td = measured_depth(tg != nullptr ? tg[3] : a.target_d[n]);
     const bool valid = depth_valid(td, a.depth_trunc);
     const float dm = td > 0.0f ? 1.0f : 0.0f;
     float fs = 0.0f, nfs = 0.0f, sl = 0.0f, nsdf = 0.0f;
@@ -107,7 +108,7 @@ __device__ __forceinline__ void loss_stage_ray(const LossStageArgs& a, const Ray
         float s0 = 0.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float e = o.rgb[c] * w - a.target_rgb[3 * (size_t)n + c] * w;
+            const float e = o.rgb[c] * w - (tg != nullptr ? tg[c] : a.target_rgb[3 * (size_t)n + c]) * w;
             s0 = fmaf(e, e, s0);
         }
         const float D = o.depth, u = o.uncert;
@@ -179,6 +180,7 @@ struct SampleArgs {
 // backward's first launch by 1: 0.2219 -> 0.2135 ms per iteration.  Same bits as the six-launch form: same routines on the same data.
 struct WalkExtra {
     uint32_t on;
+    uint32_t tv_groups;          // level groups per lattice-encode workgroup (tv_encode_blocks)
     SampleArgs sa;
     const float* rand6; const uint64_t* rng; float* x_out;
 };
@@ -196,11 +198,13 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
     if (blockIdx.x >= n_fwd_blocks) {
         bool encode = false;
         if constexpr (SPLIT) encode = wx.on != 0u;
-        if (encode) tv_encode_body(lt, bt, a.tv, wx.rand6, wx.rng, reinterpret_cast<const float2*>(p.table), wx.x_out, const_cast<float*>(a.tv_feat), blockIdx.x - n_fwd_blocks);
+        if (encode) tv_encode_body(lt, bt, a.tv, wx.rand6, wx.rng, reinterpret_cast<const float2*>(p.table), wx.x_out, const_cast<float*>(a.tv_feat), blockIdx.x - n_fwd_blocks, wx.tv_groups);
         else tv_loss_list_body(a.tv, a.tv_feat, a.tv_d_list, a.tv_scale_dev, a.tv_scale_host, a.tv_partial, blockIdx.x - n_fwd_blocks, a.n_tv_blocks, red);
         return;
     }
-    if constexpr (BF) stage_fwd_weights_bf<256>(L, p, threadIdx.x);
+    if constexpr (SPLIT && BF) stage_fwd_weights_bf_via_lds<256>(L, reinterpret_cast<float*>(slabs), p, threadIdx.x);
+    else if constexpr (SPLIT) stage_fwd_weights_via_lds<256>(L, reinterpret_cast<float*>(slabs), p, threadIdx.x);
+    else if constexpr (BF) stage_fwd_weights_bf<256>(L, p, threadIdx.x);
     else stage_fwd_weights<256>(L, p, threadIdx.x);
     __syncthreads();
     if (ee.stagger != 0u) {
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int j = lane & 31;
     const float2* __restrict__ table = reinterpret_cast<const float2*>(p.table);
-    const uint32_t tpr = ee.tiles_per_ray, S = a.S;                  // S == 64 tpr
+    const uint32_t tpr = ee.tiles_per_ray, S = a.S;                  // tpr = ceil(S / 64): a ray's last tile may be partly filled (round 5)
     const uint32_t n_groups = (a.n_rays + (uint32_t)kRaysPerBlock - 1u) / (uint32_t)kRaysPerBlock;
     const RayScratch rs = ray_scratch(ray_lds, wave, S);
     for (uint32_t group = blockIdx.x; group < n_groups; group += n_fwd_blocks) {          // uniform over the workgroup: barriers inside
@@ -223,28 +227,35 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
                 __threadfence_block();
             }
             EeState ees{false, 0.0f, 0.0f, 0.0f};
+            const uint32_t ray0 = task * S;                              // the ray's first sample in the point list
             uint32_t tq = 0;
             for (; tq < tpr; ++tq) {
-                const uint32_t tile = task * tpr + tq;
-                const uint32_t m = tile * 64u + (uint32_t)lane;          // M = n_rays * S: no padding lanes
+                // lanes past the end of the ray (its last tile when S is not a multiple of 64) redo the ray's last sample with every
+                // load and store switched off: they are dead lanes exactly like those behind the end of the band (ee_lane_live)
+                const uint32_t s = tq * 64u + (uint32_t)lane;
+                const bool valid = s < S;
+                const uint32_t t0 = ray0 + tq * 64u;
+                const uint32_t m = valid ? t0 + (uint32_t)lane : ray0 + S - 1u;
                 float x, y, z;
                 load_point(ps, bt, m, x, y, z);
-                const bool live = (tq > 0u && kEeLaneSkip) ? ee_lane_live(ees, ee, task, ps.z_vals[m]) : true;
+                const float zv = ps.z_vals[m];
+                const bool live = valid && ((tq > 0u && kEeLaneSkip) ? ee_lane_live(ees, ee, task, zv) : true);
                 const float u = live ? uncert_sample(ut, p.uncert_grid, x, y, z) : 0.0f;
                 FwdTileOut to;
                 const bool live_out = live;
-                if constexpr (BF && SPLIT) fwd_tile_split_bf<true, true>(L, slabs[wave], lt, table, x, y, z, feat_save, nullptr, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
-                else if constexpr (BF) fwd_tile_bf<true, true>(L, lt, table, x, y, z, feat_save, nullptr, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
-                else if constexpr (SPLIT) fwd_tile_split<true, true>(L, slabs[wave], lt, table, x, y, z, feat_save, nullptr, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);      // M = n_rays * 64 tpr: every tile is full
-                else fwd_tile<true, true>(L, lt, table, x, y, z, feat_save, nullptr, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
+                if constexpr (BF && SPLIT) fwd_tile_split_bf<true, true>(L, slabs[wave], lt, table, x, y, z, feat_save, nullptr, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, to, live);
+                else if constexpr (BF) fwd_tile_bf<true, true>(L, lt, table, x, y, z, feat_save, nullptr, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, to, live);
+                else if constexpr (SPLIT) fwd_tile_split<true, true>(L, slabs[wave], lt, table, x, y, z, feat_save, nullptr, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, to, live);
+                else fwd_tile<true, true>(L, lt, table, x, y, z, feat_save, nullptr, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, to, live);
                 if (!live_out) { to.rgb[0] = 0.0f; to.rgb[1] = 0.0f; to.rgb[2] = 0.0f; to.sdf = 0.0f; }
                 const float u_out = live_out ? u : 0.0f;
-                float* o = raw + (size_t)m * 5;
-                o[0] = to.rgb[0]; o[1] = to.rgb[1]; o[2] = to.rgb[2]; o[3] = to.sdf; o[4] = u_out;
-                const uint32_t s = tq * 64u + (uint32_t)lane;
-                rs.c0[s] = to.rgb[0]; rs.c1[s] = to.rgb[1]; rs.c2[s] = to.rgb[2]; rs.sdf[s] = to.sdf; rs.u[s] = u_out;
-                rs.z[s] = ps.z_vals[m];
-                if (tq + 1u < tpr && ee_after_tile(ees, ee, ps, m, tq, tpr, tile, task, to.sdf, lane, raw)) { ++tq; break; }
+                if (valid) {
+                    float* o = raw + (size_t)m * 5;
+                    o[0] = to.rgb[0]; o[1] = to.rgb[1]; o[2] = to.rgb[2]; o[3] = to.sdf; o[4] = u_out;
+                    rs.c0[s] = to.rgb[0]; rs.c1[s] = to.rgb[1]; rs.c2[s] = to.rgb[2]; rs.sdf[s] = to.sdf; rs.u[s] = u_out;
+                    rs.z[s] = zv;
+                }
+                if (tq + 1u < tpr && ee_after_tile(ees, ee, ps, m, tq, t0 + 64u, ray0 + S, task, to.sdf, lane, raw)) { ++tq; break; }
             }
             // tiles that were not evaluated: raw is zeros there (ee_after_tile wrote them), the image gets the same
             for (uint32_t s = tq * 64u + (uint32_t)lane; s < S; s += 64u) {
@@ -265,6 +276,146 @@ template __global__ void k_query_fwd_loss<false, false>(LevelTab, UncertTab, Box
 template __global__ void k_query_fwd_loss<true, false>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t, WalkExtra);
 template __global__ void k_query_fwd_loss<false, true>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t, WalkExtra);
 template __global__ void k_query_fwd_loss<true, true>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t, WalkExtra);
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// SHORT rays (round 5): the training forward + loss stage for S <= 64 samples per ray -- the sampling NARUTO ships (32 + 11,
+// configs/Replica/replica_coslam.yaml:90,92).  One wave per ray (the walk above) leaves a third of every tile empty at 43 samples and, worse,
+// needs one wave PER RAY: 2 148 rays of a BA batch are 537 workgroups on 512 resident slots, i.e. a second round of 25 (75 us against 57 at
+// 2 048 rays).  Here a workgroup takes R = 256 / S rays (5 at 43 samples) and packs their samples back to back into its four waves' tiles --
+// a workgroup-local piece of the flat point list, so feat_save rows stay contiguous -- then runs the loss stage from the rays' LDS images.
+// 2 148 rays are 430 workgroups: one round, and the slots that stay free take the lattice-encode workgroups of the five-launch iteration
+// while the rays are still being evaluated.  One row of loss partials per workgroup (R rays; the rows are only ever summed).
+// ------------------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kShortMaxRays = 8;
+inline uint32_t short_rays_per_block(uint32_t S) { const uint32_t r = 256u / (S ? S : 1u); return r > kShortMaxRays ? kShortMaxRays : (r < 1u ? 1u : r); }
+inline size_t short_lds_bytes(uint32_t S) { return (size_t)short_rays_per_block(S) * kRayFields * S * sizeof(float); }
+template <bool BF>
+__global__ __launch_bounds__(256, 2) void k_query_fwd_loss_short(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps, uint32_t M, float* __restrict__ raw,
+                                                                 float* __restrict__ feat_save, LossStageArgs a, uint32_t n_fwd_blocks, WalkExtra wx, uint32_t R,
+                                                                 unsigned long long* __restrict__ timeline) {
+    using Lds = std::conditional_t<BF, FwdLdsBf, FwdLds>;
+    __shared__ Lds L;
+    __shared__ FwdSlab slabs[kRaysPerBlock];
+    __shared__ double red[4];
+    __shared__ float terms[kShortMaxRays][10];
+    extern __shared__ float ray_lds[];
+    // profiling (naruto_debug_fwd_timeline; NULL otherwise): thread 0 of EVERY workgroup stamps the 100 MHz global counter -- 0 start, 1 depths,
+    // 2 gather phase of wave 0, 3 tiles done, 4 loss stage, 7 end (tools/short_timeline.py)
+    auto stamp = [&](int k) {
+        if (timeline != nullptr && threadIdx.x == 0) timeline[(size_t)blockIdx.x * 8u + (size_t)k] = (unsigned long long)wall_clock64();
+    };
+    stamp(0);
+    if (blockIdx.x >= n_fwd_blocks) {
+        if (wx.on != 0u) tv_encode_body(lt, bt, a.tv, wx.rand6, wx.rng, reinterpret_cast<const float2*>(p.table), wx.x_out, const_cast<float*>(a.tv_feat), blockIdx.x - n_fwd_blocks, wx.tv_groups);
+        else tv_loss_list_body(a.tv, a.tv_feat, a.tv_d_list, a.tv_scale_dev, a.tv_scale_host, a.tv_partial, blockIdx.x - n_fwd_blocks, a.n_tv_blocks, red);
+        stamp(7);
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int j = lane & 31;
+    const float2* __restrict__ table = reinterpret_cast<const float2*>(p.table);
+    const uint32_t S = a.S;
+    const uint32_t n_groups = (a.n_rays + R - 1u) / R;
+    // What the depth sampling and the loss stage wait for from memory -- the rays' measured depths and colours, the jitter key -- is
+    // requested in front of the weight staging (into LDS: tgt), so that it is there when it is needed instead of costing each ray a trip.
+    __shared__ float tgt[kShortMaxRays][4];
+    const bool use_rng = wx.on != 0u && wx.sa.rand == nullptr && wx.sa.rng != nullptr;
+    const uint64_t key_pre = use_rng ? rng_key(wx.sa.rng) : 0ull;
+    auto fetch_targets = [&](uint32_t ray_first) {
+        if (threadIdx.x < 4u * R) {
+            const uint32_t r = threadIdx.x >> 2, c = threadIdx.x & 3u, n = ray_first + r;
+            float v = 0.0f;
+            if (n < a.n_rays) v = c == 3u ? a.target_d[n] : a.target_rgb[3 * (size_t)n + c];
+            tgt[r][c] = v;
+        }
+    };
+    fetch_targets(blockIdx.x * R);
+    if constexpr (BF) stage_fwd_weights_bf_via_lds<256>(L, reinterpret_cast<float*>(slabs), p, threadIdx.x);
+    else stage_fwd_weights_via_lds<256>(L, reinterpret_cast<float*>(slabs), p, threadIdx.x);      // (its barrier also publishes tgt)
+    stamp(5);
+    for (uint32_t group = blockIdx.x; group < n_groups; group += n_fwd_blocks) {          // uniform over the workgroup: barriers inside
+        const uint32_t ray_first = group * R;
+        const uint32_t n_here = a.n_rays - ray_first < R ? a.n_rays - ray_first : R;
+        if (group != blockIdx.x) { fetch_targets(ray_first); __syncthreads(); }
+        // the packed position of this thread: sample s of the workgroup's ray r (R S <= 256)
+        const uint32_t i = (uint32_t)wave * 64u + (uint32_t)lane;
+        const uint32_t r_raw = i / S;
+        const bool valid = r_raw < n_here;
+        // lanes past the last ray redo its last sample with every load and store switched off (dead lanes, as behind the end of a band)
+        const uint32_t r = valid ? r_raw : n_here - 1u, s = valid ? i - r_raw * S : S - 1u;
+        const uint32_t n = ray_first + r;
+        const RayScratch rs = ray_scratch(ray_lds, (int)r, S);
+        // depths: sampled here, one thread per sample (five-launch iteration), or fetched; either way they end up in the rays' images
+        if (wx.on != 0u) {
+            // (the measured depth is the one the loss stage will read: target_d == wx.sa.target_d)
+            const bool has_depth = wx.sa.target_d != nullptr;
+            const float d = tgt[r][3];
+            if (!has_depth) { if (valid) rs.c0[s] = linspace_at(wx.sa.near_, wx.sa.far_, S, s); }
+            else {
+                if (valid) rs.c1[s] = sample_z_input(s, d, wx.sa.near_, wx.sa.far_, wx.sa.nu, wx.sa.nr, wx.sa.range_d);
+                __syncthreads();
+                if (valid) sample_z_merge(s, wx.sa.nu, wx.sa.nr, rs.c1, rs.c0);
+            }
+            __syncthreads();
+            if (valid) {
+                const float v = sample_z_jitter(n, s, S, rs.c0, wx.sa.rand, use_rng, key_pre);
+                wx.sa.z_vals[(size_t)n * S + s] = v;
+                rs.z[s] = v;
+            }
+        } else if (valid) {
+            rs.z[s] = ps.z_vals[(size_t)n * S + s];
+        }
+        __syncthreads();                                   // (also: the staged weights)
+        stamp(1);
+        if ((uint32_t)wave * 64u < n_here * S) {           // wave-uniform: a tile with at least one sample
+            const float zv = rs.z[s];
+            // load_point's arithmetic with the depth from the image
+            const float px = __fadd_rn(ps.rays_o[3 * n + 0], __fmul_rn(ps.rays_d[3 * n + 0], zv));
+            const float py = __fadd_rn(ps.rays_o[3 * n + 1], __fmul_rn(ps.rays_d[3 * n + 1], zv));
+            const float pz = __fadd_rn(ps.rays_o[3 * n + 2], __fmul_rn(ps.rays_d[3 * n + 2], zv));
+            const float x = __fdiv_rn(__fsub_rn(px, bt.bmin[0]), bt.bext[0]);
+            const float y = __fdiv_rn(__fsub_rn(py, bt.bmin[1]), bt.bext[1]);
+            const float z = __fdiv_rn(__fsub_rn(pz, bt.bmin[2]), bt.bext[2]);
+            const float u = valid ? uncert_sample(ut, p.uncert_grid, x, y, z) : 0.0f;
+            const uint32_t t0 = ray_first * S + (uint32_t)wave * 64u;          // the tile's first row of the flat point list
+            FwdTileOut to;
+            if constexpr (BF) fwd_tile_split_bf<true, true>(L, slabs[wave], lt, table, x, y, z, feat_save, nullptr, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, to, valid);
+            else {                                         // fwd_tile_split, with a stamp between its phases
+                if constexpr (NARUTO_FWD_GATHER_PRIO != 0) __builtin_amdgcn_s_setprio(NARUTO_FWD_GATHER_PRIO);
+                fwd_gather_tile<true>(lt, table, x, y, z, feat_save, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, slabs[wave], valid);
+                if constexpr (NARUTO_FWD_GATHER_PRIO != 0) __builtin_amdgcn_s_setprio(0);
+                stamp(2);
+                fwd_mlp_tile<true>(L, slabs[wave], x, y, z, nullptr, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, to);
+            }
+            if (valid) {
+                float* o = raw + (size_t)(t0 + (uint32_t)lane) * 5;
+                o[0] = to.rgb[0]; o[1] = to.rgb[1]; o[2] = to.rgb[2]; o[3] = to.sdf; o[4] = u;
+                rs.c0[s] = to.rgb[0]; rs.c1[s] = to.rgb[1]; rs.c2[s] = to.rgb[2]; rs.sdf[s] = to.sdf; rs.u[s] = u;
+            }
+        }
+        __syncthreads();
+        stamp(3);
+        for (uint32_t r = (uint32_t)wave; r < R; r += (uint32_t)kRaysPerBlock) {
+            if (r < n_here) loss_stage_ray(a, ray_scratch(ray_lds, (int)r, S), ray_first + r, lane, terms[r], tgt[r]);
+            else loss_stage_no_ray(lane, terms[r]);
+        }
+        __syncthreads();
+        stamp(4);
+        if (threadIdx.x < 10) {                            // the workgroup's row of the sums: its rays' terms in ray order
+            const int k = threadIdx.x;
+            double v = (double)terms[0][k];
+            for (uint32_t w = 1; w < R; ++w) {
+                const double t = (double)terms[w][k];
+                v = k == 9 ? ((t < v || t != t) ? t : v) : v + t;
+            }
+            a.partials[(size_t)group * 16 + k] = v;
+        }
+        __syncthreads();                                   // terms and the images are rewritten by the next group
+    }
+    stamp(7);
+}
+template __global__ void k_query_fwd_loss_short<false>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, LossStageArgs, uint32_t, WalkExtra, uint32_t, unsigned long long*);
+template __global__ void k_query_fwd_loss_short<true>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, LossStageArgs, uint32_t, WalkExtra, uint32_t, unsigned long long*);
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // PACKED training forward (round 4): field query + loss stage for rays of ANY sample count, evaluating only the samples some consumer
@@ -728,7 +879,8 @@ constexpr uint32_t kFusedTailMaxRays = 4096;
 struct FusedBwdArgs {
     uint32_t n_rays, S; float trunc, sc_factor; int white_bkgd;
     const float* raw; const float* z_vals; LossArgs la; float* d_raw;
-    const double* partials; uint32_t n_ray_blocks;
+    const double* partials; uint32_t n_ray_blocks;        // n_ray_blocks: THIS launch's ray workgroups (kRaysPerBlock rays each)
+    uint32_t n_rows;                                      // rows of `partials` the forward's loss stage left (its own workgroup shape)
     const uint32_t* ray_count; uint32_t* ray_off; uint32_t* active_idx; uint32_t* n_active; uint32_t n_front; uint32_t* n_list;
     LossTailArgs tail;
     void* w_img; int w_bf; NarutoParams params;       // w_img != NULL: workgroup n_ray_blocks + 1 prepares the MLP backward's weight images there
@@ -771,7 +923,7 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_bwd_fused(FusedBwdA
     }
     const uint32_t c = n < a.n_rays ? a.ray_count[n] : 0u;
     double pv[4][10];
-    if (!a.sums_given) wg_partial_load<0xD6u>(a.partials, a.n_ray_blocks, 0u, pv);          // slots 1, 2, 4, 6, 7 (at most 1 024 rows here)
+    if (!a.sums_given) wg_partial_load<0xD6u>(a.partials, a.n_rows, 0u, pv);          // slots 1, 2, 4, 6, 7 (at most 1 024 rows here)
     if (n < a.n_rays) load_ray(ray_scratch(ray_lds, wave, a.S), a.raw, a.z_vals, n, a.S, lane);
     // list offset: the counts of the rays before this workgroup's (integer sums: any order)
     uint32_t s = 0;

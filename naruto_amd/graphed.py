@@ -33,8 +33,9 @@ class GraphedIteration:
         if int(mp.get('map_accum_step', 1)) != 1 or int(mp.get('map_wait_step', 0)) != 0:
             raise NotImplementedError("GraphedIteration records a loop body whose mapping optimiser steps every iteration: "
                                       "mapping.map_accum_step must be 1 and mapping.map_wait_step 0 (every shipped config)")
-        assert isinstance(caller.map_optimizer, FusedAdam) and caller.smoothness_mode == "fused", \
-            "whole-iteration capture needs optimizer='fused' and smoothness='fused' (no host work inside the loop body)"
+        assert isinstance(caller.map_optimizer, FusedAdam) and isinstance(caller.uncert_optim, FusedAdam) and caller.smoothness_mode == "fused", \
+            "whole-iteration capture needs optimizer='fused' (BOTH optimisers: the mapping one and the uncertainty grid's -- their step counts " \
+            "live on the device and are snapshotted around the warm-up) and smoothness='fused' (no host work inside the loop body)"
         self.caller = caller
         m = caller.model
         dev = m.embed_fn.params.device

@@ -164,10 +164,11 @@ class FusedAdam(optim.Optimizer):
         for g in self.param_groups:
             for p in g['params']:
                 st = self.state[p]
-                if 'exp_avg' not in st:
-                    self._init_state(p)
-                if 'lag' not in st or p in per_param:
-                    st['lag'] = step - per_param.get(p, step)
+                fresh = 'exp_avg' not in st               # no state in the loaded dictionary (torch Adam: the parameter never saw a gradient)
+                if fresh:
+                    self._init_state(p)                   # (sets the lag against the PRE-load step count: overwritten below)
+                if fresh or 'lag' not in st or p in per_param:
+                    st['lag'] = step - per_param.get(p, 0 if fresh else step)
         if self.external_step is None:
             self.step_dev[0] = step
         self._n_steps = step

@@ -1004,7 +1004,7 @@ def test_reference_loop_shapes_for_the_uncert_grid(gpu):
     H.assert_close(tr.model.uncert_grid.grad, g_o, 2e-3 * float(g_o.abs().max()) + 1e-12, "uncert grad carried between BA calls", rel=1e-2)
 
 
-def _dp_worker(rank, world, port, backend, n_rays, steps, out):
+def _dp_worker(rank, world, port, backend, n_rays, steps, out, n_samples_d=None):
     import os
     import torch.distributed as dist
     from naruto_amd import trainer, parallel
@@ -1012,7 +1012,7 @@ def _dp_worker(rank, world, port, backend, n_rays, steps, out):
     dev = torch.device("cuda", rank if backend == "nccl" else 0)
     torch.cuda.set_device(dev)
     dist.init_process_group(backend, rank=rank, world_size=world)
-    cfg = H.office_cfg(12, perturb=0.0)             # no depth jitter: the in-kernel numbers are keyed by the LOCAL ray index
+    cfg = H.office_cfg(12, perturb=0.0) if n_samples_d is None else H.office_cfg(12, perturb=0.0, n_samples_d=n_samples_d)   # no depth jitter: the in-kernel numbers are keyed by the LOCAL ray index
     torch.manual_seed(5)
     tr = trainer.MappingTrainer(cfg, torch.tensor(cfg["mapping"]["bound"]), dev, fused_adam=True, group=dist.group.WORLD)
     losses = []
@@ -1029,8 +1029,11 @@ def _dp_worker(rank, world, port, backend, n_rays, steps, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_data_parallel_training(gpu, tmp_path):
-    """The data-parallel iteration of the PRODUCT path (MappingTrainer with a process group: sharded rays, all-reduce of the loss
+@pytest.mark.parametrize("n_samples_d", [None, 117])
+def test_two_rank_data_parallel_training(gpu, tmp_path, n_samples_d):
+    """(n_samples_d = 117: 128 samples per ray, where a single process runs the five-launch iteration with the smoothness term evaluated in
+    the backward -- the data-parallel backward must NOT evaluate it a second time: round-4 advisor finding, the total loss counted it twice.)
+    The data-parallel iteration of the PRODUCT path (MappingTrainer with a process group: sharded rays, all-reduce of the loss
     sums between forward and backward, two-phase backward with the MLP-gradient bucket reduced under the table scatter, table
     bucket, identical Adam steps) over two ranks reproduces the single-process trajectory on the whole batch.  With two GPUs
     visible the ranks use one GPU each over RCCL ("nccl"); on a one-GPU box both ranks share the GPU and the collectives go
@@ -1044,9 +1047,9 @@ def test_two_rank_data_parallel_training(gpu, tmp_path):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     out = str(tmp_path / "dp_r0.pt")
-    mp.spawn(_dp_worker, args=(2, port, backend, n_rays, steps, out), nprocs=2, join=True)
+    mp.spawn(_dp_worker, args=(2, port, backend, n_rays, steps, out, n_samples_d), nprocs=2, join=True)
     got = torch.load(out)
-    cfg = H.office_cfg(12, perturb=0.0)
+    cfg = H.office_cfg(12, perturb=0.0) if n_samples_d is None else H.office_cfg(12, perturb=0.0, n_samples_d=n_samples_d)
     torch.manual_seed(5)
     ref = trainer.MappingTrainer(cfg, torch.tensor(cfg["mapping"]["bound"]), gpu, fused_adam=True)
     ref.fuse_optimizer = False                            # same kernels as the data-parallel ranks (gradients, then k_adam_multi)
@@ -1619,6 +1622,33 @@ def test_packed_forward_equals_the_flat_one(gpu, tmp_path):
         script.write_text(_KNOB_SCRIPT.replace("n_samples_d=117", f"n_samples_d={n_samples_d}").replace("N = 333", f"N = {n_rays}"))
         res = []
         for k, env in enumerate((env_a, env_b)):
+            out = tmp_path / f"{tag}_{k}.npz"
+            e = dict(os.environ)
+            e.update(env)
+            subprocess.run([sys.executable, str(script), root, str(out)], check=True, env=e, timeout=600)
+            res.append(dict(np.load(out)))
+        a, b = res
+        for k in a:
+            scale = float(np.abs(b[k]).max()) + 1e-30
+            d = float(np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)).max())
+            assert d <= 2e-5 * scale, f"S = {tag}: {k} differs by {d:.3e} at scale {scale:.3e}"
+
+
+def test_short_and_partial_walk_forwards_equal_the_flat_one(gpu, tmp_path):
+    """Round 5: sample counts that are not a multiple of 64 get the five-launch iteration too -- S <= 64 (the shipped 32 + 11) through
+    k_query_fwd_loss_short (a workgroup packs 256 / S rays into its four waves' tiles, samples the depths itself, loss stage inside, one
+    row of loss partials per workgroup), 64 < S through the depth-ordered walk with a partly filled last tile.  NARUTO_WALK_PARTIAL=0 is the
+    round-4 form (flat tiles + k_sample_encode + k_loss_stage); both against it at the distance between OneBlob's closed and dense
+    forms (a point's tile decides which one it gets), incl. ray counts that leave the last workgroup partly filled, fewer rays than one
+    workgroup takes, S = 64 exactly (R = 4), S = 32 (R = 8) and a tile boundary inside a ray (S = 75, 139)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for tag, n_samples_d, n_rays in (("43", 32, 333), ("43_three_rays", 32, 3), ("43_partial_group", 32, 2148), ("64", 53, 257), ("32", 21, 130),
+                                     ("75", 64, 333), ("139", 128, 101)):
+        script = tmp_path / f"iteration_{tag}.py"
+        script.write_text(_KNOB_SCRIPT.replace("n_samples_d=117", f"n_samples_d={n_samples_d}").replace("N = 333", f"N = {n_rays}"))
+        res = []
+        for k, env in enumerate(({"NARUTO_WALK_PARTIAL": "2"}, {"NARUTO_WALK_PARTIAL": "0"})):
             out = tmp_path / f"{tag}_{k}.npz"
             e = dict(os.environ)
             e.update(env)
@@ -2909,6 +2939,35 @@ def test_fused_adam_is_a_torch_optimizer(gpu):
     for q, r, t in zip(pb, pd, pe):
         assert torch.equal(q, t), "torch.optim.Adam restored from FusedAdam's state_dict diverges from the original torch optimiser"
         H.assert_close(r, q, 2e-6, "FusedAdam restored from a torch.optim.Adam state_dict", rel=1e-5)
+    # a parameter WITHOUT state in a torch checkpoint (it never received a gradient there) has taken 0 steps, whatever count the loading
+    # optimiser held before (advisor, round 4): its lag is the loaded global count and its first real steps match torch's
+    pf = [torch.nn.Parameter(torch.randn(40, device=gpu, generator=gen)), torch.nn.Parameter(torch.randn(24, device=gpu, generator=gen))]
+    pg = [torch.nn.Parameter(q.detach().clone()) for q in pf]
+    of_t = torch.optim.Adam([{'params': pf}], lr=0.01)
+    for k in range(3):
+        pf[0].grad = torch.randn(40, device=gpu, generator=gen)
+        of_t.step()
+    sd_p = copy.deepcopy(of_t.state_dict())
+    assert len(sd_p['state']) == 1
+    og = FusedAdam([{'params': pg}], lr=0.01)
+    for k in range(2):                               # the loading optimiser has a history of its own (a stale step count)
+        for q in pg:
+            q.grad = torch.randn(q.shape, device=gpu, generator=gen)
+        og.step()
+    with torch.no_grad():
+        for q, r in zip(pg, pf):
+            q.copy_(r)
+    og.load_state_dict(sd_p)
+    st_g = og.state_dict()['state']
+    assert float(st_g[0]['step']) == 3.0 and float(st_g[1]['step']) == 0.0, (st_g[0]['step'], st_g[1]['step'])
+    for k in range(2):
+        g = [torch.randn(q.shape, device=gpu, generator=gen) for q in pf]
+        for ps in (pf, pg):
+            for q, gg in zip(ps, g):
+                q.grad = gg.clone()
+        of_t.step(); og.step()
+    for q, r in zip(pf, pg):
+        H.assert_close(r, q, 2e-6, "FusedAdam: parameter without state in a torch checkpoint", rel=1e-5)
 
 
 def test_graphed_caller_iteration_equals_eager(gpu):

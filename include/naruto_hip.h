@@ -324,6 +324,13 @@ typedef struct NarutoRayBatch {
     const uint64_t* dyn;
 } NarutoRayBatch;
 int naruto_assemble_rays(const NarutoRayBatch* b, void* stream);
+/* N2 + N1 in ONE launch: naruto_assemble_rays | naruto_active_ray_select without the intermediate oversampled batch (coslam.py:310-359 as
+ * one step of the mapping iteration).  Row r of the virtual batch is what naruto_assemble_rays would have written (b's own output
+ * buffers and ids_out are ignored and may be NULL); base / K / n_tail / volume arguments and the result are naruto_active_ray_select's.
+ * At most 8 192 candidates (n_global + n_cur - base - n_tail): NARUTO_ERR_INVALID beyond -- use the two calls. */
+int naruto_assemble_select(const NarutoRayBatch* b, uint32_t base, uint32_t K, uint32_t n_tail, const float* uncert_vol,
+                           const uint32_t* vol_dims, const float* bbox_min, float voxel_scale, float* out_o, float* out_d,
+                           float* out_s, float* out_t, void* stream);
 int naruto_sample_distinct(uint64_t n, uint32_t count, uint64_t seed, uint64_t counter, int64_t* out, void* stream);
 uint64_t naruto_perm_index(uint64_t i, uint64_t n, uint64_t seed, uint64_t counter, uint64_t salt);
 

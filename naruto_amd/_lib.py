@@ -158,6 +158,7 @@ SIGNATURES = {
     "naruto_rays_to_world": (_I, [_U32, _V, _V, _V, _V, _V, _V]),
     "naruto_map_volumes": (_I, [_U32, _V, _V, _V]),
     "naruto_assemble_rays": (_I, [C.POINTER(NarutoRayBatch), _V]),
+    "naruto_assemble_select": (_I, [C.POINTER(NarutoRayBatch), _U32, _U32, _U32, _V, C.POINTER(_U32), C.POINTER(_F), _F, _V, _V, _V, _V, _V]),
     "naruto_sample_distinct": (_I, [_U64, _U32, _U64, _U64, _V, _V]),
     "naruto_perm_index": (_U64, [_U64, _U64, _U64, _U64, _U64]),
     "naruto_goal_targets_workspace": (C.c_size_t, [_U32, _U32]),

@@ -19,6 +19,7 @@ construction (tests: same distribution properties, and the chained launches equa
 
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -30,12 +31,17 @@ from .trainer import MappingTrainer
 
 class FusedBA:
     def __init__(self, trainer: MappingTrainer, store: KeyFrameStoreHIP, sampler: Optional[ActiveRaySamplerHIP] = None,
-                 max_poses: int = 4096, use_graph: bool = True):
+                 max_poses: int = 4096, use_graph: bool = True, one_launch_prologue: Optional[bool] = None):
         assert trainer.direct and trainer.group is None, "FusedBA drives the single-process fused trainer (MappingTrainer(fused_adam=True))"
         self.trainer, self.store, self.sampler = trainer, store, sampler
         self.config = trainer.config
         self.device = trainer.device
         self.use_graph = use_graph
+        # assembly + selection as ONE launch (naruto_assemble_select) instead of two.  Measured (round 5, profiles/r05_ba_prologue_ab.txt): the
+        # one launch takes 43 us against 20 + 7.5 -- the selecting workgroup has to draw all 6 444 candidates itself (Feistel walks: integer
+        # multiplies on ONE CU) where k_assemble_rays spreads them over 34 -- 0.210 against 0.193 ms per iteration: OFF by default
+        # (NARUTO_BA_ONE_LAUNCH_PROLOGUE=1 or the argument switch it on; same rays either way, tested)
+        self.one_launch_prologue = (os.environ.get("NARUTO_BA_ONE_LAUNCH_PROLOGUE", "0") == "1") if one_launch_prologue is None else bool(one_launch_prologue)
         mp = self.config['mapping']
         self.active = sampler is not None
         self.sample_num = sampler.oversample_num if self.active else int(mp['sample'])
@@ -74,6 +80,11 @@ class FusedBA:
             kw = dict(filter_depth=self.filter_depth, rng=rng, dyn=self.dyn, n_cur=n_cur, n_cur_pop=self._n_cur_pop)
             if not self.active:
                 store.assemble_batch(self.sample_num, self.current, self.poses, self.min_pixels_cur, out=(rays_o, rays_d, target_rgb, target_d), **kw)
+                return
+            if self.one_launch_prologue and self.sample_num + n_cur - sampler.n_out(n_cur) <= 8192:
+                # assembly + selection in one launch (naruto_assemble_select): the oversampled batch is never written
+                store.assemble_select(sampler, self.sample_num, self.current, self.poses, self.min_pixels_cur, self.bbox,
+                                      out=(rays_o, rays_d, target_rgb, target_d), **kw)
                 return
             store.assemble_batch(self.sample_num, self.current, self.poses, self.min_pixels_cur, out=self._stage, **kw)
             sampler.sample_rays(*self._stage, n_cur, None, self.bbox, out=(rays_o, rays_d, target_rgb, target_d), workspace=self._ws)

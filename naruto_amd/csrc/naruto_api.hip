@@ -1456,7 +1456,7 @@ int naruto_active_ray_select(uint32_t n_total, uint32_t base, uint32_t K, uint32
         a.bx = bbox_min[0]; a.by = bbox_min[1]; a.bz = bbox_min[2]; a.voxel_scale = voxel_scale;
         a.o_out = out_o; a.d_out = out_d; a.s_out = out_s; a.t_out = out_t;
         const uint32_t n_copy = base + n_tail - K;
-        hipLaunchKernelGGL(k_ars_fused, dim3(1u + (n_copy + kArsFusedThreads - 1u) / kArsFusedThreads), dim3(kArsFusedThreads), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(k_ars_fused<false>, dim3(1u + (n_copy + kArsFusedThreads - 1u) / kArsFusedThreads), dim3(kArsFusedThreads), 0, (hipStream_t)stream, a, AssembleArgs{});
         return check_launch("ars_fused");
     }
     uint32_t* keys = reinterpret_cast<uint32_t*>(workspace);
@@ -1598,19 +1598,19 @@ int naruto_sample_distinct(uint64_t n, uint32_t count, uint64_t seed, uint64_t c
     return check_launch("sample_distinct");
 }
 
-int naruto_assemble_rays(const NarutoRayBatch* b, void* stream) {
-    if (b == nullptr) return fail(NARUTO_ERR_INVALID, "assemble_rays: NULL argument");
-    if (b->poses == nullptr || b->n_poses == 0 || b->rays_o == nullptr || b->rays_d == nullptr || b->target_s == nullptr || b->target_d == nullptr)
-        return fail(NARUTO_ERR_INVALID, "assemble_rays: NULL pose / output buffer");
+namespace {
+// NarutoRayBatch -> the kernels' argument block (need_out: the batch's own output buffers are written)
+int assemble_args(const NarutoRayBatch* b, bool need_out, AssembleArgs& a, const char* who) {
+    if (b == nullptr) return fail(NARUTO_ERR_INVALID, "%s: NULL argument", who);
+    if (b->poses == nullptr || b->n_poses == 0 || (need_out && (b->rays_o == nullptr || b->rays_d == nullptr || b->target_s == nullptr || b->target_d == nullptr)))
+        return fail(NARUTO_ERR_INVALID, "%s: NULL pose / output buffer", who);
     if (b->n_global > 0 && (b->store == nullptr || b->frame_ids == nullptr || b->rays_per_kf == 0 || b->n_kf == 0 || b->keyframe_every <= 0))
-        return fail(NARUTO_ERR_INVALID, "assemble_rays: the keyframe store is incomplete");
+        return fail(NARUTO_ERR_INVALID, "%s: the keyframe store is incomplete", who);
     const uint64_t n_pop = (uint64_t)b->n_kf * b->rays_per_kf;
-    if (b->n_global > n_pop) return fail(NARUTO_ERR_INVALID, "assemble_rays: %u distinct rays out of %llu stored", b->n_global, (unsigned long long)n_pop);
+    if (b->n_global > n_pop) return fail(NARUTO_ERR_INVALID, "%s: %u distinct rays out of %llu stored", who, b->n_global, (unsigned long long)n_pop);
     if (b->n_cur > 0 && (b->current == nullptr || b->n_cur_pop == 0 || b->n_cur > b->n_cur_pop))
-        return fail(NARUTO_ERR_INVALID, "assemble_rays: %u distinct current-frame rays out of %llu", b->n_cur, (unsigned long long)b->n_cur_pop);
-    const uint32_t n = b->n_global + b->n_cur;
-    if (n == 0) return NARUTO_OK;
-    AssembleArgs a{};
+        return fail(NARUTO_ERR_INVALID, "%s: %u distinct current-frame rays out of %llu", who, b->n_cur, (unsigned long long)b->n_cur_pop);
+    a = AssembleArgs{};
     a.store = b->store; a.n_pop = n_pop ? n_pop : 1; a.rays_per_kf = b->rays_per_kf ? b->rays_per_kf : 1; a.frame_ids = b->frame_ids;
     a.keyframe_every = b->keyframe_every; a.n_global = b->n_global;
     a.current = b->current; a.cur_list = b->cur_list; a.n_cur_pop = b->n_cur_pop ? b->n_cur_pop : 1; a.n_cur = b->n_cur;
@@ -1619,8 +1619,43 @@ int naruto_assemble_rays(const NarutoRayBatch* b, void* stream) {
     a.hb_global = half_bits_for(a.n_pop); a.hb_cur = half_bits_for(a.n_cur_pop);
     a.rays_o = b->rays_o; a.rays_d = b->rays_d; a.target_s = b->target_s; a.target_d = b->target_d; a.ids_out = b->ids_out;
     a.rng = b->rng; a.dyn = b->dyn; a.seed_host = b->seed; a.counter_host = b->counter;
+    return NARUTO_OK;
+}
+}  // namespace
+
+int naruto_assemble_rays(const NarutoRayBatch* b, void* stream) {
+    AssembleArgs a{};
+    if (int rc = assemble_args(b, true, a, "assemble_rays")) return rc;
+    const uint32_t n = b->n_global + b->n_cur;
+    if (n == 0) return NARUTO_OK;
     hipLaunchKernelGGL(k_assemble_rays, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("assemble_rays");
+}
+
+// N2 + N1 in one launch (round 5): the oversampled batch of naruto_assemble_rays is never written -- k_ars_fused<true> draws and rotates a
+// row where it needs one.  Same rows, same selection as naruto_assemble_rays | naruto_active_ray_select (the batch's own output buffers
+// and ids_out are not used).  Up to 8 192 candidates (n_global + n_cur - base - n_tail); beyond: NARUTO_ERR_INVALID, use the two calls.
+int naruto_assemble_select(const NarutoRayBatch* b, uint32_t base, uint32_t K, uint32_t n_tail, const float* uncert_vol, const uint32_t* vol_dims,
+                           const float* bbox_min, float voxel_scale, float* out_o, float* out_d, float* out_s, float* out_t, void* stream) {
+    AssembleArgs s{};
+    if (int rc = assemble_args(b, false, s, "assemble_select")) return rc;
+    if (uncert_vol == nullptr || vol_dims == nullptr || bbox_min == nullptr || out_o == nullptr || out_d == nullptr || out_s == nullptr || out_t == nullptr)
+        return fail(NARUTO_ERR_INVALID, "assemble_select: NULL argument");
+    const uint32_t n_total = b->n_global + b->n_cur;
+    if (n_tail == 0 || K == 0 || K > base || (uint64_t)base + n_tail >= n_total)
+        return fail(NARUTO_ERR_INVALID, "assemble_select: need 0 < K <= base, n_tail > 0, base + n_tail < n_total");
+    const uint32_t n_cand = n_total - n_tail - base;
+    if (n_cand <= K) return fail(NARUTO_ERR_INVALID, "assemble_select: %u candidates for K = %u (numpy argpartition needs K < n)", n_cand, K);
+    if (n_cand > kArsFusedMax) return fail(NARUTO_ERR_INVALID, "assemble_select: %u candidates (the one-launch form takes up to %u)", n_cand, kArsFusedMax);
+    ArsArgs a{};
+    a.n_total = n_total; a.base = base; a.K = K; a.n_tail = n_tail; a.n_cand = n_cand;
+    a.vol = uncert_vol;
+    a.X = (int)vol_dims[0]; a.Y = (int)vol_dims[1]; a.Z = (int)vol_dims[2];
+    a.bx = bbox_min[0]; a.by = bbox_min[1]; a.bz = bbox_min[2]; a.voxel_scale = voxel_scale;
+    a.o_out = out_o; a.d_out = out_d; a.s_out = out_s; a.t_out = out_t;
+    const uint32_t n_copy = base + n_tail - K;
+    hipLaunchKernelGGL(k_ars_fused<true>, dim3(1u + (n_copy + kArsFusedThreads - 1u) / kArsFusedThreads), dim3(kArsFusedThreads), 0, (hipStream_t)stream, a, s);
+    return check_launch("assemble_select");
 }
 
 uint64_t naruto_perm_index(uint64_t i, uint64_t n, uint64_t seed, uint64_t counter, uint64_t salt) {

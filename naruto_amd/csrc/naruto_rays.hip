@@ -186,6 +186,126 @@ __global__ __launch_bounds__(1024) void k_ars_select_small(uint32_t n_cand, uint
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// N2, the store side: batch assembly from a device-resident keyframe ray store.
+//
+// The reference keeps the keyframe rays on the host side of a Python `random.sample` (Co-SLAM
+// KeyFrameDatabase.sample_global_rays [not in tree]; coslam.py:310-344): every BA iteration draws `bs` DISTINCT ray indices
+// out of n_kf * rays_per_kf, gathers [bs,7] rows, appends distinct current-frame pixels, and rotates to world.  Here the
+// distinct draw is a keyed Feistel permutation of [0, n) with cycle walking -- element i of the sample is perm(i): no
+// state, no rejection bookkeeping, one kernel for draw + gather + rotation.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t feistel_f(uint32_t r, uint32_t k) {
+    uint32_t x = r * 0x9E3779B1u + k;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+
+// bijection on [0, n): 4-round balanced Feistel on 2*half_bits bits (2^(2*half_bits) >= n), cycle-walked into range
+__host__ __device__ __forceinline__ uint64_t perm_index(uint64_t i, uint64_t n, uint32_t half_bits, uint64_t key) {
+    const uint32_t mask = half_bits >= 32 ? 0xFFFFFFFFu : ((1u << half_bits) - 1u);
+    const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+    do {
+        uint32_t l = (uint32_t)(i >> half_bits) & mask, r = (uint32_t)i & mask;
+#pragma unroll
+        for (uint32_t round = 0; round < 4u; ++round) {
+            const uint32_t t = l ^ (feistel_f(r, (round & 1u ? k1 : k0) + round * 0x85EBCA6Bu) & mask);
+            l = r;
+            r = t;
+        }
+        i = ((uint64_t)l << half_bits) | r;
+    } while (i >= n);
+    return i;
+}
+
+__host__ __device__ __forceinline__ uint32_t half_bits_for(uint64_t n) {             // smallest h with 2^(2h) >= n
+    uint32_t h = 1;
+    while (h < 32u && (1ull << (2u * h)) < n) ++h;
+    return h;
+}
+__host__ __device__ __forceinline__ uint64_t mix_key(uint64_t seed, uint64_t counter, uint64_t salt) {
+    uint64_t x = seed ^ (counter * 0x9E3779B97F4A7C15ull) ^ (salt * 0xD1342543DE82EF95ull);
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+    return x;
+}
+
+struct AssembleArgs {
+    const float* store;          // [n_pop, 7] = (direction 3, rgb 3, depth 1) of the stored keyframe rays
+    uint64_t n_pop;              // n_kf * rays_per_kf
+    uint32_t rays_per_kf;
+    const int64_t* frame_ids;    // [n_kf]
+    int64_t keyframe_every;
+    uint32_t n_global;           // rays drawn from the store
+    const float* current;        // [n_cur_pop, 7] rays of the current frame
+    const uint32_t* cur_list;    // optional [n_cur_pop_list]: pixels allowed (valid depth); NULL: all n_cur_pop pixels
+    uint64_t n_cur_pop;          // population the current-frame draw is over (length of cur_list, or pixel count)
+    uint32_t n_cur;              // rays drawn from the current frame
+    const float* poses;          // [P,4,4] row-major camera-to-world; the current frame uses the LAST pose (index -1)
+    uint32_t n_poses;
+    uint64_t key_global, key_cur;
+    uint32_t hb_global, hb_cur;
+    float* rays_o; float* rays_d; float* target_s; float* target_d;
+    int64_t* ids_out;            // optional [n_global + n_cur]: pose index used per ray (-1 for current-frame rays)
+    // what changes between replays of a captured launch, read from device memory (either may be NULL = the host values above):
+    const uint64_t* rng;         // {seed, counter}: keys = mix(seed ^ seed_host, counter + counter_host, salt)
+    const uint64_t* dyn;         // {n_kf, n_poses, n_cur_pop}
+    uint64_t seed_host, counter_host;
+};
+
+// what changes between replays of a captured launch (keys, counts), from device memory
+__device__ __forceinline__ void assemble_refresh(AssembleArgs& a) {
+    if (a.rng != nullptr) {
+        const uint64_t seed = a.rng[0] ^ a.seed_host, counter = a.rng[1] + a.counter_host;
+        a.key_global = mix_key(seed, counter, 2); a.key_cur = mix_key(seed, counter, 3);
+    }
+    if (a.dyn != nullptr) {
+        a.n_pop = a.dyn[0] * a.rays_per_kf; a.n_poses = (uint32_t)a.dyn[1]; a.n_cur_pop = a.dyn[2];
+        a.hb_global = half_bits_for(a.n_pop); a.hb_cur = half_bits_for(a.n_cur_pop);
+    }
+}
+// row r of the batch (after assemble_refresh): v = {rays_o 3, rays_d 3, target_s 3, target_d}; returns the pose index used (-1: current frame)
+__device__ __forceinline__ int64_t assemble_row(const AssembleArgs& a, uint32_t r, float (&v)[10]) {
+    const float* src;
+    int64_t pose_id, id_out;
+    if (r < a.n_global) {
+        const uint64_t idx = perm_index(r, a.n_pop, a.hb_global, a.key_global);
+        src = a.store + idx * 7u;
+        pose_id = a.frame_ids[idx / a.rays_per_kf] / a.keyframe_every;          // torch.div(..., rounding_mode='trunc'), ids >= 0
+        id_out = pose_id;
+    } else {
+        uint64_t j = perm_index(r - a.n_global, a.n_cur_pop, a.hb_cur, a.key_cur);
+        if (a.cur_list != nullptr) j = a.cur_list[j];
+        src = a.current + j * 7u;
+        pose_id = (int64_t)a.n_poses - 1;
+        id_out = -1;
+    }
+    const float* P = a.poses + 16 * (size_t)pose_id;
+    const float dx = src[0], dy = src[1], dz = src[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        v[3 + i] = __fadd_rn(__fadd_rn(__fmul_rn(dx, P[4 * i + 0]), __fmul_rn(dy, P[4 * i + 1])), __fmul_rn(dz, P[4 * i + 2]));
+        v[i] = P[4 * i + 3];
+        v[6 + i] = src[3 + i];
+    }
+    v[9] = src[6];
+    return id_out;
+}
+__global__ __launch_bounds__(256) void k_assemble_rays(AssembleArgs a) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_global + a.n_cur) return;
+    assemble_refresh(a);
+    float v[10];
+    const int64_t id = assemble_row(a, r, v);
+    if (a.ids_out) a.ids_out[r] = id;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        a.rays_o[3 * (size_t)r + i] = v[i];
+        a.rays_d[3 * (size_t)r + i] = v[3 + i];
+        a.target_s[3 * (size_t)r + i] = v[6 + i];
+    }
+    a.target_d[r] = v[9];
+}
+
 // N1 in ONE launch (round 4; up to 8 192 candidates, a mapping iteration has 6 444): workgroup 0 looks the keys up, selects and gathers the K
 // selected rays; the other workgroups copy the rows that do not depend on the selection ([K, base): the first base - K rays, [base, n_out): the
 // tail).  Replaces k_ars_lookup | k_ars_select_small | k_ars_gather (4.6 + 20.5 + 4.6 us and two launch gaps inside every mapping iteration).
@@ -202,11 +322,21 @@ struct ArsArgs {
 };
 constexpr uint32_t kArsFusedThreads = 1024, kArsSelThreads = 256, kArsFusedPer = 32, kArsFusedMax = kArsSelThreads * kArsFusedPer;
 
-__device__ __forceinline__ uint32_t ars_key(const ArsArgs& a, uint32_t j) {
-    const size_t r = (size_t)a.base + j;
-    const float t = a.target_d[r];
-    const float ox = a.rays_o[3 * r + 0], oy = a.rays_o[3 * r + 1], oz = a.rays_o[3 * r + 2];
-    const float dx = a.rays_d[3 * r + 0], dy = a.rays_d[3 * r + 1], dz = a.rays_d[3 * r + 2];
+// ASM (round 5): the oversampled batch is never materialised -- a row is drawn from the keyframe store and rotated to world where it is
+// needed (assemble_row: the key lookup of every candidate, then again for the rows that make it into the output), so k_assemble_rays'
+// launch in front of the selection disappears from the mapping iteration
+template <bool ASM>
+__device__ __forceinline__ void ars_fetch_row(const ArsArgs& a, const AssembleArgs& s, size_t src, float (&v)[10]) {
+    if constexpr (ASM) {
+        assemble_row(s, (uint32_t)src, v);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { v[c] = a.rays_o[3 * src + c]; v[3 + c] = a.rays_d[3 * src + c]; v[6 + c] = a.target_s[3 * src + c]; }
+        v[9] = a.target_d[src];
+    }
+}
+// flat voxel index of the ray's end point o + d t in the cached uncertainty volume
+__device__ __forceinline__ size_t ars_voxel(const ArsArgs& a, float ox, float oy, float oz, float dx, float dy, float dz, float t) {
     const float px = __fadd_rn(ox, __fmul_rn(dx, t));
     const float py = __fadd_rn(oy, __fmul_rn(dy, t));
     const float pz = __fadd_rn(oz, __fmul_rn(dz, t));
@@ -217,13 +347,17 @@ __device__ __forceinline__ uint32_t ars_key(const ArsArgs& a, uint32_t j) {
     const int ix = (int)fminf(fmaxf(fx, 0.0f), (float)(a.X - 1));
     const int iy = (int)fminf(fmaxf(fy, 0.0f), (float)(a.Y - 1));
     const int iz = (int)fminf(fmaxf(fz, 0.0f), (float)(a.Z - 1));
-    return sortable_key(a.vol[((size_t)ix * a.Y + iy) * a.Z + iz]);
+    return ((size_t)ix * a.Y + iy) * a.Z + iz;
 }
-__device__ __forceinline__ void ars_copy_row(const ArsArgs& a, size_t src, size_t r) {
+__device__ __forceinline__ uint32_t ars_key(const ArsArgs& a, uint32_t j) {
+    const size_t r = (size_t)a.base + j;
+    const float t = a.target_d[r];
+    return sortable_key(a.vol[ars_voxel(a, a.rays_o[3 * r + 0], a.rays_o[3 * r + 1], a.rays_o[3 * r + 2], a.rays_d[3 * r + 0], a.rays_d[3 * r + 1], a.rays_d[3 * r + 2], t)]);
+}
+template <bool ASM>
+__device__ __forceinline__ void ars_copy_row(const ArsArgs& a, const AssembleArgs& s, size_t src, size_t r) {
     float v[10];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { v[c] = a.rays_o[3 * src + c]; v[3 + c] = a.rays_d[3 * src + c]; v[6 + c] = a.target_s[3 * src + c]; }
-    v[9] = a.target_d[src];
+    ars_fetch_row<ASM>(a, s, src, v);
 #pragma unroll
     for (int c = 0; c < 3; ++c) { a.o_out[3 * r + c] = v[c]; a.d_out[3 * r + c] = v[3 + c]; a.s_out[3 * r + c] = v[6 + c]; }
     a.t_out[r] = v[9];
@@ -247,23 +381,70 @@ __device__ __forceinline__ uint32_t sel_exclusive_scan(uint32_t v, uint32_t* __r
 // Workgroup 0: all sixteen waves look the keys up (eight independent lookups in flight per thread: the lookup is two dependent trips to
 // memory, ray -> voxel), the first four then select -- one wave per SIMD, the other twelve only keep the workgroup's barriers company --
 // and all sixteen gather the selected rows.
-__global__ __launch_bounds__(kArsFusedThreads) void k_ars_fused(ArsArgs a) {
+template <bool ASM>
+__global__ __launch_bounds__(kArsFusedThreads) void k_ars_fused(ArsArgs a, AssembleArgs s) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t n_out = a.base + a.n_tail;
+    if constexpr (ASM) assemble_refresh(s);
     if (blockIdx.x > 0) {                               // rows that do not depend on the selection
         const uint32_t r = a.K + (blockIdx.x - 1u) * kArsFusedThreads + (uint32_t)tid;
-        if (r < n_out) ars_copy_row(a, r < a.base ? (size_t)(r - a.K) : (size_t)a.n_total - a.n_tail + (r - a.base), r);
+        if (r < n_out) ars_copy_row<ASM>(a, s, r < a.base ? (size_t)(r - a.K) : (size_t)a.n_total - a.n_tail + (r - a.base), r);
         return;
     }
     __shared__ uint32_t l_keys[kArsFusedMax + kArsSelThreads];            // key j at j + (j >> 5): a thread's 32 consecutive keys without bank conflicts; later: sel
     __shared__ uint32_t wave_cnt[2][4][2];
     __shared__ uint32_t wave_tot[4];
     {
-        uint32_t kk[kArsFusedMax / kArsFusedThreads];
+        constexpr uint32_t NK = kArsFusedMax / kArsFusedThreads;
+        uint32_t kk[NK];
+        if constexpr (ASM) {
+            // the eight rows of a thread step by step -- all permutation walks, then all id / row loads, then all poses, then all voxels -- so
+            // that each step's loads share ONE trip to memory (row by row, the cycle-walking loop in perm_index put the 8 x 4 trips in series:
+            // 44 us for this launch against 20 + 7.5 for the two it replaces)
+            constexpr uint32_t NB = 4;                 // rows per batch (eight at once spill at 1 024 threads per workgroup)
 #pragma unroll
-        for (uint32_t i = 0; i < kArsFusedMax / kArsFusedThreads; ++i) {
-            const uint32_t j = i * kArsFusedThreads + (uint32_t)tid;
-            kk[i] = ars_key(a, j < a.n_cand ? j : a.n_cand - 1u);
+            for (uint32_t h = 0; h < NK / NB; ++h) {
+            uint64_t src_i[NB]; int64_t pid[NB]; bool glob[NB];
+#pragma unroll
+            for (uint32_t i = 0; i < NB; ++i) {
+                const uint32_t j = (h * NB + i) * kArsFusedThreads + (uint32_t)tid;
+                const uint32_t r = a.base + (j < a.n_cand ? j : a.n_cand - 1u);
+                glob[i] = r < s.n_global;
+                src_i[i] = glob[i] ? perm_index(r, s.n_pop, s.hb_global, s.key_global) : perm_index(r - s.n_global, s.n_cur_pop, s.hb_cur, s.key_cur);
+            }
+            if (s.cur_list != nullptr) {
+#pragma unroll
+                for (uint32_t i = 0; i < NB; ++i) if (!glob[i]) src_i[i] = s.cur_list[src_i[i]];
+            }
+            float row[NB][4];           // direction, depth
+#pragma unroll
+            for (uint32_t i = 0; i < NB; ++i) {
+                pid[i] = glob[i] ? s.frame_ids[src_i[i] / s.rays_per_kf] : 0;
+                const float* src = (glob[i] ? s.store : s.current) + src_i[i] * 7u;
+                row[i][0] = src[0]; row[i][1] = src[1]; row[i][2] = src[2]; row[i][3] = src[6];
+            }
+            size_t vox[NB];
+#pragma unroll
+            for (uint32_t i = 0; i < NB; ++i) {
+                const int64_t pose_id = glob[i] ? pid[i] / s.keyframe_every : (int64_t)s.n_poses - 1;
+                const float* P = s.poses + 16 * (size_t)pose_id;
+                float o[3], d[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    d[c] = __fadd_rn(__fadd_rn(__fmul_rn(row[i][0], P[4 * c + 0]), __fmul_rn(row[i][1], P[4 * c + 1])), __fmul_rn(row[i][2], P[4 * c + 2]));
+                    o[c] = P[4 * c + 3];
+                }
+                vox[i] = ars_voxel(a, o[0], o[1], o[2], d[0], d[1], d[2], row[i][3]);
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < NB; ++i) kk[h * NB + i] = sortable_key(a.vol[vox[i]]);
+            }
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < NK; ++i) {
+                const uint32_t j = i * kArsFusedThreads + (uint32_t)tid;
+                kk[i] = ars_key(a, j < a.n_cand ? j : a.n_cand - 1u);
+            }
         }
 #pragma unroll
         for (uint32_t i = 0; i < kArsFusedMax / kArsFusedThreads; ++i) {
@@ -355,8 +536,10 @@ __global__ __launch_bounds__(kArsFusedThreads) void k_ars_fused(ArsArgs a) {
         c2 &= c2 - 1u;
     }
     __syncthreads();
-    for (uint32_t r = (uint32_t)tid; r < a.K; r += kArsFusedThreads) ars_copy_row(a, (size_t)l_keys[r] + a.base, r);
+    for (uint32_t r = (uint32_t)tid; r < a.K; r += kArsFusedThreads) ars_copy_row<ASM>(a, s, (size_t)l_keys[r] + a.base, r);
 }
+template __global__ void k_ars_fused<false>(ArsArgs, AssembleArgs);
+template __global__ void k_ars_fused<true>(ArsArgs, AssembleArgs);
 
 // assemble [K selected | first (base-K) rays | last n_tail rays] (active_ray_sampler.py:128-147)
 __global__ __launch_bounds__(256) void k_ars_gather(uint32_t n_out, uint32_t K, uint32_t base, uint32_t n_total, uint32_t n_tail,
@@ -391,108 +574,6 @@ __global__ __launch_bounds__(256) void k_rays_to_world(uint32_t n, const float* 
         rays_d[3 * (size_t)r + i] = __fadd_rn(__fadd_rn(__fmul_rn(dx, P[4 * i + 0]), __fmul_rn(dy, P[4 * i + 1])), __fmul_rn(dz, P[4 * i + 2]));
         rays_o[3 * (size_t)r + i] = P[4 * i + 3];
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// N2, the store side: batch assembly from a device-resident keyframe ray store.
-//
-// The reference keeps the keyframe rays on the host side of a Python `random.sample` (Co-SLAM
-// KeyFrameDatabase.sample_global_rays [not in tree]; coslam.py:310-344): every BA iteration draws `bs` DISTINCT ray indices
-// out of n_kf * rays_per_kf, gathers [bs,7] rows, appends distinct current-frame pixels, and rotates to world.  Here the
-// distinct draw is a keyed Feistel permutation of [0, n) with cycle walking -- element i of the sample is perm(i): no
-// state, no rejection bookkeeping, one kernel for draw + gather + rotation.
-// ------------------------------------------------------------------------------------------------
-__host__ __device__ __forceinline__ uint32_t feistel_f(uint32_t r, uint32_t k) {
-    uint32_t x = r * 0x9E3779B1u + k;
-    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-    return x;
-}
-
-// bijection on [0, n): 4-round balanced Feistel on 2*half_bits bits (2^(2*half_bits) >= n), cycle-walked into range
-__host__ __device__ __forceinline__ uint64_t perm_index(uint64_t i, uint64_t n, uint32_t half_bits, uint64_t key) {
-    const uint32_t mask = half_bits >= 32 ? 0xFFFFFFFFu : ((1u << half_bits) - 1u);
-    const uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
-    do {
-        uint32_t l = (uint32_t)(i >> half_bits) & mask, r = (uint32_t)i & mask;
-#pragma unroll
-        for (uint32_t round = 0; round < 4u; ++round) {
-            const uint32_t t = l ^ (feistel_f(r, (round & 1u ? k1 : k0) + round * 0x85EBCA6Bu) & mask);
-            l = r;
-            r = t;
-        }
-        i = ((uint64_t)l << half_bits) | r;
-    } while (i >= n);
-    return i;
-}
-
-__host__ __device__ __forceinline__ uint32_t half_bits_for(uint64_t n) {             // smallest h with 2^(2h) >= n
-    uint32_t h = 1;
-    while (h < 32u && (1ull << (2u * h)) < n) ++h;
-    return h;
-}
-__host__ __device__ __forceinline__ uint64_t mix_key(uint64_t seed, uint64_t counter, uint64_t salt) {
-    uint64_t x = seed ^ (counter * 0x9E3779B97F4A7C15ull) ^ (salt * 0xD1342543DE82EF95ull);
-    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
-    return x;
-}
-
-struct AssembleArgs {
-    const float* store;          // [n_pop, 7] = (direction 3, rgb 3, depth 1) of the stored keyframe rays
-    uint64_t n_pop;              // n_kf * rays_per_kf
-    uint32_t rays_per_kf;
-    const int64_t* frame_ids;    // [n_kf]
-    int64_t keyframe_every;
-    uint32_t n_global;           // rays drawn from the store
-    const float* current;        // [n_cur_pop, 7] rays of the current frame
-    const uint32_t* cur_list;    // optional [n_cur_pop_list]: pixels allowed (valid depth); NULL: all n_cur_pop pixels
-    uint64_t n_cur_pop;          // population the current-frame draw is over (length of cur_list, or pixel count)
-    uint32_t n_cur;              // rays drawn from the current frame
-    const float* poses;          // [P,4,4] row-major camera-to-world; the current frame uses the LAST pose (index -1)
-    uint32_t n_poses;
-    uint64_t key_global, key_cur;
-    uint32_t hb_global, hb_cur;
-    float* rays_o; float* rays_d; float* target_s; float* target_d;
-    int64_t* ids_out;            // optional [n_global + n_cur]: pose index used per ray (-1 for current-frame rays)
-    // what changes between replays of a captured launch, read from device memory (either may be NULL = the host values above):
-    const uint64_t* rng;         // {seed, counter}: keys = mix(seed ^ seed_host, counter + counter_host, salt)
-    const uint64_t* dyn;         // {n_kf, n_poses, n_cur_pop}
-    uint64_t seed_host, counter_host;
-};
-
-__global__ __launch_bounds__(256) void k_assemble_rays(AssembleArgs a) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.n_global + a.n_cur) return;
-    if (a.rng != nullptr) {
-        const uint64_t seed = a.rng[0] ^ a.seed_host, counter = a.rng[1] + a.counter_host;
-        a.key_global = mix_key(seed, counter, 2); a.key_cur = mix_key(seed, counter, 3);
-    }
-    if (a.dyn != nullptr) {
-        a.n_pop = a.dyn[0] * a.rays_per_kf; a.n_poses = (uint32_t)a.dyn[1]; a.n_cur_pop = a.dyn[2];
-        a.hb_global = half_bits_for(a.n_pop); a.hb_cur = half_bits_for(a.n_cur_pop);
-    }
-    const float* src;
-    int64_t pose_id;
-    if (r < a.n_global) {
-        const uint64_t idx = perm_index(r, a.n_pop, a.hb_global, a.key_global);
-        src = a.store + idx * 7u;
-        pose_id = a.frame_ids[idx / a.rays_per_kf] / a.keyframe_every;          // torch.div(..., rounding_mode='trunc'), ids >= 0
-        if (a.ids_out) a.ids_out[r] = pose_id;
-    } else {
-        uint64_t j = perm_index(r - a.n_global, a.n_cur_pop, a.hb_cur, a.key_cur);
-        if (a.cur_list != nullptr) j = a.cur_list[j];
-        src = a.current + j * 7u;
-        pose_id = (int64_t)a.n_poses - 1;
-        if (a.ids_out) a.ids_out[r] = -1;
-    }
-    const float* P = a.poses + 16 * (size_t)pose_id;
-    const float dx = src[0], dy = src[1], dz = src[2];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        a.rays_d[3 * (size_t)r + i] = __fadd_rn(__fadd_rn(__fmul_rn(dx, P[4 * i + 0]), __fmul_rn(dy, P[4 * i + 1])), __fmul_rn(dz, P[4 * i + 2]));
-        a.rays_o[3 * (size_t)r + i] = P[4 * i + 3];
-        a.target_s[3 * (size_t)r + i] = src[3 + i];
-    }
-    a.target_d[r] = src[6];
 }
 
 // out[i] = perm(first + i): `count` distinct pseudo-random indices in [0, n)

@@ -109,19 +109,8 @@ class KeyFrameStoreHIP:
         rays = self.rays[:n_kf].reshape(-1, 7)[idx]
         return rays, self.frame_ids[idx // self.num_rays_to_save]
 
-    def assemble_batch(self, sample_num: int, current_rays: torch.Tensor, poses_all: torch.Tensor, min_pixels_cur: int,
-                       filter_depth: bool = False, return_ids: bool = False, out=None, rng: Optional[torch.Tensor] = None,
-                       dyn: Optional[torch.Tensor] = None, n_cur: Optional[int] = None, n_cur_pop: Optional[int] = None):
-        """coslam.py:310-344 fused: -> rays_o [N,3], rays_d [N,3], target_s [N,3], target_d [N,1], n_cur (and ids_all).
-        N = sample_num + n_cur, n_cur = max(sample_num // n_kf, min_pixels_cur) (capped by the valid pixels).
-        current_rays [H*W,7]; poses_all [P,4,4] camera-to-world with the current frame's pose LAST (index -1).
-        ``out``: (rays_o, rays_d, target_s, target_d) to write into -- contiguous fp32 device tensors of exactly N rows, e.g. a
-        captured trainer's ``ray_buffers()``.
-        For a launch captured in a hipGraph (naruto_amd.ba_loop.FusedBA): ``rng`` int64[2] device {seed, counter} keys the draws
-        instead of this store's host counter, ``dyn`` int64[3] device {n_kf, n_poses, n_cur_pop} replaces the host values at replay
-        time; ``n_cur`` / ``n_cur_pop`` then fix the current-frame draw's size and population up front (no device read-back; with
-        ``filter_depth`` in the reference's mode the population is the number of valid-depth pixels, counted by the caller)."""
-        lib = _lib.load()
+    def _draw(self, sample_num, current_rays, poses_all, min_pixels_cur, filter_depth, rng, dyn, n_cur, n_cur_pop):
+        """The NarutoRayBatch of one draw (everything but the output buffers) + what it keeps alive."""
         n_kf = len(self)
         assert n_kf > 0, "no keyframe stored yet"
         cur = current_rays.to(self.device, torch.float32).reshape(-1, 7).contiguous()
@@ -140,6 +129,36 @@ class KeyFrameStoreHIP:
             n_cur = min(n_cur_pop, n_cur)
             if self.filter_depth_mode == "reference":
                 cur_list = None                   # pixels 0 .. n_valid-1 of the unfiltered frame (coslam.py:318-327)
+        if rng is None:
+            self.counter += 1                  # the host-keyed draw; with ``rng`` the device-side {seed, counter} keys it and this one rests
+        b = _lib.NarutoRayBatch()
+        b.store, b.n_kf, b.rays_per_kf = self.rays.data_ptr(), n_kf, self.num_rays_to_save
+        b.frame_ids, b.keyframe_every, b.n_global = self._ids.data_ptr(), int(self.config['mapping']['keyframe_every']), int(sample_num)
+        b.current, b.cur_list = cur.data_ptr(), (cur_list.data_ptr() if cur_list is not None and n_cur_pop > 0 else None)
+        b.n_cur_pop, b.n_cur = max(n_cur_pop, 1), n_cur
+        b.poses, b.n_poses, b.seed, b.counter = poses.data_ptr(), poses.shape[0], self.seed, self.counter
+        if rng is not None:
+            assert rng.is_cuda and rng.dtype == torch.int64 and rng.numel() >= 2
+            b.rng, b.seed, b.counter = rng.data_ptr(), 0, 0
+        if dyn is not None:
+            assert dyn.is_cuda and dyn.dtype == torch.int64 and dyn.numel() >= 3
+            b.dyn = dyn.data_ptr()
+        return b, n_cur, (cur, poses, cur_list)
+
+    def assemble_batch(self, sample_num: int, current_rays: torch.Tensor, poses_all: torch.Tensor, min_pixels_cur: int,
+                       filter_depth: bool = False, return_ids: bool = False, out=None, rng: Optional[torch.Tensor] = None,
+                       dyn: Optional[torch.Tensor] = None, n_cur: Optional[int] = None, n_cur_pop: Optional[int] = None):
+        """coslam.py:310-344 fused: -> rays_o [N,3], rays_d [N,3], target_s [N,3], target_d [N,1], n_cur (and ids_all).
+        N = sample_num + n_cur, n_cur = max(sample_num // n_kf, min_pixels_cur) (capped by the valid pixels).
+        current_rays [H*W,7]; poses_all [P,4,4] camera-to-world with the current frame's pose LAST (index -1).
+        ``out``: (rays_o, rays_d, target_s, target_d) to write into -- contiguous fp32 device tensors of exactly N rows, e.g. a
+        captured trainer's ``ray_buffers()``.
+        For a launch captured in a hipGraph (naruto_amd.ba_loop.FusedBA): ``rng`` int64[2] device {seed, counter} keys the draws
+        instead of this store's host counter, ``dyn`` int64[3] device {n_kf, n_poses, n_cur_pop} replaces the host values at replay
+        time; ``n_cur`` / ``n_cur_pop`` then fix the current-frame draw's size and population up front (no device read-back; with
+        ``filter_depth`` in the reference's mode the population is the number of valid-depth pixels, counted by the caller)."""
+        lib = _lib.load()
+        b, n_cur, keep = self._draw(sample_num, current_rays, poses_all, min_pixels_cur, filter_depth, rng, dyn, n_cur, n_cur_pop)
         n = sample_num + n_cur
         f32 = dict(dtype=torch.float32, device=self.device)
         if out is not None:
@@ -151,23 +170,37 @@ class KeyFrameStoreHIP:
             rays_o, rays_d, target_s = torch.empty(n, 3, **f32), torch.empty(n, 3, **f32), torch.empty(n, 3, **f32)
             target_d = torch.empty(n, 1, **f32)
         ids = torch.empty(n, dtype=torch.int64, device=self.device) if return_ids else None
-        if rng is None:
-            self.counter += 1                  # the host-keyed draw; with ``rng`` the device-side {seed, counter} keys it and this one rests
-        b = _lib.NarutoRayBatch()
-        b.store, b.n_kf, b.rays_per_kf = self.rays.data_ptr(), n_kf, self.num_rays_to_save
-        b.frame_ids, b.keyframe_every, b.n_global = self._ids.data_ptr(), int(self.config['mapping']['keyframe_every']), int(sample_num)
-        b.current, b.cur_list = cur.data_ptr(), (cur_list.data_ptr() if cur_list is not None and n_cur_pop > 0 else None)
-        b.n_cur_pop, b.n_cur = max(n_cur_pop, 1), n_cur
-        b.poses, b.n_poses, b.seed, b.counter = poses.data_ptr(), poses.shape[0], self.seed, self.counter
         b.rays_o, b.rays_d, b.target_s, b.target_d = rays_o.data_ptr(), rays_d.data_ptr(), target_s.data_ptr(), target_d.data_ptr()
         b.ids_out = ids.data_ptr() if ids is not None else None
-        if rng is not None:
-            assert rng.is_cuda and rng.dtype == torch.int64 and rng.numel() >= 2
-            b.rng, b.seed, b.counter = rng.data_ptr(), 0, 0
-        if dyn is not None:
-            assert dyn.is_cuda and dyn.dtype == torch.int64 and dyn.numel() >= 3
-            b.dyn = dyn.data_ptr()
         with torch.cuda.device(self.device):
             check(lib.naruto_assemble_rays(C.byref(b), _stream()), "naruto_assemble_rays")
         out = (rays_o, rays_d, target_s, target_d, n_cur)
         return out + (ids,) if return_ids else out
+
+    def assemble_select(self, sampler, sample_num: int, current_rays: torch.Tensor, poses_all: torch.Tensor, min_pixels_cur: int, bbox,
+                        uncert_vol=None, filter_depth: bool = False, out=None, rng: Optional[torch.Tensor] = None,
+                        dyn: Optional[torch.Tensor] = None, n_cur: Optional[int] = None, n_cur_pop: Optional[int] = None):
+        """``assemble_batch`` followed by ``sampler.sample_rays`` (coslam.py:310-359) in ONE launch, without the oversampled batch in
+        between (``naruto_assemble_select``): row r of the virtual batch is what ``assemble_batch`` draws for the same keys, the selection
+        is ``ActiveRaySamplerHIP.sample_rays``'s.  -> rays_o, rays_d, target_s [n_out,3], target_d [n_out,1], n_cur."""
+        lib = _lib.load()
+        b, n_cur, keep = self._draw(sample_num, current_rays, poses_all, min_pixels_cur, filter_depth, rng, dyn, n_cur, n_cur_pop)
+        vol = sampler._volume(uncert_vol, self.device)
+        base, K = sampler.base_sample_num, sampler.num_uncert_sample
+        n_tail = -((-int(n_cur)) // sampler.oversample_mul)
+        n_out = base + n_tail
+        f32 = dict(dtype=torch.float32, device=self.device)
+        if out is not None:
+            o_out, d_out, s_out, t_out = out
+            for a, c in ((o_out, 3), (d_out, 3), (s_out, 3), (t_out, 1)):
+                if not (a.is_cuda and a.dtype == torch.float32 and a.is_contiguous() and a.numel() == n_out * c):
+                    raise RuntimeError(f"assemble_select: out tensors must be contiguous fp32 device tensors of {n_out} rows")
+        else:
+            o_out, d_out, s_out = torch.empty(n_out, 3, **f32), torch.empty(n_out, 3, **f32), torch.empty(n_out, 3, **f32)
+            t_out = torch.empty(n_out, 1, **f32)
+        dims = (C.c_uint32 * 3)(*vol.shape)
+        bmin = (C.c_float * 3)(*(float(r[0]) for r in bbox))
+        with torch.cuda.device(self.device):
+            check(lib.naruto_assemble_select(C.byref(b), base, K, n_tail, vol.data_ptr(), dims, bmin, 10.0, o_out.data_ptr(), d_out.data_ptr(),
+                                             s_out.data_ptr(), t_out.data_ptr(), _stream()), "naruto_assemble_select")
+        return o_out, d_out, s_out, t_out, n_cur

@@ -2639,7 +2639,8 @@ def test_fused_ba_iteration_equals_its_pieces(gpu, active):
         tr = trainer.MappingTrainer(cfg, bound, gpu, fused_adam=True)
         store, current, poses, vol = _ba_scene(cfg, gpu, n_kf=8)
         smp = ActiveRaySamplerHIP(config=cfg, num_uncert_sample=48, oversample_mul=4) if active else None
-        twins.append((FusedBA(tr, store, smp, max_poses=64, use_graph=use_graph), current, poses, vol))
+        # (the graph twin draws and selects in ONE launch, naruto_assemble_select -- round 5, off by default --, the eager twin in two)
+        twins.append((FusedBA(tr, store, smp, max_poses=64, use_graph=use_graph, one_launch_prologue=use_graph), current, poses, vol))
     (a, cur, poses, vol), (b, _, _, _) = twins
     b.trainer.model.load_state_dict(a.trainer.model.state_dict())
     b.trainer.iter_state.copy_(a.trainer.iter_state)

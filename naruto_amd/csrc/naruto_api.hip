@@ -118,7 +118,12 @@ inline LevelSplits level_splits(const NarutoField* f, uint32_t M) {
         for (int l = 0; l < kLevels; ++l) {
             // hashed levels only: the dense units are bound by their LDS adds and gain nothing from shorter shares (T = 2^22, where only
             // dense levels are tiled: 10.12 -> 10.63 ms with the multiplier on them)
-            const uint32_t s = (uint32_t)f->plan.s_lvl[l] * (((f->lt.hashed >> l) & 1u) && mult ? mult : 1u);
+            // (the long list's count is `mult` splits in all -- measured from a planned 1: x2 no gain, x4 6.42 -> 5.70 ms --, not mult
+            // times whatever the one-round plan chose: 2 x 4 = 8 splits lost 7 % at 131 072 x 43 against 4)
+            const uint32_t base = (uint32_t)f->plan.s_lvl[l];
+            // (the dense levels of a long list take the most the partial tables allow: such a launch is several rounds of workgroups, and a
+            // dense unit cut in 4 -- the one-round plan's count -- is a 1.9 ms workgroup at 131 072 x 43: the launch's whole time)
+            const uint32_t s = mult > 1u ? (((f->lt.hashed >> l) & 1u) ? (base > mult ? base : mult) : 8u) : base;
             ls.s[l] = (uint8_t)(s > 8u ? 8u : s);
         }
         for (uint32_t u = 0; u < f->plan.n_dense + f->plan.n_hashed; ++u) blocks += ls.s[f->plan.level[u]];
@@ -143,6 +148,8 @@ inline ScatterPlan scatter_plan(const NarutoField* f, uint32_t M) {
     // a level's slice of the list (16 B per point and feature) stays in an XCD's 4 MB L2 up to ~300 k points
     static const int dbg_xcd = getenv("NARUTO_DEBUG_SCATTER_XCD_AWARE") ? atoi(getenv("NARUTO_DEBUG_SCATTER_XCD_AWARE")) : -1;       // profiling knob
     plan.xcd_aware = (uint8_t)(dbg_xcd >= 0 ? (dbg_xcd != 0) : (M <= 300000u));
+    static const int dbg_cyc = getenv("NARUTO_DEBUG_SCATTER_CYCLIC") ? atoi(getenv("NARUTO_DEBUG_SCATTER_CYCLIC")) : -1;             // profiling knob
+    plan.cyclic = (uint8_t)(dbg_cyc >= 0 ? (dbg_cyc != 0) : (M <= 300000u));
     return plan;
 }
 
@@ -225,7 +232,7 @@ int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const f
         }
         const uint32_t blocks = ((uint32_t)plan.n_level_blocks + (us.g != nullptr ? plan.n_uncert * us.n_splits : 0u) + 7u) / 8u * 8u;      // XCD-aware order: multiple of 8
         hipLaunchKernelGGL(k_hash_scatter_lds, dim3(blocks), dim3(kScatterThreads), lds, st, f->lt, f->bt, ps, M, d_feat, stride_m, stride_l, plan,
-                           w.partial, 2u * n_plane, m_dev, scale_dev, us);
+                           w.partial, 2u * n_plane, m_dev, scale_dev, us, g_fwd_timeline);
         if (int rc = check_launch("hash_scatter_lds")) return rc;
         if (do_reduce) {
             const uint32_t n_table_blocks = d_table != nullptr ? (uint32_t)((n_tiled_params / 4u + 255u) / 256u) : 0u;
@@ -400,22 +407,59 @@ int naruto_field_create(const NarutoFieldDesc* d, NarutoField** out) {
             f->plan.s_uncert = uch <= 8u ? 2u : 1u;
         }
         const uint32_t cus = cu_count(f);
-        const uint32_t unc_blocks = f->plan.n_uncert * f->plan.s_uncert;
-        uint32_t sh = f->plan.n_hashed ? (cus * 7u / 10u) / f->plan.n_hashed : 1u;
-        sh = sh < 1u ? 1u : (sh > 8u ? 8u : sh);
-        // the dense units share what the hashed units and the grid's units leave
-        const uint32_t left = cus > f->plan.n_hashed * sh + unc_blocks ? cus - f->plan.n_hashed * sh - unc_blocks : 0u;
-        uint32_t sd = f->plan.n_dense ? left / f->plan.n_dense : 1u;
-        sd = sd < 1u ? 1u : (sd > 8u ? 8u : sd);
-        f->plan.s_hashed = sh;
-        f->plan.s_dense = sd;
+        // Point splits per level and for the grid's chunks (round 5; it was "70 % of the CUs to the hashed units, the rest to the dense
+        // ones", one count per unit type).  A workgroup's time is its share of the list times what a visit costs in its unit type --
+        // measured per workgroup with tools/scatter_timeline.py at the headline batch (123 k list points; relative to a hashed unit's
+        // visit, hashed_corner_addr8 form): dense levels 1.75 (every point applies all eight corners, same-address conflicts), the
+        // uncertainty grid 1.1 over the 3/4 of the list behind the lattice -- and the launch ends with its slowest workgroup.  So: start
+        // from one split each and keep giving one more to whatever is slowest while the workgroups still fit the CUs in ONE round.
+        {
+            float cost[kLevels + 1];                 // per unit of level l; [kLevels]: per chunk of the uncertainty grid
+            uint32_t units[kLevels + 1] = {}, sp[kLevels + 1];
+            for (uint32_t u = 0; u < f->plan.n_dense + f->plan.n_hashed; ++u) ++units[f->plan.level[u]];
+            units[kLevels] = f->plan.n_uncert;
+            for (uint32_t l = 0; l <= (uint32_t)kLevels; ++l) {
+                sp[l] = 1u;
+                cost[l] = l == (uint32_t)kLevels ? 1.1f : (((f->lt.hashed >> l) & 1u) ? 1.0f : 1.75f);
+            }
+            uint32_t used = 0;
+            for (uint32_t l = 0; l <= (uint32_t)kLevels; ++l) used += units[l];
+            bool full[kLevels + 1] = {};             // one more split of this type would not fit any more
+            for (;;) {
+                int worst = -1;
+                for (uint32_t l = 0; l <= (uint32_t)kLevels; ++l)
+                    if (units[l] != 0u && sp[l] < 8u && !full[l] && (worst < 0 || cost[l] / (float)sp[l] > cost[worst] / (float)sp[worst])) worst = (int)l;
+                if (worst < 0) break;
+                // (a type that no longer fits is also the one the launch waits for: speeding up the others buys nothing, stop there --
+                // unless the others are within 10 % of it, where a finer cut of THEM still trims the tail)
+                if (used + units[worst] > cus) { full[worst] = true; continue; }
+                bool slowest_is_full = false;
+                for (uint32_t l = 0; l <= (uint32_t)kLevels; ++l)
+                    if (full[l] && cost[l] / (float)sp[l] > 1.1f * cost[worst] / (float)sp[worst]) slowest_is_full = true;
+                if (slowest_is_full) break;
+                used += units[worst];
+                ++sp[worst];
+            }
+            for (uint32_t l = 0; l < (uint32_t)kLevels; ++l) f->plan.s_lvl[l] = (uint8_t)sp[l];
+            f->plan.s_uncert = f->plan.n_uncert ? sp[kLevels] : 1u;
+            uint32_t sh = 1u, sd = 1u;                   // (the defaults the per-type knobs below start from)
+            for (uint32_t l = 0; l < (uint32_t)kLevels; ++l) {
+                if (!units[l]) continue;
+                if ((f->lt.hashed >> l) & 1u) sh = sp[l]; else sd = sp[l];
+            }
+            f->plan.s_hashed = sh;
+            f->plan.s_dense = sd;
+        }
         // profiling knobs (performance only: the split counts change the summation order, nothing else)
         if (const char* e1 = getenv("NARUTO_DEBUG_SCATTER_SPLITS_HASHED")) f->plan.s_hashed = (uint32_t)atoi(e1) < 1 ? 1u : ((uint32_t)atoi(e1) > 8u ? 8u : (uint32_t)atoi(e1));
         f->plan.role_mask = 7u;
         if (const char* e0 = getenv("NARUTO_DEBUG_SCATTER_ROLES")) f->plan.role_mask = (uint32_t)atoi(e0);
         if (const char* e3 = getenv("NARUTO_DEBUG_SCATTER_SPLITS_UNCERT")) { const uint32_t v = (uint32_t)atoi(e3); f->plan.s_uncert = v < 1u ? 1u : (v > 8u ? 8u : v); }
         if (const char* e2 = getenv("NARUTO_DEBUG_SCATTER_SPLITS_DENSE")) f->plan.s_dense = (uint32_t)atoi(e2) < 1 ? 1u : ((uint32_t)atoi(e2) > 8u ? 8u : (uint32_t)atoi(e2));
-        for (uint32_t l = 0; l < (uint32_t)kLevels; ++l) f->plan.s_lvl[l] = (uint8_t)(((f->lt.hashed >> l) & 1u) ? f->plan.s_hashed : f->plan.s_dense);
+        for (uint32_t l = 0; l < (uint32_t)kLevels; ++l) {
+            if (((f->lt.hashed >> l) & 1u) && getenv("NARUTO_DEBUG_SCATTER_SPLITS_HASHED") != nullptr) f->plan.s_lvl[l] = (uint8_t)f->plan.s_hashed;
+            if (!((f->lt.hashed >> l) & 1u) && getenv("NARUTO_DEBUG_SCATTER_SPLITS_DENSE") != nullptr) f->plan.s_lvl[l] = (uint8_t)f->plan.s_dense;
+        }
         // NARUTO_DEBUG_SCATTER_SPLITS_LEVELS="l:s,l:s,...": per-level override
         if (const char* e4 = getenv("NARUTO_DEBUG_SCATTER_SPLITS_LEVELS")) {
             const char* q = e4;
@@ -440,6 +484,11 @@ int naruto_field_create(const NarutoFieldDesc* d, NarutoField** out) {
             }
         }
         f->plan.n_level_blocks = (uint16_t)nb;
+        if (getenv("NARUTO_DEBUG_PLAN") != nullptr) {
+            fprintf(stderr, "naruto scatter plan: %u dense + %u hashed units, %u uncertainty chunks x %u; splits per level:", f->plan.n_dense, f->plan.n_hashed, f->plan.n_uncert, f->plan.s_uncert);
+            for (int l = 0; l < kLevels; ++l) fprintf(stderr, " %u%s", (unsigned)f->plan.s_lvl[l], ((f->lt.hashed >> l) & 1u) ? "h" : "d");
+            fprintf(stderr, "; %u level workgroups\n", nb);
+        }
     }
     *out = f;
     return NARUTO_OK;

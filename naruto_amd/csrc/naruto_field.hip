@@ -974,6 +974,7 @@ struct ScatterPlan {
     uint8_t s_lvl[kLevels];       // point splits per unit, by level (the partial tables hold s_lvl[level] planes of a level's entries)
     uint16_t n_level_blocks;      // workgroups of the level units = sum over units of s_lvl[level of the unit]
     uint8_t xcd_aware;            // 1: the workgroups of a level share an XCD (their list slice is re-read from its L2); 0: natural order
+    uint8_t cyclic;               // 1: dense / uncertainty units take the list dealt out wave by wave (short lists); 0: contiguous shares
     uint8_t blk_unit[kMaxLevelBlocks], blk_split[kMaxLevelBlocks];     // level workgroup (in unit order) -> unit, split
     uint32_t atomic_levels;       // bit l: level l goes through the global-atomic kernel instead
     // the uncertainty voxel grid as one more (dense, single-feature) table: n_uncert chunks x (per-launch) point splits, after the
@@ -1098,10 +1099,53 @@ __device__ __forceinline__ void fix_add_corners(unsigned long long* __restrict__
     for (int c = 0; c < 8; ++c) fix_add_rel(acc, idx[c] - chunk_base, (f[c & 1] * f[2 + ((c >> 1) & 1)] * f[4 + (c >> 2)]) * g);
 }
 
+// The hashed units' visit with everything the in-chunk test and the LDS address need folded into the hash itself (round 5: the unit is bound
+// by VALU issue -- SQ counters: 81 % of the SIMD's cycles -- and a visit was 86 instructions, 24 of them {idx - chunk_base, shift to a byte
+// offset} x 8 corners).  a8[c] = ((idx_c XOR this unit's chunk number in the entry's high bits) << 3): the three hash terms are formed
+// pre-shifted (gx << 3; gy * ((P1 mod size) << 3): only the bits below the level's mask matter, and 8 (P mod 2^17) fits umul24), the chunk
+// bits ride in the z term -- so a corner lies in this unit's chunk iff a8 < kChunk * 8, and a8 is then its byte offset in the image.
+// Same entries, same contributions as hash_corner_index + fix_add_corners (levels of up to 2^17 entries: larger ones are binned).
+template <int T>
+__device__ __forceinline__ void hash_corner_addr8(const LevelTab& lt, float x, float y, float z, uint32_t chunk8, uint32_t (&a8)[8], float (&f)[6]) {
+    const float scale = lt.scale[T];
+    const uint32_t mask = lt.size[T] - 1u, mask8 = mask << 3;
+    const float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
+    const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+    const uint32_t gx = (uint32_t)(int)fx, gy = (uint32_t)(int)fy, gz = (uint32_t)(int)fz;
+    const float wx = px - fx, wy = py - fy, wz = pz - fz;
+    const uint32_t p1 = (kPrime1Low & mask) << 3, p2 = (kPrime2Low & mask) << 3;
+    const uint32_t gx0 = gx << 3, gx1 = gx0 + 8u;
+    const uint32_t hy0 = __umul24(gy, p1), hy1 = hy0 + p1;
+    const uint32_t hz0 = __umul24(gz, p2) ^ chunk8, hz1 = (__umul24(gz, p2) + p2) ^ chunk8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) a8[c] = (((c & 1) ? gx1 : gx0) ^ ((c & 2) ? hy1 : hy0) ^ ((c & 4) ? hz1 : hz0)) & mask8;
+    f[0] = 1.0f - wx; f[1] = wx; f[2] = 1.0f - wy; f[3] = wy; f[4] = 1.0f - wz; f[5] = wz;
+}
+__device__ __forceinline__ void fix_add_corners8(unsigned long long* __restrict__ acc, const uint32_t (&a8)[8], const float (&f)[6], float g) {
+    char* __restrict__ base = reinterpret_cast<char*>(acc);
+#if NARUTO_FIX_F64
+    if (__builtin_expect(fabsf(g) <= kFixMagicRange, 1)) {             // per LANE: what a point adds does not depend on its wave
+        const double gd = (double)g;
+        const double gx0 = gd * (double)f[0], gx1 = gd * (double)f[1];
+        const double y0 = (double)f[2], y1 = (double)f[3], z0 = (double)f[4], z1 = (double)f[5];
+        const double gxy[4] = {gx0 * y0, gx1 * y0, gx0 * y1, gx1 * y1};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const double s = __fma_rn(gxy[c & 3], (c & 4) ? z1 : z0, kFixMagic);
+            if (a8[c] < kChunk * 8u) atomicAdd(reinterpret_cast<unsigned long long*>(base + a8[c]), fix40_bits(s));
+        }
+        return;
+    }
+    if (!(fabsf(g) < 4194304.0f)) return;                   // NaN / Inf / beyond the fixed point's range: the point adds nothing (as on the dense levels)
+#endif
+#pragma unroll
+    for (int c = 0; c < 8; ++c) fix_add_rel(acc, a8[c] >> 3, (f[c & 1] * f[2 + ((c >> 1) & 1)] * f[4 + (c >> 2)]) * g);
+}
+
 template <int T>
 __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const BoxTab& bt, const PointSrc& ps, const float* __restrict__ d_feat,
                                                     size_t stride_m, size_t stride_l, uint32_t m_lo, uint32_t m_hi, uint32_t chunk,
-                                                    unsigned long long* __restrict__ acc, uint32_t feat) {
+                                                    unsigned long long* __restrict__ acc, uint32_t feat, uint32_t split, uint32_t n_splits, uint32_t M, bool cyclic) {
     // d_feat already points at this unit's feature (0 or 1)
     const uint32_t sm32 = (uint32_t)stride_m, sl32 = (uint32_t)stride_l, chunk_base = chunk * kChunk;
     if ((lt.hashed >> T) & 1u) {
@@ -1147,10 +1191,10 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
 #pragma unroll
                 for (uint32_t b = 0; b < V; ++b) {
                     if (base + b >= m_hi || q.g[b] == 0.0f) continue;
-                    uint32_t idx[8];
+                    uint32_t a8[8];
                     float f[6];
-                    hash_corner_index<T>(lt, q.x[b], q.y[b], q.z[b], idx, f);
-                    fix_add_corners(acc, idx, chunk_base, f, q.g[b]);
+                    hash_corner_addr8<T>(lt, q.x[b], q.y[b], q.z[b], chunk << (kChunkLog2 + 3), a8, f);
+                    fix_add_corners8(acc, a8, f, q.g[b]);
                 }
             }
             return;
@@ -1186,7 +1230,25 @@ __device__ __forceinline__ void scatter_tile_points(const LevelTab& lt, const Bo
         const bool single_chunk = size <= kChunk;          // levels of one chunk: every entry is this unit's
         const uint32_t magic = lt.magic[T];
         const uint32_t interior = size - (1u + res + r2);  // cells below this number have all eight corners inside the level (res >= 2: size >= res^3 > 1 + res + res^2)
-        for (uint32_t r0 = m_lo + threadIdx.x * kScatterRun; r0 < m_hi; r0 += kScatterThreads * kScatterRun) {
+        // Shares of the dense units are CYCLIC (round 5): the list is dealt out to the splits in turn.  Contiguous shares had put the whole smoothness lattice -- 30 k points at the front of the list, every one with a
+        // cotangent and few of them sharing a cell -- into split 0: level 0's split 0 took 59 us where its other splits took 42
+        // (tools/scatter_timeline.py), and the launch waited for it.  The runs of 8 points are now the same whatever the split count,
+        // so the dense levels' sums no longer move with it either.
+        // (dealt WAVE by wave -- chunk q of 64 runs goes to split q mod n_splits, inside the split to its waves in turn --: a unit is bound by
+        // throughput, its time is its share's SIZE, and whole 8 192-point steps dealt out leave the splits up to a step apart: measured +4 us)
+        // (Tried on top, measured, not kept: the LANES of a wave on runs far apart in the list -- other rays, other cells -- against
+        // same-address conflicts of the LDS adds: the fine dense levels 40 -> 47 us, the grid's units 52 -> 58; neighbouring lanes adding to
+        // the SAME entry are cheaper than lanes adding all over the image.)
+        // Lists too long for an L2 (cyclic == false, see scatter_plan) keep contiguous shares: 131 072 x 43 lost 7 % with the cyclic ones, and
+        // the lattice is a negligible part of such a list.
+        constexpr uint32_t kWaveRun = 64u * (uint32_t)kScatterRun, kWaves = (uint32_t)kScatterThreads / 64u;
+        uint32_t r_first = m_lo + threadIdx.x * kScatterRun, r_step = kScatterThreads * kScatterRun;
+        if (cyclic) {
+            m_lo = 0; m_hi = M;
+            r_first = ((threadIdx.x >> 6) * n_splits + split) * kWaveRun + (threadIdx.x & 63u) * kScatterRun;
+            r_step = kWaves * n_splits * kWaveRun;
+        }
+        for (uint32_t r0 = r_first; r0 < m_hi; r0 += r_step) {
             float a0[8];
             uint32_t cur = 0xFFFFFFFFu;
             bool have = false;
@@ -1301,8 +1363,13 @@ struct UncertScatter {
 __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab lt, BoxTab bt, PointSrc ps, uint32_t M, const float* __restrict__ d_feat,
                                                                        size_t stride_m, size_t stride_l, ScatterPlan plan,
                                                                        float* __restrict__ partial, size_t n_params,
-                                                                       const uint32_t* __restrict__ m_dev, const float* __restrict__ scale_dev, UncertScatter unc) {
+                                                                       const uint32_t* __restrict__ m_dev, const float* __restrict__ scale_dev, UncertScatter unc,
+                                                                       unsigned long long* __restrict__ timeline) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long acc[];
+    // profiling (naruto_debug_fwd_timeline's buffer; NULL otherwise): thread 0 of every workgroup stamps the 100 MHz counter -- 0 start, 1 image
+    // zeroed, 2 points done, 3 end, 4 = (unit << 8 | split) + 1 or 0x10000 + uncertainty block (tools/scatter_timeline.py)
+    auto stamp = [&](int k) { if (timeline != nullptr && threadIdx.x == 0) timeline[(size_t)blockIdx.x * 8u + (size_t)k] = (unsigned long long)wall_clock64(); };
+    stamp(0);
     if (m_dev != nullptr) M = m_dev[0];          // compacted point list: the count lives on the device
     const float gscale = scale_dev != nullptr ? scale_dev[0] : 1.0f;     // cotangent of a scalar loss (smoothness term)
     // XCD-aware placement: workgroups go to the 8 XCDs round-robin by id, and every workgroup streams the point list of ITS
@@ -1323,15 +1390,20 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
         const uint32_t chunk = ub / unc.n_splits, split = ub % unc.n_splits;
         for (uint32_t i = threadIdx.x; i < kChunk; i += kScatterThreads) acc[i] = 0ull;
         __syncthreads();
+        stamp(1);
+        if (timeline != nullptr && threadIdx.x == 0) timeline[(size_t)blockIdx.x * 8u + 4u] = 0x10000ull + ub;
         // the smoothness lattice at the front of the list carries no raw[...,4] cotangent: the units share the points behind it
         const uint32_t first = unc.first < M ? unc.first : M, Mu = M - first;
+        // cyclic shares, as the dense units' (the list behind the lattice dealt out wave by wave), or contiguous ones (long lists)
         const uint32_t per = ((Mu + unc.n_splits - 1u) / unc.n_splits + 3u) & ~3u;
-        const uint32_t m_lo = first + (split * per < Mu ? split * per : Mu);
-        const uint32_t m_hi = m_lo + per < M ? m_lo + per : M;
+        const uint32_t c_lo = first + (split * per < Mu ? split * per : Mu);
+        const uint32_t m_hi = plan.cyclic ? M : (c_lo + per < M ? c_lo + per : M);
+        const uint32_t u_first = plan.cyclic ? first + ((threadIdx.x >> 6) * unc.n_splits + split) * 512u + (threadIdx.x & 63u) * 8u : c_lo + threadIdx.x * 8u;
+        const uint32_t u_step = plan.cyclic ? (kScatterThreads / 64u) * unc.n_splits * 512u : kScatterThreads * 8u;
         const uint32_t chunk_base = chunk * kChunk;
         // consecutive list entries are consecutive samples of a ray and stay in one voxel for a few samples: a thread walks a run of
         // 8 points and sums the corner contributions in registers while the base voxel does not change (fewer, less conflicting LDS adds)
-        for (uint32_t r0 = m_lo + threadIdx.x * 8u; r0 < m_hi; r0 += kScatterThreads * 8u) {
+        for (uint32_t r0 = u_first; r0 < m_hi; r0 += u_step) {
             float rx[8], ry[8], rz[8], rg[8];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -1346,11 +1418,14 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
             // (keeps the 16-byte loads whole and up front: left alone, the compiler sinks the first point's three coordinates into the
             // "cotangent is not zero" branch as scalar loads -- a memory round trip inside the run)
             asm volatile("" : "+v"(rx[0]), "+v"(ry[0]), "+v"(rz[0]));
-            int32_t cur[8];
+            // (round 5: the base voxel as ONE packed key -- compared per point, expanded into the eight corner indices only when a run of
+            // equal keys is flushed; the per-point form derived and compared all eight indices: ~100 instructions a point, and these
+            // twelve workgroups were what the launch waited for.  Same sums in the same order: same bits.)
+            uint32_t cur = 0xFFFFFFFFu;
             float a0[8];
             bool have = false;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) { cur[c] = -1; a0[c] = 0.0f; }
+            for (int c = 0; c < 8; ++c) a0[c] = 0.0f;
             bool magic_ok = true;                                                         // as in the dense units
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -1359,9 +1434,11 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
             }
             auto flush_as = [&](auto magic_c) {
                 constexpr bool MAGIC = decltype(magic_c)::value;
+                int32_t ci[8];
+                uncert_base_corners(unc.ut, cur, ci);
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    const uint32_t rel = (uint32_t)cur[c] - chunk_base;                       // idx -1 (outside the grid) wraps out of every chunk
+                    const uint32_t rel = (uint32_t)ci[c] - chunk_base;                        // idx -1 (outside the grid) wraps out of every chunk
                     if (rel < kChunk) atomicAdd(acc + rel, to_fix40_sum<MAGIC>(a0[c]));
                     a0[c] = 0.0f;
                 }
@@ -1375,27 +1452,27 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
             for (int k = 0; k < 8; ++k) {
                 if (r0 + (uint32_t)k >= m_hi) break;
                 if (rg[k] == 0.0f) continue;
-                int32_t ui[8];
-                float uw[8];
-                uncert_corners(unc.ut, rx[k], ry[k], rz[k], ui, uw);
-                bool same = have;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) same = same && ui[c] == cur[c];
-                if (!same) {
+                float fx, fy, fz;
+                const uint32_t key = uncert_base(unc.ut, rx[k], ry[k], rz[k], fx, fy, fz);
+                if (!have || key != cur) {
                     flush();
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) cur[c] = ui[c];
+                    cur = key;
                     have = true;
                 }
 #pragma unroll
-                for (int c = 0; c < 8; ++c) a0[c] = fmaf(uw[c], rg[k], a0[c]);
+                for (int c = 0; c < 8; ++c) {
+                    const float w = ((c & 1) ? fx : 1.0f - fx) * ((c & 2) ? fy : 1.0f - fy) * ((c & 4) ? fz : 1.0f - fz);      // uncert_corners' weights
+                    a0[c] = fmaf(w, rg[k], a0[c]);
+                }
             }
             flush();
         }
         __syncthreads();
+        stamp(2);
         const uint32_t n_e = plan.uncert_voxels - chunk_base < kChunk ? plan.uncert_voxels - chunk_base : kChunk;
         float* out = unc.partial + (size_t)split * unc.voxels_pad + chunk_base;
         for (uint32_t i = threadIdx.x; i < n_e; i += kScatterThreads) out[i] = (float)((double)(long long)acc[i] * kFixInv);
+        stamp(3);
         return;
     }
     unit = plan.blk_unit[pos];
@@ -1407,16 +1484,19 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
     d_feat += feat;
     for (uint32_t i = threadIdx.x; i < kChunk; i += kScatterThreads) acc[i] = 0ull;
     __syncthreads();
+    stamp(1);
+    if (timeline != nullptr && threadIdx.x == 0) timeline[(size_t)blockIdx.x * 8u + 4u] = ((unsigned long long)unit << 8 | split) + 1ull;
     const uint32_t per = ((M + n_splits - 1u) / n_splits + 3u) & ~3u;         // multiple of 4: 16-byte aligned shares
     const uint32_t m_lo = split * per < M ? split * per : M;
     const uint32_t m_hi = m_lo + per < M ? m_lo + per : M;
     switch (level) {
-#define NARUTO_CASE(T) case T: scatter_tile_points<T>(lt, bt, ps, d_feat, stride_m, stride_l, m_lo, m_hi, chunk, acc, feat); break;
+#define NARUTO_CASE(T) case T: scatter_tile_points<T>(lt, bt, ps, d_feat, stride_m, stride_l, m_lo, m_hi, chunk, acc, feat, split, n_splits, M, plan.cyclic != 0); break;
         NARUTO_CASE(0) NARUTO_CASE(1) NARUTO_CASE(2) NARUTO_CASE(3) NARUTO_CASE(4) NARUTO_CASE(5) NARUTO_CASE(6) NARUTO_CASE(7)
         NARUTO_CASE(8) NARUTO_CASE(9) NARUTO_CASE(10) NARUTO_CASE(11) NARUTO_CASE(12) NARUTO_CASE(13) NARUTO_CASE(14) NARUTO_CASE(15)
 #undef NARUTO_CASE
     }
     __syncthreads();
+    stamp(2);
     // partial tables are feature-planar: [split][feature][n_entries]; level sizes are multiples of 8 entries and chunks
     // start at multiples of 16 384: float4-aligned slices
     const uint32_t n_e = lt.size[level] - chunk * kChunk < kChunk ? lt.size[level] - chunk * kChunk : kChunk;
@@ -1431,6 +1511,7 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
         v.w = (float)((double)(long long)acc[4 * i + 3] * inv);
         out[i] = v;
     }
+    stamp(3);
 }
 
 // the uncertainty grid's share of a reduction launch: d_uncert[v] += sum over splits of the partial images (always accumulated: the

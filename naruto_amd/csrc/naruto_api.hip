@@ -910,7 +910,8 @@ TrainFwdPlan train_fwd_plan(const NarutoField* f, const NarutoTrainStep* t, bool
     pl.form = FwdForm::Walk;
     pl.tpr = tpr;
     pl.fused = can_fuse;
-    pl.split = pl.fused && kFwdSplit && sizeof(FwdLds) + (size_t)kRaysPerBlock * sizeof(FwdSlab) + ray_scratch_bytes(S) + 512u <= (size_t)80u * 1024u;
+    // (two workgroups per CU: static LDS -- weight images, four slabs, the loss rows -- + the rays' images within half a CU's 160 KB)
+    pl.split = pl.fused && kFwdSplit && sizeof(FwdLdsExact) + (size_t)kRaysPerBlock * sizeof(FwdSlab) + ray_scratch_fwd_bytes(S) + 256u <= (size_t)80u * 1024u;
     pl.tv_moved = tv_on && deferred && t->smooth_points != 0 && pl.fused && pl.split;
     return pl;
 }
@@ -1036,7 +1037,7 @@ int launch_train_query(const NarutoField* f, const NarutoParams* p, const Naruto
         const bool bfm = f->desc.mlp_mode == NARUTO_MLP_BF16;
         const WalkExtra wxa = walk_extra != nullptr ? *walk_extra : WalkExtra{};
         const uint32_t tail_blocks = wxa.on ? tv_encode_blocks(loss->tv.n * loss->tv.n * loss->tv.n, wxa.tv_groups) : loss->n_tv_blocks;
-#define NARUTO_LAUNCH_WALK(BFV, SPV) hipLaunchKernelGGL((k_query_fwd_loss<BFV, SPV>), dim3(blocks + tail_blocks), dim3(256), ray_scratch_bytes(S), st, f->lt, f->ut, f->bt, *p, ps, M, \
+#define NARUTO_LAUNCH_WALK(BFV, SPV) hipLaunchKernelGGL((k_query_fwd_loss<BFV, SPV>), dim3(blocks + tail_blocks), dim3(256), ray_scratch_fwd_bytes(S), st, f->lt, f->ut, f->bt, *p, ps, M, \
                                                         t->raw, t->feat_save, ee, *loss, blocks, wxa)
         if (pl.split) { if (bfm) NARUTO_LAUNCH_WALK(true, true); else NARUTO_LAUNCH_WALK(false, true); }
         else { if (bfm) NARUTO_LAUNCH_WALK(true, false); else NARUTO_LAUNCH_WALK(false, false); }

@@ -591,6 +591,206 @@ __device__ __forceinline__ void fwd_mlp_tile(const FwdLds& L, const FwdSlab& sl,
     fwd_epilogue<COLOR>(L, oA, oB, cA, cB, geo, M, mA, mB, lane, out);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The EXACT mode's matrix chain on the bf16 (XDL) matrix instruction: fp32 operands as three bf16 pieces each (round 5).
+//
+// Measured (tools/mfma_valu_overlap_bench.hip, profiles/r05_mfma_valu_overlap.txt): the fp32 matrix instruction overlaps with NO vector
+// instruction of its own or of the SIMD's other wave -- it runs on the vector ALU's fp32 lanes -- while the bf16 one overlaps 0.8 - 0.95.
+// An fp32 value is EXACTLY hi + mid + lo with three bf16 numbers (8 + 8 + 8 significand bits, split by truncation: two and-masks and
+// two subtractions), and a product of two bf16 numbers is exact in the instruction's fp32 accumulation, so
+//     x w = (xh + xm + xl)(wh + wm + wl) ~ xh wh + xh wm + xm wh + xh wl + xl wh + xm wm           (six products)
+// drops only terms below 2^-24 |x w| -- the size of ONE fp32 rounding, where the fp32 fma chain rounds after every one of its K
+// steps.  Six 8-pass instructions with K = 16 per K block against eight 16-pass instructions with K = 2: 12 cycles of the matrix pipe
+// per K instead of 32, and they run beside the other wave's address arithmetic.  Price: ~5.5 vector instructions per operand value for
+// the split (the weights are split once, at staging).  NOT bit-identical to the fp32 chain (both are within fp32 rounding of the exact
+// product sums; measured in tools/fwd_lab.hip), deterministic.
+// ------------------------------------------------------------------------------------------------------------------------------
+struct FwdLdsX3 {
+    u32x4_t s0[3][5 * 64];      // [piece hi | mid | lo][K block][lane]: FwdLdsBf's images, three times
+    u32x4_t c0[3][4 * 64];
+    u32x4_t s1[3][2 * 64];
+    float c1[3 * 16 * 2];
+};
+struct Pack3 { u32x4_t h, m, l; };
+// v = h + m + l exactly, each piece a bf16 number given as the high half of a word (low half zero)
+__device__ __forceinline__ void split3(float v, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = __float_as_uint(v) & 0xFFFF0000u;
+    const float r1 = v - __uint_as_float(h);
+    m = __float_as_uint(r1) & 0xFFFF0000u;
+    l = __float_as_uint(r1 - __uint_as_float(m));          // at most 8 significant bits are left: the low half of the word is zero
+}
+__device__ __forceinline__ uint32_t pk_hi16(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }      // (lo >> 16) | (hi & 0xFFFF0000)
+__device__ __forceinline__ Pack3 pack8x3(const float (&v)[8]) {
+    uint32_t h[8], m[8], l[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) split3(v[q], h[q], m[q], l[q]);
+    Pack3 p;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { p.h[q] = pk_hi16(h[2 * q], h[2 * q + 1]); p.m[q] = pk_hi16(m[2 * q], m[2 * q + 1]); p.l[q] = pk_hi16(l[2 * q], l[2 * q + 1]); }
+    return p;
+}
+template <bool RELU>
+__device__ __forceinline__ Pack3 pack8x3_acc(const f32x16& a, int r0) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = RELU ? fmaxf(a[r0 + q], 0.0f) : a[r0 + q];
+    return pack8x3(v);
+}
+// acc += W X over one K block, six products, the small ones first
+__device__ __forceinline__ f32x16 mfma16x3(const u32x4_t (&w)[3], const Pack3& x, f32x16 acc) {
+    acc = mfma16(w[1], x.m, acc);
+    acc = mfma16(w[2], x.h, acc);
+    acc = mfma16(w[0], x.l, acc);
+    acc = mfma16(w[1], x.h, acc);
+    acc = mfma16(w[0], x.m, acc);
+    acc = mfma16(w[0], x.h, acc);
+    return acc;
+}
+template <int NT, typename SRC>
+__device__ __forceinline__ void stage_fwd_weights_x3_from(FwdLdsX3& L, const SRC& w, int tid) {
+#pragma unroll
+    for (int e0 = 0; e0 < 11 * 64; e0 += NT) {
+        const int e = e0 + tid;
+        if (e >= 11 * 64) continue;
+        const int t = e >> 6, l = e & 63, i = l & 31, hh = l >> 5;
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (t < 2) v[q] = w.sdf_w0(i, 2 * (8 * t + q) + hh);
+            else if (t < 5) v[q] = w.sdf_w0(i, kFeat + 16 * (t - 2) + 8 * hh + q);
+            else if (t < 8) v[q] = w.col_w0(i, 16 * (t - 5) + 8 * hh + q);
+            else if (t == 8) { const int row = crow(q, hh); v[q] = row >= 1 ? w.col_w0(i, kPos + row - 1) : 0.0f; }
+            else v[q] = i < kOut ? w.sdf_w1(i, crow(8 * (t - 9) + q, hh)) : 0.0f;
+        }
+        const Pack3 pk = pack8x3(v);
+        const u32x4_t pc[3] = {pk.h, pk.m, pk.l};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (t < 5) L.s0[k][t * 64 + l] = pc[k];
+            else if (t < 9) L.c0[k][(t - 5) * 64 + l] = pc[k];
+            else L.s1[k][(t - 9) * 64 + l] = pc[k];
+        }
+    }
+#pragma unroll
+    for (int e0 = 0; e0 < 3 * 16 * 2; e0 += NT) {
+        const int e = e0 + tid;
+        if (e >= 3 * 16 * 2) continue;
+        const int c = e / 32, r = (e >> 1) & 15, hh = e & 1;
+        L.c1[e] = w.col_w1(c * kHidden + crow(r, hh));
+    }
+}
+template <int NT>
+__device__ __forceinline__ void stage_fwd_weights_x3_via_lds(FwdLdsX3& L, float* __restrict__ raw, const NarutoParams& p, int tid) {
+    fetch_raw_weights<NT>(raw, p, tid);
+    stage_fwd_weights_x3_from<NT>(L, WSrcLds{raw, p}, tid);
+}
+// the matrix phase of a tile (fwd_mlp_tile's counterpart): hash part of the B operands from the slab
+template <bool COLOR>
+__device__ __forceinline__ void fwd_mlp_tile_x3(const FwdLdsX3& L, const FwdSlab& sl, float x, float y, float z, float* __restrict__ geo, uint32_t M, uint32_t mA, uint32_t mB,
+                                                int lane, FwdTileOut& out) {
+    const int hh = lane >> 5;
+    f32x16 hA = zero16(), hB = zero16(), cA = zero16(), cB = zero16();
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        float fa[8], fb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { fa[e] = sl.feat[8 * kb + e][0][lane]; fb[e] = sl.feat[8 * kb + e][1][lane]; }
+        const u32x4_t w[3] = {L.s0[0][kb * 64 + lane], L.s0[1][kb * 64 + lane], L.s0[2][kb * 64 + lane]};
+        hA = mfma16x3(w, pack8x3(fa), hA);
+        hB = mfma16x3(w, pack8x3(fb), hB);
+    }
+    const bool blob_fast = __all(oneblob_sparse_ok(x) && oneblob_sparse_ok(y) && oneblob_sparse_ok(z));
+    static_for<0, 3>([&](auto dc) {
+        constexpr int D = decltype(dc)::value;
+        float e[kBins];
+        oneblob16_auto(D == 0 ? x : (D == 1 ? y : z), blob_fast, e);
+        float lo8[8], hi8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { lo8[q] = e[q]; hi8[q] = e[8 + q]; }
+        Pack3 lo = pack8x3(lo8), hi = pack8x3(hi8);
+        // (the exchange of fwd_tail_bf, on each of the three pieces)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t a = lo.h[q], b = hi.h[q]; swap32u(a, b); lo.h[q] = a; hi.h[q] = b;
+            a = lo.m[q]; b = hi.m[q]; swap32u(a, b); lo.m[q] = a; hi.m[q] = b;
+            a = lo.l[q]; b = hi.l[q]; swap32u(a, b); lo.l[q] = a; hi.l[q] = b;
+        }
+        const u32x4_t ws[3] = {L.s0[0][(2 + D) * 64 + lane], L.s0[1][(2 + D) * 64 + lane], L.s0[2][(2 + D) * 64 + lane]};
+        hA = mfma16x3(ws, lo, hA);
+        hB = mfma16x3(ws, hi, hB);
+        if constexpr (COLOR) {
+            const u32x4_t wc[3] = {L.c0[0][D * 64 + lane], L.c0[1][D * 64 + lane], L.c0[2][D * 64 + lane]};
+            cA = mfma16x3(wc, lo, cA);
+            cB = mfma16x3(wc, hi, cB);
+        }
+    });
+    f32x16 oA = zero16(), oB = zero16();
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const u32x4_t w[3] = {L.s1[0][kb * 64 + lane], L.s1[1][kb * 64 + lane], L.s1[2][kb * 64 + lane]};
+        oA = mfma16x3(w, pack8x3_acc<true>(hA, 8 * kb), oA);
+        oB = mfma16x3(w, pack8x3_acc<true>(hB, 8 * kb), oB);
+    }
+    float sdf = oA[0], sdf_b = oB[0];
+    swap32(sdf, sdf_b);
+    out.sdf = sdf;
+    if (geo != nullptr) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int row = crow(r, hh);
+            if (row >= 1) {
+                if (mA < M) geo[(size_t)mA * kGeo + row - 1] = oA[r];
+                if (mB < M) geo[(size_t)mB * kGeo + row - 1] = oB[r];
+            }
+        }
+    }
+    if constexpr (COLOR) {
+        const u32x4_t wg[3] = {L.c0[0][3 * 64 + lane], L.c0[1][3 * 64 + lane], L.c0[2][3 * 64 + lane]};
+        cA = mfma16x3(wg, pack8x3_acc<false>(oA, 0), cA);
+        cB = mfma16x3(wg, pack8x3_acc<false>(oB, 0), cB);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float pa = 0.0f, pb = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float w = L.c1[(c * 16 + r) * 2 + hh];
+                pa = fmaf(w, fmaxf(cA[r], 0.0f), pa);
+                pb = fmaf(w, fmaxf(cB[r], 0.0f), pb);
+            }
+            swap32(pa, pb);
+            out.rgb[c] = pa + pb;
+        }
+    }
+}
+
+#ifndef NARUTO_EXACT_X3
+#define NARUTO_EXACT_X3 1
+#endif
+// the exact (fp32) mode's forward kernels run their matrix phase as the x3 chain wherever they use the two-phase tile (NARUTO_EXACT_X3=0:
+// the fp32 matrix instruction there too; the register-form tile -- rays of more than 192 samples, the inference render -- keeps it)
+constexpr bool kExactX3 = NARUTO_EXACT_X3 != 0 && kFwdSplit;
+using FwdLdsExact = std::conditional_t<kExactX3, FwdLdsX3, FwdLds>;
+template <bool COLOR, bool MASK>
+__device__ __forceinline__ void fwd_tile_split(const FwdLdsX3& L, FwdSlab& sl, const LevelTab& lt, const float2* __restrict__ table, float x, float y, float z,
+                                               float* __restrict__ feat_save, float* __restrict__ geo, uint32_t M, uint32_t mA, uint32_t mB, int lane, FwdTileOut& out,
+                                               bool live = true) {
+    if constexpr (NARUTO_FWD_GATHER_PRIO != 0) __builtin_amdgcn_s_setprio(NARUTO_FWD_GATHER_PRIO);
+    fwd_gather_tile<MASK>(lt, table, x, y, z, feat_save, M, mA, mB, lane, sl, live);
+    if constexpr (NARUTO_FWD_GATHER_PRIO != 0) __builtin_amdgcn_s_setprio(0);
+    fwd_mlp_tile_x3<COLOR>(L, sl, x, y, z, geo, M, mA, mB, lane, out);
+}
+// weight staging of whichever image the kernel holds: through the raw area (the slabs) when it is large enough
+template <int NT, size_t RAW_BYTES>
+__device__ __forceinline__ void stage_fwd_exact(FwdLds& L, void* raw, const NarutoParams& p, int tid) {
+    if constexpr (RAW_BYTES >= kFwdRawFloats * sizeof(float)) stage_fwd_weights_via_lds<NT>(L, reinterpret_cast<float*>(raw), p, tid);
+    else stage_fwd_weights<NT>(L, p, tid);
+}
+template <int NT, size_t RAW_BYTES>
+__device__ __forceinline__ void stage_fwd_exact(FwdLdsX3& L, void* raw, const NarutoParams& p, int tid) {
+    if constexpr (RAW_BYTES >= kFwdRawFloats * sizeof(float)) stage_fwd_weights_x3_via_lds<NT>(L, reinterpret_cast<float*>(raw), p, tid);
+    else stage_fwd_weights_x3_from<NT>(L, WSrcGlobal{p}, tid);
+}
+
 // one FULL tile (all 64 points < M), both phases; same results as fwd_tile<COLOR, MASK>
 template <bool COLOR, bool MASK>
 __device__ __forceinline__ void fwd_tile_split(const FwdLds& L, FwdSlab& sl, const LevelTab& lt, const float2* __restrict__ table, float x, float y, float z,
@@ -609,10 +809,9 @@ template <bool COLOR, int NT = 256, bool EE = false>
 __global__ __launch_bounds__(NT, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps,
                                                    uint32_t M, float* __restrict__ raw, float* __restrict__ sdf_uncert,
                                                    float* __restrict__ geo, float* __restrict__ feat_save, EarlyExit ee) {
-    __shared__ FwdLds L;
+    __shared__ FwdLdsExact L;
     __shared__ FwdSlab slabs[kFwdSplit ? NT / 64 : 1];
-    if constexpr (sizeof(slabs) >= kFwdRawFloats * sizeof(float)) stage_fwd_weights_via_lds<NT>(L, reinterpret_cast<float*>(slabs), p, threadIdx.x);
-    else stage_fwd_weights<NT>(L, p, threadIdx.x);
+    stage_fwd_exact<NT, sizeof(slabs)>(L, slabs, p, threadIdx.x);
     __syncthreads();
     constexpr uint32_t kW = NT / 64;
     const int lane = threadIdx.x & 63, wave = kFwdSplit ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);
@@ -637,6 +836,8 @@ __global__ __launch_bounds__(NT, NARUTO_FWD_MINWAVES) void k_query_fwd(LevelTab 
         const bool live_out = live;
         if (kFwdSplit && tile * 64u + 63u < M)
             fwd_tile_split<COLOR, EE>(L, slabs[kFwdSplit ? wave : 0], lt, table, x, y, z, feat_save, geo, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
+        else if constexpr (kExactX3)        // the list's last, partly filled tile: the same two phases with its padding lanes switched off (one chain per kernel)
+            fwd_tile_split<COLOR, true>(L, slabs[wave], lt, table, x, y, z, feat_save, geo, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live && valid);
         else
             fwd_tile<COLOR, EE>(L, lt, table, x, y, z, feat_save, geo, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to, live);
         if (!live_out) { to.rgb[0] = 0.0f; to.rgb[1] = 0.0f; to.rgb[2] = 0.0f; to.sdf = 0.0f; }

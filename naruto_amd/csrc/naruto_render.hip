@@ -143,6 +143,13 @@ __device__ __forceinline__ RayScratch ray_scratch(float* __restrict__ base, int 
     return {p, p + S, p + 2 * (size_t)S, p + 3 * (size_t)S, p + 4 * (size_t)S, p + 5 * (size_t)S, p + 6 * (size_t)S, p + 7 * (size_t)S};
 }
 inline size_t ray_scratch_bytes(uint32_t S) { return (size_t)kRaysPerBlock * kRayFields * S * sizeof(float); }
+// the forward's image: everything but gw (the backward's weight cotangents) -- k_query_fwd_loss keeps two workgroups per CU at S = 128 with it
+constexpr int kRayFieldsFwd = 7;
+__device__ __forceinline__ RayScratch ray_scratch_fwd(float* __restrict__ base, int wave, uint32_t S) {
+    float* p = base + (size_t)wave * kRayFieldsFwd * S;
+    return {p, p + S, p + 2 * (size_t)S, p + 3 * (size_t)S, p + 4 * (size_t)S, p + 5 * (size_t)S, p + 6 * (size_t)S, nullptr};
+}
+inline size_t ray_scratch_fwd_bytes(uint32_t S) { return (size_t)kRaysPerBlock * kRayFieldsFwd * S * sizeof(float); }
 
 __device__ __forceinline__ float softplus_(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float softplus_grad_(float x) {

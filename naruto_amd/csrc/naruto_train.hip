@@ -189,7 +189,7 @@ struct WalkExtra {
 template <bool BF, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps, uint32_t M, float* __restrict__ raw,
                                                            float* __restrict__ feat_save, EarlyExit ee, LossStageArgs a, uint32_t n_fwd_blocks, WalkExtra wx) {
-    using Lds = std::conditional_t<BF, FwdLdsBf, FwdLds>;
+    using Lds = std::conditional_t<BF, FwdLdsBf, std::conditional_t<SPLIT, FwdLdsExact, FwdLds>>;      // (two-phase tile, exact mode: the x3 chain)
     __shared__ Lds L;
     __shared__ FwdSlab slabs[SPLIT ? kRaysPerBlock : 1];
     __shared__ double red[4];
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
         return;
     }
     if constexpr (SPLIT && BF) stage_fwd_weights_bf_via_lds<256>(L, reinterpret_cast<float*>(slabs), p, threadIdx.x);
-    else if constexpr (SPLIT) stage_fwd_weights_via_lds<256>(L, reinterpret_cast<float*>(slabs), p, threadIdx.x);
+    else if constexpr (SPLIT) stage_fwd_exact<256, sizeof(slabs)>(L, slabs, p, threadIdx.x);
     else if constexpr (BF) stage_fwd_weights_bf<256>(L, p, threadIdx.x);
     else stage_fwd_weights<256>(L, p, threadIdx.x);
     __syncthreads();
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
     const float2* __restrict__ table = reinterpret_cast<const float2*>(p.table);
     const uint32_t tpr = ee.tiles_per_ray, S = a.S;                  // tpr = ceil(S / 64): a ray's last tile may be partly filled (round 5)
     const uint32_t n_groups = (a.n_rays + (uint32_t)kRaysPerBlock - 1u) / (uint32_t)kRaysPerBlock;
-    const RayScratch rs = ray_scratch(ray_lds, wave, S);
+    const RayScratch rs = ray_scratch_fwd(ray_lds, wave, S);
     for (uint32_t group = blockIdx.x; group < n_groups; group += n_fwd_blocks) {          // uniform over the workgroup: barriers inside
         const uint32_t task = group * (uint32_t)kRaysPerBlock + (uint32_t)wave;
         if (task < a.n_rays) {
@@ -293,7 +293,7 @@ template <bool BF>
 __global__ __launch_bounds__(256, 2) void k_query_fwd_loss_short(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps, uint32_t M, float* __restrict__ raw,
                                                                  float* __restrict__ feat_save, LossStageArgs a, uint32_t n_fwd_blocks, WalkExtra wx, uint32_t R,
                                                                  unsigned long long* __restrict__ timeline) {
-    using Lds = std::conditional_t<BF, FwdLdsBf, FwdLds>;
+    using Lds = std::conditional_t<BF, FwdLdsBf, FwdLdsExact>;
     __shared__ Lds L;
     __shared__ FwdSlab slabs[kRaysPerBlock];
     __shared__ double red[4];
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss_short(LevelTab lt, Un
     };
     fetch_targets(blockIdx.x * R);
     if constexpr (BF) stage_fwd_weights_bf_via_lds<256>(L, reinterpret_cast<float*>(slabs), p, threadIdx.x);
-    else stage_fwd_weights_via_lds<256>(L, reinterpret_cast<float*>(slabs), p, threadIdx.x);      // (its barrier also publishes tgt)
+    else stage_fwd_exact<256, sizeof(slabs)>(L, slabs, p, threadIdx.x);      // (its barrier also publishes tgt)
     stamp(5);
     for (uint32_t group = blockIdx.x; group < n_groups; group += n_fwd_blocks) {          // uniform over the workgroup: barriers inside
         const uint32_t ray_first = group * R;
@@ -385,7 +385,8 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss_short(LevelTab lt, Un
                 fwd_gather_tile<true>(lt, table, x, y, z, feat_save, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, slabs[wave], valid);
                 if constexpr (NARUTO_FWD_GATHER_PRIO != 0) __builtin_amdgcn_s_setprio(0);
                 stamp(2);
-                fwd_mlp_tile<true>(L, slabs[wave], x, y, z, nullptr, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, to);
+                if constexpr (kExactX3) fwd_mlp_tile_x3<true>(L, slabs[wave], x, y, z, nullptr, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, to);
+                else fwd_mlp_tile<true>(L, slabs[wave], x, y, z, nullptr, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, to);
             }
             if (valid) {
                 float* o = raw + (size_t)(t0 + (uint32_t)lane) * 5;

@@ -259,7 +259,10 @@ def test_render_fused_equals_the_three_operators(gpu, mode, n_samples_d, with_de
     # Same tile code; what can differ is which points share a 64-point tile (the operator chain tiles the flat point list, the fused
     # kernel tiles ray by ray): the OneBlob closed form / dense form is chosen per tile, and the two agree to ~1e-6.  When the
     # samples per ray are a multiple of 64 the tilings coincide and everything is bit-identical.
-    same_tiles = S_tot % 64 == 0
+    # (Round 5, exact mode: the operator chain's field query runs its matrix phase as three-piece bf16 products on the XDL pipe, the fused
+    # render's register-form tile -- rays of more than 64 samples -- keeps the fp32 matrix instruction: both within one fp32 rounding of the
+    # exact sums, 6e-8 apart (tools/fwd_lab.hip).  The bf16 mode runs the same chain in both and stays bit-identical.)
+    same_tiles = S_tot % 64 == 0 and mode != "fp32"
     for k in ("raw", "rgb", "depth", "disp_map", "acc_map", "depth_var", "uncert_map"):
         if same_tiles:
             assert torch.equal(a[k], b[k]), f"{k}: fused render differs from the operator chain ({mode}, S={S_tot})"

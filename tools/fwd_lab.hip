@@ -179,6 +179,102 @@ __global__ __launch_bounds__(256, 2) void k_mlp_only(BoxTab bt, NarutoParams p, 
     }
 }
 
+// ---- consumer alone, exact mode on the bf16 matrix instruction (three-piece operands, six products per K block): round 5 ----
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void k_mlp_only_x3(BoxTab bt, NarutoParams p, PointSrc ps, uint32_t M, const float* __restrict__ feat_save, const float* __restrict__ u_in,
+                                                           float* __restrict__ raw) {
+    __shared__ FwdLdsX3 L;
+    __shared__ FwdSlab slabs[4];
+    stage_fwd_weights_x3_via_lds<256>(L, reinterpret_cast<float*>(slabs), p, threadIdx.x);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hh = lane >> 5, j = lane & 31;
+    const uint32_t n_tiles = (M + 63u) / 64u;
+    for (uint32_t tile = blockIdx.x * 4u + wave; tile < n_tiles; tile += gridDim.x * 4u) {
+        const uint32_t m_raw = tile * 64u + lane;
+        const bool valid = m_raw < M;
+        const uint32_t m = valid ? m_raw : M - 1u;
+        float x, y, z;
+        load_point(ps, bt, m, x, y, z);
+        const uint32_t mA = tile * 64u + (uint32_t)j, mB = mA + 32u;
+#pragma unroll
+        for (int T = 0; T < kLevels; ++T) {
+            const float* fs = feat_save + (size_t)T * M * 2u;
+            slabs[wave].feat[T][0][lane] = mA < M ? fs[mA * 2u + hh] : 0.0f;
+            slabs[wave].feat[T][1][lane] = mB < M ? fs[mB * 2u + hh] : 0.0f;
+        }
+        FwdTileOut to;
+        fwd_mlp_tile_x3<true>(L, slabs[wave], x, y, z, nullptr, M, mA, mB, lane, to);
+        if (valid) {
+            float* o = raw + (size_t)m * 5;
+            o[0] = to.rgb[0]; o[1] = to.rgb[1]; o[2] = to.rgb[2]; o[3] = to.sdf; o[4] = u_in[m];
+        }
+    }
+}
+// the same loop around the shipped fp32 chain (fwd_mlp_tile, features through the slab): the like-for-like partner of k_mlp_only_x3
+__global__ __launch_bounds__(256, 2) void k_mlp_only_slab(BoxTab bt, NarutoParams p, PointSrc ps, uint32_t M, const float* __restrict__ feat_save, const float* __restrict__ u_in,
+                                                          float* __restrict__ raw) {
+    __shared__ FwdLds L;
+    __shared__ FwdSlab slabs[4];
+    stage_fwd_weights_via_lds<256>(L, reinterpret_cast<float*>(slabs), p, threadIdx.x);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hh = lane >> 5, j = lane & 31;
+    const uint32_t n_tiles = (M + 63u) / 64u;
+    for (uint32_t tile = blockIdx.x * 4u + wave; tile < n_tiles; tile += gridDim.x * 4u) {
+        const uint32_t m_raw = tile * 64u + lane;
+        const bool valid = m_raw < M;
+        const uint32_t m = valid ? m_raw : M - 1u;
+        float x, y, z;
+        load_point(ps, bt, m, x, y, z);
+        const uint32_t mA = tile * 64u + (uint32_t)j, mB = mA + 32u;
+#pragma unroll
+        for (int T = 0; T < kLevels; ++T) {
+            const float* fs = feat_save + (size_t)T * M * 2u;
+            slabs[wave].feat[T][0][lane] = mA < M ? fs[mA * 2u + hh] : 0.0f;
+            slabs[wave].feat[T][1][lane] = mB < M ? fs[mB * 2u + hh] : 0.0f;
+        }
+        FwdTileOut to;
+        fwd_mlp_tile<true>(L, slabs[wave], x, y, z, nullptr, M, mA, mB, lane, to);
+        if (valid) {
+            float* o = raw + (size_t)m * 5;
+            o[0] = to.rgb[0]; o[1] = to.rgb[1]; o[2] = to.rgb[2]; o[3] = to.sdf; o[4] = u_in[m];
+        }
+    }
+}
+
+// ---- the shipped flat kernel's shape (persistent 512-thread workgroups, two-phase tile) with the x3 chain in the matrix phase: round 5 ----
+template <int NT>
+__global__ __launch_bounds__(NT, 2) void k_query_fwd_x3(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps, uint32_t M, float* __restrict__ raw,
+                                                        float* __restrict__ feat_save) {
+    __shared__ FwdLdsX3 L;
+    __shared__ FwdSlab slabs[NT / 64];
+    stage_fwd_weights_x3_via_lds<NT>(L, reinterpret_cast<float*>(slabs), p, threadIdx.x);
+    __syncthreads();
+    constexpr uint32_t kW = NT / 64;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int j = lane & 31;
+    const uint32_t n_tiles = (M + 63u) / 64u;
+    const float2* __restrict__ table = reinterpret_cast<const float2*>(p.table);
+    for (uint32_t tile = blockIdx.x * kW + wave; tile < n_tiles; tile += gridDim.x * kW) {
+        const uint32_t m_raw = tile * 64u + lane;
+        const bool valid = m_raw < M;
+        const uint32_t m = valid ? m_raw : M - 1u;
+        float x, y, z;
+        load_point(ps, bt, m, x, y, z);
+        const float u = uncert_sample(ut, p.uncert_grid, x, y, z);
+        FwdTileOut to;
+        __builtin_amdgcn_s_setprio(NARUTO_FWD_GATHER_PRIO);
+        fwd_gather_tile<false>(lt, table, x, y, z, feat_save, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, slabs[wave], true);
+        __builtin_amdgcn_s_setprio(0);
+        fwd_mlp_tile_x3<true>(L, slabs[wave], x, y, z, nullptr, M, tile * 64u + (uint32_t)j, tile * 64u + (uint32_t)j + 32u, lane, to);
+        if (valid) {
+            float* o = raw + (size_t)m * 5;
+            o[0] = to.rgb[0]; o[1] = to.rgb[1]; o[2] = to.rgb[2]; o[3] = to.sdf; o[4] = u;
+        }
+    }
+}
+
 // ---- producer / consumer in one launch ----
 constexpr int kPairs = 4;
 template <int NBUF>
@@ -740,6 +836,39 @@ int main(int argc, char** argv) {
         const uint32_t blocks = std::min((n_tiles + 3u) / 4u, cus * 2u);
         const float t = time_us([&] { hipLaunchKernelGGL(lab::k_mlp_only, dim3(blocks), dim3(256), 0, 0, f->bt, p, ps, M, fs1, u1, raw2); });
         printf("mlp    k_mlp_only     2 waves/SIMD     %8.2f us\n", t);
+    }
+    {
+        const uint32_t blocks = std::min((n_tiles + 3u) / 4u, cus * 2u);
+        const float t = time_us([&] { hipLaunchKernelGGL(lab::k_mlp_only_slab, dim3(blocks), dim3(256), 0, 0, f->bt, p, ps, M, fs1, u1, raw2); });
+        printf("mlp    k_mlp_only_slab (fp32 chain, features through the slab) 2 waves/SIMD  %8.2f us\n", t);
+    }
+    float* raw3 = nullptr;
+    CK(hipMalloc(&raw3, (size_t)M * 20));
+    {
+        const uint32_t blocks = std::min((n_tiles + 3u) / 4u, cus * 2u);
+        const float t = time_us([&] { hipLaunchKernelGGL(lab::k_mlp_only_x3<2>, dim3(blocks), dim3(256), 0, 0, f->bt, p, ps, M, fs1, u1, raw3); });
+        printf("mlp    k_mlp_only_x3   (bf16 x 3 pieces, 6 products)           2 waves/SIMD  %8.2f us\n", t);
+        // distance to the fp32 chain (both are within fp32 rounding of the exact sums)
+        std::vector<float> a((size_t)M * 5), b((size_t)M * 5);
+        (void)hipMemcpy(a.data(), raw3, a.size() * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(b.data(), raw2, b.size() * 4, hipMemcpyDeviceToHost);
+        double mx[5] = {0, 0, 0, 0, 0}, sc[5] = {0, 0, 0, 0, 0};
+        for (size_t i = 0; i < (size_t)M; ++i) for (int c = 0; c < 5; ++c) { mx[c] = std::max(mx[c], (double)std::fabs(a[i * 5 + c] - b[i * 5 + c])); sc[c] = std::max(sc[c], (double)std::fabs(b[i * 5 + c])); }
+        printf("       x3 against the fp32 chain, max |difference| (scale): rgb %.3e %.3e %.3e (%.2f), sdf %.3e (%.2f)\n", mx[0], mx[1], mx[2], sc[0], mx[3], sc[3]);
+    }
+    if (M % 64u == 0u) {
+        for (int shape = 0; shape < 2; ++shape) {
+            float t;
+            if (shape == 0) t = time_us([&] { hipLaunchKernelGGL(lab::k_query_fwd_x3<512>, dim3(cus), dim3(512), 0, 0, f->lt, f->ut, f->bt, p, ps, M, raw3, fs1); });
+            else t = time_us([&] { hipLaunchKernelGGL(lab::k_query_fwd_x3<256>, dim3(std::min((n_tiles + 3u) / 4u, cus * 2u)), dim3(256), 0, 0, f->lt, f->ut, f->bt, p, ps, M, raw3, fs1); });
+            printf("x3     k_query_fwd_x3<%d> (two-phase tile, x3 chain)   %8.2f us   (base: the shipped fp32 kernel above)\n", shape == 0 ? 512 : 256, t);
+        }
+        std::vector<float> a((size_t)M * 5), b((size_t)M * 5);
+        (void)hipMemcpy(a.data(), raw3, a.size() * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(b.data(), raw0, b.size() * 4, hipMemcpyDeviceToHost);
+        double mx = 0;
+        for (size_t i = 0; i < a.size(); ++i) mx = std::max(mx, (double)std::fabs(a[i] - b[i]));
+        printf("       x3 kernel against the shipped kernel, max |difference| over raw: %.3e\n", mx);
     }
     auto compare = [&](const char* what, const float* a, const float* b, size_t n) {
         std::vector<uint32_t> ha(n), hb(n);

@@ -191,6 +191,16 @@ def kernel_table(tr, rays, cfg, iters: int):
     for name, ms in (("naruto_train_forward (eager)", fwd_ms), ("naruto_train_backward (eager)", bwd_ms),
                      ("k_query_fwd<color> as launched by the iteration (with the loss stage in the same launch when S % 64 == 0)", qit_ms)):
         rows.append({"kernel": name, "ms": round(ms, 5), "alg_bytes": 0, "alg_flops": 0, "GBps": 0.0, "TFLOPs": 0.0, "bound": None})
+    # what the iteration's forward launch actually evaluates: samples behind the end of a ray's band are skipped and their raw written as
+    # zeros (depth-ordered early termination) -- counted from the raw the launch above left (an evaluated sample's sdf is 0.0 with
+    # probability nil), charged SURVEY 8(d)'s 1 056 B each + 64 B per ray
+    try:
+        raw_t = ts.raw.reshape(N, S, 5)
+        n_eval = int((raw_t.abs().sum(dim=-1) > 0).sum().item())
+        it_bytes = n_eval * (16 * 8 * 8 + 32) + N * 64
+        rows[-1].update({"evaluated_samples": n_eval, "samples": int(M), "alg_bytes": int(it_bytes), "GBps": round(it_bytes / qit_ms / 1e6, 1)})
+    except Exception:
+        pass
     rows.append({"kernel": "(active sample fraction)", "ms": 0.0, "alg_bytes": 0, "alg_flops": 0, "GBps": 0.0, "TFLOPs": 0.0,
                  "bound": "hbm", "fraction": round(frac, 4)})
     return rows
@@ -866,6 +876,14 @@ def main():
             if g_.get("traffic") is not None:
                 g_["traffic_GBps"] = round(g_["traffic"] / g_["kernel_ms"] / 1e6, 1)
                 g_["traffic_frac"] = round(g_["traffic"] / g_["kernel_ms"] / 1e6 / HBM_PEAK_GBS, 4)
+            # the launch the TIMED STEP runs (the depth-ordered walk / the short-ray form: depth sampling, field query over the samples some
+            # consumer can see, loss stage, lattice encode in its tail workgroups), on the samples it actually evaluates
+            if it.get("evaluated_samples") is not None:
+                out["roofline_in_iteration"] = {"bound": "hbm", "kernel": "k_query_fwd_loss / k_query_fwd_loss_short as launched by the timed step "
+                                                "(with depth sampling, loss stage and the smoothness lattice's encode in the same launch)",
+                                                "kernel_ms": it["ms"], "evaluated_samples": it["evaluated_samples"], "samples": it["samples"],
+                                                "alg_bytes": it["alg_bytes"], "achieved": it["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                "frac": round(it["GBps"] / HBM_PEAK_GBS, 4)}
             # What actually binds the hash gather: the rate at which a CU's vector memory path takes RANDOM 64-byte lines -- out of L2 for
             # the shipped 6.5 MB table (one line per ~3 cycles and CU, whatever the occupancy: tools/gather_valu_overlap_bench.hip), out
             # of HBM for tables no cache holds (T = 2^22: 281 MB; tools/hbm_random_line_bench.hip).  Measured here, live, by a launch that
@@ -884,15 +902,16 @@ def main():
                 run = lambda: _lib.check(lib_.naruto_debug_random_lines(tb.data_ptr(), table_bytes, 64, sink.data_ptr(), CT.byref(n_lines), ops._stream()))
                 rl_ms = events_ms(run, 5)
                 rate = n_lines.value / (rl_ms * 1e-3)
-                lt_scale, lt_res, lt_size, lt_off = tr.model._handle().levels()
-                thresh = (4 << 20) if hbm_resident else (64 << 10)                            # one XCD's L2 / a CU's L1 and then some
-                n_big = sum(1 for sz in lt_size if sz * 8 > thresh)
-                lines_model = n_rays * S_tot * n_big * 4                                      # four lines per (sample, level): x-neighbour corners share one
                 g_ = out["roofline_gather"]
+                # (round 5: the four-lines-per-sample-and-level MODEL is gone -- it put the kernel at 1.3 of a roof, i.e. it overcounted what
+                # ray neighbours share; the kernel's line count is now MEASURED: requests arriving at the L2 per launch, TCC_REQ_sum from a
+                # rocprofv3 --pmc pass over eager launches (tools/profile_round.sh), for HBM-resident tables also the fabric-side traffic / 64)
                 rr = {"lines_per_s": round(rate, 1), "TBps_of_64B_lines": round(rate * 64 / 1e12, 3), "served_from": "HBM" if hbm_resident else "L2",
-                      "measured": "naruto_debug_random_lines over this table (32 random lines per load instruction, 8 loads in flight per wave, 8 waves per SIMD), HIP events",
-                      "levels_counted": n_big, "lines_per_launch_model": int(lines_model),
-                      "frac_model": round(lines_model / (g_["kernel_ms"] * 1e-3) / rate, 4)}
+                      "measured": "naruto_debug_random_lines over this table (32 random lines per load instruction, 8 loads in flight per wave, 8 waves per SIMD), HIP events"}
+                if gprof.get("tcc_req") is not None:
+                    rr["l2_requests_per_launch_pmc"] = int(gprof["tcc_req"])
+                    rr["frac_l2_requests"] = round(gprof["tcc_req"] / (g_["kernel_ms"] * 1e-3) / rate, 4)
+                    rr["l2_requests_source"] = f"profiles/{gsrc} (TCC_REQ_sum: every request the L1s pass on, gathers and streamed rows alike)"
                 if hbm_resident and g_.get("traffic") is not None:
                     rr["lines_per_launch_pmc"] = int(g_["traffic"] // 64)
                     rr["frac_pmc"] = round(g_["traffic"] / 64 / (g_["kernel_ms"] * 1e-3) / rate, 4)

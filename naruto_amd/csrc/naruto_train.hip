@@ -202,6 +202,12 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
         else tv_loss_list_body(a.tv, a.tv_feat, a.tv_d_list, a.tv_scale_dev, a.tv_scale_host, a.tv_partial, blockIdx.x - n_fwd_blocks, a.n_tv_blocks, red);
         return;
     }
+    // The loss stage's and the depth sampling's arguments go through LDS (round 5): kept in scalar registers next to the tile's own state they
+    // were what this kernel spilled -- 214 scalar registers parked in vector lanes around the tile loop -- although each is read once or
+    // twice per ray; from LDS a field costs one broadcast read where it is used.
+    __shared__ LossStageArgs a_s;
+    __shared__ WalkExtra wx_s;
+    if (threadIdx.x == 0) { a_s = a; wx_s = wx; }
     if constexpr (SPLIT && BF) stage_fwd_weights_bf_via_lds<256>(L, reinterpret_cast<float*>(slabs), p, threadIdx.x);
     else if constexpr (SPLIT) stage_fwd_exact<256, sizeof(slabs)>(L, slabs, p, threadIdx.x);
     else if constexpr (BF) stage_fwd_weights_bf<256>(L, p, threadIdx.x);
@@ -223,7 +229,8 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
         const uint32_t task = group * (uint32_t)kRaysPerBlock + (uint32_t)wave;
         if (task < a.n_rays) {
             if constexpr (SPLIT) if (wx.on) {
-                sample_z_ray(task, wx.sa.target_d, wx.sa.near_, wx.sa.far_, wx.sa.nu, wx.sa.nr, wx.sa.range_d, wx.sa.rand, wx.sa.rng, wx.sa.z_vals, rs.c0, rs.c1, lane);
+                const SampleArgs& sa = wx_s.sa;
+                sample_z_ray(task, sa.target_d, sa.near_, sa.far_, sa.nu, sa.nr, sa.range_d, sa.rand, sa.rng, sa.z_vals, rs.c0, rs.c1, lane);
                 __threadfence_block();
             }
             EeState ees{false, 0.0f, 0.0f, 0.0f};
@@ -263,12 +270,12 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
                 rs.z[s] = ps.z_vals[(size_t)task * S + s];
             }
             wave_lds_sync();
-            loss_stage_ray(a, rs, task, lane, terms[wave]);
+            loss_stage_ray(a_s, rs, task, lane, terms[wave]);
         } else {
             loss_stage_no_ray(lane, terms[wave]);
         }
         __syncthreads();
-        loss_stage_row(a, terms, group);
+        loss_stage_row(a_s, terms, group);
         __syncthreads();                                   // terms are rewritten by the next group
     }
 }

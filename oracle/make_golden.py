@@ -394,6 +394,20 @@ def case_extract_mesh(name, hash_size, table_amp, seed, voxel):
     print(f"{name}: ok, volume {out['vol'].shape}, {len(out['verts_index'])} vertices, {len(out['faces'])} triangles, isolevel {iso:.4f}, gap {gap:.2e}")
 
 
+def case_state_dict(name, hash_size, seed):
+    """The reference model's own state_dict -- what CoSLAMNaruto.save_ckpt / load_ckpt write and read (coslam.py:494-517) --: key -> shape.
+    Every array is the integer shape of the tensor stored under that key (the key set IS the fixture; tests/test_host.py holds the HIP
+    module's state_dict to it)."""
+    cfg = C.office0_config()
+    cfg["grid"]["hash_size"] = hash_size
+    ref, ora, w, dims = build_pair(cfg, 0.25, seed)
+    sd = ref.state_dict()
+    out = {k: np.asarray(tuple(v.shape), dtype=np.int64) for k, v in sd.items()}
+    assert len(out) == len(sd) and "uncert_grid" in out and "embed_fn.params" in out
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: {len(out)} state_dict keys", sorted(out))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -408,6 +422,7 @@ def main():
     case_active_ray("g8_active_ray", 8)
     case_planner_aggregation("g9_planner_aggregation", 9)
     case_extract_mesh("g10_extract_mesh", 12, 0.25, 10, 0.3)
+    case_state_dict("g11_state_dict_t12", 12, 11)
 
 
 if __name__ == "__main__":

@@ -67,8 +67,14 @@ def test_hot_path_refuses_cpu_tensors(built_lib):
     m.get_uncert_grid(0.1)
     with pytest.raises(RuntimeError, match="no CPU implementation"):
         m.query_sdf(torch.rand(10, 3))
-    # state_dict keeps the reference's key set, incl. the aliased top-level nets
-    keys = set(m.state_dict().keys())
+    # state_dict keeps the REFERENCE MODEL's own key set and shapes -- recorded from JointEncodingNaruto.state_dict() by oracle/make_golden.py
+    # (fixture g11: what CoSLAMNaruto.save_ckpt / load_ckpt exchange, coslam.py:494-517) --, incl. the aliased top-level nets
+    g11 = H.load_golden("g11_state_dict_t12")
+    sd = m.state_dict()
+    assert set(sd.keys()) == set(g11.keys()), set(sd.keys()) ^ set(g11.keys())
+    for k, shape in g11.items():
+        assert tuple(sd[k].shape) == tuple(int(v) for v in shape), (k, tuple(sd[k].shape), shape)
+    keys = set(sd.keys())
     want = {"uncert_grid", "embed_fn.params", "embedpos_fn.params",
             "decoder.sdf_net.model.0.weight", "decoder.sdf_net.model.2.weight",
             "decoder.color_net.model.0.weight", "decoder.color_net.model.2.weight",
@@ -262,3 +268,13 @@ def test_no_kernel_spills_to_scratch(built_lib):
               "k_render_fwd_packed<false>": 256, "k_render_fwd_packed<true>": 256, "k_hash_scatter_lds": 128, "k_query_bwd": 512, "k_query_bwd_bf": 512}
     for k, b in budget.items():
         assert res[k]["vgpr_count"] <= b, (k, res[k])            # .vgpr_count is the unified total (architectural + accumulation registers)
+    # Spilled SCALAR registers (round 5): they live in lanes of a vector register -- v_writelane / v_readlane around the code that needs the
+    # scalar file -- not in memory, so they cost issue slots, not traffic; the kernels of the mapping iteration are held to a budget so that
+    # a change that doubles them is seen.  (End of round 4: k_query_fwd_loss<false,true> 214, k_hash_scatter_lds 186, k_query_bwd 18; the
+    # walk's loss-stage / sampling arguments now go through LDS instead of being held in scalar registers across the tile loop.)
+    sgpr_budget = {"k_query_fwd_loss<false,true>": 128, "k_query_fwd_loss<true,true>": 128, "k_query_fwd_loss_short<false>": 128, "k_query_fwd_loss_short<true>": 128,
+                   "k_hash_scatter_lds": 128, "k_query_bwd": 32, "k_query_bwd_bf": 32, "k_loss_bwd_fused": 0, "k_bwd_finish": 0,
+                   "k_query_fwd<true,512,false>": 16, "k_query_fwd<true,256,false>": 16}
+    for k, b in sgpr_budget.items():
+        assert k in res, f"{k} not found in the code object"
+        assert res[k].get("sgpr_spill_count", 0) <= b, (k, res[k])

@@ -50,4 +50,8 @@ NARUTO_FWD_PACKED=2 timeout 300 python tools/fwd_timeline.py office0_2048x128 > 
 NARUTO_FWD_PACKED=3 timeout 600 python tools/time_trained_step.py > gpurun_out/${TAG}_trained_step.txt 2>&1
 timeout 600 python tools/time_trained_step.py > gpurun_out/${TAG}_trained_step_flat.txt 2>&1
 timeout 1500 python tests/accuracy_study.py --out gpurun_out/${TAG}_accuracy_study.json > gpurun_out/${TAG}_accuracy_study.txt 2>&1
+# round 5: per-phase timelines of the short-ray forward and of the scatter's workgroups, the forward lab (fp32 chain against the x3 chain)
+timeout 300 python tools/short_timeline.py 2148 > gpurun_out/${TAG}_short_timeline.txt 2>&1
+timeout 300 python tools/scatter_timeline.py > gpurun_out/${TAG}_scatter_timeline.txt 2>&1
+[ -x tools/fwd_lab ] && timeout 300 tools/fwd_lab > gpurun_out/${TAG}_fwd_lab.txt 2>&1
 git -C $R rev-parse HEAD > gpurun_out/${TAG}_commit.txt 2>/dev/null || true

@@ -2,6 +2,7 @@
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), as summarised by prof_summary.py.
 
     python tools/pmc_json.py <workload> <fetch.txt> <write.txt> [<workload> <fetch.txt> <write.txt> ...] > profiles/r02_pmc.json
+    (round 5: a <write.txt> given as "<write.txt>,<tcc_req.txt>" adds tcc_req = TCC_REQ_sum per launch -- the requests reaching the L2)
 
 The output is keyed by workload (bench.py --workload), then by bench.py's kernel-table row.
 
@@ -53,7 +54,9 @@ out = {"note": "per-dispatch averages, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE i
 args = sys.argv[1:]
 for k in range(0, len(args) - 2, 3):
     wl = args[k]
-    fetch, write = parse(args[k + 1]), parse(args[k + 2])
+    wpath, _, tpath = args[k + 2].partition(",")
+    fetch, write = parse(args[k + 1]), parse(wpath)
+    tcc = parse(tpath) if tpath else {}
     res = {}
     for label, keys in NAMES.items():
         f = sum(v for kk, v in fetch.items() if any(x in kk for x in keys))
@@ -62,5 +65,8 @@ for k in range(0, len(args) - 2, 3):
             continue
         res[label] = {"fetch_bytes": int(f * 1024), "fetch_bytes_x2": int(2 * f * 1024), "write_bytes": int(w * 1024),
                       "traffic_bytes": int((f + w) * 1024)}
+        q = sum(v for kk, v in tcc.items() if any(x in kk for x in keys))
+        if q:
+            res[label]["tcc_req"] = int(q)
     out[wl] = res
 print(json.dumps(out, indent=1))

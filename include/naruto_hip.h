@@ -178,6 +178,12 @@ typedef struct NarutoExtraPoints {
  * or its MLP_ONLY phase) then replaces naruto_train_finalize | composite backward | compaction by the same single launch, whose
  * extra workgroup turns the sums into losses[0..7] and the total.  Do not call naruto_train_finalize in addition. */
 #define NARUTO_TRAIN_BWD_SUMS_GIVEN 32u
+/* ... and its five-launch form (round 5): naruto_train_forward(finalize = NARUTO_TRAIN_FWD_SUMS_TV_LATER) stops at this rank's sums like
+ * finalize = 0, but where the launch plan allows it the forward samples its own depths and only ENCODES the smoothness lattice (no
+ * k_sample_encode launch); naruto_train_backward(NARUTO_TRAIN_BWD_SUMS_GIVEN | NARUTO_TRAIN_BWD_TV_MOVED) then evaluates the term in its
+ * first launch and adds its value to losses[8] / losses[9] at its end.  losses[8] is 0 in between.  Both must be given together. */
+#define NARUTO_TRAIN_FWD_SUMS_TV_LATER 3
+#define NARUTO_TRAIN_BWD_TV_MOVED 64u
 /* The model's sub-modules called on their own (forward only; the query entry points above never need them -- they evaluate all of
  * this in registers).  naruto_oneblob_fwd = embedpos_fn(x) (tcnn OneBlob, 16 bins): x [M,3] -> out [M,48].
  * naruto_decoder_fwd, by `part`:

@@ -55,6 +55,7 @@ BWD_OVERWRITE_WEIGHT_GRADS = 1
 BWD_OVERWRITE_TABLE_GRAD = 2
 TRAIN_BWD_MLP_ONLY, TRAIN_BWD_TABLE_ONLY = 4, 8
 TRAIN_FWD_DEFER_TAIL, TRAIN_BWD_DEFERRED_TAIL, TRAIN_BWD_SUMS_GIVEN = 2, 16, 32
+TRAIN_FWD_SUMS_TV_LATER, TRAIN_BWD_TV_MOVED = 3, 64
 ADAM_ADVANCE = 1
 ADAM_ZERO_GRAD = 2
 

@@ -1123,7 +1123,8 @@ int naruto_train_forward(const NarutoField* f, const NarutoParams* p, const Naru
     TvArgs tva = tv_args(t);
     tva.cap = list_cap(M + w.n3);
     const BwdWs bw = bwd_ws(f, w.bwd, list_cap(M + w.n3));
-    const bool deferred_ = finalize == NARUTO_TRAIN_FWD_DEFER_TAIL && tail_rides_in_backward(t);
+    // (the smoothness term is left to the backward: the single-process deferred tail, or the data-parallel SUMS_TV_LATER form)
+    const bool deferred_ = (finalize == NARUTO_TRAIN_FWD_DEFER_TAIL || finalize == NARUTO_TRAIN_FWD_SUMS_TV_LATER) && tail_rides_in_backward(t);
     WalkExtra wx{};
     if (tv_moved(f, t, deferred_)) {
         wx.on = 1u;
@@ -1147,7 +1148,7 @@ int naruto_train_forward(const NarutoField* f, const NarutoParams* p, const Naru
     const bool deferred = finalize == NARUTO_TRAIN_FWD_DEFER_TAIL && tail_rides_in_backward(t);
     if (int rc = ray_lds_attr()) return rc;
     bool loss_done = false;
-    if (int rc = launch_train_query(f, p, t, st, &a, &loss_done, &wx, deferred)) return rc;
+    if (int rc = launch_train_query(f, p, t, st, &a, &loss_done, &wx, deferred_)) return rc;
     if (!loss_done) {
         static const int dbg_ls_roles = getenv("NARUTO_DEBUG_LOSS_STAGE_ROLES") ? atoi(getenv("NARUTO_DEBUG_LOSS_STAGE_ROLES")) : 3;     // profiling knob: 1 rays, 2 lattice
         if (dbg_ls_roles == 1) a.n_tv_blocks = 0;
@@ -1156,8 +1157,9 @@ int naruto_train_forward(const NarutoField* f, const NarutoParams* p, const Naru
         if (int rc = check_launch("loss_stage")) return rc;
     }
     if (deferred) return NARUTO_OK;                          // the tail is a workgroup of the backward's first launch
-    const uint32_t n_rows = loss_done ? loss_rows(f, t, deferred) : a.n_ray_blocks;      // rows of partial sums the loss stage left
-    LossTailArgs tl = loss_tail_args(t, w, n_rows, a.n_tv_blocks, tva.inv_p3, finalize != 0);
+    const uint32_t n_rows = loss_done ? loss_rows(f, t, deferred_) : a.n_ray_blocks;      // rows of partial sums the loss stage left
+    // (SUMS_TV_LATER with the term moved: nothing has evaluated it yet -- the tail writes losses[8] = 0, the backward adds the value)
+    LossTailArgs tl = loss_tail_args(t, w, n_rows, wx.on != 0u ? 0u : a.n_tv_blocks, tva.inv_p3, finalize == 1);
     if (n_rows > 4u * kTailRows) {          // large batch: fold the per-workgroup rows first
         hipLaunchKernelGGL(k_loss_fold, dim3(kTailRows), dim3(64), 0, st, tl.partials, n_rows, w.fold);
         if (int rc = check_launch("loss_fold")) return rc;
@@ -1285,7 +1287,9 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
     // the smoothness term moved into this backward only where the FORWARD was told to defer its tail (NARUTO_TRAIN_BWD_DEFERRED_TAIL): with
     // NARUTO_TRAIN_BWD_SUMS_GIVEN (data parallel, the autograd node) the forward ran k_sample_encode, evaluated the term itself and its
     // value is already in losses[8] -- evaluating it here again would count it twice in the total (round-4 advisor finding)
-    const bool moved = (flags & NARUTO_TRAIN_BWD_DEFERRED_TAIL) != 0u && deferred && tv_moved(f, t, true);
+    const bool moved = (flags & (NARUTO_TRAIN_BWD_DEFERRED_TAIL | NARUTO_TRAIN_BWD_TV_MOVED)) != 0u && deferred && tv_moved(f, t, true);
+    if ((flags & NARUTO_TRAIN_BWD_TV_MOVED) != 0u && !sums_given && !table_only)
+        return fail(NARUTO_ERR_INVALID, "train_backward: NARUTO_TRAIN_BWD_TV_MOVED belongs to NARUTO_TRAIN_BWD_SUMS_GIVEN (a forward with NARUTO_TRAIN_FWD_SUMS_TV_LATER)");
     if (deferred) {
         const bool smooth_d = t->smooth_points != 0 && (g->table != nullptr || opt != nullptr);
         const BwdWs bwd = bwd_ws(f, w.bwd, list_cap(M + w.n3));
@@ -1297,7 +1301,7 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
         fa.n_front = smooth_d ? w.n3 : 0u; fa.n_list = bwd.n_total;
         // (the term moved into this launch: the tail cannot see its partial sums -- the last launch of the backward adds the value, TvLate)
         // rows the forward's loss stage left: the plan's, when this backward belongs to a forward that deferred its tail (sums_given: unused)
-        fa.n_rows = (flags & NARUTO_TRAIN_BWD_DEFERRED_TAIL) != 0u ? loss_rows(f, t, true) : fa.n_ray_blocks;
+        fa.n_rows = (flags & (NARUTO_TRAIN_BWD_DEFERRED_TAIL | NARUTO_TRAIN_BWD_TV_MOVED)) != 0u ? loss_rows(f, t, true) : fa.n_ray_blocks;
         fa.tail = loss_tail_args(t, w, fa.n_rows, (t->smooth_points != 0 && !moved) ? w.n_tv_blocks : 0u, tv_args(t).inv_p3, 1);
         fa.sums_given = sums_given ? 1 : 0;
         // one more workgroup prepares the MLP backward's weight images (the parameters do not change before k_query_bwd reads them)

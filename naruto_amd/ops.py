@@ -864,7 +864,10 @@ class TrainStep:
             st = _stream()
             if self._zero_table:
                 self.grads["table"].zero_()
-            fin = 0 if self.group is not None else (_lib.TRAIN_FWD_DEFER_TAIL if _defer_tail else 1)
+            # data parallel: stop at this rank's sums; with the fused first launch of the backward the smoothness term is left to it
+            # (five launches + the collectives instead of six: no k_sample_encode)
+            fin = ((_lib.TRAIN_FWD_SUMS_TV_LATER if self.fuse_tail else 0) if self.group is not None
+                   else (_lib.TRAIN_FWD_DEFER_TAIL if _defer_tail else 1))
             check(lib.naruto_train_forward(self.handle.ptr, C.byref(self.ps), C.byref(t), fin, st), "naruto_train_forward")
 
     def run_backward(self, phase: int = 0, _deferred_tail: bool = False):
@@ -875,7 +878,7 @@ class TrainStep:
         with _on_device(self.device):
             st = _stream()
             # data parallel: self.sums holds the all-reduced sums; finalize + composite backward + compaction are one launch
-            given = _lib.TRAIN_BWD_SUMS_GIVEN if (self.group is not None and self.fuse_tail) else 0
+            given = (_lib.TRAIN_BWD_SUMS_GIVEN | _lib.TRAIN_BWD_TV_MOVED) if (self.group is not None and self.fuse_tail) else 0
             if phase != 0:
                 assert self.opt is None, "the fused optimiser runs the backward in one piece"
                 if phase == 1 and self.group is not None and not given:

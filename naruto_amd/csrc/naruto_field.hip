@@ -73,24 +73,39 @@ struct WSrcLds {
     __device__ __forceinline__ float sdf_w1(int i, int u) const { return raw[kRawS1 + i * kRawS1Ld + u]; }
     __device__ __forceinline__ float col_w1(int e) const { return p.col_w1[e]; }
 };
-// hop 1: the three weight matrices, coalesced, into the raw area (all of a thread's loads in flight together); ends with a barrier
+// hop 1: the three weight matrices, coalesced, into the raw area -- as two steps, so that a kernel with latency of its own to spend (the
+// rays' depth sampling) can put it between the loads and the stores.  The loads are relaxed WAVEFRONT-scope atomic loads: plain
+// global_load_dword in the ISA, but ordered memory references for the compiler, which otherwise sinks these "invariant" loads down to
+// their first use (the stores) and the overlap with it.
+template <int NT>
+struct RawWeights {
+    static constexpr int n0 = kHidden * kInSdf, n1 = kHidden * kInCol, n2 = kOut * kHidden;
+    static constexpr int q0 = (n0 + NT - 1) / NT, q1 = (n1 + NT - 1) / NT, q2 = (n2 + NT - 1) / NT;
+    uint32_t v0[q0], v1[q1], v2[q2];
+    __device__ __forceinline__ static uint32_t ld(const float* ptr) { return __hip_atomic_load(reinterpret_cast<const uint32_t*>(ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+    __device__ __forceinline__ void load(const NarutoParams& p, int tid) {
+#pragma unroll
+        for (int q = 0; q < q0; ++q) { const int g = q * NT + tid; v0[q] = g < n0 ? ld(p.sdf_w0 + g) : 0u; }
+#pragma unroll
+        for (int q = 0; q < q1; ++q) { const int g = q * NT + tid; v1[q] = g < n1 ? ld(p.col_w0 + g) : 0u; }
+#pragma unroll
+        for (int q = 0; q < q2; ++q) { const int g = q * NT + tid; v2[q] = g < n2 ? ld(p.sdf_w1 + g) : 0u; }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ raw, int tid) const {
+#pragma unroll
+        for (int q = 0; q < q0; ++q) { const int g = q * NT + tid; if (g < n0) raw[g + g / kInSdf] = __uint_as_float(v0[q]); }           // row i starts at i * 81
+#pragma unroll
+        for (int q = 0; q < q1; ++q) { const int g = q * NT + tid; if (g < n1) raw[kRawC0 + g] = __uint_as_float(v1[q]); }
+#pragma unroll
+        for (int q = 0; q < q2; ++q) { const int g = q * NT + tid; if (g < n2) raw[kRawS1 + g + g / kHidden] = __uint_as_float(v2[q]); }
+    }
+};
+// (both steps + the barrier behind them)
 template <int NT>
 __device__ __forceinline__ void fetch_raw_weights(float* __restrict__ raw, const NarutoParams& p, int tid) {
-    constexpr int n0 = kHidden * kInSdf, n1 = kHidden * kInCol, n2 = kOut * kHidden;
-    constexpr int q0 = (n0 + NT - 1) / NT, q1 = (n1 + NT - 1) / NT, q2 = (n2 + NT - 1) / NT;
-    float v0[q0], v1[q1], v2[q2];
-#pragma unroll
-    for (int q = 0; q < q0; ++q) { const int g = q * NT + tid; v0[q] = g < n0 ? p.sdf_w0[g] : 0.0f; }
-#pragma unroll
-    for (int q = 0; q < q1; ++q) { const int g = q * NT + tid; v1[q] = g < n1 ? p.col_w0[g] : 0.0f; }
-#pragma unroll
-    for (int q = 0; q < q2; ++q) { const int g = q * NT + tid; v2[q] = g < n2 ? p.sdf_w1[g] : 0.0f; }
-#pragma unroll
-    for (int q = 0; q < q0; ++q) { const int g = q * NT + tid; if (g < n0) raw[g + g / kInSdf] = v0[q]; }           // row i starts at i * 81
-#pragma unroll
-    for (int q = 0; q < q1; ++q) { const int g = q * NT + tid; if (g < n1) raw[kRawC0 + g] = v1[q]; }
-#pragma unroll
-    for (int q = 0; q < q2; ++q) { const int g = q * NT + tid; if (g < n2) raw[kRawS1 + g + g / kHidden] = v2[q]; }
+    RawWeights<NT> w;
+    w.load(p, tid);
+    w.store(raw, tid);
     __syncthreads();
 }
 
@@ -785,6 +800,11 @@ __device__ __forceinline__ void stage_fwd_exact(FwdLds& L, void* raw, const Naru
     if constexpr (RAW_BYTES >= kFwdRawFloats * sizeof(float)) stage_fwd_weights_via_lds<NT>(L, reinterpret_cast<float*>(raw), p, tid);
     else stage_fwd_weights<NT>(L, p, tid);
 }
+// hop 2 alone: the raw area already holds the weights (RawWeights::store + a barrier by the caller)
+template <int NT>
+__device__ __forceinline__ void stage_fwd_exact_from_raw(FwdLds& L, const float* raw, const NarutoParams& p, int tid) { stage_fwd_weights_from<NT>(L, WSrcLds{raw, p}, tid); }
+template <int NT>
+__device__ __forceinline__ void stage_fwd_exact_from_raw(FwdLdsX3& L, const float* raw, const NarutoParams& p, int tid) { stage_fwd_weights_x3_from<NT>(L, WSrcLds{raw, p}, tid); }
 template <int NT, size_t RAW_BYTES>
 __device__ __forceinline__ void stage_fwd_exact(FwdLdsX3& L, void* raw, const NarutoParams& p, int tid) {
     if constexpr (RAW_BYTES >= kFwdRawFloats * sizeof(float)) stage_fwd_weights_x3_via_lds<NT>(L, reinterpret_cast<float*>(raw), p, tid);

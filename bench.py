@@ -539,17 +539,18 @@ def mapping_iter_ms(mlp: str, dev, steps: int, warmup: int):
         cfg, tr, store, smp, current, poses, vol, _dims = ba_scene(mlp, active, dev)
         ba = FusedBA(tr, store, smp, max_poses=256, use_graph=True)
         n_cur, n_train = ba.prepare(current, poses, vol if active else None)
-        for i in range(warmup):
-            ba.iteration(i)
+        iters = int(cfg["mapping"]["iters"])       # iteration index within a global_BA call: 1 in `iters` is a call's first (it assembles its own
+        for i in range(warmup):                    # batch; the others find theirs prepared by the previous iteration's last launch), every 5th steps the grid
+            ba.iteration(i % iters)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         i = 0
         while time.perf_counter() - t0 < PREWARM_MS * 1e-3:
             for _ in range(16):
-                ba.iteration(i)
+                ba.iteration(i % iters)
                 i += 1
             torch.cuda.synchronize()
-        ms = timed_chunks(lambda k: ba.iteration(k), 5 * steps)
+        ms = timed_chunks(lambda k: ba.iteration(k % iters), 5 * steps)
         tr.model.check_asserts(block=True)
         out["active_ray_on" if active else "active_ray_off"] = {"ms": round(ms, 4), "rays_per_iteration": n_train, "rays_per_s": round(n_train / ms * 1e3, 1)}
         del ba, tr, store, smp
@@ -568,13 +569,14 @@ def run_ba_iter(args, dev):
     for mode in ("graph", "eager"):
         ba = FusedBA(tr, store, smp, max_poses=256, use_graph=(mode == "graph"))
         n_cur, n_train = ba.prepare(current, poses, vol if args.active_ray else None)
+        iters = int(cfg["mapping"]["iters"])       # 1 in `iters` iterations is a global_BA call's first (assembles its own batch)
         for i in range(args.warmup):
-            ba.iteration(i)
+            ba.iteration(i % iters)
         tr.model.check_asserts(block=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            ba.iteration(i)
+            ba.iteration(i % iters)
         torch.cuda.synchronize()
         res[mode] = (time.perf_counter() - t0) / args.steps * 1e3
         tr.model.check_asserts(block=True)

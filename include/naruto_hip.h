@@ -441,6 +441,10 @@ typedef struct NarutoFusedAdam {
     float lr[5], eps[5], weight_decay[5];
     float beta1, beta2;
     const int32_t* step_dev;              /* device int32: this step's 1-based number                               */
+    /* optional (round 5): the NEXT iteration's ray batch -- naruto_assemble_rays' work rides in the launch that finishes the gradients
+     * (nothing of this iteration reads the ray buffers any more by then; a device-side rng is read AFTER this iteration's forward
+     * advanced it, i.e. it keys the next iteration's draw).  NULL: off. */
+    const struct NarutoRayBatch* next_batch;
 } NarutoFusedAdam;
 size_t naruto_train_workspace(const NarutoField* f, const NarutoTrainStep* t);
 int naruto_train_forward(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, int finalize, void* stream);

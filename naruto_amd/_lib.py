@@ -71,7 +71,7 @@ class NarutoRayBatch(C.Structure):
 class NarutoFusedAdam(C.Structure):
     _fields_ = [("param", C.c_void_p * 5), ("exp_avg", C.c_void_p * 5), ("exp_avg_sq", C.c_void_p * 5),
                 ("lr", C.c_float * 5), ("eps", C.c_float * 5), ("weight_decay", C.c_float * 5),
-                ("beta1", C.c_float), ("beta2", C.c_float), ("step_dev", C.c_void_p)]
+                ("beta1", C.c_float), ("beta2", C.c_float), ("step_dev", C.c_void_p), ("next_batch", C.c_void_p)]
 
 
 class NarutoTrainStep(C.Structure):

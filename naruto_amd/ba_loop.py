@@ -31,7 +31,7 @@ from .trainer import MappingTrainer
 
 class FusedBA:
     def __init__(self, trainer: MappingTrainer, store: KeyFrameStoreHIP, sampler: Optional[ActiveRaySamplerHIP] = None,
-                 max_poses: int = 4096, use_graph: bool = True, one_launch_prologue: Optional[bool] = None):
+                 max_poses: int = 4096, use_graph: bool = True, one_launch_prologue: Optional[bool] = None, prefetch: Optional[bool] = None):
         assert trainer.direct and trainer.group is None, "FusedBA drives the single-process fused trainer (MappingTrainer(fused_adam=True))"
         self.trainer, self.store, self.sampler = trainer, store, sampler
         self.config = trainer.config
@@ -42,6 +42,12 @@ class FusedBA:
         # multiplies on ONE CU) where k_assemble_rays spreads them over 34 -- 0.210 against 0.193 ms per iteration: OFF by default
         # (NARUTO_BA_ONE_LAUNCH_PROLOGUE=1 or the argument switch it on; same rays either way, tested)
         self.one_launch_prologue = (os.environ.get("NARUTO_BA_ONE_LAUNCH_PROLOGUE", "0") == "1") if one_launch_prologue is None else bool(one_launch_prologue)
+        # PREFETCH (round 5, on by default; NARUTO_BA_PREFETCH=0 or the argument switch it off): the ray assembly of iteration i + 1 rides in the
+        # LAST launch of iteration i (k_bwd_finish_next: NarutoFusedAdam.next_batch) -- by then nothing reads the ray buffers any more and the
+        # iteration counter that keys the draw has been advanced -- so only the FIRST iteration of a global_BA call launches k_assemble_rays
+        # itself.  Same batches, same trajectory (tests: the graph twin prefetches, the eager twin does not).
+        self.prefetch = (os.environ.get("NARUTO_BA_PREFETCH", "1") != "0") if prefetch is None else bool(prefetch)
+        self._next_batch = None
         mp = self.config['mapping']
         self.active = sampler is not None
         self.sample_num = sampler.oversample_num if self.active else int(mp['sample'])
@@ -71,6 +77,27 @@ class FusedBA:
             n_cur = min(n_valid_cur, n_cur)
         n_train = self.sampler.n_out(n_cur) if self.active else self.sample_num + n_cur
         return n_cur, n_train
+
+    def _later_prologue(self, n_cur: int):
+        """With prefetch: what an iteration that finds its batch assembled still has to launch (the selection), or None."""
+        if not self.active:
+            return None
+        sampler = self.sampler
+
+        def prologue(rays_o, rays_d, target_rgb, target_d):
+            sampler.sample_rays(*self._stage, n_cur, None, self.bbox, out=(rays_o, rays_d, target_rgb, target_d), workspace=self._ws)
+        return prologue
+
+    def _arm_prefetch(self, n_cur: int, bufs, train_step):
+        """Point the fused optimiser's next_batch at the draw of the NEXT iteration (into the stage when active rays select from it, else
+        straight into the iteration's own input buffers)."""
+        out = self._stage if self.active else bufs
+        b, keep = self.store.next_batch_struct(self.sample_num, self.current, self.poses, self.min_pixels_cur, out, filter_depth=self.filter_depth,
+                                               rng=self.trainer.iter_state, dyn=self.dyn, n_cur=n_cur, n_cur_pop=self._n_cur_pop)
+        assert train_step.opt is not None, "prefetch needs the optimiser in the backward (MappingTrainer(fused_adam=True))"
+        self._next_batch = (b, keep)
+        import ctypes as C
+        train_step.opt.next_batch = C.cast(C.pointer(b), C.c_void_p)
 
     def _prologue(self, n_cur: int):
         store, sampler = self.store, self.sampler
@@ -130,13 +157,21 @@ class FusedBA:
                 self._stage = (torch.empty(n_stage, 3, **f32), torch.empty(n_stage, 3, **f32), torch.empty(n_stage, 3, **f32), torch.empty(n_stage, 1, **f32))
                 self._ws = torch.empty(self.sampler.workspace_elems(n_stage), dtype=torch.int32, device=dev)
             self._pro = self._prologue(n_cur)
+            self._pro_later = self._later_prologue(n_cur) if self.prefetch else self._pro
             if self.use_graph:
-                self.trainer.capture(n_train, smooth=smooth, prologue=self._pro)
+                if self.prefetch:
+                    self.trainer.capture(n_train, smooth=smooth, prologue=self._pro_later, first_prologue=self._pro,
+                                         on_buffers=lambda ro, rd, tc, td, ts: self._arm_prefetch(n_cur, (ro, rd, tc, td), ts))
+                else:
+                    self.trainer.capture(n_train, smooth=smooth, prologue=self._pro)
             else:
                 f = torch.zeros(n_train * 10, **f32)
                 from .trainer import unpack_rays
                 self._eager_bufs = unpack_rays(f, n_train)
                 self.trainer._graphs = None
+                if self.prefetch:
+                    tr_cfg = self.config['training']
+                    self._arm_prefetch(n_cur, self._eager_bufs, self.trainer._train_step(n_train, bool(smooth and tr_cfg['smooth_weight'] > 0)))
             self._shape = (n_cur, n_train, smooth)
         return n_cur, n_train
 
@@ -146,9 +181,11 @@ class FusedBA:
         tr = self.trainer
         if self.use_graph:
             bufs = tr.ray_buffers()
-            return tr.step(*bufs, smooth=smooth, uncert_step=(i + 1) % 5 == 0)           # the replay starts with the prologue's launches
+            return tr.step(*bufs, smooth=smooth, uncert_step=(i + 1) % 5 == 0, first=(i == 0))           # the replay starts with the prologue's launches
         bufs = self._eager_bufs
-        self._pro(*bufs)
+        pro = self._pro if (i == 0 or not self.prefetch) else self._pro_later
+        if pro is not None:
+            pro(*bufs)
         return tr.step(*bufs, smooth=smooth, uncert_step=(i + 1) % 5 == 0)
 
     def global_BA(self, current_rays: torch.Tensor, poses_all: torch.Tensor, n_iters: Optional[int] = None, uncert_vol=None, smooth: bool = True):

@@ -678,7 +678,7 @@ BwdWs bwd_ws(const NarutoField* f, void* workspace, uint32_t cap) {
 int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, const NarutoPoints* pts, const float* feat_save,
                    const float* d_raw, const float* d_geo, const uint32_t* active_idx, const uint32_t* n_active, const NarutoExtraPoints* extra,
                    uint32_t flags, const NarutoGrads* g, void* workspace, void* stream, uint32_t n_front, const uint32_t* n_list_dev,
-                   const AdamFuse* adam = nullptr, const void* w_img = nullptr, const TvLate* tv_late = nullptr) {
+                   const AdamFuse* adam = nullptr, const void* w_img = nullptr, const TvLate* tv_late = nullptr, const AssembleArgs* next = nullptr) {
     if ((active_idx == nullptr) != (n_active == nullptr)) return fail(NARUTO_ERR_INVALID, "query_bwd: active_idx and n_active go together");
     if (n_front > 0 && (extra != nullptr || n_list_dev == nullptr)) return fail(NARUTO_ERR_INVALID, "query_bwd: front list excludes extra points");
     const uint32_t E = n_front > 0 ? n_front : ((extra != nullptr && g != nullptr && g->table != nullptr) ? extra->n : 0u);
@@ -749,6 +749,14 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
         }
         const uint32_t n_unc_blocks = unc_scatter ? (ur.n_voxels + 255u) / 256u : 0u;
         const TvLate tvl = tv_late != nullptr ? *tv_late : TvLate{};
+        const uint32_t n_finish = n_table_blocks + kAccFloats / 32 + n_unc_blocks + (tvl.n_tv_blocks != 0u ? 1u : 0u);
+        if (next != nullptr) {
+            const uint32_t n_asm = (next->n_global + next->n_cur + 255u) / 256u;
+            hipLaunchKernelGGL(k_bwd_finish_next, dim3(n_finish + n_asm), dim3(256), 0, (hipStream_t)stream, f->lt, scatter_ws,
+                               level_splits(f, cnt != nullptr ? cap : M),
+                               n_params, partial_plane(f), partials, blocks, *g, *adam, n_table_blocks, ur, tvl, n_unc_blocks, n_finish, *next);
+            return check_launch("bwd_finish_next");
+        }
         hipLaunchKernelGGL(k_bwd_finish, dim3(n_table_blocks + kAccFloats / 32 + n_unc_blocks + (tvl.n_tv_blocks != 0u ? 1u : 0u)), dim3(256), 0, (hipStream_t)stream, f->lt, scatter_ws,
                            level_splits(f, cnt != nullptr ? cap : M),
                            n_params, partial_plane(f), partials, blocks, *g, *adam, n_table_blocks, ur, tvl, n_unc_blocks);
@@ -1229,6 +1237,8 @@ int naruto_debug_train_scatter(const NarutoField* f, const NarutoParams* p, cons
                           nullptr, unc_g, unc_g != nullptr ? const_cast<float*>(p->uncert_grid) : nullptr, n_front);
 }
 
+namespace { int assemble_args(const NarutoRayBatch* b, bool need_out, AssembleArgs& a, const char* who); }
+
 int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t_in, const NarutoGrads* g, uint32_t flags,
                           const NarutoFusedAdam* opt, void* stream) {
     if (int rc = train_check(f, p, t_in, "train_backward")) return rc;
@@ -1339,6 +1349,13 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
     NarutoPoints pts{};
     pts.rays_o = t->rays_o; pts.rays_d = t->rays_d; pts.z_vals = t->z_vals; pts.n_samples = S;
     const AdamFuse* ad = opt != nullptr ? &adam : nullptr;
+    // the next iteration's ray batch assembled by the launch that finishes this one's gradients (NarutoFusedAdam.next_batch)
+    AssembleArgs next_args{};
+    const AssembleArgs* next = nullptr;
+    if (opt != nullptr && opt->next_batch != nullptr) {
+        if (int rc2 = assemble_args(opt->next_batch, true, next_args, "train_backward (next_batch)")) return rc2;
+        if (next_args.n_global + next_args.n_cur != 0u) next = &next_args;
+    }
     const void* w_img = deferred ? w.w_img : nullptr;            // prepared by k_loss_bwd_fused just above
     TvLate tvl{};
     const bool late = moved;
@@ -1346,9 +1363,9 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
     int rc;
     if (n_front > 0)
         rc = query_bwd_impl(f, p, M, &pts, t->feat_save, t->d_raw, nullptr, t->active_idx, t->n_active, nullptr, flags, g, w.bwd, stream, n_front, bw.n_total, ad, w_img,
-                            (late && ad != nullptr) ? &tvl : nullptr);
+                            (late && ad != nullptr) ? &tvl : nullptr, next);
     else        // no smoothness term: the workspace was sized for cap = M + n3 with n3 = 0
-        rc = query_bwd_impl(f, p, M, &pts, t->feat_save, t->d_raw, nullptr, t->active_idx, t->n_active, nullptr, flags, g, w.bwd, stream, 0u, nullptr, ad, w_img);
+        rc = query_bwd_impl(f, p, M, &pts, t->feat_save, t->d_raw, nullptr, t->active_idx, t->n_active, nullptr, flags, g, w.bwd, stream, 0u, nullptr, ad, w_img, nullptr, next);
     if (rc != NARUTO_OK) return rc;
     if (late && ad == nullptr) {                                 // no optimiser in the backward: the value gets a (tiny) launch of its own
         hipLaunchKernelGGL(k_tv_late, dim3(1), dim3(256), 0, st, tvl);

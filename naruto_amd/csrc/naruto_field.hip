@@ -2854,16 +2854,17 @@ __device__ __forceinline__ void tv_late_body(const TvLate& a) {
 }
 __global__ __launch_bounds__(256) void k_tv_late(TvLate a) { tv_late_body(a); }
 
-__global__ __launch_bounds__(256) void k_bwd_finish(LevelTab lt, const float* __restrict__ partial, LevelSplits ls, size_t n_params,
-                                                    size_t n_plane, const float* __restrict__ wpartials, uint32_t n_wblocks, NarutoGrads g, AdamFuse adam,
-                                                    uint32_t n_table_blocks, UncertReduce unc, TvLate tvl, uint32_t n_unc_blocks) {
-    if (blockIdx.x >= n_table_blocks + kAccFloats / 32 + n_unc_blocks) { tv_late_body(tvl); return; }
-    if (blockIdx.x >= n_table_blocks + kAccFloats / 32) { uncert_reduce_body(unc, blockIdx.x - n_table_blocks - kAccFloats / 32); return; }
-    if (blockIdx.x >= n_table_blocks) {
-        wgrad_reduce_body(wpartials, n_wblocks, g, 1, blockIdx.x - n_table_blocks, &adam);
+// (the body by workgroup number, so that a launch with further roles behind these can call it: k_bwd_finish_next in naruto_rays.hip)
+__device__ __forceinline__ void bwd_finish_body(uint32_t block, const LevelTab& lt, const float* __restrict__ partial, const LevelSplits& ls, size_t n_params,
+                                                size_t n_plane, const float* __restrict__ wpartials, uint32_t n_wblocks, const NarutoGrads& g, const AdamFuse& adam,
+                                                uint32_t n_table_blocks, const UncertReduce& unc, const TvLate& tvl, uint32_t n_unc_blocks) {
+    if (block >= n_table_blocks + kAccFloats / 32 + n_unc_blocks) { tv_late_body(tvl); return; }
+    if (block >= n_table_blocks + kAccFloats / 32) { uncert_reduce_body(unc, block - n_table_blocks - kAccFloats / 32); return; }
+    if (block >= n_table_blocks) {
+        wgrad_reduce_body(wpartials, n_wblocks, g, 1, block - n_table_blocks, &adam);
         return;
     }
-    const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // float4 index = entries 2 i4, 2 i4 + 1
+    const size_t i4 = (size_t)block * blockDim.x + threadIdx.x;       // float4 index = entries 2 i4, 2 i4 + 1
     if (i4 * 4 >= n_params) return;
     const uint32_t entry = (uint32_t)(i4 * 2);
     int level = 0;
@@ -2879,6 +2880,11 @@ __global__ __launch_bounds__(256) void k_bwd_finish(LevelTab lt, const float* __
     }
     if (g.table != nullptr) reinterpret_cast<float4*>(g.table)[i4] = s;
     if (adam.on && adam.p[0] != nullptr) adam_apply4(adam, adam_coef(adam), i4, s);
+}
+__global__ __launch_bounds__(256) void k_bwd_finish(LevelTab lt, const float* __restrict__ partial, LevelSplits ls, size_t n_params,
+                                                    size_t n_plane, const float* __restrict__ wpartials, uint32_t n_wblocks, NarutoGrads g, AdamFuse adam,
+                                                    uint32_t n_table_blocks, UncertReduce unc, TvLate tvl, uint32_t n_unc_blocks) {
+    bwd_finish_body(blockIdx.x, lt, partial, ls, n_params, n_plane, wpartials, n_wblocks, g, adam, n_table_blocks, unc, tvl, n_unc_blocks);
 }
 
 }  // namespace naruto

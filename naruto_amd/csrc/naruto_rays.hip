@@ -576,6 +576,32 @@ __global__ __launch_bounds__(256) void k_rays_to_world(uint32_t n, const float* 
     }
 }
 
+// The iteration's LAST launch with the NEXT iteration's ray assembly riding along (round 5): workgroups [0, n_finish) are k_bwd_finish's,
+// the rest draw, gather and rotate the next batch (k_assemble_rays' rows).  By then nothing of this iteration reads the ray buffers any more,
+// and the iteration counter that keys the draw was advanced by this iteration's forward tail two launches ago: the batch is the one a
+// k_assemble_rays launch in front of the next iteration would produce -- without that launch (7.5 us + a gap per mapping iteration).
+__global__ __launch_bounds__(256) void k_bwd_finish_next(LevelTab lt, const float* __restrict__ partial, LevelSplits ls, size_t n_params,
+                                                         size_t n_plane, const float* __restrict__ wpartials, uint32_t n_wblocks, NarutoGrads g, AdamFuse adam,
+                                                         uint32_t n_table_blocks, UncertReduce unc, TvLate tvl, uint32_t n_unc_blocks, uint32_t n_finish, AssembleArgs a) {
+    if (blockIdx.x < n_finish) {
+        bwd_finish_body(blockIdx.x, lt, partial, ls, n_params, n_plane, wpartials, n_wblocks, g, adam, n_table_blocks, unc, tvl, n_unc_blocks);
+        return;
+    }
+    const uint32_t r = (blockIdx.x - n_finish) * blockDim.x + threadIdx.x;
+    if (r >= a.n_global + a.n_cur) return;
+    assemble_refresh(a);
+    float v[10];
+    const int64_t id = assemble_row(a, r, v);
+    if (a.ids_out) a.ids_out[r] = id;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        a.rays_o[3 * (size_t)r + i] = v[i];
+        a.rays_d[3 * (size_t)r + i] = v[3 + i];
+        a.target_s[3 * (size_t)r + i] = v[6 + i];
+    }
+    a.target_d[r] = v[9];
+}
+
 // out[i] = perm(first + i): `count` distinct pseudo-random indices in [0, n)
 __global__ __launch_bounds__(256) void k_sample_distinct(uint64_t n, uint32_t count, uint64_t first, uint32_t half_bits, uint64_t key, int64_t* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -177,6 +177,22 @@ class KeyFrameStoreHIP:
         out = (rays_o, rays_d, target_s, target_d, n_cur)
         return out + (ids,) if return_ids else out
 
+    def next_batch_struct(self, sample_num: int, current_rays: torch.Tensor, poses_all: torch.Tensor, min_pixels_cur: int, out, filter_depth: bool = False,
+                          rng: Optional[torch.Tensor] = None, dyn: Optional[torch.Tensor] = None, n_cur: Optional[int] = None, n_cur_pop: Optional[int] = None):
+        """The ``NarutoRayBatch`` of ``assemble_batch(..., out=out)`` WITHOUT launching anything: for ``NarutoFusedAdam.next_batch`` (the next
+        iteration's batch assembled by the launch that finishes this iteration's gradients).  Device-keyed draws only (``rng``).  Returns the
+        struct and the tensors it points into (keep both alive as long as the struct is in use)."""
+        assert rng is not None, "a prefetched batch is keyed by the device-side iteration state"
+        b, n_cur, keep = self._draw(sample_num, current_rays, poses_all, min_pixels_cur, filter_depth, rng, dyn, n_cur, n_cur_pop)
+        n = sample_num + n_cur
+        rays_o, rays_d, target_s, target_d = out
+        for a, c in ((rays_o, 3), (rays_d, 3), (target_s, 3), (target_d, 1)):
+            if not (a.is_cuda and a.dtype == torch.float32 and a.is_contiguous() and a.numel() == n * c):
+                raise RuntimeError(f"next_batch_struct: out tensors must be contiguous fp32 device tensors of {n} rows")
+        b.rays_o, b.rays_d, b.target_s, b.target_d = rays_o.data_ptr(), rays_d.data_ptr(), target_s.data_ptr(), target_d.data_ptr()
+        b.ids_out = None
+        return b, (keep, out, rng, dyn)
+
     def assemble_select(self, sampler, sample_num: int, current_rays: torch.Tensor, poses_all: torch.Tensor, min_pixels_cur: int, bbox,
                         uncert_vol=None, filter_depth: bool = False, out=None, rng: Optional[torch.Tensor] = None,
                         dyn: Optional[torch.Tensor] = None, n_cur: Optional[int] = None, n_cur_pop: Optional[int] = None):

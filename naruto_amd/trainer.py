@@ -456,7 +456,7 @@ class MappingTrainer:
         return ret, loss
 
     def step(self, rays_o, rays_d, target_rgb, target_d, smooth: bool = False, n_rays_total: int = 0,
-             uncert_step: Optional[bool] = None):
+             uncert_step: Optional[bool] = None, first: bool = False):
         """One mapping iteration (global_BA body, coslam.py:361-399).  With a process group the rays passed
         in are THIS RANK's shard; gradients are summed over ranks before the (identical) Adam steps.
 
@@ -507,8 +507,9 @@ class MappingTrainer:
                     self.model.note_min_uncert(self.model.min_uncert_running())
                     self.model.check_asserts()
                 return st['ret'][0], st['loss'][0]
-            self._graphs[1 if uncert_step else 0].replay()
-            ret = st['ret'][1 if uncert_step else 0]
+            which = 2 if (first and len(self._graphs) > 2 and not uncert_step) else (1 if uncert_step else 0)      # (2: capture(first_prologue=...))
+            self._graphs[which].replay()
+            ret = st['ret'][which]
             # the reference's in-line ``assert uncert_map.min() > 0`` (scene_rep.py:280) as a deferred check: every replay folds its
             # minimum into one device word (the loss tail does, NarutoTrainStep.min_uncert_running), and every ``assert_every``-th
             # replay queues an asynchronous copy of that RUNNING minimum and tests whatever has landed -- no host sync, and no
@@ -516,7 +517,7 @@ class MappingTrainer:
             if self.iter % self.assert_every == 0:
                 self.model.note_min_uncert(self.model.min_uncert_running() if self.direct else ret['_losses'][6])
                 self.model.check_asserts()
-            return ret, st['loss'][1 if uncert_step else 0]
+            return ret, st['loss'][which]
         return self._iteration(rays_o, rays_d, target_rgb, target_d, smooth, uncert_step)
 
     def ray_buffers(self):
@@ -557,10 +558,14 @@ class MappingTrainer:
                 self.uncert_optim.step()
         return out
 
-    def capture(self, n_rays: int, smooth: bool = False, n_rays_total: int = 0, warmup: int = 3, prologue=None):
+    def capture(self, n_rays: int, smooth: bool = False, n_rays_total: int = 0, warmup: int = 3, prologue=None, first_prologue=None, on_buffers=None):
         """Record the iteration into hipGraphs (static shapes: n_rays rays per call).
         ``prologue(rays_o, rays_d, target_rgb, target_d)``: launches recorded IN FRONT of the iteration inside the same graphs -- the
-        ray assembly / active ray selection that fill the iteration's input buffers (naruto_amd.ba_loop.FusedBA); single process."""
+        ray assembly / active ray selection that fill the iteration's input buffers (naruto_amd.ba_loop.FusedBA); single process.
+        ``first_prologue``: a third graph (no uncertainty-grid step) with THIS prologue instead, replayed by ``step(first=True)`` -- the
+        first iteration of a ``global_BA`` call, which has to assemble its own batch where later ones find theirs prepared by the
+        previous iteration's last launch (``NarutoFusedAdam.next_batch``).  ``on_buffers(rays_o, rays_d, target_rgb, target_d, train_step)``
+        is called once the graph's input buffers and the persistent TrainStep exist, before anything is launched."""
         dev = self.device
         self.model.n_rays_total = n_rays_total
         flat = torch.zeros(n_rays * 10, device=dev)
@@ -582,11 +587,16 @@ class MappingTrainer:
             else:
                 import copy
                 opt_snap.append(copy.deepcopy(opt.state_dict()))
+        if on_buffers is not None:
+            tr_cfg0 = self.config['training']
+            on_buffers(st['rays_o'], st['rays_d'], st['target_rgb'], st['target_d'], self._train_step(n_rays, bool(smooth and tr_cfg0['smooth_weight'] > 0)))
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
             for i in range(warmup):
-                if prologue is not None:
+                if first_prologue is not None and i == 0:
+                    first_prologue(st['rays_o'], st['rays_d'], st['target_rgb'], st['target_d'])
+                elif prologue is not None:
                     prologue(st['rays_o'], st['rays_d'], st['target_rgb'], st['target_d'])
                 self._iteration(st['rays_o'], st['rays_d'], st['target_rgb'], st['target_d'], smooth, i == warmup - 1, check=False)
         torch.cuda.current_stream(dev).wait_stream(s)
@@ -650,6 +660,14 @@ class MappingTrainer:
             pool = g.pool()
             st['ret'][1 if variant else 0] = ret
             st['loss'][1 if variant else 0] = loss
+            graphs.append(g)
+        if first_prologue is not None and not segmented:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, capture_error_mode=cap_mode):
+                first_prologue(st['rays_o'], st['rays_d'], st['target_rgb'], st['target_d'])
+                ret, loss = self._iteration(st['rays_o'], st['rays_d'], st['target_rgb'], st['target_d'], smooth, False, check=False)
+            st['ret'].append(ret)
+            st['loss'].append(loss)
             graphs.append(g)
         if self.direct and not segmented:
             # the graphs hold the ADDRESSES of this TrainStep's buffers: keep it alive with them, whatever the LRU cache below evicts

@@ -2643,7 +2643,8 @@ def test_fused_ba_iteration_equals_its_pieces(gpu, active):
         store, current, poses, vol = _ba_scene(cfg, gpu, n_kf=8)
         smp = ActiveRaySamplerHIP(config=cfg, num_uncert_sample=48, oversample_mul=4) if active else None
         # (the graph twin draws and selects in ONE launch, naruto_assemble_select -- round 5, off by default --, the eager twin in two)
-        twins.append((FusedBA(tr, store, smp, max_poses=64, use_graph=use_graph, one_launch_prologue=use_graph), current, poses, vol))
+        # and has every iteration's last launch assemble the NEXT iteration's batch (prefetch, round 5), the eager twin assembles its own
+        twins.append((FusedBA(tr, store, smp, max_poses=64, use_graph=use_graph, one_launch_prologue=use_graph, prefetch=use_graph), current, poses, vol))
     (a, cur, poses, vol), (b, _, _, _) = twins
     b.trainer.model.load_state_dict(a.trainer.model.state_dict())
     b.trainer.iter_state.copy_(a.trainer.iter_state)
@@ -2663,7 +2664,9 @@ def test_fused_ba_iteration_equals_its_pieces(gpu, active):
     # the batch the last replay trained on, recomputed from the host-keyed operators: seed / counter of the iteration state BEFORE it
     st = b.trainer.iter_state.cpu()
     bufs = a.trainer.ray_buffers()
-    seed, counter = int(st[0]), int(st[1]) - 1
+    # (without active rays the prefetching twin's input buffers already hold the batch of the iteration that WOULD come next; with them
+    # the prefetched draw sits in the stage and the input buffers still hold the last selection)
+    seed, counter = int(st[0]), int(st[1]) - (1 if active else 0)
     store = b.store
     saved_seed, saved_counter = store.seed, store.counter
     store.seed, store.counter = seed, counter - 1            # assemble_batch pre-increments its host counter

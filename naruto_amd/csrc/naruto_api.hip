@@ -1167,7 +1167,8 @@ int naruto_train_forward(const NarutoField* f, const NarutoParams* p, const Naru
     if (deferred) return NARUTO_OK;                          // the tail is a workgroup of the backward's first launch
     const uint32_t n_rows = loss_done ? loss_rows(f, t, deferred_) : a.n_ray_blocks;      // rows of partial sums the loss stage left
     // (SUMS_TV_LATER with the term moved: nothing has evaluated it yet -- the tail writes losses[8] = 0, the backward adds the value)
-    LossTailArgs tl = loss_tail_args(t, w, n_rows, wx.on != 0u ? 0u : a.n_tv_blocks, tva.inv_p3, finalize == 1);
+    LossTailArgs tl = loss_tail_args(t, w, n_rows, wx.on != 0u ? 0u : a.n_tv_blocks, tva.inv_p3,
+                                     finalize == 1 || finalize == NARUTO_TRAIN_FWD_DEFER_TAIL);      // (DEFER_TAIL beyond kFusedTailMaxRays rays: the ordinary tail, here)
     if (n_rows > 4u * kTailRows) {          // large batch: fold the per-workgroup rows first
         hipLaunchKernelGGL(k_loss_fold, dim3(kTailRows), dim3(64), 0, st, tl.partials, n_rows, w.fold);
         if (int rc = check_launch("loss_fold")) return rc;

@@ -539,18 +539,18 @@ def mapping_iter_ms(mlp: str, dev, steps: int, warmup: int):
         cfg, tr, store, smp, current, poses, vol, _dims = ba_scene(mlp, active, dev)
         ba = FusedBA(tr, store, smp, max_poses=256, use_graph=True)
         n_cur, n_train = ba.prepare(current, poses, vol if active else None)
-        iters = int(cfg["mapping"]["iters"])       # iteration index within a global_BA call: 1 in `iters` is a call's first (it assembles its own
-        for i in range(warmup):                    # batch; the others find theirs prepared by the previous iteration's last launch), every 5th steps the grid
-            ba.iteration(i % iters)
+        # the iterations of whole global_BA calls (mapping.iters = 10 each: the call's first assembles its own batch, the others find theirs
+        # prepared by the previous iteration's last launch, every 5th steps the grid), one graph launch per call; ms per ITERATION
+        iters = int(cfg["mapping"]["iters"])
+        for i in range(max(1, warmup // iters)):
+            ba.call_iterations()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        i = 0
         while time.perf_counter() - t0 < PREWARM_MS * 1e-3:
-            for _ in range(16):
-                ba.iteration(i % iters)
-                i += 1
+            for _ in range(4):
+                ba.call_iterations()
             torch.cuda.synchronize()
-        ms = timed_chunks(lambda k: ba.iteration(k % iters), 5 * steps)
+        ms = timed_chunks(lambda k: ba.call_iterations(), max(5, 5 * steps // iters)) / iters
         tr.model.check_asserts(block=True)
         out["active_ray_on" if active else "active_ray_off"] = {"ms": round(ms, 4), "rays_per_iteration": n_train, "rays_per_s": round(n_train / ms * 1e3, 1)}
         del ba, tr, store, smp
@@ -569,16 +569,24 @@ def run_ba_iter(args, dev):
     for mode in ("graph", "eager"):
         ba = FusedBA(tr, store, smp, max_poses=256, use_graph=(mode == "graph"))
         n_cur, n_train = ba.prepare(current, poses, vol if args.active_ray else None)
-        iters = int(cfg["mapping"]["iters"])       # 1 in `iters` iterations is a global_BA call's first (assembles its own batch)
-        for i in range(args.warmup):
-            ba.iteration(i % iters)
+        iters = int(cfg["mapping"]["iters"])       # whole calls of mapping.iters iterations (graph mode: one graph launch per call)
+        n_calls = max(1, args.steps // iters)
+        for i in range(max(1, args.warmup // iters)):
+            ba.call_iterations()
         tr.model.check_asserts(block=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            ba.iteration(i % iters)
+        for i in range(n_calls):
+            ba.call_iterations()
         torch.cuda.synchronize()
-        res[mode] = (time.perf_counter() - t0) / args.steps * 1e3
+        res[mode] = (time.perf_counter() - t0) / (n_calls * iters) * 1e3
+        if mode == "graph":
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n_calls * iters):
+                ba.iteration(i % iters)
+            torch.cuda.synchronize()
+            res["graph_per_iteration"] = (time.perf_counter() - t0) / (n_calls * iters) * 1e3
         tr.model.check_asserts(block=True)
         if mode == "graph":
             per_call = []                          # a whole global_BA call of mapping.iters iterations incl. its per-call preparation
@@ -604,9 +612,9 @@ def run_ba_iter(args, dev):
            "rays_per_s": round(n_train / ms * 1e3, 1),
            "config": {"workload": f"{args.workload} = BASELINE {WORKLOADS[args.workload][2]}: office_0 bbox, {n_kf} keyframes x {R} stored rays, {Hh} x {Ww} current frame, "
                                   f"mapping.sample 2048, active_ray {'on (4x oversampled batch of ' + str(ba.sample_num + n_cur) + ' rays, K = 500)' if args.active_ray else 'off'}, "
-                                  f"{n_train} rays x {S_tot} samples into the training step; hash L16 F2 T2^16, MLP 2x32 {args.mlp}; one hipGraph per iteration",
+                                  f"{n_train} rays x {S_tot} samples into the training step; hash L16 F2 T2^16, MLP 2x32 {args.mlp}; one hipGraph per global_BA call of {int(cfg['mapping']['iters'])} iterations",
                       "rays_per_step": n_train, "samples_per_ray": S_tot, "n_cur": n_cur, "active_ray": bool(args.active_ray)},
-           "eager_ms_per_iteration": round(res["eager"], 4),
+           "eager_ms_per_iteration": round(res["eager"], 4), "one_graph_per_iteration_ms": round(res["graph_per_iteration"], 4),
            "global_BA_call_ms": {"iters": int(cfg["mapping"]["iters"]), "ms": round(res["call"], 4),
                                  "note": "per call: frame + pose upload into the static buffers, one valid-pixel count read back, mapping.iters replays"},
            "pieces_eager_ms": {"assemble" + (" + active ray select" if args.active_ray else ""): round(t_pro, 5), "training step": round(t_step, 5)}}
@@ -627,6 +635,7 @@ def main():
     ap.add_argument("--no-kernels", action="store_true")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of the fused HIP Adam")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying the captured hipGraph")
+    ap.add_argument("--no-chain", action="store_true", help="one graph launch per iteration instead of one per global_BA call of mapping.iters iterations")
     ap.add_argument("--path", choices=("trainer", "dropin"), default="trainer",
                     help="trainer: MappingTrainer's fused iteration (hipGraph replay), the headline; dropin: the reference's unchanged loop body "
                          "(coslam.py:361-399) around NarutoFieldHIP is the timed step (its figures ride in the default line too, as `dropin`)")
@@ -718,7 +727,10 @@ def main():
     use_graph = (not args.no_graph) and (group is None or os.environ.get("NARUTO_GRAPH_DIST", "eager") in ("segmented", "whole"))
     if use_graph:
         try:
-            tr.capture(n_rays, smooth=True, n_rays_total=n_total)
+            # single process: besides the per-iteration graphs ONE graph that holds the mapping.iters (10) iterations of a global_BA call -- the
+            # launch-to-launch gap between graphs (5 - 8 us) is paid once per call instead of once per iteration (--no-chain: per-iteration graphs)
+            chain_n = int(cfg["mapping"]["iters"]) if (group is None and not args.no_chain) else 0
+            tr.capture(n_rays, smooth=True, n_rays_total=n_total, chain=[(i + 1) % 5 == 0 for i in range(chain_n)] if chain_n else None)
         except Exception as e:                      # data parallel only: a failed capture must not cost the run -- eager launches instead
             if group is None:
                 raise
@@ -742,8 +754,17 @@ def main():
     def step():
         tr.step(rays["rays_o"], rays["rays_d"], rays["target_rgb"], rays["target_d"], smooth=True, n_rays_total=n_total)
 
-    for _ in range(args.warmup):
-        step()
+    chain_n = tr.chain_length() if use_graph and tr._graphs is not None else 0
+
+    def steps(k: int):
+        """k iterations: whole calls of chain_n iterations as one graph launch each, the remainder iteration by iteration"""
+        while chain_n and k >= chain_n:
+            tr.step_chain(n_rays_total=n_total)
+            k -= chain_n
+        for _ in range(k):
+            step()
+
+    steps(args.warmup)
     # pre-warm: the timed window of the default run is ~5 ms (20 - 50 steps of ~0.23 ms) -- short enough to be read at ramping clocks right
     # after the captures and copies above.  Untimed steps for >= PREWARM_MS of wall time first (every rank the same count: the collectives
     # of a data-parallel step must pair up), stated in the line.
@@ -758,15 +779,13 @@ def main():
         t = torch.tensor([n_prewarm], dtype=torch.int64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
         n_prewarm = int(t.item())
-    for _ in range(n_prewarm):
-        step()
+    steps(n_prewarm)
     tr.model.check_asserts(block=True)
     if group is not None:
         torch.distributed.barrier(group)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    steps(args.steps)
     torch.cuda.synchronize()
     if group is not None:
         torch.distributed.barrier(group)
@@ -778,9 +797,14 @@ def main():
     tr.model.check_asserts(block=True)
     # beside the contract's figure (exactly K steps between two syncs, above): the MEDIAN over five further chunks of K steps each, which a
     # single disturbed chunk cannot move (single process only: the chunks' syncs would need barriers of their own)
-    ms_chunks = None
+    ms_chunks = ms_single = None
     if group is None:
-        ms_chunks = timed_chunks(lambda i: step(), 5 * args.steps)
+        if chain_n:
+            per = max(chain_n, args.steps // chain_n * chain_n)
+            ms_chunks = timed_chunks(lambda i: steps(per), 5) / per
+            ms_single = timed_chunks(lambda i: step(), 5 * args.steps)          # one graph launch per iteration
+        else:
+            ms_chunks = timed_chunks(lambda i: step(), 5 * args.steps)
 
     if rank == 0:
         trc = cfg["training"]
@@ -796,6 +820,9 @@ def main():
             "vs_baseline": None, "dtype": "f32" if args.mlp == "fp32" else "bf16 (MLP operands; fp32 accumulate, fp32 elsewhere)", "data": "synthetic",
             "prewarm": {"untimed_steps_before_the_timed_region": args.warmup + 8 + n_prewarm, "target_ms": PREWARM_MS},
             "ms_per_step_median_of_5_chunks": None if ms_chunks is None else round(ms_chunks, 4),
+            "graph_launches": (f"one hipGraph per {chain_n} iterations (= one global_BA call, mapping.iters); the remainder of K and --no-chain: one per iteration"
+                               if chain_n else ("one hipGraph per iteration" if use_graph and tr._graphs is not None else "eager")),
+            "ms_per_step_one_graph_per_iteration": None if ms_single is None else round(ms_single, 4),
             "multi_gpu_note": "no multi-GPU scaling curve has been measured by the builder (one-GPU boxes only): values at n_gpus > 1 come from the driver's runs",
 
             "config": {"workload": f"{args.workload} = BASELINE {WORKLOADS[args.workload][2]}: {volume}, {n_rays} rays x {S_tot} samples per GPU "

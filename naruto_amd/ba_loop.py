@@ -48,6 +48,9 @@ class FusedBA:
         # itself.  Same batches, same trajectory (tests: the graph twin prefetches, the eager twin does not).
         self.prefetch = (os.environ.get("NARUTO_BA_PREFETCH", "1") != "0") if prefetch is None else bool(prefetch)
         self._next_batch = None
+        # CALL GRAPH (round 5; NARUTO_BA_CALL_GRAPH=0 switches it off): the mapping.iters iterations of a global_BA call recorded as ONE graph
+        # next to the per-iteration graphs -- a call of the configured length is one graph launch
+        self.call_graph = use_graph and os.environ.get("NARUTO_BA_CALL_GRAPH", "1") != "0"
         mp = self.config['mapping']
         self.active = sampler is not None
         self.sample_num = sampler.oversample_num if self.active else int(mp['sample'])
@@ -159,11 +162,12 @@ class FusedBA:
             self._pro = self._prologue(n_cur)
             self._pro_later = self._later_prologue(n_cur) if self.prefetch else self._pro
             if self.use_graph:
+                chain = [(i + 1) % 5 == 0 for i in range(int(self.config['mapping']['iters']))] if self.call_graph else None
                 if self.prefetch:
-                    self.trainer.capture(n_train, smooth=smooth, prologue=self._pro_later, first_prologue=self._pro,
+                    self.trainer.capture(n_train, smooth=smooth, prologue=self._pro_later, first_prologue=self._pro, chain=chain,
                                          on_buffers=lambda ro, rd, tc, td, ts: self._arm_prefetch(n_cur, (ro, rd, tc, td), ts))
                 else:
-                    self.trainer.capture(n_train, smooth=smooth, prologue=self._pro)
+                    self.trainer.capture(n_train, smooth=smooth, prologue=self._pro, chain=chain)
             else:
                 f = torch.zeros(n_train * 10, **f32)
                 from .trainer import unpack_rays
@@ -192,7 +196,14 @@ class FusedBA:
         """The optimisation loop of one ``global_BA`` call (coslam.py:293-399 without pose optimisation: tracking is off in every
         shipped config)."""
         self.prepare(current_rays, poses_all, uncert_vol, smooth)
+        return self.call_iterations(n_iters, smooth)
+
+    def call_iterations(self, n_iters: Optional[int] = None, smooth: bool = True):
+        """The iterations of the current ``global_BA`` call (after ``prepare``): one launch of the call graph when the call has the
+        configured length, iteration by iteration otherwise.  Returns the last iteration's (ret, loss)."""
         n_iters = int(self.config['mapping']['iters']) if n_iters is None else int(n_iters)
+        if self.use_graph and self.trainer.chain_length() == n_iters and self._shape is not None and self._shape[2] == smooth:
+            return self.trainer.step_chain()
         out = None
         for i in range(n_iters):
             out = self.iteration(i, smooth)

@@ -520,6 +520,23 @@ class MappingTrainer:
             return ret, st['loss'][which]
         return self._iteration(rays_o, rays_d, target_rgb, target_d, smooth, uncert_step)
 
+    def chain_length(self) -> int:
+        """Iterations the chained graph of capture(chain=...) holds (0: none)."""
+        ch = self._static.get('chain') if self._graphs is not None else None
+        return ch[3] if ch else 0
+
+    def step_chain(self, n_rays_total: int = 0):
+        """Replay the chained graph of ``capture(chain=...)``: len(chain) iterations, the batches drawn by the captured prologues."""
+        g, ret, loss, n = self._static['chain']
+        self.model.n_rays_total = n_rays_total
+        before = self.iter
+        self.iter += n
+        g.replay()
+        if self.iter // self.assert_every != before // self.assert_every:
+            self.model.note_min_uncert(self.model.min_uncert_running() if self.direct else ret['_losses'][6])
+            self.model.check_asserts()
+        return ret, loss
+
     def ray_buffers(self):
         """After capture(): the graph's own input buffers (rays_o [N,3], rays_d [N,3], target_rgb [N,3], target_d [N,1]).  A batch
         written straight into them (``KeyframeRayStore.assemble_batch(..., out=trainer.ray_buffers())``) and passed to ``step``
@@ -558,14 +575,17 @@ class MappingTrainer:
                 self.uncert_optim.step()
         return out
 
-    def capture(self, n_rays: int, smooth: bool = False, n_rays_total: int = 0, warmup: int = 3, prologue=None, first_prologue=None, on_buffers=None):
+    def capture(self, n_rays: int, smooth: bool = False, n_rays_total: int = 0, warmup: int = 3, prologue=None, first_prologue=None, on_buffers=None, chain=None):
         """Record the iteration into hipGraphs (static shapes: n_rays rays per call).
         ``prologue(rays_o, rays_d, target_rgb, target_d)``: launches recorded IN FRONT of the iteration inside the same graphs -- the
         ray assembly / active ray selection that fill the iteration's input buffers (naruto_amd.ba_loop.FusedBA); single process.
         ``first_prologue``: a third graph (no uncertainty-grid step) with THIS prologue instead, replayed by ``step(first=True)`` -- the
         first iteration of a ``global_BA`` call, which has to assemble its own batch where later ones find theirs prepared by the
         previous iteration's last launch (``NarutoFusedAdam.next_batch``).  ``on_buffers(rays_o, rays_d, target_rgb, target_d, train_step)``
-        is called once the graph's input buffers and the persistent TrainStep exist, before anything is launched."""
+        is called once the graph's input buffers and the persistent TrainStep exist, before anything is launched.
+        ``chain``: a list of uncert_step flags -- ONE more graph that holds len(chain) iterations back to back (the first with ``first_prologue``
+        when given), replayed by ``step_chain()``: a whole ``global_BA`` call as one graph launch (the launch-to-launch gap between graphs, 5 - 8 us
+        on MI355X, is paid once per call instead of once per iteration)."""
         dev = self.device
         self.model.n_rays_total = n_rays_total
         flat = torch.zeros(n_rays * 10, device=dev)
@@ -669,6 +689,16 @@ class MappingTrainer:
             st['ret'].append(ret)
             st['loss'].append(loss)
             graphs.append(g)
+        st['chain'] = None
+        if chain and not segmented:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, capture_error_mode=cap_mode):
+                for i, u in enumerate(chain):
+                    pro = first_prologue if (i == 0 and first_prologue is not None) else prologue
+                    if pro is not None:
+                        pro(st['rays_o'], st['rays_d'], st['target_rgb'], st['target_d'])
+                    ret, loss = self._iteration(st['rays_o'], st['rays_d'], st['target_rgb'], st['target_d'], smooth, bool(u), check=False)
+            st['chain'] = (g, ret, loss, len(chain))
         if self.direct and not segmented:
             # the graphs hold the ADDRESSES of this TrainStep's buffers: keep it alive with them, whatever the LRU cache below evicts
             tr_cfg = self.config['training']

@@ -2691,6 +2691,13 @@ def test_fused_ba_iteration_equals_its_pieces(gpu, active):
         assert ba.trainer._graphs is graphs_before, "the ray count did not change: no re-capture"
     for (n, p), (_, q) in zip(a.trainer.model.named_parameters(), b.trainer.model.named_parameters()):
         assert torch.equal(p, q), f"parameter {n}: graph replay != eager launches"
+    # a call of the CONFIGURED length: the graph twin replays ONE graph that holds all mapping.iters iterations (round 5)
+    assert a.trainer.chain_length() == cfg["mapping"]["iters"] and b.trainer.chain_length() == 0
+    outs = [ba.global_BA(cur, poses2, uncert_vol=vol if active else None) for ba in (a, b)]
+    assert float(outs[0][1]) == float(outs[1][1]), "last iteration's loss: call graph != eager launches"
+    for (n, p), (_, q) in zip(a.trainer.model.named_parameters(), b.trainer.model.named_parameters()):
+        assert torch.equal(p, q), f"parameter {n}: call graph != eager launches"
+    assert torch.equal(a.trainer.iter_state, b.trainer.iter_state)
     a.trainer.model.check_asserts(block=True)
 
 

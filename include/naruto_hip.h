@@ -295,6 +295,12 @@ int naruto_active_ray_select(uint32_t n_total, uint32_t base, uint32_t K, uint32
                              float voxel_scale, float* out_o, float* out_d, float* out_s, float* out_t,
                              void* workspace, void* stream);
 
+/* naruto_active_ray_select with the candidates' keys given (keys[j] for candidate base + j, as NarutoRayBatch.keys_out leaves them): the
+ * lookup -- two dependent trips to memory per candidate -- is skipped.  At most 8 192 candidates (NARUTO_ERR_INVALID beyond). */
+int naruto_active_ray_select_keyed(uint32_t n_total, uint32_t base, uint32_t K, uint32_t n_tail, const float* rays_o,
+                                   const float* rays_d, const float* target_s, const float* target_d, const uint32_t* keys,
+                                   float* out_o, float* out_d, float* out_s, float* out_t, void* stream);
+
 /* N2 ("next" row) -- camera-frame directions to world rays (coslam.py:342-344): rays_d[r] = R[pose_id[r]] . d_cam[r],
  * rays_o[r] = t[pose_id[r]]; poses [P,4,4] row-major camera-to-world, pose_id int64 [n]. */
 int naruto_rays_to_world(uint32_t n, const float* d_cam, const int64_t* pose_id, const float* poses, float* rays_o,
@@ -328,6 +334,16 @@ typedef struct NarutoRayBatch {
      * keyframes / poses / another current frame need no re-capture as long as n_global and n_cur stay the same.             */
     const uint64_t* rng;
     const uint64_t* dyn;
+    /* optional (round 5): the active ray sampler's lookup done where the rows are in registers -- keys_out[r - key_base] = the sortable key
+     * of row r's cached-uncertainty value (what naruto_active_ray_select derives from the row: round((o + d*depth - key_bbox_min) *
+     * key_voxel_scale), clipped) for rows key_base <= r < n_global + n_cur - key_tail; consumed by naruto_active_ray_select_keyed.
+     * keys_out NULL: off (the other key_* fields are then ignored). */
+    uint32_t* keys_out;
+    uint32_t key_base, key_tail;
+    const float* key_vol;      /* [X,Y,Z] fp32, device                                                               */
+    uint32_t key_dims[3];
+    float key_bbox_min[3];
+    float key_voxel_scale;
 } NarutoRayBatch;
 int naruto_assemble_rays(const NarutoRayBatch* b, void* stream);
 /* N2 + N1 in ONE launch: naruto_assemble_rays | naruto_active_ray_select without the intermediate oversampled batch (coslam.py:310-359 as

@@ -65,7 +65,9 @@ class NarutoRayBatch(C.Structure):
                 ("keyframe_every", C.c_int64), ("n_global", C.c_uint32), ("current", C.c_void_p), ("cur_list", C.c_void_p),
                 ("n_cur_pop", C.c_uint64), ("n_cur", C.c_uint32), ("poses", C.c_void_p), ("n_poses", C.c_uint32),
                 ("seed", C.c_uint64), ("counter", C.c_uint64), ("rays_o", C.c_void_p), ("rays_d", C.c_void_p),
-                ("target_s", C.c_void_p), ("target_d", C.c_void_p), ("ids_out", C.c_void_p), ("rng", C.c_void_p), ("dyn", C.c_void_p)]
+                ("target_s", C.c_void_p), ("target_d", C.c_void_p), ("ids_out", C.c_void_p), ("rng", C.c_void_p), ("dyn", C.c_void_p),
+                ("keys_out", C.c_void_p), ("key_base", C.c_uint32), ("key_tail", C.c_uint32), ("key_vol", C.c_void_p), ("key_dims", C.c_uint32 * 3),
+                ("key_bbox_min", C.c_float * 3), ("key_voxel_scale", C.c_float)]
 
 
 class NarutoFusedAdam(C.Structure):
@@ -155,6 +157,7 @@ SIGNATURES = {
     "naruto_query_bwd": (_I, [_V, C.POINTER(NarutoParams), _U32, C.POINTER(NarutoPoints), _V, _V, _V, _V, _V,
                               C.POINTER(NarutoExtraPoints), _U32, C.POINTER(NarutoGrads), _V, _V]),
     "naruto_active_ray_workspace": (C.c_size_t, [_U32, _U32]),
+    "naruto_active_ray_select_keyed": (_I, [_U32, _U32, _U32, _U32, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V]),
     "naruto_active_ray_select": (_I, [_U32, _U32, _U32, _U32, _V, _V, _V, _V, _V, C.POINTER(_U32), C.POINTER(_F), _F, _V, _V, _V, _V, _V, _V]),
     "naruto_rays_to_world": (_I, [_U32, _V, _V, _V, _V, _V, _V]),
     "naruto_map_volumes": (_I, [_U32, _V, _V, _V]),

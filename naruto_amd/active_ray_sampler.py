@@ -78,15 +78,26 @@ class ActiveRaySamplerHIP:
     def workspace_elems(self, n_total: int) -> int:
         return _lib.load().naruto_active_ray_workspace(int(n_total), self.num_uncert_sample) // 4 + 4
 
-    def sample_rays(self, rays_o, rays_d, target_s, target_d, idx_cur, uncert_vol, bbox: List, out=None, workspace=None):
+    def key_lookup(self, n_total: int, idx_cur, bbox: List, keys: torch.Tensor):
+        """What ``KeyFrameStoreHIP.assemble_batch(..., keys=...)`` needs to look the candidates' keys up while it assembles a batch of
+        ``n_total`` rows (``NarutoRayBatch.keys_out``): (keys tensor, base, n_tail, pinned volume, bbox_min); ``sample_rays(..., keys=keys)``
+        then skips its own lookup."""
+        vol = self._volume(None, keys.device)
+        n_idx = int(idx_cur) if isinstance(idx_cur, int) else len(idx_cur)
+        n_tail = -((-n_idx) // self.oversample_mul)
+        assert keys.is_cuda and keys.dtype == torch.int32 and keys.numel() >= n_total - n_tail - self.base_sample_num
+        return keys, self.base_sample_num, n_tail, vol, tuple(float(b[0]) for b in bbox)
+
+    def sample_rays(self, rays_o, rays_d, target_s, target_d, idx_cur, uncert_vol, bbox: List, out=None, workspace=None, keys=None):
         """active_ray_sampler.py:77-149.  ``idx_cur``: the current-frame indices (only their NUMBER is used, as in the reference) or
         that number.  ``out`` = (rays_o, rays_d, target_s, target_d) to write into (e.g. a captured trainer's ``ray_buffers()``) and
-        ``workspace`` (int32, ``workspace_elems`` long) make the call allocation-free."""
+        ``workspace`` (int32, ``workspace_elems`` long) make the call allocation-free.  ``keys`` (int32 [candidates]): the candidates' keys as
+        the batch's assembly left them (``key_lookup``): the lookup is skipped (``uncert_vol`` is then not read)."""
         lib = _lib.load()
         rays_o, rays_d, target_s = _f32c(rays_o, "rays_o"), _f32c(rays_d, "rays_d"), _f32c(target_s, "target_s")
         td = _f32c(target_d, "target_d").reshape(-1)
         dev = rays_o.device
-        vol = self._volume(uncert_vol, dev)
+        vol = self._volume(uncert_vol, dev) if keys is None else None
         n_total, base, K = rays_o.shape[0], self.base_sample_num, self.num_uncert_sample
         n_idx = int(idx_cur) if isinstance(idx_cur, int) else len(idx_cur)
         n_tail = -((-n_idx) // self.oversample_mul)                 # ceil(len / mul), as the reference's -len//mul slice
@@ -99,6 +110,12 @@ class ActiveRaySamplerHIP:
         else:
             o_out, d_out, s_out = (torch.empty(n_out, 3, device=dev) for _ in range(3))
             t_out = torch.empty(n_out, 1, device=dev)
+        if keys is not None:
+            assert keys.is_cuda and keys.dtype == torch.int32 and keys.numel() >= n_total - n_tail - base
+            with torch.cuda.device(dev):
+                _lib.check(lib.naruto_active_ray_select_keyed(n_total, base, K, n_tail, _p(rays_o), _p(rays_d), _p(target_s), _p(td), _p(keys),
+                                                              _p(o_out), _p(d_out), _p(s_out), _p(t_out), _stream()), "naruto_active_ray_select_keyed")
+            return o_out, d_out, s_out, t_out
         dims = (C.c_uint32 * 3)(*vol.shape)
         bmin = (C.c_float * 3)(*(float(b[0]) for b in bbox))
         with torch.cuda.device(dev):

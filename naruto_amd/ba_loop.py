@@ -48,6 +48,11 @@ class FusedBA:
         # itself.  Same batches, same trajectory (tests: the graph twin prefetches, the eager twin does not).
         self.prefetch = (os.environ.get("NARUTO_BA_PREFETCH", "1") != "0") if prefetch is None else bool(prefetch)
         self._next_batch = None
+        # ... and with active rays that assembly also looks the candidates' keys up (NarutoRayBatch.keys_out): the selection in front of the
+        # next forward starts from the keys (naruto_active_ray_select_keyed) instead of two dependent trips to memory per candidate.
+        # NARUTO_BA_KEYED_SELECT=0 switches it off.
+        self.keyed = sampler is not None and os.environ.get("NARUTO_BA_KEYED_SELECT", "1") != "0"
+        self._keys = None
         # CALL GRAPH (round 5; NARUTO_BA_CALL_GRAPH=0 switches it off): the mapping.iters iterations of a global_BA call recorded as ONE graph
         # next to the per-iteration graphs -- a call of the configured length is one graph launch
         self.call_graph = use_graph and os.environ.get("NARUTO_BA_CALL_GRAPH", "1") != "0"
@@ -88,15 +93,21 @@ class FusedBA:
         sampler = self.sampler
 
         def prologue(rays_o, rays_d, target_rgb, target_d):
-            sampler.sample_rays(*self._stage, n_cur, None, self.bbox, out=(rays_o, rays_d, target_rgb, target_d), workspace=self._ws)
+            # (the candidates' keys were looked up by the assembly that rode in the previous iteration's finishing launch)
+            sampler.sample_rays(*self._stage, n_cur, None, self.bbox, out=(rays_o, rays_d, target_rgb, target_d), workspace=self._ws,
+                                keys=self._keys if self._keyed(n_cur) else None)
         return prologue
+
+    def _keyed(self, n_cur: int) -> bool:
+        return self.keyed and self.sample_num + n_cur - self.sampler.n_out(n_cur) <= 8192
 
     def _arm_prefetch(self, n_cur: int, bufs, train_step):
         """Point the fused optimiser's next_batch at the draw of the NEXT iteration (into the stage when active rays select from it, else
         straight into the iteration's own input buffers)."""
         out = self._stage if self.active else bufs
+        keys = self.sampler.key_lookup(self.sample_num + n_cur, n_cur, self.bbox, self._keys) if (self.active and self._keyed(n_cur)) else None
         b, keep = self.store.next_batch_struct(self.sample_num, self.current, self.poses, self.min_pixels_cur, out, filter_depth=self.filter_depth,
-                                               rng=self.trainer.iter_state, dyn=self.dyn, n_cur=n_cur, n_cur_pop=self._n_cur_pop)
+                                               rng=self.trainer.iter_state, dyn=self.dyn, n_cur=n_cur, n_cur_pop=self._n_cur_pop, keys=keys)
         assert train_step.opt is not None, "prefetch needs the optimiser in the backward (MappingTrainer(fused_adam=True))"
         self._next_batch = (b, keep)
         import ctypes as C
@@ -115,6 +126,11 @@ class FusedBA:
                 # assembly + selection in one launch (naruto_assemble_select): the oversampled batch is never written
                 store.assemble_select(sampler, self.sample_num, self.current, self.poses, self.min_pixels_cur, self.bbox,
                                       out=(rays_o, rays_d, target_rgb, target_d), **kw)
+                return
+            if self._keyed(n_cur):         # the assembly looks the candidates' keys up while the rows are in registers (NarutoRayBatch.keys_out)
+                store.assemble_batch(self.sample_num, self.current, self.poses, self.min_pixels_cur, out=self._stage,
+                                     keys=sampler.key_lookup(self.sample_num + n_cur, n_cur, self.bbox, self._keys), **kw)
+                sampler.sample_rays(*self._stage, n_cur, None, self.bbox, out=(rays_o, rays_d, target_rgb, target_d), workspace=self._ws, keys=self._keys)
                 return
             store.assemble_batch(self.sample_num, self.current, self.poses, self.min_pixels_cur, out=self._stage, **kw)
             sampler.sample_rays(*self._stage, n_cur, None, self.bbox, out=(rays_o, rays_d, target_rgb, target_d), workspace=self._ws)
@@ -153,12 +169,13 @@ class FusedBA:
             vol_moved = self._vol_ptr is not None and vol.data_ptr() != self._vol_ptr      # a new tensor (other shape): the captured launch reads the old one
             self._vol_ptr = vol.data_ptr()
         n_cur, n_train = self.sizes(n_kf, n_valid)
-        if self._shape != (n_cur, n_train, smooth) or (vol_moved and self.use_graph):
+        if self._shape != (n_cur, n_train, smooth) or (vol_moved and (self.use_graph or self.keyed)):
             f32 = dict(dtype=torch.float32, device=dev)
             n_stage = self.sample_num + n_cur
             if self.active:
                 self._stage = (torch.empty(n_stage, 3, **f32), torch.empty(n_stage, 3, **f32), torch.empty(n_stage, 3, **f32), torch.empty(n_stage, 1, **f32))
                 self._ws = torch.empty(self.sampler.workspace_elems(n_stage), dtype=torch.int32, device=dev)
+                self._keys = torch.zeros(n_stage, dtype=torch.int32, device=dev)
             self._pro = self._prologue(n_cur)
             self._pro_later = self._later_prologue(n_cur) if self.prefetch else self._pro
             if self.use_graph:

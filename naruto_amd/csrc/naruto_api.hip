@@ -1545,6 +1545,25 @@ int naruto_active_ray_select(uint32_t n_total, uint32_t base, uint32_t K, uint32
     return check_launch("ars_gather");
 }
 
+int naruto_active_ray_select_keyed(uint32_t n_total, uint32_t base, uint32_t K, uint32_t n_tail, const float* rays_o, const float* rays_d, const float* target_s,
+                                   const float* target_d, const uint32_t* keys, float* out_o, float* out_d, float* out_s, float* out_t, void* stream) {
+    if (rays_o == nullptr || rays_d == nullptr || target_s == nullptr || target_d == nullptr || keys == nullptr || out_o == nullptr || out_d == nullptr ||
+        out_s == nullptr || out_t == nullptr)
+        return fail(NARUTO_ERR_INVALID, "active_ray_select_keyed: NULL argument");
+    if (n_tail == 0 || K == 0 || K > base || (uint64_t)base + n_tail >= n_total)
+        return fail(NARUTO_ERR_INVALID, "active_ray_select_keyed: need 0 < K <= base, n_tail > 0, base + n_tail < n_total");
+    const uint32_t n_cand = n_total - n_tail - base;
+    if (n_cand <= K || n_cand > kArsFusedMax)
+        return fail(NARUTO_ERR_INVALID, "active_ray_select_keyed: %u candidates for K = %u (need K < candidates <= %u)", n_cand, K, kArsFusedMax);
+    ArsArgs a{};
+    a.n_total = n_total; a.base = base; a.K = K; a.n_tail = n_tail; a.n_cand = n_cand;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.target_s = target_s; a.target_d = target_d; a.keys = keys;
+    a.o_out = out_o; a.d_out = out_d; a.s_out = out_s; a.t_out = out_t;
+    const uint32_t n_copy = base + n_tail - K;
+    hipLaunchKernelGGL(k_ars_fused<false>, dim3(1u + (n_copy + kArsFusedThreads - 1u) / kArsFusedThreads), dim3(kArsFusedThreads), 0, (hipStream_t)stream, a, AssembleArgs{});
+    return check_launch("ars_fused (keyed)");
+}
+
 int naruto_rays_to_world(uint32_t n, const float* d_cam, const int64_t* pose_id, const float* poses, float* rays_o, float* rays_d, void* stream) {
     if (d_cam == nullptr || pose_id == nullptr || poses == nullptr || rays_o == nullptr || rays_d == nullptr)
         return fail(NARUTO_ERR_INVALID, "rays_to_world: NULL argument");
@@ -1691,6 +1710,14 @@ int assemble_args(const NarutoRayBatch* b, bool need_out, AssembleArgs& a, const
     a.hb_global = half_bits_for(a.n_pop); a.hb_cur = half_bits_for(a.n_cur_pop);
     a.rays_o = b->rays_o; a.rays_d = b->rays_d; a.target_s = b->target_s; a.target_d = b->target_d; a.ids_out = b->ids_out;
     a.rng = b->rng; a.dyn = b->dyn; a.seed_host = b->seed; a.counter_host = b->counter;
+    if (b->keys_out != nullptr) {
+        const uint32_t n = b->n_global + b->n_cur;
+        if (b->key_vol == nullptr || b->key_dims[0] == 0 || b->key_dims[1] == 0 || b->key_dims[2] == 0 || (uint64_t)b->key_base + b->key_tail > n)
+            return fail(NARUTO_ERR_INVALID, "%s: keys_out needs key_vol, key_dims and key_base + key_tail <= rows", who);
+        a.keys_out = b->keys_out; a.key_base = b->key_base; a.key_end = n - b->key_tail;
+        a.kv = ArsVol{b->key_vol, (int)b->key_dims[0], (int)b->key_dims[1], (int)b->key_dims[2], b->key_bbox_min[0], b->key_bbox_min[1], b->key_bbox_min[2],
+                      b->key_voxel_scale};
+    }
     return NARUTO_OK;
 }
 }  // namespace

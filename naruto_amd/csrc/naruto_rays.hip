@@ -229,6 +229,27 @@ __host__ __device__ __forceinline__ uint64_t mix_key(uint64_t seed, uint64_t cou
     return x;
 }
 
+// the planner's cached uncertainty volume as the active ray sampler looks it up
+struct ArsVol {
+    const float* vol;
+    int X, Y, Z;
+    float bx, by, bz, voxel_scale;
+};
+// flat voxel index of the ray's end point o + d t in the cached uncertainty volume
+__device__ __forceinline__ size_t ars_voxel(const ArsVol& a, float ox, float oy, float oz, float dx, float dy, float dz, float t) {
+    const float px = __fadd_rn(ox, __fmul_rn(dx, t));
+    const float py = __fadd_rn(oy, __fmul_rn(dy, t));
+    const float pz = __fadd_rn(oz, __fmul_rn(dz, t));
+    // numpy: ((pts - bbox_min) * 10).round().astype(int), then np.clip -- rintf is round-half-to-even like np.round
+    const float fx = rintf(__fmul_rn(__fsub_rn(px, a.bx), a.voxel_scale));
+    const float fy = rintf(__fmul_rn(__fsub_rn(py, a.by), a.voxel_scale));
+    const float fz = rintf(__fmul_rn(__fsub_rn(pz, a.bz), a.voxel_scale));
+    const int ix = (int)fminf(fmaxf(fx, 0.0f), (float)(a.X - 1));
+    const int iy = (int)fminf(fmaxf(fy, 0.0f), (float)(a.Y - 1));
+    const int iz = (int)fminf(fmaxf(fz, 0.0f), (float)(a.Z - 1));
+    return ((size_t)ix * a.Y + iy) * a.Z + iz;
+}
+
 struct AssembleArgs {
     const float* store;          // [n_pop, 7] = (direction 3, rgb 3, depth 1) of the stored keyframe rays
     uint64_t n_pop;              // n_kf * rays_per_kf
@@ -250,7 +271,15 @@ struct AssembleArgs {
     const uint64_t* rng;         // {seed, counter}: keys = mix(seed ^ seed_host, counter + counter_host, salt)
     const uint64_t* dyn;         // {n_kf, n_poses, n_cur_pop}
     uint64_t seed_host, counter_host;
+    // optional: the active ray sampler's key of row r (key_base <= r < key_end) -> keys_out[r - key_base], computed while the row is in registers
+    uint32_t* keys_out;
+    uint32_t key_base, key_end;
+    ArsVol kv;
 };
+__device__ __forceinline__ void assemble_emit_key(const AssembleArgs& a, uint32_t r, const float (&v)[10]) {
+    if (a.keys_out != nullptr && r >= a.key_base && r < a.key_end)
+        a.keys_out[r - a.key_base] = sortable_key(a.kv.vol[ars_voxel(a.kv, v[0], v[1], v[2], v[3], v[4], v[5], v[9])]);
+}
 
 // what changes between replays of a captured launch (keys, counts), from device memory
 __device__ __forceinline__ void assemble_refresh(AssembleArgs& a) {
@@ -304,6 +333,7 @@ __global__ __launch_bounds__(256) void k_assemble_rays(AssembleArgs a) {
         a.target_s[3 * (size_t)r + i] = v[6 + i];
     }
     a.target_d[r] = v[9];
+    assemble_emit_key(a, r, v);
 }
 
 // N1 in ONE launch (round 4; up to 8 192 candidates, a mapping iteration has 6 444): workgroup 0 looks the keys up, selects and gathers the K
@@ -319,6 +349,7 @@ struct ArsArgs {
     int X, Y, Z;
     float bx, by, bz, voxel_scale;
     float *o_out, *d_out, *s_out, *t_out;
+    const uint32_t* keys;         // optional [n_cand]: the candidates' keys, already looked up (AssembleArgs.keys_out)
 };
 constexpr uint32_t kArsFusedThreads = 1024, kArsSelThreads = 256, kArsFusedPer = 32, kArsFusedMax = kArsSelThreads * kArsFusedPer;
 
@@ -335,19 +366,8 @@ __device__ __forceinline__ void ars_fetch_row(const ArsArgs& a, const AssembleAr
         v[9] = a.target_d[src];
     }
 }
-// flat voxel index of the ray's end point o + d t in the cached uncertainty volume
 __device__ __forceinline__ size_t ars_voxel(const ArsArgs& a, float ox, float oy, float oz, float dx, float dy, float dz, float t) {
-    const float px = __fadd_rn(ox, __fmul_rn(dx, t));
-    const float py = __fadd_rn(oy, __fmul_rn(dy, t));
-    const float pz = __fadd_rn(oz, __fmul_rn(dz, t));
-    // numpy: ((pts - bbox_min) * 10).round().astype(int), then np.clip -- rintf is round-half-to-even like np.round
-    const float fx = rintf(__fmul_rn(__fsub_rn(px, a.bx), a.voxel_scale));
-    const float fy = rintf(__fmul_rn(__fsub_rn(py, a.by), a.voxel_scale));
-    const float fz = rintf(__fmul_rn(__fsub_rn(pz, a.bz), a.voxel_scale));
-    const int ix = (int)fminf(fmaxf(fx, 0.0f), (float)(a.X - 1));
-    const int iy = (int)fminf(fmaxf(fy, 0.0f), (float)(a.Y - 1));
-    const int iz = (int)fminf(fmaxf(fz, 0.0f), (float)(a.Z - 1));
-    return ((size_t)ix * a.Y + iy) * a.Z + iz;
+    return ars_voxel(ArsVol{a.vol, a.X, a.Y, a.Z, a.bx, a.by, a.bz, a.voxel_scale}, ox, oy, oz, dx, dy, dz, t);
 }
 __device__ __forceinline__ uint32_t ars_key(const ArsArgs& a, uint32_t j) {
     const size_t r = (size_t)a.base + j;
@@ -443,7 +463,8 @@ __global__ __launch_bounds__(kArsFusedThreads) void k_ars_fused(ArsArgs a, Assem
 #pragma unroll
             for (uint32_t i = 0; i < NK; ++i) {
                 const uint32_t j = i * kArsFusedThreads + (uint32_t)tid;
-                kk[i] = ars_key(a, j < a.n_cand ? j : a.n_cand - 1u);
+                const uint32_t jc = j < a.n_cand ? j : a.n_cand - 1u;
+                kk[i] = a.keys != nullptr ? a.keys[jc] : ars_key(a, jc);
             }
         }
 #pragma unroll
@@ -600,6 +621,7 @@ __global__ __launch_bounds__(256) void k_bwd_finish_next(LevelTab lt, const floa
         a.target_s[3 * (size_t)r + i] = v[6 + i];
     }
     a.target_d[r] = v[9];
+    assemble_emit_key(a, r, v);
 }
 
 // out[i] = perm(first + i): `count` distinct pseudo-random indices in [0, n)

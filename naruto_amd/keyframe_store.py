@@ -109,6 +109,18 @@ class KeyFrameStoreHIP:
         rays = self.rays[:n_kf].reshape(-1, 7)[idx]
         return rays, self.frame_ids[idx // self.num_rays_to_save]
 
+    @staticmethod
+    def _set_keys(b, keys):
+        """NarutoRayBatch.keys_out from ``ActiveRaySamplerHIP.key_lookup``'s tuple (None: off)."""
+        if keys is None:
+            return
+        k, base, n_tail, vol, bmin = keys
+        b.keys_out, b.key_base, b.key_tail = k.data_ptr(), int(base), int(n_tail)
+        b.key_vol = vol.data_ptr()
+        b.key_dims = (C.c_uint32 * 3)(*vol.shape)
+        b.key_bbox_min = (C.c_float * 3)(*bmin)
+        b.key_voxel_scale = 10.0
+
     def _draw(self, sample_num, current_rays, poses_all, min_pixels_cur, filter_depth, rng, dyn, n_cur, n_cur_pop):
         """The NarutoRayBatch of one draw (everything but the output buffers) + what it keeps alive."""
         n_kf = len(self)
@@ -147,7 +159,7 @@ class KeyFrameStoreHIP:
 
     def assemble_batch(self, sample_num: int, current_rays: torch.Tensor, poses_all: torch.Tensor, min_pixels_cur: int,
                        filter_depth: bool = False, return_ids: bool = False, out=None, rng: Optional[torch.Tensor] = None,
-                       dyn: Optional[torch.Tensor] = None, n_cur: Optional[int] = None, n_cur_pop: Optional[int] = None):
+                       dyn: Optional[torch.Tensor] = None, n_cur: Optional[int] = None, n_cur_pop: Optional[int] = None, keys=None):
         """coslam.py:310-344 fused: -> rays_o [N,3], rays_d [N,3], target_s [N,3], target_d [N,1], n_cur (and ids_all).
         N = sample_num + n_cur, n_cur = max(sample_num // n_kf, min_pixels_cur) (capped by the valid pixels).
         current_rays [H*W,7]; poses_all [P,4,4] camera-to-world with the current frame's pose LAST (index -1).
@@ -156,7 +168,9 @@ class KeyFrameStoreHIP:
         For a launch captured in a hipGraph (naruto_amd.ba_loop.FusedBA): ``rng`` int64[2] device {seed, counter} keys the draws
         instead of this store's host counter, ``dyn`` int64[3] device {n_kf, n_poses, n_cur_pop} replaces the host values at replay
         time; ``n_cur`` / ``n_cur_pop`` then fix the current-frame draw's size and population up front (no device read-back; with
-        ``filter_depth`` in the reference's mode the population is the number of valid-depth pixels, counted by the caller)."""
+        ``filter_depth`` in the reference's mode the population is the number of valid-depth pixels, counted by the caller).
+        ``keys``: ``ActiveRaySamplerHIP.key_lookup(...)`` -- the active ray sampler's candidate keys are looked up here, while the rows are
+        in registers, for ``sample_rays(..., keys=...)``."""
         lib = _lib.load()
         b, n_cur, keep = self._draw(sample_num, current_rays, poses_all, min_pixels_cur, filter_depth, rng, dyn, n_cur, n_cur_pop)
         n = sample_num + n_cur
@@ -172,13 +186,15 @@ class KeyFrameStoreHIP:
         ids = torch.empty(n, dtype=torch.int64, device=self.device) if return_ids else None
         b.rays_o, b.rays_d, b.target_s, b.target_d = rays_o.data_ptr(), rays_d.data_ptr(), target_s.data_ptr(), target_d.data_ptr()
         b.ids_out = ids.data_ptr() if ids is not None else None
+        self._set_keys(b, keys)
         with torch.cuda.device(self.device):
             check(lib.naruto_assemble_rays(C.byref(b), _stream()), "naruto_assemble_rays")
         out = (rays_o, rays_d, target_s, target_d, n_cur)
         return out + (ids,) if return_ids else out
 
     def next_batch_struct(self, sample_num: int, current_rays: torch.Tensor, poses_all: torch.Tensor, min_pixels_cur: int, out, filter_depth: bool = False,
-                          rng: Optional[torch.Tensor] = None, dyn: Optional[torch.Tensor] = None, n_cur: Optional[int] = None, n_cur_pop: Optional[int] = None):
+                          rng: Optional[torch.Tensor] = None, dyn: Optional[torch.Tensor] = None, n_cur: Optional[int] = None, n_cur_pop: Optional[int] = None,
+                          keys=None):
         """The ``NarutoRayBatch`` of ``assemble_batch(..., out=out)`` WITHOUT launching anything: for ``NarutoFusedAdam.next_batch`` (the next
         iteration's batch assembled by the launch that finishes this iteration's gradients).  Device-keyed draws only (``rng``).  Returns the
         struct and the tensors it points into (keep both alive as long as the struct is in use)."""
@@ -191,7 +207,8 @@ class KeyFrameStoreHIP:
                 raise RuntimeError(f"next_batch_struct: out tensors must be contiguous fp32 device tensors of {n} rows")
         b.rays_o, b.rays_d, b.target_s, b.target_d = rays_o.data_ptr(), rays_d.data_ptr(), target_s.data_ptr(), target_d.data_ptr()
         b.ids_out = None
-        return b, (keep, out, rng, dyn)
+        self._set_keys(b, keys)
+        return b, (keep, out, rng, dyn, keys)
 
     def assemble_select(self, sampler, sample_num: int, current_rays: torch.Tensor, poses_all: torch.Tensor, min_pixels_cur: int, bbox,
                         uncert_vol=None, filter_depth: bool = False, out=None, rng: Optional[torch.Tensor] = None,

@@ -2701,6 +2701,45 @@ def test_fused_ba_iteration_equals_its_pieces(gpu, active):
     a.trainer.model.check_asserts(block=True)
 
 
+def test_active_ray_keys_looked_up_by_the_assembly(gpu):
+    """NarutoRayBatch.keys_out + naruto_active_ray_select_keyed (round 5): the candidates' keys looked up by the batch assembly, while the
+    rows are in registers, and the selection started from them -- the same selected batch, bit for bit, as assembly | selection with its
+    own lookup; keys_out leaves every other output of the assembly untouched."""
+    from naruto_amd import _lib
+    from naruto_amd.active_ray_sampler import ActiveRaySamplerHIP
+    cfg = H.office_cfg(12, perturb=1.0)
+    cfg["mapping"].update(sample=256, min_pixels_cur=40, filter_depth=True, keyframe_every=5)
+    store, current, poses, vol = _ba_scene(cfg, gpu, n_kf=8)
+    smp = ActiveRaySamplerHIP(config=cfg, num_uncert_sample=48, oversample_mul=4)
+    smp.set_volume(torch.from_numpy(vol), gpu)
+    bbox = [[float(b[0]), float(b[1])] for b in cfg["mapping"]["bound"]]
+    sample_num, min_cur = smp.oversample_num, smp.min_pixels_cur
+    cur = current.to(gpu)
+    pos = poses.to(gpu)
+    store.seed, store.counter = 1234, 7
+    o, d, s_, t_, n_cur = store.assemble_batch(sample_num, cur, pos, min_cur, filter_depth=True)
+    want = smp.sample_rays(o, d, s_, t_, n_cur, None, bbox)
+    keys = torch.full((o.shape[0],), -1, dtype=torch.int32, device=gpu)
+    store.counter = 7
+    o2, d2, s2, t2, n_cur2 = store.assemble_batch(sample_num, cur, pos, min_cur, filter_depth=True, keys=smp.key_lookup(o.shape[0], n_cur, bbox, keys))
+    assert n_cur2 == n_cur
+    for a_, b_ in ((o, o2), (d, d2), (s_, s2), (t_, t2)):
+        assert torch.equal(a_, b_)
+    n_tail = -((-n_cur) // smp.oversample_mul)
+    n_cand = o.shape[0] - n_tail - smp.base_sample_num
+    assert (keys[n_cand:] == -1).all(), "keys beyond the candidates are not written"
+    got = smp.sample_rays(o2, d2, s2, t2, n_cur, None, bbox, keys=keys)
+    for a_, b_, k in zip(got, want, ("rays_o", "rays_d", "target_s", "target_d")):
+        assert torch.equal(a_, b_), k
+    # errors: too many candidates / NULL keys
+    lib = _lib.load()
+    big = 2 * 8192 + 1024
+    z = torch.zeros(big * 3, device=gpu)
+    rc = lib.naruto_active_ray_select_keyed(big, 512, 48, 8, z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), keys.data_ptr(), z.data_ptr(), z.data_ptr(),
+                                            z.data_ptr(), z.data_ptr(), None)
+    assert rc != 0 and b"candidates" in lib.naruto_last_error()
+
+
 def test_fused_ba_back_to_back_calls_and_volume_refresh(gpu):
     """Two advisor findings of round 3.  (i) FusedBA.prepare refreshes {n_kf, n_poses, n_cur_pop} through pinned staging with an
     asynchronous copy: two global_BA calls issued back to back WITHOUT a host sync in between (filter_depth off, so nothing reads back)

@@ -754,7 +754,7 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
             const uint32_t n_asm = (next->n_global + next->n_cur + 255u) / 256u;
             hipLaunchKernelGGL(k_bwd_finish_next, dim3(n_finish + n_asm), dim3(256), 0, (hipStream_t)stream, f->lt, scatter_ws,
                                level_splits(f, cnt != nullptr ? cap : M),
-                               n_params, partial_plane(f), partials, blocks, *g, *adam, n_table_blocks, ur, tvl, n_unc_blocks, n_finish, *next);
+                               n_params, partial_plane(f), partials, blocks, *g, *adam, n_table_blocks, ur, tvl, n_unc_blocks, n_asm, *next);
             return check_launch("bwd_finish_next");
         }
         hipLaunchKernelGGL(k_bwd_finish, dim3(n_table_blocks + kAccFloats / 32 + n_unc_blocks + (tvl.n_tv_blocks != 0u ? 1u : 0u)), dim3(256), 0, (hipStream_t)stream, f->lt, scatter_ws,

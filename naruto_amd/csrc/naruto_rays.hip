@@ -603,12 +603,14 @@ __global__ __launch_bounds__(256) void k_rays_to_world(uint32_t n, const float* 
 // k_assemble_rays launch in front of the next iteration would produce -- without that launch (7.5 us + a gap per mapping iteration).
 __global__ __launch_bounds__(256) void k_bwd_finish_next(LevelTab lt, const float* __restrict__ partial, LevelSplits ls, size_t n_params,
                                                          size_t n_plane, const float* __restrict__ wpartials, uint32_t n_wblocks, NarutoGrads g, AdamFuse adam,
-                                                         uint32_t n_table_blocks, UncertReduce unc, TvLate tvl, uint32_t n_unc_blocks, uint32_t n_finish, AssembleArgs a) {
-    if (blockIdx.x < n_finish) {
-        bwd_finish_body(blockIdx.x, lt, partial, ls, n_params, n_plane, wpartials, n_wblocks, g, adam, n_table_blocks, unc, tvl, n_unc_blocks);
+                                                         uint32_t n_table_blocks, UncertReduce unc, TvLate tvl, uint32_t n_unc_blocks, uint32_t n_asm, AssembleArgs a) {
+    // the assembly workgroups are the FIRST of the grid: their chain of dependent trips starts with the launch and ends long before the ~2 000
+    // finishing workgroups are through (behind them -- more than one round of resident slots -- it would start when a slot frees up and end the launch: + 2 us)
+    if (blockIdx.x >= n_asm) {
+        bwd_finish_body(blockIdx.x - n_asm, lt, partial, ls, n_params, n_plane, wpartials, n_wblocks, g, adam, n_table_blocks, unc, tvl, n_unc_blocks);
         return;
     }
-    const uint32_t r = (blockIdx.x - n_finish) * blockDim.x + threadIdx.x;
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.n_global + a.n_cur) return;
     assemble_refresh(a);
     float v[10];

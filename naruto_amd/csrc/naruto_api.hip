@@ -172,7 +172,11 @@ constexpr uint32_t kMaxUncertSplits = 32;
 inline uint32_t uncert_splits(const NarutoField* f, uint32_t M) {
     uint32_t s = (M + 262143u) / 262144u;             // M is the list's CAPACITY (all samples); about a third of it carries a cotangent
     if (s < f->plan.s_uncert) s = f->plan.s_uncert;
-    const uint32_t cap = f->plan.n_uncert ? (64u / f->plan.n_uncert > 1u ? 64u / f->plan.n_uncert : 1u) : 1u;
+    // (long lists raise the count above the one-round plan's only while the grid's units stay few; the plan's own count -- chosen against the
+    // launch's budget of workgroups, field_create -- always stands: MP3D's 57-chunk grid had been cut back to ONE split here, 57 workgroups of
+    // 183 us next to 63 idle CUs)
+    uint32_t cap = f->plan.n_uncert ? (64u / f->plan.n_uncert > 1u ? 64u / f->plan.n_uncert : 1u) : 1u;
+    if (cap < f->plan.s_uncert) cap = f->plan.s_uncert;
     if (s > cap) s = cap;
     if (s > kMaxUncertSplits) s = kMaxUncertSplits;
     return s < 1u ? 1u : s;

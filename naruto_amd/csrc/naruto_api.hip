@@ -228,7 +228,7 @@ int launch_scatter(const NarutoField* f, const PointSrc& ps, uint32_t M, const f
     if (d_table == nullptr && adam == nullptr) { plan.n_dense = plan.n_hashed = 0; plan.n_level_blocks = 0; }        // only the uncertainty grid's gradient is wanted
     if (f->plan.n_dense + f->plan.n_hashed > 0) {
         static bool attr_set = false;
-        const size_t lds = (size_t)kChunk * sizeof(unsigned long long);
+        const size_t lds = kScatterLdsBytes;
         if (!attr_set) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_hash_scatter_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return fail(NARUTO_ERR_LAUNCH, "hash_scatter: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(hipGetLastError()));

@@ -1581,6 +1581,11 @@ struct UncertScatter {
     uint32_t first;             // list entries before this one carry no cotangent (a multiple of 4: 16-byte aligned rows)
 };
 
+#ifndef NARUTO_UNC_COMPACT
+#define NARUTO_UNC_COMPACT 1
+#endif
+constexpr uint32_t kUncBatch = (uint32_t)kScatterThreads * 8u;      // list entries per scan of the uncertainty units (NARUTO_UNC_COMPACT): 16 KB of queue
+constexpr size_t kScatterLdsBytes = (size_t)kChunk * sizeof(unsigned long long) + (NARUTO_UNC_COMPACT ? (size_t)kUncBatch * sizeof(uint16_t) + 16u : 0u);      // image + queue + its count
 __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab lt, BoxTab bt, PointSrc ps, uint32_t M, const float* __restrict__ d_feat,
                                                                        size_t stride_m, size_t stride_l, ScatterPlan plan,
                                                                        float* __restrict__ partial, size_t n_params,
@@ -1622,6 +1627,83 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
         const uint32_t u_first = plan.cyclic ? first + ((threadIdx.x >> 6) * unc.n_splits + split) * 512u + (threadIdx.x & 63u) * 8u : c_lo + threadIdx.x * 8u;
         const uint32_t u_step = plan.cyclic ? (kScatterThreads / 64u) * unc.n_splits * 512u : kScatterThreads * 8u;
         const uint32_t chunk_base = chunk * kChunk;
+#if NARUTO_UNC_COMPACT
+        // Round 5: scan + compaction.  Every workgroup of the grid's units used to run the full per-point arithmetic on every point of the list,
+        // although only the points near ITS chunk (one in twelve at the headline) add anything -- and a branch on that buys nothing: the 64
+        // lanes of a wave sit on 64 different points, some lane always hits, the wave executes the hit path at every step.  So, per batch of
+        // 8 192 consecutive list entries: (1) every thread tests its 8 points (cotangent not zero, base voxel's index range against the
+        // chunk's: conservative) and the hits' positions are packed into an LDS queue (ballot + rank, one LDS atomic per wave); (2) the queue
+        // is worked off by full waves: base voxel, fractions, the eight corners into the image (fix_add_corners: the exact per-corner test and
+        // the fixed-point conversion of the dense levels).  What a point adds depends on nothing but the point: same bits in any order.
+        // 52 -> 29 us per workgroup at the headline; the launch 57 -> 51 us (profiles/r05_scatter_timeline.txt).
+        {
+            // (the queue sits BEHIND the image in the dynamic allocation: static LDS in this kernel would move the image off address 0, and
+            // every address the level units form would carry the offset -- 127 -> 307 spilled scalar registers, measured)
+            uint16_t* __restrict__ q = reinterpret_cast<uint16_t*>(acc + kChunk);
+            uint32_t& q_n = *reinterpret_cast<uint32_t*>(q + kUncBatch);
+            const int lane = threadIdx.x & 63;
+            const uint32_t n_batches = (Mu + kUncBatch - 1u) / kUncBatch;
+            const int HW = unc.ut.H * unc.ut.W;
+            const int lo = (int)chunk_base, hi = (int)(chunk_base + kChunk);
+            for (uint32_t b = split; b < n_batches; b += unc.n_splits) {
+                const uint32_t base = first + b * kUncBatch;
+                if (threadIdx.x == 0) q_n = 0u;
+                __syncthreads();
+                const uint32_t p0 = base + threadIdx.x * 8u;
+                uint32_t flags = 0u;
+                if (p0 < M) {
+                    float rx[8], ry[8], rz[8], rg[8];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t b4 = (p0 + 4u * h < M) ? p0 + 4u * h : p0;
+                        const float4 X = *reinterpret_cast<const float4*>(ps.xsoa + b4), Y = *reinterpret_cast<const float4*>(ps.xsoa + ps.M + b4);
+                        const float4 Z = *reinterpret_cast<const float4*>(ps.xsoa + 2u * ps.M + b4), G = *reinterpret_cast<const float4*>(unc.g + b4);
+                        rx[4 * h] = X.x; rx[4 * h + 1] = X.y; rx[4 * h + 2] = X.z; rx[4 * h + 3] = X.w;
+                        ry[4 * h] = Y.x; ry[4 * h + 1] = Y.y; ry[4 * h + 2] = Y.z; ry[4 * h + 3] = Y.w;
+                        rz[4 * h] = Z.x; rz[4 * h + 1] = Z.y; rz[4 * h + 2] = Z.z; rz[4 * h + 3] = Z.w;
+                        rg[4 * h] = G.x; rg[4 * h + 1] = G.y; rg[4 * h + 2] = G.z; rg[4 * h + 3] = G.w;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        float fx, fy, fz;
+                        const uint32_t key = uncert_base(unc.ut, rx[k], ry[k], rz[k], fx, fy, fz);
+                        const int x0 = (int)(key & 1023u) - 2, y0 = (int)((key >> 10) & 1023u) - 2, z0 = (int)(key >> 20) - 2;
+                        const int i000 = z0 * HW + y0 * unc.ut.W + x0;                         // (of the voxel's eight corners, in-grid or not)
+                        const bool hit = (p0 + (uint32_t)k < M) & (rg[k] != 0.0f) & (fabsf(rg[k]) < 4194304.0f) & (i000 + HW + unc.ut.W + 1 >= lo) & (i000 < hi);
+                        flags |= hit ? (1u << k) : 0u;
+                    }
+                }
+                // pack the hits: one LDS atomic per wave reserves the wave's stretch of the queue, per step k a ballot ranks the lanes
+                const uint32_t n_wave = wave_sum_u32((uint32_t)__popc(flags));
+                uint32_t w0 = 0u;
+                if (lane == 0 && n_wave != 0u) w0 = atomicAdd(&q_n, n_wave);
+                w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)w0);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const unsigned long long m = __ballot((flags >> k) & 1u);
+                    const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if ((flags >> k) & 1u) q[w0 + r] = (uint16_t)(threadIdx.x * 8u + (uint32_t)k);
+                    w0 += (uint32_t)__popcll(m);
+                }
+                __syncthreads();
+                const uint32_t n_q = q_n;
+                for (uint32_t i = threadIdx.x; i < n_q; i += kScatterThreads) {
+                    const uint32_t pt = base + (uint32_t)q[i];
+                    const float x = ps.xsoa[pt], y = ps.xsoa[ps.M + pt], z = ps.xsoa[2u * ps.M + pt], g = unc.g[pt];
+                    float fx, fy, fz;
+                    const uint32_t key = uncert_base(unc.ut, x, y, z, fx, fy, fz);
+                    int32_t ci[8];
+                    uncert_base_corners(unc.ut, key, ci);
+                    uint32_t idx[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) idx[c] = (uint32_t)ci[c];                      // idx -1 (outside the grid) wraps out of every chunk
+                    const float f[6] = {1.0f - fx, fx, 1.0f - fy, fy, 1.0f - fz, fz};            // uncert_corners' weights, per axis
+                    fix_add_corners(acc, idx, chunk_base, f, g);
+                }
+                __syncthreads();                          // the queue is rewritten by the next batch
+            }
+        }
+#else
         // consecutive list entries are consecutive samples of a ray and stay in one voxel for a few samples: a thread walks a run of
         // 8 points and sums the corner contributions in registers while the base voxel does not change (fewer, less conflicting LDS adds)
         for (uint32_t r0 = u_first; r0 < m_hi; r0 += u_step) {
@@ -1688,6 +1770,7 @@ __global__ __launch_bounds__(kScatterThreads) void k_hash_scatter_lds(LevelTab l
             }
             flush();
         }
+#endif
         __syncthreads();
         stamp(2);
         const uint32_t n_e = plan.uncert_voxels - chunk_base < kChunk ? plan.uncert_voxels - chunk_base : kChunk;

@@ -2296,7 +2296,7 @@ __global__ __launch_bounds__(64 * kBwdWaves) void k_query_bwd(LevelTab lt, Uncer
         static_for<0, kLevels>([&](auto tc) {
             constexpr int T = decltype(tc)::value;
             const float b = cur.feat[T];
-            xs[j * kStageLd + 2 * T + hh] = valid ? b : 0.0f;
+            xs[j * kStageLd + 2 * T + hh] = b;            // (padding points: finite inputs of the last valid point x exact-zero cotangents = 0 in every dW sum)
             h = mfma32(L.f.s0[T * 64 + lane], b, h);
         });
         const bool blob_fast = __all(oneblob_sparse_ok(x) && oneblob_sparse_ok(y) && oneblob_sparse_ok(z));
@@ -2316,7 +2316,7 @@ __global__ __launch_bounds__(64 * kBwdWaves) void k_query_bwd(LevelTab lt, Uncer
                 constexpr int Q = decltype(qc)::value;
                 constexpr int P = D * 8 + Q;
                 const float b = hh ? eb[D][2 * Q + 1] : eb[D][2 * Q];
-                xs[j * kStageLd + kFeat + 2 * P + hh] = valid ? b : 0.0f;
+                xs[j * kStageLd + kFeat + 2 * P + hh] = b;
                 if ((pairs >> P) & 1u) {
                     h = mfma32(L.f.s0[(16 + P) * 64 + lane], b, h);
                     c = mfma32(L.f.c0p[P * 64 + lane], b, c);
@@ -2334,7 +2334,7 @@ __global__ __launch_bounds__(64 * kBwdWaves) void k_query_bwd(LevelTab lt, Uncer
         });
         // sdf-net outputs -> stage columns 80..95 (colour layer-0 inputs); padding points -> 0
 #pragma unroll
-        for (int r = 0; r < 8; ++r) xs[j * kStageLd + 80 + crow(r, hh)] = valid ? o[r] : 0.0f;
+        for (int r = 0; r < 8; ++r) xs[j * kStageLd + 80 + crow(r, hh)] = o[r];
 
         // ---- colour layer 1 backward (VALU): d_c = relu'(c) * (col_w1^T . d_rgb)
         f32x16 dcv, cact;

@@ -47,7 +47,7 @@ class FusedBA:
         # iteration counter that keys the draw has been advanced -- so only the FIRST iteration of a global_BA call launches k_assemble_rays
         # itself.  Same batches, same trajectory (tests: the graph twin prefetches, the eager twin does not).
         self.prefetch = (os.environ.get("NARUTO_BA_PREFETCH", "1") != "0") if prefetch is None else bool(prefetch)
-        self._next_batch = None
+        self._armed = None            # the TrainStep whose finishing launch draws the next batch (it holds the struct and its keep-alives)
         # ... and with active rays that assembly also looks the candidates' keys up (NarutoRayBatch.keys_out): the selection in front of the
         # next forward starts from the keys (naruto_active_ray_select_keyed) instead of two dependent trips to memory per candidate.
         # NARUTO_BA_KEYED_SELECT=0 switches it off.
@@ -109,9 +109,38 @@ class FusedBA:
         b, keep = self.store.next_batch_struct(self.sample_num, self.current, self.poses, self.min_pixels_cur, out, filter_depth=self.filter_depth,
                                                rng=self.trainer.iter_state, dyn=self.dyn, n_cur=n_cur, n_cur_pop=self._n_cur_pop, keys=keys)
         assert train_step.opt is not None, "prefetch needs the optimiser in the backward (MappingTrainer(fused_adam=True))"
-        self._next_batch = (b, keep)
         import ctypes as C
+        self._disarm_prefetch()
+        # the struct and everything it points into live ON the TrainStep whose backward reads them (the trainer's cache and a captured graph's
+        # _static['ts'] outlive this object): the host pointer in opt.next_batch can never dangle
+        train_step._next_batch_keep = (b, keep)
         train_step.opt.next_batch = C.cast(C.pointer(b), C.c_void_p)
+        self._armed = train_step
+
+    def _disarm_prefetch(self):
+        """Take the next-batch draw off the TrainStep it rides on: its backward no longer assembles anything (and no longer overwrites the stage /
+        ray buffers of this object).  Called on re-arm, on close() and when this object is dropped."""
+        ts = getattr(self, "_armed", None)
+        self._armed = None
+        if ts is not None and getattr(ts, "opt", None) is not None:
+            ts.opt.next_batch = None
+            ts._next_batch_keep = None
+
+    def close(self):
+        """Detach from the trainer: the TrainStep this object armed keeps working as a plain training step (trainer.step, first_frame_mapping).
+        A graph captured with the prefetch inside is dropped (its finishing launch would go on drawing batches)."""
+        armed = getattr(self, "_armed", None)
+        st = getattr(self.trainer, "_static", None)
+        if armed is not None and self.use_graph and st is not None and st.get('ts') is armed:
+            self.trainer._graphs = None
+        self._disarm_prefetch()
+        self._shape = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _prologue(self, n_cur: int):
         store, sampler = self.store, self.sampler
@@ -190,6 +219,7 @@ class FusedBA:
                 from .trainer import unpack_rays
                 self._eager_bufs = unpack_rays(f, n_train)
                 self.trainer._graphs = None
+                self._disarm_prefetch()
                 if self.prefetch:
                     tr_cfg = self.config['training']
                     self._arm_prefetch(n_cur, self._eager_bufs, self.trainer._train_step(n_train, bool(smooth and tr_cfg['smooth_weight'] > 0)))
@@ -204,7 +234,17 @@ class FusedBA:
             bufs = tr.ray_buffers()
             return tr.step(*bufs, smooth=smooth, uncert_step=(i + 1) % 5 == 0, first=(i == 0))           # the replay starts with the prologue's launches
         bufs = self._eager_bufs
-        pro = self._pro if (i == 0 or not self.prefetch) else self._pro_later
+        full = i == 0 or not self.prefetch
+        if self.prefetch:
+            # the TrainStep this iteration WILL run on (the trainer's cache is keyed on (n_rays, smooth, n_rays_total) and evicts): if it is not
+            # the one whose finishing launch draws the batches, nothing drew this iteration's batch and nothing would draw the next one --
+            # arm it and assemble this batch with the full prologue (the draw is keyed by the iteration counter: assembling twice is idempotent)
+            tr_cfg = self.config['training']
+            ts = tr._train_step(bufs[0].shape[0], bool(smooth and tr_cfg['smooth_weight'] > 0))
+            if ts is not self._armed or ts.opt is None or not ts.opt.next_batch:
+                self._arm_prefetch(self._shape[0], bufs, ts)
+                full = True
+        pro = self._pro if full else self._pro_later
         if pro is not None:
             pro(*bufs)
         return tr.step(*bufs, smooth=smooth, uncert_step=(i + 1) % 5 == 0)

@@ -324,6 +324,15 @@ __device__ __forceinline__ bool ee_lane_live(const EeState& st, const EarlyExit&
     return !(z > lim + 1e-5f * fabsf(lim) + 1e-6f);
 }
 
+// What is known of that limit BEFORE any network output (round 6): it is at least measured depth + truncation, so a sample up to there is
+// needed whatever the sdf turns out to be; a ray without a measured depth gives nothing away.  The gather launch in front of the walk
+// (k_gather_walk) fetches these samples' features; one truncation distance more than needed, so that a first sign change slightly BEHIND the
+// measured depth (z_first in (d, d + trunc]) still finds its samples fetched.  The walk evaluates the same predicate on the same numbers.
+__device__ __forceinline__ bool ee_apriori_live(const EarlyExit& ee, float td, float z) {
+    if (!(td > 0.0f)) return true;
+    return !(z > td + 2.0f * ee.trunc_sc);
+}
+
 // One 64-point tile of the forward: hash gather (lane half hh fetches the corners with x offset hh of points 0..31, then 32..63),
 // OneBlob, both MLPs.  x, y, z: THIS lane's point (lane = point within the tile); mA / mB: feat_save rows of point j / j + 32.
 // Results: out.rgb / out.sdf for this lane's point; geo (optional) [M,15]: the sdf-net's geometric features of both halves.
@@ -554,6 +563,91 @@ __device__ __forceinline__ void fwd_gather_tile(const LevelTab& lt, const float2
         sl.feat[T][0][lane] = b0;
         sl.feat[T][1][lane] = b1;
     });
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// XCD-partitioned gather (round 6).  MI355X has eight XCDs with 4 MB of L2 each; the shipped table is 6.5 MB.  A wave that gathers all 16
+// levels makes every XCD's L2 see the whole table: random 64-byte lines then arrive at 154 G lines/s chip-wide -- against 265 - 274 G lines/s
+// when every XCD only ever touches a slice of at most 4 MB (tools/xcd_partition_bench.hip, profiles/r06_xcd_partition_bench.txt: the drop sits
+// exactly between 4 and 5 MB per XCD).  Workgroups are dealt round-robin over the XCDs (blockIdx % 8), so a launch whose workgroup b gathers
+// only the levels of group (b % 8) * G / 8 keeps each L2's working set at 6.5 MB / G.  The features of a point then come from G different
+// workgroups: they meet in feat_save ([level][M][2], which the training forward writes for the backward anyway) and the matrix phase -- a
+// second launch -- fetches them with coalesced loads (fwd_reload_tile) instead of gathering.  Same index / load / blend functions as
+// fwd_gather_tile: the same bits.
+// ------------------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kXcds = 8;
+struct LevelGroups {
+    uint32_t G;                  // 1, 2, 4 or 8 groups
+    uint32_t begin[kXcds + 1];   // group g gathers levels [begin[g], begin[g + 1])
+};
+// workgroup b of a grid-partitioned launch: its level group and its index among the workgroups of that group
+__device__ __forceinline__ void xcd_group_of_block(const LevelGroups& lg, uint32_t b, uint32_t& g, uint32_t& q) {
+    const uint32_t xcd = b & (kXcds - 1u), per = kXcds / lg.G;
+    g = xcd / per;
+    q = (b >> 3) * per + (xcd - g * per);
+}
+inline uint32_t xcd_grid_blocks(uint32_t G, uint32_t units_per_group) {       // blocks of a launch in which every group has >= units_per_group workgroups
+    const uint32_t per = kXcds / G;
+    return ((units_per_group + per - 1u) / per) * kXcds;
+}
+// levels [T0, T1) of one 64-point tile -> feat_save (two levels' loads in flight); dead lanes (MASK) issue entry-0 loads and store nothing
+template <bool MASK>
+__device__ __forceinline__ void gather_levels_to_save(const LevelTab& lt, const float2* __restrict__ table, float x, float y, float z, float* __restrict__ feat_save,
+                                                      uint32_t M, uint32_t mA, uint32_t mB, int lane, bool live, uint32_t T0, uint32_t T1) {
+    const uint32_t hh = (uint32_t)lane >> 5;
+    float la = live ? 1.0f : 0.0f, lb = la;
+    if constexpr (MASK) swap32(la, lb);
+    const bool liveA = MASK ? la != 0.0f : true, liveB = MASK ? lb != 0.0f : true;
+    float xa = x, xb = x, ya = y, yb = y, za = z, zb = z;
+    swap32(xa, xb); swap32(ya, yb); swap32(za, zb);
+    auto retire = [&](uint32_t T, const HalfCorners& ha, const HalfCorners& hb, const float2 (&va)[4], const float2 (&vb)[4]) {
+        const float2 pa = hash_level_half_blend(ha, va);
+        const float2 pb = hash_level_half_blend(hb, vb);
+        float ua = pa.x, wa = pa.y, ub = pb.x, wb = pb.y;
+        swap32(ua, wa);
+        swap32(ub, wb);
+        const float b0 = ua + wa, b1 = ub + wb;
+        char* __restrict__ fs = reinterpret_cast<char*>(feat_save + (size_t)T * M * 2u);
+        if (liveA) *reinterpret_cast<float*>(fs + ((mA * 2u + hh) << 2)) = b0;
+        if (liveB) *reinterpret_cast<float*>(fs + ((mB * 2u + hh) << 2)) = b1;
+    };
+    for (uint32_t T = T0; T < T1; T += 2u) {
+        const bool two = T + 1u < T1;
+        HalfCorners ha0, hb0, ha1, hb1;
+        float2 va0[4], vb0[4], va1[4], vb1[4];
+        ha0 = hash_level_half_index(lt, (int)T, xa, ya, za, hh);
+        hb0 = hash_level_half_index(lt, (int)T, xb, yb, zb, hh);
+        hash_level_half_load_sel<MASK>(lt, (int)T, table, ha0, va0, liveA);
+        hash_level_half_load_sel<MASK>(lt, (int)T, table, hb0, vb0, liveB);
+        if (two) {
+            ha1 = hash_level_half_index(lt, (int)T + 1, xa, ya, za, hh);
+            hb1 = hash_level_half_index(lt, (int)T + 1, xb, yb, zb, hh);
+            hash_level_half_load_sel<MASK>(lt, (int)T + 1, table, ha1, va1, liveA);
+            hash_level_half_load_sel<MASK>(lt, (int)T + 1, table, hb1, vb1, liveB);
+        }
+        retire(T, ha0, hb0, va0, vb0);
+        if (two) retire(T + 1u, ha1, hb1, va1, vb1);
+    }
+}
+// the gather phase's stand-in where the tile's features already sit in feat_save (rows of live lanes): 32 independent coalesced loads -> the slab;
+// dead lanes' features are zeros, as fwd_gather_tile<true> leaves them
+__device__ __forceinline__ void fwd_reload_tile(const float* __restrict__ feat_save, uint32_t M, uint32_t mA, uint32_t mB, int lane, FwdSlab& sl, bool live) {
+    const uint32_t hh = (uint32_t)lane >> 5;
+    float la = live ? 1.0f : 0.0f, lb = la;
+    swap32(la, lb);
+    const bool liveA = la != 0.0f, liveB = lb != 0.0f;
+    float b0[kLevels], b1[kLevels];
+#pragma unroll
+    for (int T = 0; T < kLevels; ++T) {
+        const char* __restrict__ fs = reinterpret_cast<const char*>(feat_save + (size_t)T * M * 2u);
+        b0[T] = liveA ? *reinterpret_cast<const float*>(fs + ((mA * 2u + hh) << 2)) : 0.0f;
+        b1[T] = liveB ? *reinterpret_cast<const float*>(fs + ((mB * 2u + hh) << 2)) : 0.0f;
+    }
+#pragma unroll
+    for (int T = 0; T < kLevels; ++T) {
+        sl.feat[T][0][lane] = b0[T];
+        sl.feat[T][1][lane] = b1[T];
+    }
 }
 
 // the matrix phase: fwd_tile's chain in fwd_tile's order (same accumulation order: same bits), hash-part B operands from the slab
@@ -1068,14 +1162,10 @@ __device__ __forceinline__ void fwd_tile_bf(const FwdLdsBf& L, const LevelTab& l
         fwd_tail_bf<COLOR>(L, hA, hB, cA, cB, x, y, z, geo, M, mA, mB, lane, out);
 }
 
-// phase-split form of a FULL bf16 tile (see fwd_tile_split): the same gather phase, then the two hash K blocks from the slab
-template <bool COLOR, bool MASK>
-__device__ __forceinline__ void fwd_tile_split_bf(const FwdLdsBf& L, FwdSlab& sl, const LevelTab& lt, const float2* __restrict__ table, float x, float y, float z,
-                                                  float* __restrict__ feat_save, float* __restrict__ geo, uint32_t M, uint32_t mA, uint32_t mB, int lane, FwdTileOut& out,
-                                                  bool live = true) {
-    if constexpr (NARUTO_FWD_GATHER_PRIO != 0) __builtin_amdgcn_s_setprio(NARUTO_FWD_GATHER_PRIO);
-    fwd_gather_tile<MASK>(lt, table, x, y, z, feat_save, M, mA, mB, lane, sl, live);
-    if constexpr (NARUTO_FWD_GATHER_PRIO != 0) __builtin_amdgcn_s_setprio(0);
+// the bf16 mode's matrix phase: the two hash K blocks from the slab, then the tail
+template <bool COLOR>
+__device__ __forceinline__ void fwd_mlp_tile_bf(const FwdLdsBf& L, const FwdSlab& sl, float x, float y, float z, float* __restrict__ geo, uint32_t M, uint32_t mA, uint32_t mB,
+                                                int lane, FwdTileOut& out) {
     f32x16 hA = zero16(), hB = zero16(), cA = zero16(), cB = zero16();
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -1087,6 +1177,16 @@ __device__ __forceinline__ void fwd_tile_split_bf(const FwdLdsBf& L, FwdSlab& sl
         hB = mfma16(w, pack8(fb), hB);
     }
     fwd_tail_bf<COLOR>(L, hA, hB, cA, cB, x, y, z, geo, M, mA, mB, lane, out);
+}
+// phase-split form of a FULL bf16 tile (see fwd_tile_split): the same gather phase, then the two hash K blocks from the slab
+template <bool COLOR, bool MASK>
+__device__ __forceinline__ void fwd_tile_split_bf(const FwdLdsBf& L, FwdSlab& sl, const LevelTab& lt, const float2* __restrict__ table, float x, float y, float z,
+                                                  float* __restrict__ feat_save, float* __restrict__ geo, uint32_t M, uint32_t mA, uint32_t mB, int lane, FwdTileOut& out,
+                                                  bool live = true) {
+    if constexpr (NARUTO_FWD_GATHER_PRIO != 0) __builtin_amdgcn_s_setprio(NARUTO_FWD_GATHER_PRIO);
+    fwd_gather_tile<MASK>(lt, table, x, y, z, feat_save, M, mA, mB, lane, sl, live);
+    if constexpr (NARUTO_FWD_GATHER_PRIO != 0) __builtin_amdgcn_s_setprio(0);
+    fwd_mlp_tile_bf<COLOR>(L, sl, x, y, z, geo, M, mA, mB, lane, out);
 }
 
 // 2, not 3, waves per SIMD: at 3 (<= 168 registers) the kernel spills 65 registers and the forward takes 65 us instead of 51

@@ -183,13 +183,82 @@ struct WalkExtra {
     uint32_t tv_groups;          // level groups per lattice-encode workgroup (tv_encode_blocks)
     SampleArgs sa;
     const float* rand6; const uint64_t* rng; float* x_out;
+    uint32_t pre;                // round 6, what a gather launch in front (k_gather_walk / k_gather_short) has left: bit 0 the depths in z_vals,
+                                 // bit 1 the hash features of every a-priori-needed sample (ee_apriori_live; all of a ray's first tile) in feat_save
 };
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The gather launch in front of the depth-ordered walk (round 6; see "XCD-partitioned gather" in naruto_field.hip): one wave per (ray, level
+// group).  The wave samples its ray's depths (sample_z_ray: the walk's own routine -- every group of a ray computes the same numbers, group 0
+// writes them to z_vals), then for each of the ray's tiles fetches the features of the samples that are needed whatever the network says
+// (ee_apriori_live; the whole first tile) for ITS levels only and writes them to feat_save.  Workgroups of group g sit on XCDs
+// [g * 8 / G, (g + 1) * 8 / G): each L2 serves 6.5 MB / G of table.  No weights, no matrix registers: short waves at high occupancy.
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather_walk(LevelTab lt, BoxTab bt, PointSrc ps, const float2* __restrict__ table, uint32_t M, float* __restrict__ feat_save,
+                                                     EarlyExit ee, SampleArgs sa, uint32_t sample_on, uint32_t n_rays, LevelGroups lg,
+                                                     unsigned long long* __restrict__ timeline) {
+    extern __shared__ float z_lds[];                   // per wave: zs | us | keep, S floats each
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int j = lane & 31;
+    uint32_t g, q;
+    xcd_group_of_block(lg, blockIdx.x, g, q);
+    const uint32_t task = q * (uint32_t)kRaysPerBlock + (uint32_t)wave;
+    // profiling (naruto_debug_fwd_timeline, rows behind the walk's: tools/walk_timeline.py): 0 start, 1 depths sampled, 2 first tile, 3 end; 6 = group, 7 = tiles
+    auto stamp = [&](int k) {
+        if (timeline != nullptr && lane == 0) timeline[((size_t)16384u + (size_t)blockIdx.x * 4u + (size_t)wave) * 8u + (size_t)k] = (unsigned long long)wall_clock64();
+    };
+    stamp(0);
+    if (task >= n_rays) return;
+    const uint32_t S = ps.S, tpr = ee.tiles_per_ray;
+    const uint32_t T0 = lg.begin[g], T1 = lg.begin[g + 1u];
+    float* __restrict__ zs = z_lds + (size_t)wave * 3u * S;
+    float* __restrict__ us = zs + S;
+    float* __restrict__ keep = us + S;
+    if (sample_on != 0u) {
+        sample_z_ray(task, sa.target_d, sa.near_, sa.far_, sa.nu, sa.nr, sa.range_d, sa.rand, sa.rng, g == 0u ? sa.z_vals : nullptr, zs, us, lane, keep);
+    } else {
+        for (uint32_t s = lane; s < S; s += 64u) keep[s] = ps.z_vals[(size_t)task * S + s];
+    }
+    wave_lds_sync();
+    stamp(1);
+    const float td = ee.target_d != nullptr ? ee.target_d[task] : 0.0f;
+    const float ox = ps.rays_o[3 * task + 0], oy = ps.rays_o[3 * task + 1], oz = ps.rays_o[3 * task + 2];
+    const float dx = ps.rays_d[3 * task + 0], dy = ps.rays_d[3 * task + 1], dz = ps.rays_d[3 * task + 2];
+    const uint32_t ray0 = task * S;
+    for (uint32_t tq = 0; tq < tpr; ++tq) {
+        const uint32_t s = tq * 64u + (uint32_t)lane;
+        const bool valid = s < S;
+        const float zv = keep[valid ? s : S - 1u];
+        const bool live = valid && (tq == 0u || ee_apriori_live(ee, td, zv));
+        if (!__any(live)) break;                       // (depths are sorted: nothing further along the ray is needed a priori either)
+        // load_point's arithmetic with the depth from the image
+        const float px = __fadd_rn(ox, __fmul_rn(dx, zv));
+        const float py = __fadd_rn(oy, __fmul_rn(dy, zv));
+        const float pz = __fadd_rn(oz, __fmul_rn(dz, zv));
+        const float x = __fdiv_rn(__fsub_rn(px, bt.bmin[0]), bt.bext[0]);
+        const float y = __fdiv_rn(__fsub_rn(py, bt.bmin[1]), bt.bext[1]);
+        const float z = __fdiv_rn(__fsub_rn(pz, bt.bmin[2]), bt.bext[2]);
+        const uint32_t t0 = ray0 + tq * 64u;
+        gather_levels_to_save<true>(lt, table, x, y, z, feat_save, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, live, T0, T1);
+        if (tq == 0u) stamp(2);
+        if (timeline != nullptr && lane == 0) timeline[((size_t)16384u + (size_t)blockIdx.x * 4u + (size_t)wave) * 8u + 7u] = tq + 1u;
+    }
+    stamp(3);
+    if (timeline != nullptr && lane == 0) timeline[((size_t)16384u + (size_t)blockIdx.x * 4u + (size_t)wave) * 8u + 6u] = g + 1u;
+}
 // SPLIT: the tile in two phases through a per-wave LDS slab (fwd_tile_split) -- 32 KB per workgroup, so the launcher uses it only while two
 // workgroups still fit a CU next to the rays' images (up to 192 samples per ray); longer rays keep the register form (fwd_tile).
 template <bool BF, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, PointSrc ps, uint32_t M, float* __restrict__ raw,
-                                                           float* __restrict__ feat_save, EarlyExit ee, LossStageArgs a, uint32_t n_fwd_blocks, WalkExtra wx) {
+                                                           float* __restrict__ feat_save, EarlyExit ee, LossStageArgs a, uint32_t n_fwd_blocks, WalkExtra wx,
+                                                           unsigned long long* __restrict__ timeline) {
     using Lds = std::conditional_t<BF, FwdLdsBf, std::conditional_t<SPLIT, FwdLdsExact, FwdLds>>;      // (two-phase tile, exact mode: the x3 chain)
+    // profiling (naruto_debug_fwd_timeline; NULL otherwise): lane 0 of every WAVE stamps the 100 MHz counter into its row of 8 -- 0 start, 1 weights
+    // staged, 2 depths sampled, 3 first tile's gathers, 4 first tile done, 5 all tiles done, 6 loss stage; slot 7 = tiles evaluated (tools/walk_timeline.py)
+    auto stamp = [&](int k) {
+        if (timeline != nullptr && (threadIdx.x & 63u) == 0u && blockIdx.x < n_fwd_blocks) timeline[((size_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * 8u + (size_t)k] = (unsigned long long)wall_clock64();
+    };
+    stamp(0);
     __shared__ Lds L;
     __shared__ FwdSlab slabs[SPLIT ? kRaysPerBlock : 1];
     __shared__ double red[4];
@@ -213,6 +282,7 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
     else if constexpr (BF) stage_fwd_weights_bf<256>(L, p, threadIdx.x);
     else stage_fwd_weights<256>(L, p, threadIdx.x);
     __syncthreads();
+    stamp(1);
     if (ee.stagger != 0u) {
         const bool late = (ee.stagger & 256u) ? (blockIdx.x & 1u) != 0u : blockIdx.x >= n_fwd_blocks / 2u;
         if (late) for (uint32_t i = 0; i < (ee.stagger & 255u); ++i) __builtin_amdgcn_s_sleep(127);
@@ -228,12 +298,16 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
     for (uint32_t group = blockIdx.x; group < n_groups; group += n_fwd_blocks) {          // uniform over the workgroup: barriers inside
         const uint32_t task = group * (uint32_t)kRaysPerBlock + (uint32_t)wave;
         if (task < a.n_rays) {
-            if constexpr (SPLIT) if (wx.on) {
+            if constexpr (SPLIT) if (wx.on != 0u && (wx.pre & 1u) == 0u) {
                 const SampleArgs& sa = wx_s.sa;
                 sample_z_ray(task, sa.target_d, sa.near_, sa.far_, sa.nu, sa.nr, sa.range_d, sa.rand, sa.rng, sa.z_vals, rs.c0, rs.c1, lane);
                 __threadfence_block();
             }
+            if (group == blockIdx.x) stamp(2);
             EeState ees{false, 0.0f, 0.0f, 0.0f};
+            bool pre_feat = false;
+            if constexpr (SPLIT) pre_feat = (wx.pre & 2u) != 0u;
+            const float td_ap = pre_feat ? ee.target_d[task] : 0.0f;
             const uint32_t ray0 = task * S;                              // the ray's first sample in the point list
             uint32_t tq = 0;
             for (; tq < tpr; ++tq) {
@@ -250,9 +324,24 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
                 const float u = live ? uncert_sample(ut, p.uncert_grid, x, y, z) : 0.0f;
                 FwdTileOut to;
                 const bool live_out = live;
-                if constexpr (BF && SPLIT) fwd_tile_split_bf<true, true>(L, slabs[wave], lt, table, x, y, z, feat_save, nullptr, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, to, live);
+                if constexpr (SPLIT) {                       // the tile in two phases (fwd_tile_split / fwd_tile_split_bf), with a stamp between them
+                    // a gather launch in front left the a-priori-needed samples' features in feat_save (wx.pre): where that covers every live lane
+                    // -- always in a ray's first tile -- the gather phase is 32 coalesced loads; else (first sign change beyond depth + truncation, or
+                    // none yet) the tile gathers for itself as before.  Same features either way: same bits.
+                    bool reload = false;
+                    if (pre_feat) reload = !__any(live && !(tq == 0u || ee_apriori_live(ee, td_ap, zv)));
+                    if (reload) fwd_reload_tile(feat_save, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, slabs[wave], live);
+                    else {
+                        if constexpr (NARUTO_FWD_GATHER_PRIO != 0) __builtin_amdgcn_s_setprio(NARUTO_FWD_GATHER_PRIO);
+                        fwd_gather_tile<true>(lt, table, x, y, z, feat_save, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, slabs[wave], live);
+                        if constexpr (NARUTO_FWD_GATHER_PRIO != 0) __builtin_amdgcn_s_setprio(0);
+                    }
+                    if (tq == 0u && group == blockIdx.x) stamp(3);
+                    if constexpr (BF) fwd_mlp_tile_bf<true>(L, slabs[wave], x, y, z, nullptr, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, to);
+                    else if constexpr (kExactX3) fwd_mlp_tile_x3<true>(L, slabs[wave], x, y, z, nullptr, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, to);
+                    else fwd_mlp_tile<true>(L, slabs[wave], x, y, z, nullptr, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, to);
+                }
                 else if constexpr (BF) fwd_tile_bf<true, true>(L, lt, table, x, y, z, feat_save, nullptr, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, to, live);
-                else if constexpr (SPLIT) fwd_tile_split<true, true>(L, slabs[wave], lt, table, x, y, z, feat_save, nullptr, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, to, live);
                 else fwd_tile<true, true>(L, lt, table, x, y, z, feat_save, nullptr, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, to, live);
                 if (!live_out) { to.rgb[0] = 0.0f; to.rgb[1] = 0.0f; to.rgb[2] = 0.0f; to.sdf = 0.0f; }
                 const float u_out = live_out ? u : 0.0f;
@@ -262,6 +351,7 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
                     rs.c0[s] = to.rgb[0]; rs.c1[s] = to.rgb[1]; rs.c2[s] = to.rgb[2]; rs.sdf[s] = to.sdf; rs.u[s] = u_out;
                     rs.z[s] = zv;
                 }
+                if (tq == 0u && group == blockIdx.x) stamp(4);
                 if (tq + 1u < tpr && ee_after_tile(ees, ee, ps, m, tq, t0 + 64u, ray0 + S, task, to.sdf, lane, raw)) { ++tq; break; }
             }
             // tiles that were not evaluated: raw is zeros there (ee_after_tile wrote them), the image gets the same
@@ -270,7 +360,12 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
                 rs.z[s] = ps.z_vals[(size_t)task * S + s];
             }
             wave_lds_sync();
+            if (group == blockIdx.x) {
+                stamp(5);
+                if (timeline != nullptr && lane == 0) timeline[((size_t)blockIdx.x * 4u + (size_t)wave) * 8u + 7u] = tq;
+            }
             loss_stage_ray(a_s, rs, task, lane, terms[wave]);
+            if (group == blockIdx.x) stamp(6);
         } else {
             loss_stage_no_ray(lane, terms[wave]);
         }
@@ -279,10 +374,10 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
         __syncthreads();                                   // terms are rewritten by the next group
     }
 }
-template __global__ void k_query_fwd_loss<false, false>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t, WalkExtra);
-template __global__ void k_query_fwd_loss<true, false>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t, WalkExtra);
-template __global__ void k_query_fwd_loss<false, true>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t, WalkExtra);
-template __global__ void k_query_fwd_loss<true, true>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t, WalkExtra);
+template __global__ void k_query_fwd_loss<false, false>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t, WalkExtra, unsigned long long*);
+template __global__ void k_query_fwd_loss<true, false>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t, WalkExtra, unsigned long long*);
+template __global__ void k_query_fwd_loss<false, true>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t, WalkExtra, unsigned long long*);
+template __global__ void k_query_fwd_loss<true, true>(LevelTab, UncertTab, BoxTab, NarutoParams, PointSrc, uint32_t, float*, float*, EarlyExit, LossStageArgs, uint32_t, WalkExtra, unsigned long long*);
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // SHORT rays (round 5): the training forward + loss stage for S <= 64 samples per ray -- the sampling NARUTO ships (32 + 11,

@@ -2701,6 +2701,70 @@ def test_fused_ba_iteration_equals_its_pieces(gpu, active):
     a.trainer.model.check_asserts(block=True)
 
 
+@pytest.mark.parametrize("active", [False, True])
+def test_fused_ba_prefetch_survives_eviction_and_close(gpu, active):
+    """Two advisor findings of round 5.  (i) The eager prefetch rides on ONE TrainStep; the trainer's cache (keyed on ray count / smoothness,
+    LRU of max_cached_steps) may hand the next iteration another one: every iteration must then still train on its own freshly drawn batch
+    (trajectory = the twin that assembles every batch itself, bit for bit), not silently on stale rays.  (ii) The NarutoRayBatch the fused
+    optimiser points at lives on the TrainStep, and close() / dropping the FusedBA disarms it: a later trainer.step on the same TrainStep
+    neither reads freed host memory nor overwrites anybody's ray buffers."""
+    import gc
+    from naruto_amd import trainer
+    from naruto_amd.active_ray_sampler import ActiveRaySamplerHIP
+    from naruto_amd.ba_loop import FusedBA
+    cfg = H.office_cfg(12, perturb=1.0)
+    cfg["mapping"].update(sample=256, min_pixels_cur=40, filter_depth=True, keyframe_every=5)
+    bound = torch.tensor(cfg["mapping"]["bound"])
+    twins = []
+    for prefetch in (True, False):
+        torch.manual_seed(35)
+        tr = trainer.MappingTrainer(cfg, bound, gpu, fused_adam=True)
+        store, current, poses, vol = _ba_scene(cfg, gpu, n_kf=8)
+        smp = ActiveRaySamplerHIP(config=cfg, num_uncert_sample=48, oversample_mul=4) if active else None
+        twins.append((FusedBA(tr, store, smp, max_poses=64, use_graph=False, prefetch=prefetch), current, poses, vol))
+    (a, cur, poses, vol), (b, _, _, _) = twins
+    b.trainer.model.load_state_dict(a.trainer.model.state_dict())
+    b.trainer.iter_state.copy_(a.trainer.iter_state)
+    a.trainer.max_cached_steps = 1                       # every other ray count evicts the armed TrainStep
+    rays = syn.random_rays(64, cfg["mapping"]["bound"], seed=3)
+    other = [torch.from_numpy(rays[k]).to(gpu) for k in ("rays_o", "rays_d", "target_rgb", "target_d")]
+    losses = {"a": [], "b": []}
+    for tag, ba in (("a", a), ("b", b)):
+        ba.prepare(cur, poses, vol if active else None)
+        for i in range(6):
+            if i in (2, 4):
+                # a foreign step of another size between two iterations (both twins, so the trajectories stay comparable): on twin a it evicts
+                # the TrainStep whose finishing launch was to draw iteration i's batch
+                ba.trainer.step(*other, smooth=True, uncert_step=False)
+            ret, loss = ba.iteration(i)
+            losses[tag].append(float(loss))
+    assert losses["a"] == losses["b"], losses
+    assert len(set(losses["a"])) == 6, "every iteration draws another batch"
+    for (n, p), (_, q) in zip(a.trainer.model.named_parameters(), b.trainer.model.named_parameters()):
+        assert torch.equal(p, q), f"parameter {n}: prefetching twin (with evictions) != the twin that assembles every batch"
+    # (ii) the struct lives on the TrainStep; close() disarms
+    ts = a._armed
+    assert ts is not None and ts.opt.next_batch and ts._next_batch_keep is not None
+    bufs = [t.clone() for t in a._eager_bufs]
+    stage = [t.clone() for t in a._stage] if active else None
+    tr_a = a.trainer
+    n_train = bufs[0].shape[0]
+    a.close()
+    assert not ts.opt.next_batch and ts._next_batch_keep is None
+    eager_bufs, stage_live = a._eager_bufs, a._stage
+    del a
+    gc.collect()
+    mine = [t.clone() for t in bufs]
+    tr_a.step(*mine, smooth=True, uncert_step=False)     # same ray count: the TrainStep the FusedBA had armed
+    torch.cuda.synchronize()
+    for t0, t1 in zip(bufs, eager_bufs):
+        assert torch.equal(t0, t1), "a disarmed TrainStep no longer draws into the FusedBA's ray buffers"
+    if active:
+        for t0, t1 in zip(stage, stage_live):
+            assert torch.equal(t0, t1), "... nor into its stage"
+    assert tr_a._train_step(n_train, True) is ts
+
+
 def test_active_ray_keys_looked_up_by_the_assembly(gpu):
     """NarutoRayBatch.keys_out + naruto_active_ray_select_keyed (round 5): the candidates' keys looked up by the batch assembly, while the
     rows are in registers, and the selection started from them -- the same selected batch, bit for bit, as assembly | selection with its

@@ -858,47 +858,6 @@ int train_check(const NarutoField* f, const NarutoParams* p, const NarutoTrainSt
     if (t->smooth_points != 0 && t->loss_weights == nullptr) return fail(NARUTO_ERR_INVALID, "%s: the smoothness term needs loss_weights", who);
     return NARUTO_OK;
 }
-// Round 6: the XCD-partitioned gather in front of the training forward (see naruto_field.hip).  On for tables that fit the chip's L2s once they
-// are cut into level groups (a cache-resident table: at most 32 MB -- beyond, every gather is an HBM / Infinity-Cache line whatever the
-// partition); NARUTO_FWD_XCD_SPLIT=0 switches it off (the one-launch forward), NARUTO_XCD_G = 1 / 2 / 4 / 8 sets the group count,
-// NARUTO_XCD_GROUPS="7,10,13" the group boundaries (first level of groups 1 .. G - 1).
-inline bool xcd_gather_on(const NarutoField* f) {
-    static const int on = getenv("NARUTO_FWD_XCD_SPLIT") ? atoi(getenv("NARUTO_FWD_XCD_SPLIT")) : 1;
-    if (on == 0) return false;
-    return on == 2 || (size_t)f->n_entries * 2u * sizeof(float) <= ((size_t)32u << 20);
-}
-inline LevelGroups level_groups(const NarutoField* f) {
-    static const uint32_t g_env = getenv("NARUTO_XCD_G") ? (uint32_t)atoi(getenv("NARUTO_XCD_G")) : 4u;
-    static const char* b_env = getenv("NARUTO_XCD_GROUPS");
-    LevelGroups lg{};
-    uint32_t G = (g_env == 1u || g_env == 2u || g_env == 4u || g_env == 8u) ? g_env : 4u;
-    lg.G = G;
-    lg.begin[0] = 0u;
-    bool given = false;
-    if (b_env != nullptr) {                       // explicit boundaries: G - 1 increasing level indices
-        uint32_t k = 1;
-        const char* c = b_env;
-        while (*c != 0 && k < G) {
-            const uint32_t v = (uint32_t)strtoul(c, const_cast<char**>(&c), 10);
-            if (v <= lg.begin[k - 1u] || v >= (uint32_t)kLevels) break;
-            lg.begin[k++] = v;
-            while (*c == ',' || *c == ' ') ++c;
-        }
-        given = k == G;
-    }
-    if (!given) {
-        // equal shares of the table's BYTES (what an L2 has to hold), every group at least one level
-        const double total = (double)f->n_entries;
-        uint32_t T = 0;
-        for (uint32_t g = 1; g < G; ++g) {
-            const double want = total * (double)g / (double)G;
-            while (T < (uint32_t)kLevels - (G - g) && ((double)f->lt.off[T] + (double)f->lt.size[T] <= want || T < lg.begin[g - 1u] + 1u)) ++T;
-            lg.begin[g] = T;
-        }
-    }
-    for (uint32_t g = G; g <= kXcds; ++g) lg.begin[g] = (uint32_t)kLevels;
-    return lg;
-}
 // A2..A5 of the training forward: k_query_fwd over the batch's samples, one wave per ray with depth-ordered early termination
 // when the samples per ray are a multiple of 64 (otherwise flat 64-sample tiles)
 // loss != NULL: the loss stage may ride in the field query's launch (k_query_fwd_loss: the depth-ordered walk only); *fused tells
@@ -1088,17 +1047,7 @@ int launch_train_query(const NarutoField* f, const NarutoParams* p, const Naruto
         if (int rc = ray_lds_attr()) return rc;
         // the two-phase tile costs 32 KB of slabs per workgroup: only while two workgroups still share a CU (S <= 192), see k_query_fwd_loss
         const bool bfm = f->desc.mlp_mode == NARUTO_MLP_BF16;
-        WalkExtra wxa = walk_extra != nullptr ? *walk_extra : WalkExtra{};
-        // round 6: the XCD-partitioned gather launch in front (k_gather_walk) -- depths + the a-priori-needed samples' features, each XCD on its
-        // level group's slice of the table; the walk then fetches those features from feat_save
-        if (pl.split && xcd_gather_on(f)) {
-            const LevelGroups lg = level_groups(f);
-            SampleArgs sa = wxa.sa;
-            hipLaunchKernelGGL(k_gather_walk, dim3(xcd_grid_blocks(lg.G, (N + 3u) / 4u)), dim3(256), (size_t)kRaysPerBlock * 3u * S * sizeof(float), st, f->lt, f->bt, ps,
-                               reinterpret_cast<const float2*>(p->table), M, t->feat_save, ee, sa, wxa.on, N, lg, g_fwd_timeline);
-            if (int rc = check_launch("gather_walk")) return rc;
-            wxa.pre = wxa.on != 0u ? 3u : 2u;
-        }
+        const WalkExtra wxa = walk_extra != nullptr ? *walk_extra : WalkExtra{};
         const uint32_t tail_blocks = wxa.on ? tv_encode_blocks(loss->tv.n * loss->tv.n * loss->tv.n, wxa.tv_groups) : loss->n_tv_blocks;
 #define NARUTO_LAUNCH_WALK(BFV, SPV) hipLaunchKernelGGL((k_query_fwd_loss<BFV, SPV>), dim3(blocks + tail_blocks), dim3(256), ray_scratch_fwd_bytes(S), st, f->lt, f->ut, f->bt, *p, ps, M, \
                                                         t->raw, t->feat_save, ee, *loss, blocks, wxa, g_fwd_timeline)

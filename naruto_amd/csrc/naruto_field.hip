@@ -325,9 +325,9 @@ __device__ __forceinline__ bool ee_lane_live(const EeState& st, const EarlyExit&
 }
 
 // What is known of that limit BEFORE any network output (round 6): it is at least measured depth + truncation, so a sample up to there is
-// needed whatever the sdf turns out to be; a ray without a measured depth gives nothing away.  The gather launch in front of the walk
-// (k_gather_walk) fetches these samples' features; one truncation distance more than needed, so that a first sign change slightly BEHIND the
-// measured depth (z_first in (d, d + trunc]) still finds its samples fetched.  The walk evaluates the same predicate on the same numbers.
+// needed whatever the sdf turns out to be; a ray without a measured depth gives nothing away.  The walk fetches these samples' features one tile
+// ahead (fwd_gather_tile_dual); one truncation distance more than needed, so that a first sign change slightly BEHIND the measured depth
+// (z_first in (d, d + trunc]) still finds its samples fetched.
 __device__ __forceinline__ bool ee_apriori_live(const EarlyExit& ee, float td, float z) {
     if (!(td > 0.0f)) return true;
     return !(z > td + 2.0f * ee.trunc_sc);
@@ -566,82 +566,93 @@ __device__ __forceinline__ void fwd_gather_tile(const LevelTab& lt, const float2
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// XCD-partitioned gather (round 6).  MI355X has eight XCDs with 4 MB of L2 each; the shipped table is 6.5 MB.  A wave that gathers all 16
-// levels makes every XCD's L2 see the whole table: random 64-byte lines then arrive at 154 G lines/s chip-wide -- against 265 - 274 G lines/s
-// when every XCD only ever touches a slice of at most 4 MB (tools/xcd_partition_bench.hip, profiles/r06_xcd_partition_bench.txt: the drop sits
-// exactly between 4 and 5 MB per XCD).  Workgroups are dealt round-robin over the XCDs (blockIdx % 8), so a launch whose workgroup b gathers
-// only the levels of group (b % 8) * G / 8 keeps each L2's working set at 6.5 MB / G.  The features of a point then come from G different
-// workgroups: they meet in feat_save ([level][M][2], which the training forward writes for the backward anyway) and the matrix phase -- a
-// second launch -- fetches them with coalesced loads (fwd_reload_tile) instead of gathering.  Same index / load / blend functions as
-// fwd_gather_tile: the same bits.
+// Round 6: the depth-ordered walk fetches the NEXT tile's a-priori-needed samples during this tile's gather phase.
+//
+// Per-wave timeline of the walk at the headline (tools/walk_timeline.py, profiles/r06_walk_timeline_before.txt, trained state): all 2 048 waves
+// gather tile 0 together (20 us: the chip's random-line rate), run its matrix phase (5 us) -- and then the 17 % of the rays whose band reaches
+// into tile 1 (measured depth + truncation behind the 64th sample) start a second chain of 16 dependent gather round trips for ~10 live lanes
+// each, 13 us during which the rest of the chip idles.  Which samples those are is known BEFORE any network output (ee_apriori_live), so
+// their gathers ride in tile 0's gather phase -- fwd_gather_tile_dual: per level the loads of both tiles issued together, the next tile's
+// features written to feat_save (where they have to go anyway) -- and tile 1's gather phase becomes fwd_reload_tile: 32 independent
+// coalesced loads, one round trip.  Same index / load / blend functions: the same bits.
 // ------------------------------------------------------------------------------------------------------------------------------
-constexpr uint32_t kXcds = 8;
-struct LevelGroups {
-    uint32_t G;                  // 1, 2, 4 or 8 groups
-    uint32_t begin[kXcds + 1];   // group g gathers levels [begin[g], begin[g + 1])
-};
-// workgroup b of a grid-partitioned launch: its level group and its index among the workgroups of that group
-__device__ __forceinline__ void xcd_group_of_block(const LevelGroups& lg, uint32_t b, uint32_t& g, uint32_t& q) {
-    const uint32_t xcd = b & (kXcds - 1u), per = kXcds / lg.G;
-    g = xcd / per;
-    q = (b >> 3) * per + (xcd - g * per);
-}
-inline uint32_t xcd_grid_blocks(uint32_t G, uint32_t units_per_group) {       // blocks of a launch in which every group has >= units_per_group workgroups
-    const uint32_t per = kXcds / G;
-    return ((units_per_group + per - 1u) / per) * kXcds;
-}
-// levels [T0, T1) of one 64-point tile -> feat_save (two levels' loads in flight); dead lanes (MASK) issue entry-0 loads and store nothing
-template <bool MASK>
-__device__ __forceinline__ void gather_levels_to_save(const LevelTab& lt, const float2* __restrict__ table, float x, float y, float z, float* __restrict__ feat_save,
-                                                      uint32_t M, uint32_t mA, uint32_t mB, int lane, bool live, uint32_t T0, uint32_t T1) {
+#ifndef NARUTO_WALK_PREFETCH
+#define NARUTO_WALK_PREFETCH 1
+#endif
+constexpr bool kWalkPrefetch = NARUTO_WALK_PREFETCH != 0;
+// fwd_gather_tile<true> for this tile (-> slab + feat_save) and, interleaved level by level, the gathers of the next tile's lanes `live1`
+// (points x1, y1, z1; feat_save rows mA1 / mB1) -> feat_save only
+__device__ __forceinline__ void fwd_gather_tile_dual(const LevelTab& lt, const float2* __restrict__ table, float x, float y, float z, float* __restrict__ feat_save,
+                                                     uint32_t M, uint32_t mA, uint32_t mB, int lane, FwdSlab& sl, bool live,
+                                                     float x1, float y1, float z1, uint32_t mA1, uint32_t mB1, bool live1) {
     const uint32_t hh = (uint32_t)lane >> 5;
-    float la = live ? 1.0f : 0.0f, lb = la;
-    if constexpr (MASK) swap32(la, lb);
-    const bool liveA = MASK ? la != 0.0f : true, liveB = MASK ? lb != 0.0f : true;
+    float la = live ? 1.0f : 0.0f, lb = la, la1 = live1 ? 1.0f : 0.0f, lb1 = la1;
+    swap32(la, lb); swap32(la1, lb1);
+    const bool liveA = la != 0.0f, liveB = lb != 0.0f, liveA1 = la1 != 0.0f, liveB1 = lb1 != 0.0f;
     float xa = x, xb = x, ya = y, yb = y, za = z, zb = z;
     swap32(xa, xb); swap32(ya, yb); swap32(za, zb);
-    auto retire = [&](uint32_t T, const HalfCorners& ha, const HalfCorners& hb, const float2 (&va)[4], const float2 (&vb)[4]) {
-        const float2 pa = hash_level_half_blend(ha, va);
-        const float2 pb = hash_level_half_blend(hb, vb);
-        float ua = pa.x, wa = pa.y, ub = pb.x, wb = pb.y;
-        swap32(ua, wa);
-        swap32(ub, wb);
-        const float b0 = ua + wa, b1 = ub + wb;
-        char* __restrict__ fs = reinterpret_cast<char*>(feat_save + (size_t)T * M * 2u);
-        if (liveA) *reinterpret_cast<float*>(fs + ((mA * 2u + hh) << 2)) = b0;
-        if (liveB) *reinterpret_cast<float*>(fs + ((mB * 2u + hh) << 2)) = b1;
+    float xa1 = x1, xb1 = x1, ya1 = y1, yb1 = y1, za1 = z1, zb1 = z1;
+    swap32(xa1, xb1); swap32(ya1, yb1); swap32(za1, zb1);
+    HalfCorners ha[2], hb[2], ga[2], gb[2];
+    float2 va[2][4], vb[2][4], ua_[2][4], ub_[2][4];
+    auto issue = [&](auto tc) {
+        constexpr int T = decltype(tc)::value;
+        int Tr = T;
+        asm volatile("" : "+s"(Tr));
+        ha[T & 1] = hash_level_half_index(lt, Tr, xa, ya, za, hh);
+        hb[T & 1] = hash_level_half_index(lt, Tr, xb, yb, zb, hh);
+        ga[T & 1] = hash_level_half_index(lt, Tr, xa1, ya1, za1, hh);
+        gb[T & 1] = hash_level_half_index(lt, Tr, xb1, yb1, zb1, hh);
+        hash_level_half_load_sel<true>(lt, Tr, table, ha[T & 1], va[T & 1], liveA);
+        hash_level_half_load_sel<true>(lt, Tr, table, hb[T & 1], vb[T & 1], liveB);
+        hash_level_half_load_sel<true>(lt, Tr, table, ga[T & 1], ua_[T & 1], liveA1);
+        hash_level_half_load_sel<true>(lt, Tr, table, gb[T & 1], ub_[T & 1], liveB1);
     };
-    for (uint32_t T = T0; T < T1; T += 2u) {
-        const bool two = T + 1u < T1;
-        HalfCorners ha0, hb0, ha1, hb1;
-        float2 va0[4], vb0[4], va1[4], vb1[4];
-        ha0 = hash_level_half_index(lt, (int)T, xa, ya, za, hh);
-        hb0 = hash_level_half_index(lt, (int)T, xb, yb, zb, hh);
-        hash_level_half_load_sel<MASK>(lt, (int)T, table, ha0, va0, liveA);
-        hash_level_half_load_sel<MASK>(lt, (int)T, table, hb0, vb0, liveB);
-        if (two) {
-            ha1 = hash_level_half_index(lt, (int)T + 1, xa, ya, za, hh);
-            hb1 = hash_level_half_index(lt, (int)T + 1, xb, yb, zb, hh);
-            hash_level_half_load_sel<MASK>(lt, (int)T + 1, table, ha1, va1, liveA);
-            hash_level_half_load_sel<MASK>(lt, (int)T + 1, table, hb1, vb1, liveB);
+    issue(std::integral_constant<int, 0>{});
+    static_for<0, kLevels>([&](auto tc) {
+        constexpr int T = decltype(tc)::value;
+        if constexpr (T + 1 < kLevels) issue(std::integral_constant<int, T + 1>{});
+        char* __restrict__ fs = reinterpret_cast<char*>(feat_save + (size_t)T * M * 2u);
+        {
+            const float2 pa = hash_level_half_blend(ha[T & 1], va[T & 1]);
+            const float2 pb = hash_level_half_blend(hb[T & 1], vb[T & 1]);
+            float ua = pa.x, wa = pa.y, ub = pb.x, wb = pb.y;
+            swap32(ua, wa);
+            swap32(ub, wb);
+            float b0 = ua + wa, b1 = ub + wb;
+            b0 = liveA ? b0 : 0.0f; b1 = liveB ? b1 : 0.0f;
+            if (liveA) *reinterpret_cast<float*>(fs + ((mA * 2u + hh) << 2)) = b0;
+            if (liveB) *reinterpret_cast<float*>(fs + ((mB * 2u + hh) << 2)) = b1;
+            sl.feat[T][0][lane] = b0;
+            sl.feat[T][1][lane] = b1;
         }
-        retire(T, ha0, hb0, va0, vb0);
-        if (two) retire(T + 1u, ha1, hb1, va1, vb1);
-    }
+        {
+            const float2 pa = hash_level_half_blend(ga[T & 1], ua_[T & 1]);
+            const float2 pb = hash_level_half_blend(gb[T & 1], ub_[T & 1]);
+            float ua = pa.x, wa = pa.y, ub = pb.x, wb = pb.y;
+            swap32(ua, wa);
+            swap32(ub, wb);
+            const float b0 = ua + wa, b1 = ub + wb;
+            if (liveA1) *reinterpret_cast<float*>(fs + ((mA1 * 2u + hh) << 2)) = b0;
+            if (liveB1) *reinterpret_cast<float*>(fs + ((mB1 * 2u + hh) << 2)) = b1;
+        }
+    });
 }
-// the gather phase's stand-in where the tile's features already sit in feat_save (rows of live lanes): 32 independent coalesced loads -> the slab;
-// dead lanes' features are zeros, as fwd_gather_tile<true> leaves them
+// the gather phase's stand-in where the features of the tile's live lanes already sit in feat_save: 32 independent coalesced loads -> the slab; dead
+// lanes' features are zeros, as fwd_gather_tile<true> leaves them.  The rows were written by THIS wave (other lanes) earlier in the kernel: the
+// stores are waited for (gfx9: vmcnt counts them, the acknowledgement comes from L2) and the loads go past the CU's L1 to that L2 (agent scope).
 __device__ __forceinline__ void fwd_reload_tile(const float* __restrict__ feat_save, uint32_t M, uint32_t mA, uint32_t mB, int lane, FwdSlab& sl, bool live) {
     const uint32_t hh = (uint32_t)lane >> 5;
     float la = live ? 1.0f : 0.0f, lb = la;
     swap32(la, lb);
     const bool liveA = la != 0.0f, liveB = lb != 0.0f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float b0[kLevels], b1[kLevels];
 #pragma unroll
     for (int T = 0; T < kLevels; ++T) {
         const char* __restrict__ fs = reinterpret_cast<const char*>(feat_save + (size_t)T * M * 2u);
-        b0[T] = liveA ? *reinterpret_cast<const float*>(fs + ((mA * 2u + hh) << 2)) : 0.0f;
-        b1[T] = liveB ? *reinterpret_cast<const float*>(fs + ((mB * 2u + hh) << 2)) : 0.0f;
+        b0[T] = liveA ? __hip_atomic_load(reinterpret_cast<const float*>(fs + ((mA * 2u + hh) << 2)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+        b1[T] = liveB ? __hip_atomic_load(reinterpret_cast<const float*>(fs + ((mB * 2u + hh) << 2)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
     }
 #pragma unroll
     for (int T = 0; T < kLevels; ++T) {

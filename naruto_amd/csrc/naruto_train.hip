@@ -183,69 +183,8 @@ struct WalkExtra {
     uint32_t tv_groups;          // level groups per lattice-encode workgroup (tv_encode_blocks)
     SampleArgs sa;
     const float* rand6; const uint64_t* rng; float* x_out;
-    uint32_t pre;                // round 6, what a gather launch in front (k_gather_walk / k_gather_short) has left: bit 0 the depths in z_vals,
-                                 // bit 1 the hash features of every a-priori-needed sample (ee_apriori_live; all of a ray's first tile) in feat_save
 };
 
-// ------------------------------------------------------------------------------------------------------------------------------
-// The gather launch in front of the depth-ordered walk (round 6; see "XCD-partitioned gather" in naruto_field.hip): one wave per (ray, level
-// group).  The wave samples its ray's depths (sample_z_ray: the walk's own routine -- every group of a ray computes the same numbers, group 0
-// writes them to z_vals), then for each of the ray's tiles fetches the features of the samples that are needed whatever the network says
-// (ee_apriori_live; the whole first tile) for ITS levels only and writes them to feat_save.  Workgroups of group g sit on XCDs
-// [g * 8 / G, (g + 1) * 8 / G): each L2 serves 6.5 MB / G of table.  No weights, no matrix registers: short waves at high occupancy.
-// ------------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gather_walk(LevelTab lt, BoxTab bt, PointSrc ps, const float2* __restrict__ table, uint32_t M, float* __restrict__ feat_save,
-                                                     EarlyExit ee, SampleArgs sa, uint32_t sample_on, uint32_t n_rays, LevelGroups lg,
-                                                     unsigned long long* __restrict__ timeline) {
-    extern __shared__ float z_lds[];                   // per wave: zs | us | keep, S floats each
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int j = lane & 31;
-    uint32_t g, q;
-    xcd_group_of_block(lg, blockIdx.x, g, q);
-    const uint32_t task = q * (uint32_t)kRaysPerBlock + (uint32_t)wave;
-    // profiling (naruto_debug_fwd_timeline, rows behind the walk's: tools/walk_timeline.py): 0 start, 1 depths sampled, 2 first tile, 3 end; 6 = group, 7 = tiles
-    auto stamp = [&](int k) {
-        if (timeline != nullptr && lane == 0) timeline[((size_t)16384u + (size_t)blockIdx.x * 4u + (size_t)wave) * 8u + (size_t)k] = (unsigned long long)wall_clock64();
-    };
-    stamp(0);
-    if (task >= n_rays) return;
-    const uint32_t S = ps.S, tpr = ee.tiles_per_ray;
-    const uint32_t T0 = lg.begin[g], T1 = lg.begin[g + 1u];
-    float* __restrict__ zs = z_lds + (size_t)wave * 3u * S;
-    float* __restrict__ us = zs + S;
-    float* __restrict__ keep = us + S;
-    if (sample_on != 0u) {
-        sample_z_ray(task, sa.target_d, sa.near_, sa.far_, sa.nu, sa.nr, sa.range_d, sa.rand, sa.rng, g == 0u ? sa.z_vals : nullptr, zs, us, lane, keep);
-    } else {
-        for (uint32_t s = lane; s < S; s += 64u) keep[s] = ps.z_vals[(size_t)task * S + s];
-    }
-    wave_lds_sync();
-    stamp(1);
-    const float td = ee.target_d != nullptr ? ee.target_d[task] : 0.0f;
-    const float ox = ps.rays_o[3 * task + 0], oy = ps.rays_o[3 * task + 1], oz = ps.rays_o[3 * task + 2];
-    const float dx = ps.rays_d[3 * task + 0], dy = ps.rays_d[3 * task + 1], dz = ps.rays_d[3 * task + 2];
-    const uint32_t ray0 = task * S;
-    for (uint32_t tq = 0; tq < tpr; ++tq) {
-        const uint32_t s = tq * 64u + (uint32_t)lane;
-        const bool valid = s < S;
-        const float zv = keep[valid ? s : S - 1u];
-        const bool live = valid && (tq == 0u || ee_apriori_live(ee, td, zv));
-        if (!__any(live)) break;                       // (depths are sorted: nothing further along the ray is needed a priori either)
-        // load_point's arithmetic with the depth from the image
-        const float px = __fadd_rn(ox, __fmul_rn(dx, zv));
-        const float py = __fadd_rn(oy, __fmul_rn(dy, zv));
-        const float pz = __fadd_rn(oz, __fmul_rn(dz, zv));
-        const float x = __fdiv_rn(__fsub_rn(px, bt.bmin[0]), bt.bext[0]);
-        const float y = __fdiv_rn(__fsub_rn(py, bt.bmin[1]), bt.bext[1]);
-        const float z = __fdiv_rn(__fsub_rn(pz, bt.bmin[2]), bt.bext[2]);
-        const uint32_t t0 = ray0 + tq * 64u;
-        gather_levels_to_save<true>(lt, table, x, y, z, feat_save, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, live, T0, T1);
-        if (tq == 0u) stamp(2);
-        if (timeline != nullptr && lane == 0) timeline[((size_t)16384u + (size_t)blockIdx.x * 4u + (size_t)wave) * 8u + 7u] = tq + 1u;
-    }
-    stamp(3);
-    if (timeline != nullptr && lane == 0) timeline[((size_t)16384u + (size_t)blockIdx.x * 4u + (size_t)wave) * 8u + 6u] = g + 1u;
-}
 // SPLIT: the tile in two phases through a per-wave LDS slab (fwd_tile_split) -- 32 KB per workgroup, so the launcher uses it only while two
 // workgroups still fit a CU next to the rays' images (up to 192 samples per ray); longer rays keep the register form (fwd_tile).
 template <bool BF, bool SPLIT>
@@ -298,16 +237,17 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
     for (uint32_t group = blockIdx.x; group < n_groups; group += n_fwd_blocks) {          // uniform over the workgroup: barriers inside
         const uint32_t task = group * (uint32_t)kRaysPerBlock + (uint32_t)wave;
         if (task < a.n_rays) {
-            if constexpr (SPLIT) if (wx.on != 0u && (wx.pre & 1u) == 0u) {
+            if constexpr (SPLIT) if (wx.on) {
                 const SampleArgs& sa = wx_s.sa;
                 sample_z_ray(task, sa.target_d, sa.near_, sa.far_, sa.nu, sa.nr, sa.range_d, sa.rand, sa.rng, sa.z_vals, rs.c0, rs.c1, lane);
                 __threadfence_block();
             }
             if (group == blockIdx.x) stamp(2);
             EeState ees{false, 0.0f, 0.0f, 0.0f};
-            bool pre_feat = false;
-            if constexpr (SPLIT) pre_feat = (wx.pre & 2u) != 0u;
-            const float td_ap = pre_feat ? ee.target_d[task] : 0.0f;
+            // round 6 (fwd_gather_tile_dual): lanes of the NEXT tile whose features this tile's gather phase has already left in feat_save
+            bool pf = false;
+            float td_ap = 0.0f;
+            if constexpr (SPLIT && kWalkPrefetch) td_ap = ee.target_d[task];
             const uint32_t ray0 = task * S;                              // the ray's first sample in the point list
             uint32_t tq = 0;
             for (; tq < tpr; ++tq) {
@@ -325,17 +265,31 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
                 FwdTileOut to;
                 const bool live_out = live;
                 if constexpr (SPLIT) {                       // the tile in two phases (fwd_tile_split / fwd_tile_split_bf), with a stamp between them
-                    // a gather launch in front left the a-priori-needed samples' features in feat_save (wx.pre): where that covers every live lane
-                    // -- always in a ray's first tile -- the gather phase is 32 coalesced loads; else (first sign change beyond depth + truncation, or
-                    // none yet) the tile gathers for itself as before.  Same features either way: same bits.
-                    bool reload = false;
-                    if (pre_feat) reload = !__any(live && !(tq == 0u || ee_apriori_live(ee, td_ap, zv)));
-                    if (reload) fwd_reload_tile(feat_save, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, slabs[wave], live);
-                    else {
-                        if constexpr (NARUTO_FWD_GATHER_PRIO != 0) __builtin_amdgcn_s_setprio(NARUTO_FWD_GATHER_PRIO);
-                        fwd_gather_tile<true>(lt, table, x, y, z, feat_save, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, slabs[wave], live);
-                        if constexpr (NARUTO_FWD_GATHER_PRIO != 0) __builtin_amdgcn_s_setprio(0);
+                    // Where the previous tile's gather phase already fetched every live lane of this tile (pf), the gather phase is 32 coalesced
+                    // loads (fwd_reload_tile); else (first sign change behind depth + 2 truncations, or none yet on a ray with a depth) the tile
+                    // gathers for itself.  And this tile's gather phase fetches the next tile's a-priori-needed lanes along the way: all of them once
+                    // the first sign change is known (ee_lane_live is then exact), those up to the measured depth + truncation before.
+                    bool reload = false, pf_next = false;
+                    float x1 = 0.0f, y1 = 0.0f, z1 = 0.0f;
+                    if constexpr (kWalkPrefetch) {
+                        reload = tq > 0u && !__any(live && !pf);
+                        if (tq + 1u < tpr) {
+                            const uint32_t s1 = s + 64u;
+                            const bool valid1 = s1 < S;
+                            const uint32_t m1 = valid1 ? t0 + 64u + (uint32_t)lane : ray0 + S - 1u;
+                            const float zv1 = ps.z_vals[m1];
+                            pf_next = valid1 && (ees.found ? ee_lane_live(ees, ee, task, zv1) : ee_apriori_live(ee, td_ap, zv1));
+                            if (__any(pf_next)) load_point(ps, bt, m1, x1, y1, z1);
+                        }
                     }
+                    if (reload) fwd_reload_tile(feat_save, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, slabs[wave], live);
+                    if constexpr (NARUTO_FWD_GATHER_PRIO != 0) __builtin_amdgcn_s_setprio(NARUTO_FWD_GATHER_PRIO);
+                    if (__any(pf_next) && !reload)
+                        fwd_gather_tile_dual(lt, table, x, y, z, feat_save, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, slabs[wave], live,
+                                             x1, y1, z1, t0 + 64u + (uint32_t)j, t0 + 96u + (uint32_t)j, pf_next);
+                    else if (!reload) fwd_gather_tile<true>(lt, table, x, y, z, feat_save, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, slabs[wave], live);
+                    if constexpr (NARUTO_FWD_GATHER_PRIO != 0) __builtin_amdgcn_s_setprio(0);
+                    pf = pf_next && !reload;            // (a reloaded tile fetched nothing ahead: the tile after it gathers for itself)
                     if (tq == 0u && group == blockIdx.x) stamp(3);
                     if constexpr (BF) fwd_mlp_tile_bf<true>(L, slabs[wave], x, y, z, nullptr, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, to);
                     else if constexpr (kExactX3) fwd_mlp_tile_x3<true>(L, slabs[wave], x, y, z, nullptr, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, to);

@@ -325,9 +325,8 @@ __device__ __forceinline__ bool ee_lane_live(const EeState& st, const EarlyExit&
 }
 
 // What is known of that limit BEFORE any network output (round 6): it is at least measured depth + truncation, so a sample up to there is
-// needed whatever the sdf turns out to be; a ray without a measured depth gives nothing away.  The walk fetches these samples' features one tile
-// ahead (fwd_gather_tile_dual); one truncation distance more than needed, so that a first sign change slightly BEHIND the measured depth
-// (z_first in (d, d + trunc]) still finds its samples fetched.
+// needed whatever the sdf turns out to be; a ray without a measured depth gives nothing away.  (Used by the round-6 experiments that fetched these
+// samples ahead of the network's output; the shipped walk does not call it.)
 __device__ __forceinline__ bool ee_apriori_live(const EarlyExit& ee, float td, float z) {
     if (!(td > 0.0f)) return true;
     return !(z > td + 2.0f * ee.trunc_sc);
@@ -566,99 +565,61 @@ __device__ __forceinline__ void fwd_gather_tile(const LevelTab& lt, const float2
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// Round 6: the depth-ordered walk fetches the NEXT tile's a-priori-needed samples during this tile's gather phase.
+// Round 6: HALF tiles in the depth-ordered walk.
 //
 // Per-wave timeline of the walk at the headline (tools/walk_timeline.py, profiles/r06_walk_timeline_before.txt, trained state): all 2 048 waves
 // gather tile 0 together (20 us: the chip's random-line rate), run its matrix phase (5 us) -- and then the 17 % of the rays whose band reaches
-// into tile 1 (measured depth + truncation behind the 64th sample) start a second chain of 16 dependent gather round trips for ~10 live lanes
-// each, 13 us during which the rest of the chip idles.  Which samples those are is known BEFORE any network output (ee_apriori_live), so
-// their gathers ride in tile 0's gather phase -- fwd_gather_tile_dual: per level the loads of both tiles issued together, the next tile's
-// features written to feat_save (where they have to go anyway) -- and tile 1's gather phase becomes fwd_reload_tile: 32 independent
-// coalesced loads, one round trip.  Same index / load / blend functions: the same bits.
+// into tile 1 (measured depth + truncation behind the 64th sample) run a second tile for ~10 live lanes each: 16 levels, two in flight = 8
+// dependent round trips, then the whole matrix chain: 13 us during which the rest of the chip idles.  The live lanes of such a tile are a
+// PREFIX (depths are sorted); where it ends within the first 32 lanes only the tile's A half (points 0..31) exists:
+//   * its gather phase fetches the A points only -- half the load instructions and registers -- with EIGHT levels in flight: 3 round trips;
+//   * its matrix phase runs the A chains only (the halves never mix: same bits for the A points; the B lanes are dead, their outputs
+//     are written as zeros by the walk as before).
+// Tried first and not kept (profiles/r06_xcd_gather_split_tried.txt, r06_walk_dual_gather_tried.txt): a gather launch in front with the levels
+// partitioned over the XCDs' L2s (the table's L2 cliff is real -- 154 vs 265 G random lines/s, tools/xcd_partition_bench.hip -- but the walk's
+// gather phase is bound by the CUs' own line rate), and the next tile's a-priori-needed lanes fetched during this tile's gather phase
+// (+6 us on tile 0 for -5 on tile 1).
 // ------------------------------------------------------------------------------------------------------------------------------
-#ifndef NARUTO_WALK_PREFETCH
-#define NARUTO_WALK_PREFETCH 1
+#ifndef NARUTO_WALK_HALF
+#define NARUTO_WALK_HALF 1
 #endif
-constexpr bool kWalkPrefetch = NARUTO_WALK_PREFETCH != 0;
-// fwd_gather_tile<true> for this tile (-> slab + feat_save) and, interleaved level by level, the gathers of the next tile's lanes `live1`
-// (points x1, y1, z1; feat_save rows mA1 / mB1) -> feat_save only
-__device__ __forceinline__ void fwd_gather_tile_dual(const LevelTab& lt, const float2* __restrict__ table, float x, float y, float z, float* __restrict__ feat_save,
-                                                     uint32_t M, uint32_t mA, uint32_t mB, int lane, FwdSlab& sl, bool live,
-                                                     float x1, float y1, float z1, uint32_t mA1, uint32_t mB1, bool live1) {
+constexpr bool kWalkHalf = NARUTO_WALK_HALF != 0;
+// gather phase of a tile whose live lanes all lie in [0, 32): points 0..31 only (lane half hh fetches their corners with x offset hh), features
+// -> slab half 0 + feat_save rows mA; slab half 1 is not written (fwd_mlp_tile_x3<.., true> does not read it)
+__device__ __forceinline__ void fwd_gather_tile_half(const LevelTab& lt, const float2* __restrict__ table, float x, float y, float z, float* __restrict__ feat_save,
+                                                     uint32_t M, uint32_t mA, int lane, FwdSlab& sl, bool live) {
     const uint32_t hh = (uint32_t)lane >> 5;
-    float la = live ? 1.0f : 0.0f, lb = la, la1 = live1 ? 1.0f : 0.0f, lb1 = la1;
-    swap32(la, lb); swap32(la1, lb1);
-    const bool liveA = la != 0.0f, liveB = lb != 0.0f, liveA1 = la1 != 0.0f, liveB1 = lb1 != 0.0f;
+    float la = live ? 1.0f : 0.0f, lb = la;
+    swap32(la, lb);
+    const bool liveA = la != 0.0f;
     float xa = x, xb = x, ya = y, yb = y, za = z, zb = z;
-    swap32(xa, xb); swap32(ya, yb); swap32(za, zb);
-    float xa1 = x1, xb1 = x1, ya1 = y1, yb1 = y1, za1 = z1, zb1 = z1;
-    swap32(xa1, xb1); swap32(ya1, yb1); swap32(za1, zb1);
-    HalfCorners ha[2], hb[2], ga[2], gb[2];
-    float2 va[2][4], vb[2][4], ua_[2][4], ub_[2][4];
+    swap32(xa, xb); swap32(ya, yb); swap32(za, zb);        // xa = x of points (0..31 | 0..31)
+    constexpr int kDepth = 8;                               // levels in flight
+    HalfCorners ha[kDepth];
+    float2 va[kDepth][4];
     auto issue = [&](auto tc) {
         constexpr int T = decltype(tc)::value;
         int Tr = T;
         asm volatile("" : "+s"(Tr));
-        ha[T & 1] = hash_level_half_index(lt, Tr, xa, ya, za, hh);
-        hb[T & 1] = hash_level_half_index(lt, Tr, xb, yb, zb, hh);
-        ga[T & 1] = hash_level_half_index(lt, Tr, xa1, ya1, za1, hh);
-        gb[T & 1] = hash_level_half_index(lt, Tr, xb1, yb1, zb1, hh);
-        hash_level_half_load_sel<true>(lt, Tr, table, ha[T & 1], va[T & 1], liveA);
-        hash_level_half_load_sel<true>(lt, Tr, table, hb[T & 1], vb[T & 1], liveB);
-        hash_level_half_load_sel<true>(lt, Tr, table, ga[T & 1], ua_[T & 1], liveA1);
-        hash_level_half_load_sel<true>(lt, Tr, table, gb[T & 1], ub_[T & 1], liveB1);
+        ha[T % kDepth] = hash_level_half_index(lt, Tr, xa, ya, za, hh);
+        hash_level_half_load_sel<true>(lt, Tr, table, ha[T % kDepth], va[T % kDepth], liveA);
     };
-    issue(std::integral_constant<int, 0>{});
+    static_for<0, kDepth>([&](auto tc) { issue(tc); });
     static_for<0, kLevels>([&](auto tc) {
         constexpr int T = decltype(tc)::value;
-        if constexpr (T + 1 < kLevels) issue(std::integral_constant<int, T + 1>{});
-        char* __restrict__ fs = reinterpret_cast<char*>(feat_save + (size_t)T * M * 2u);
-        {
-            const float2 pa = hash_level_half_blend(ha[T & 1], va[T & 1]);
-            const float2 pb = hash_level_half_blend(hb[T & 1], vb[T & 1]);
-            float ua = pa.x, wa = pa.y, ub = pb.x, wb = pb.y;
-            swap32(ua, wa);
-            swap32(ub, wb);
-            float b0 = ua + wa, b1 = ub + wb;
-            b0 = liveA ? b0 : 0.0f; b1 = liveB ? b1 : 0.0f;
+        const float2 pa = hash_level_half_blend(ha[T % kDepth], va[T % kDepth]);
+        float ua = pa.x, wa = pa.y;
+        swap32(ua, wa);
+        float b0 = ua + wa;
+        b0 = liveA ? b0 : 0.0f;
+        if (feat_save != nullptr) {
+            char* __restrict__ fs = reinterpret_cast<char*>(feat_save + (size_t)T * M * 2u);
             if (liveA) *reinterpret_cast<float*>(fs + ((mA * 2u + hh) << 2)) = b0;
-            if (liveB) *reinterpret_cast<float*>(fs + ((mB * 2u + hh) << 2)) = b1;
-            sl.feat[T][0][lane] = b0;
-            sl.feat[T][1][lane] = b1;
         }
-        {
-            const float2 pa = hash_level_half_blend(ga[T & 1], ua_[T & 1]);
-            const float2 pb = hash_level_half_blend(gb[T & 1], ub_[T & 1]);
-            float ua = pa.x, wa = pa.y, ub = pb.x, wb = pb.y;
-            swap32(ua, wa);
-            swap32(ub, wb);
-            const float b0 = ua + wa, b1 = ub + wb;
-            if (liveA1) *reinterpret_cast<float*>(fs + ((mA1 * 2u + hh) << 2)) = b0;
-            if (liveB1) *reinterpret_cast<float*>(fs + ((mB1 * 2u + hh) << 2)) = b1;
-        }
+        sl.feat[T][0][lane] = b0;
+        // (in groups of four: the slots of levels T - 3 .. T are free again)
+        if constexpr (T % 4 == 3 && T + kDepth - 3 < kLevels) static_for<T + kDepth - 3, T + kDepth + 1>([&](auto uc) { issue(uc); });
     });
-}
-// the gather phase's stand-in where the features of the tile's live lanes already sit in feat_save: 32 independent coalesced loads -> the slab; dead
-// lanes' features are zeros, as fwd_gather_tile<true> leaves them.  The rows were written by THIS wave (other lanes) earlier in the kernel: the
-// stores are waited for (gfx9: vmcnt counts them, the acknowledgement comes from L2) and the loads go past the CU's L1 to that L2 (agent scope).
-__device__ __forceinline__ void fwd_reload_tile(const float* __restrict__ feat_save, uint32_t M, uint32_t mA, uint32_t mB, int lane, FwdSlab& sl, bool live) {
-    const uint32_t hh = (uint32_t)lane >> 5;
-    float la = live ? 1.0f : 0.0f, lb = la;
-    swap32(la, lb);
-    const bool liveA = la != 0.0f, liveB = lb != 0.0f;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    float b0[kLevels], b1[kLevels];
-#pragma unroll
-    for (int T = 0; T < kLevels; ++T) {
-        const char* __restrict__ fs = reinterpret_cast<const char*>(feat_save + (size_t)T * M * 2u);
-        b0[T] = liveA ? __hip_atomic_load(reinterpret_cast<const float*>(fs + ((mA * 2u + hh) << 2)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
-        b1[T] = liveB ? __hip_atomic_load(reinterpret_cast<const float*>(fs + ((mB * 2u + hh) << 2)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
-    }
-#pragma unroll
-    for (int T = 0; T < kLevels; ++T) {
-        sl.feat[T][0][lane] = b0[T];
-        sl.feat[T][1][lane] = b1[T];
-    }
 }
 
 // the matrix phase: fwd_tile's chain in fwd_tile's order (same accumulation order: same bits), hash-part B operands from the slab
@@ -805,7 +766,8 @@ __device__ __forceinline__ void stage_fwd_weights_x3_via_lds(FwdLdsX3& L, float*
     stage_fwd_weights_x3_from<NT>(L, WSrcLds{raw, p}, tid);
 }
 // the matrix phase of a tile (fwd_mlp_tile's counterpart): hash part of the B operands from the slab
-template <bool COLOR>
+// HALF (round 6): the tile's B points (32..63) are dead -- only the A chains run; the B lanes' outputs are unspecified (the caller writes zeros)
+template <bool COLOR, bool HALF = false>
 __device__ __forceinline__ void fwd_mlp_tile_x3(const FwdLdsX3& L, const FwdSlab& sl, float x, float y, float z, float* __restrict__ geo, uint32_t M, uint32_t mA, uint32_t mB,
                                                 int lane, FwdTileOut& out) {
     const int hh = lane >> 5;
@@ -814,10 +776,10 @@ __device__ __forceinline__ void fwd_mlp_tile_x3(const FwdLdsX3& L, const FwdSlab
     for (int kb = 0; kb < 2; ++kb) {
         float fa[8], fb[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { fa[e] = sl.feat[8 * kb + e][0][lane]; fb[e] = sl.feat[8 * kb + e][1][lane]; }
+        for (int e = 0; e < 8; ++e) { fa[e] = sl.feat[8 * kb + e][0][lane]; fb[e] = HALF ? 0.0f : sl.feat[8 * kb + e][1][lane]; }
         const u32x4_t w[3] = {L.s0[0][kb * 64 + lane], L.s0[1][kb * 64 + lane], L.s0[2][kb * 64 + lane]};
         hA = mfma16x3(w, pack8x3(fa), hA);
-        hB = mfma16x3(w, pack8x3(fb), hB);
+        if constexpr (!HALF) hB = mfma16x3(w, pack8x3(fb), hB);
     }
     const bool blob_fast = __all(oneblob_sparse_ok(x) && oneblob_sparse_ok(y) && oneblob_sparse_ok(z));
     static_for<0, 3>([&](auto dc) {
@@ -837,11 +799,11 @@ __device__ __forceinline__ void fwd_mlp_tile_x3(const FwdLdsX3& L, const FwdSlab
         }
         const u32x4_t ws[3] = {L.s0[0][(2 + D) * 64 + lane], L.s0[1][(2 + D) * 64 + lane], L.s0[2][(2 + D) * 64 + lane]};
         hA = mfma16x3(ws, lo, hA);
-        hB = mfma16x3(ws, hi, hB);
+        if constexpr (!HALF) hB = mfma16x3(ws, hi, hB);
         if constexpr (COLOR) {
             const u32x4_t wc[3] = {L.c0[0][D * 64 + lane], L.c0[1][D * 64 + lane], L.c0[2][D * 64 + lane]};
             cA = mfma16x3(wc, lo, cA);
-            cB = mfma16x3(wc, hi, cB);
+            if constexpr (!HALF) cB = mfma16x3(wc, hi, cB);
         }
     });
     f32x16 oA = zero16(), oB = zero16();
@@ -849,7 +811,7 @@ __device__ __forceinline__ void fwd_mlp_tile_x3(const FwdLdsX3& L, const FwdSlab
     for (int kb = 0; kb < 2; ++kb) {
         const u32x4_t w[3] = {L.s1[0][kb * 64 + lane], L.s1[1][kb * 64 + lane], L.s1[2][kb * 64 + lane]};
         oA = mfma16x3(w, pack8x3_acc<true>(hA, 8 * kb), oA);
-        oB = mfma16x3(w, pack8x3_acc<true>(hB, 8 * kb), oB);
+        if constexpr (!HALF) oB = mfma16x3(w, pack8x3_acc<true>(hB, 8 * kb), oB);
     }
     float sdf = oA[0], sdf_b = oB[0];
     swap32(sdf, sdf_b);
@@ -867,7 +829,7 @@ __device__ __forceinline__ void fwd_mlp_tile_x3(const FwdLdsX3& L, const FwdSlab
     if constexpr (COLOR) {
         const u32x4_t wg[3] = {L.c0[0][3 * 64 + lane], L.c0[1][3 * 64 + lane], L.c0[2][3 * 64 + lane]};
         cA = mfma16x3(wg, pack8x3_acc<false>(oA, 0), cA);
-        cB = mfma16x3(wg, pack8x3_acc<false>(oB, 0), cB);
+        if constexpr (!HALF) cB = mfma16x3(wg, pack8x3_acc<false>(oB, 0), cB);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float pa = 0.0f, pb = 0.0f;

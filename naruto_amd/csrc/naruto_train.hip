@@ -244,10 +244,6 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
             }
             if (group == blockIdx.x) stamp(2);
             EeState ees{false, 0.0f, 0.0f, 0.0f};
-            // round 6 (fwd_gather_tile_dual): lanes of the NEXT tile whose features this tile's gather phase has already left in feat_save
-            bool pf = false;
-            float td_ap = 0.0f;
-            if constexpr (SPLIT && kWalkPrefetch) td_ap = ee.target_d[task];
             const uint32_t ray0 = task * S;                              // the ray's first sample in the point list
             uint32_t tq = 0;
             for (; tq < tpr; ++tq) {
@@ -265,34 +261,20 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
                 FwdTileOut to;
                 const bool live_out = live;
                 if constexpr (SPLIT) {                       // the tile in two phases (fwd_tile_split / fwd_tile_split_bf), with a stamp between them
-                    // Where the previous tile's gather phase already fetched every live lane of this tile (pf), the gather phase is 32 coalesced
-                    // loads (fwd_reload_tile); else (first sign change behind depth + 2 truncations, or none yet on a ray with a depth) the tile
-                    // gathers for itself.  And this tile's gather phase fetches the next tile's a-priori-needed lanes along the way: all of them once
-                    // the first sign change is known (ee_lane_live is then exact), those up to the measured depth + truncation before.
-                    bool reload = false, pf_next = false;
-                    float x1 = 0.0f, y1 = 0.0f, z1 = 0.0f;
-                    if constexpr (kWalkPrefetch) {
-                        reload = tq > 0u && !__any(live && !pf);
-                        if (tq + 1u < tpr) {
-                            const uint32_t s1 = s + 64u;
-                            const bool valid1 = s1 < S;
-                            const uint32_t m1 = valid1 ? t0 + 64u + (uint32_t)lane : ray0 + S - 1u;
-                            const float zv1 = ps.z_vals[m1];
-                            pf_next = valid1 && (ees.found ? ee_lane_live(ees, ee, task, zv1) : ee_apriori_live(ee, td_ap, zv1));
-                            if (__any(pf_next)) load_point(ps, bt, m1, x1, y1, z1);
-                        }
-                    }
-                    if (reload) fwd_reload_tile(feat_save, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, slabs[wave], live);
+                    // round 6: a tile behind the first whose live lanes (a prefix: depths are sorted) end within its first 32 points runs as a HALF
+                    // tile -- A points only, eight levels' gathers in flight, the A matrix chains (fwd_gather_tile_half)
+                    bool half = false;
+                    if constexpr (kWalkHalf && !BF && kExactX3) half = tq > 0u && !__any(live && lane >= 32);
                     if constexpr (NARUTO_FWD_GATHER_PRIO != 0) __builtin_amdgcn_s_setprio(NARUTO_FWD_GATHER_PRIO);
-                    if (__any(pf_next) && !reload)
-                        fwd_gather_tile_dual(lt, table, x, y, z, feat_save, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, slabs[wave], live,
-                                             x1, y1, z1, t0 + 64u + (uint32_t)j, t0 + 96u + (uint32_t)j, pf_next);
-                    else if (!reload) fwd_gather_tile<true>(lt, table, x, y, z, feat_save, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, slabs[wave], live);
+                    if (half) fwd_gather_tile_half(lt, table, x, y, z, feat_save, M, t0 + (uint32_t)j, lane, slabs[wave], live);
+                    else fwd_gather_tile<true>(lt, table, x, y, z, feat_save, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, slabs[wave], live);
                     if constexpr (NARUTO_FWD_GATHER_PRIO != 0) __builtin_amdgcn_s_setprio(0);
-                    pf = pf_next && !reload;            // (a reloaded tile fetched nothing ahead: the tile after it gathers for itself)
                     if (tq == 0u && group == blockIdx.x) stamp(3);
                     if constexpr (BF) fwd_mlp_tile_bf<true>(L, slabs[wave], x, y, z, nullptr, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, to);
-                    else if constexpr (kExactX3) fwd_mlp_tile_x3<true>(L, slabs[wave], x, y, z, nullptr, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, to);
+                    else if constexpr (kExactX3) {
+                        if (half) fwd_mlp_tile_x3<true, true>(L, slabs[wave], x, y, z, nullptr, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, to);
+                        else fwd_mlp_tile_x3<true>(L, slabs[wave], x, y, z, nullptr, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, to);
+                    }
                     else fwd_mlp_tile<true>(L, slabs[wave], x, y, z, nullptr, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, to);
                 }
                 else if constexpr (BF) fwd_tile_bf<true, true>(L, lt, table, x, y, z, feat_save, nullptr, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, to, live);

@@ -1406,10 +1406,29 @@ int naruto_render_fwd(const NarutoField* f, const NarutoParams* p, const NarutoR
     }
     const bool bf = f->desc.mlp_mode == NARUTO_MLP_BF16;
     if (S <= 64u) {              // short rays: 16 rays per workgroup, samples packed into full 64-sample tiles
+        // round 6: from one group per CU upwards, eight-wave workgroups (one per CU) whose exact-mode matrix phase is the x3 chain (k_render_fwd_packed<*, 512>)
+        static const int wide_env = getenv("NARUTO_RENDER_WIDE") ? atoi(getenv("NARUTO_RENDER_WIDE")) : 1;
+        const uint32_t R8 = render_packed8_rays(S);
+        // (measured, 8 192 x 43: exact mode 0.1213 -> 0.1077 ms; bf16 mode 0.1041 -> 0.1057: its chain is short either way, the four-wave form stays)
+        if (kFwdSplit && wide_env != 0 && R8 >= 8u && (wide_env == 2 || (!bf && (r->n_rays + R8 - 1u) / R8 >= cu_count(f)))) {
+            static bool attr8 = false;
+            if (!attr8) {
+                const int bytes = (int)render_packed_lds_bytes(64u, render_packed8_rays(64u));
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_fwd_packed<false, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(k_render_fwd_packed<true, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+                    return fail(NARUTO_ERR_LAUNCH, "render_fwd: cannot reserve %d bytes of LDS: %s", bytes, hipGetErrorString(hipGetLastError()));
+                attr8 = true;
+            }
+            uint32_t blocks8 = (r->n_rays + R8 - 1u) / R8;
+            if (blocks8 > cu_count(f)) blocks8 = cu_count(f);
+            if (bf) hipLaunchKernelGGL((k_render_fwd_packed<true, 512>), dim3(blocks8), dim3(512), render_packed_lds_bytes(S, R8), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, a, R8);
+            else hipLaunchKernelGGL((k_render_fwd_packed<false, 512>), dim3(blocks8), dim3(512), render_packed_lds_bytes(S, R8), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, a, R8);
+            return check_launch("render_fwd_packed8");
+        }
         uint32_t blocks = (r->n_rays + kPackRays - 1u) / kPackRays;
         if (blocks > cu_count(f) * 4u) blocks = cu_count(f) * 4u;
-        if (bf) hipLaunchKernelGGL(k_render_fwd_packed<true>, dim3(blocks), dim3(256), render_packed_lds_bytes(S), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, a);
-        else hipLaunchKernelGGL(k_render_fwd_packed<false>, dim3(blocks), dim3(256), render_packed_lds_bytes(S), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, a);
+        if (bf) hipLaunchKernelGGL((k_render_fwd_packed<true, 256>), dim3(blocks), dim3(256), render_packed_lds_bytes(S), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, a, kPackRays);
+        else hipLaunchKernelGGL((k_render_fwd_packed<false, 256>), dim3(blocks), dim3(256), render_packed_lds_bytes(S), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, a, kPackRays);
         return check_launch("render_fwd_packed");
     }
     uint32_t blocks = (r->n_rays + 3u) / 4u;

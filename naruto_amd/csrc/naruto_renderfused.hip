@@ -122,36 +122,45 @@ __global__ __launch_bounds__(256, 2) void k_render_fwd(LevelTab lt, UncertTab ut
 // kPackRays rays, tiles their samples back to back into 64-sample tiles over its four waves, keeps the raw values of all of them in
 // LDS and composites ray by ray afterwards (16 rays x 43 samples = 688 samples = 11 tiles: 98 % of the lanes carry a sample).
 constexpr uint32_t kPackRays = 16;
-inline size_t render_packed_lds_bytes(uint32_t S) { return (size_t)kPackRays * kRayFields * S * sizeof(float); }
+inline size_t render_packed_lds_bytes(uint32_t S, uint32_t rays = kPackRays) { return (size_t)rays * kRayFields * S * sizeof(float); }
 
 #ifndef NARUTO_RENDER_PACKED_MINWAVES
 #define NARUTO_RENDER_PACKED_MINWAVES 2
 #endif
-template <bool BF>
-__global__ __launch_bounds__(256, NARUTO_RENDER_PACKED_MINWAVES) void k_render_fwd_packed(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, RenderArgs a) {
-    using Lds = std::conditional_t<BF, FwdLdsBf, FwdLds>;
+// NT = 256: four waves, kPackRays rays per group, two workgroups per CU, the fp32 matrix instruction (FwdLds: next to the four slabs and the rays'
+// images the x3 weight images do not fit half a CU's LDS).
+// NT = 512 (round 6): ONE eight-wave workgroup per CU -- one copy of the weight images instead of two, which is what makes room for them in
+// their three-piece form: the exact mode's matrix phase runs on the XDL pipe (fwd_mlp_tile_x3, as in the training forward since round 5) beside
+// the other waves' gathers, staged through the slabs (stage_fwd_exact); R rays per group as the LDS allows (32 at 43 samples).  The launcher
+// uses it from one group per CU upwards (4 096 rays at 43 samples).
+template <bool BF, int NT>
+__global__ __launch_bounds__(NT, NT == 256 ? NARUTO_RENDER_PACKED_MINWAVES : 1) void k_render_fwd_packed(LevelTab lt, UncertTab ut, BoxTab bt, NarutoParams p, RenderArgs a, uint32_t rays_per_group) {
+    constexpr uint32_t kW = NT / 64;
+    using Lds = std::conditional_t<BF, FwdLdsBf, std::conditional_t<NT == 512, FwdLdsExact, FwdLds>>;
     __shared__ Lds L;
-    __shared__ FwdSlab slabs[kFwdSplit ? 4 : 1];
+    __shared__ FwdSlab slabs[kFwdSplit ? kW : 1];
     extern __shared__ float ray_lds[];
-    if constexpr (BF) stage_fwd_weights_bf<256>(L, p, threadIdx.x);
-    else stage_fwd_weights<256>(L, p, threadIdx.x);
+    if constexpr (BF && NT == 512) stage_fwd_weights_bf_via_lds<NT>(L, reinterpret_cast<float*>(slabs), p, threadIdx.x);
+    else if constexpr (BF) stage_fwd_weights_bf<NT>(L, p, threadIdx.x);
+    else if constexpr (NT == 512) stage_fwd_exact<NT, sizeof(slabs)>(L, slabs, p, threadIdx.x);
+    else stage_fwd_weights<NT>(L, p, threadIdx.x);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // scalar: see k_query_fwd_loss
     const uint32_t S = a.nu + a.nr;
     const float inv_S = 1.0f / (float)S;
     const float2* __restrict__ table = reinterpret_cast<const float2*>(p.table);
     auto image = [&](uint32_t r) { return ray_scratch(ray_lds, (int)r, S); };          // ray r of the group: kRayFields x S floats
-    for (uint32_t n0 = blockIdx.x * kPackRays; n0 < a.n_rays; n0 += gridDim.x * kPackRays) {
-        const uint32_t R = a.n_rays - n0 < kPackRays ? a.n_rays - n0 : kPackRays;
-        // A1: wave w samples rays w, w + 4, ...
-        for (uint32_t r = (uint32_t)wave; r < R; r += 4u) {
+    for (uint32_t n0 = blockIdx.x * rays_per_group; n0 < a.n_rays; n0 += gridDim.x * rays_per_group) {
+        const uint32_t R = a.n_rays - n0 < rays_per_group ? a.n_rays - n0 : rays_per_group;
+        // A1: wave w samples rays w, w + kW, ...
+        for (uint32_t r = (uint32_t)wave; r < R; r += kW) {
             const RayScratch rs = image(r);
             sample_z_ray(n0 + r, a.target_d, a.near_, a.far_, a.nu, a.nr, a.range_d, a.rand, a.rng, a.z_vals, rs.wb, rs.gw, lane, rs.z);
         }
         __syncthreads();
         // A2..A5 on the group's samples, 64 at a time
         const uint32_t T = R * S, n_tiles = (T + 63u) / 64u;
-        for (uint32_t tq = (uint32_t)wave; tq < n_tiles; tq += 4u) {
+        for (uint32_t tq = (uint32_t)wave; tq < n_tiles; tq += kW) {
             const uint32_t g_raw = tq * 64u + (uint32_t)lane;
             const bool valid = g_raw < T;
             const uint32_t g = valid ? g_raw : T - 1u;
@@ -184,8 +193,8 @@ __global__ __launch_bounds__(256, NARUTO_RENDER_PACKED_MINWAVES) void k_render_f
             }
         }
         __syncthreads();
-        // A6 + A7: wave w composites rays w, w + 4, ...
-        for (uint32_t r = (uint32_t)wave; r < R; r += 4u) {
+        // A6 + A7: wave w composites rays w, w + kW, ...
+        for (uint32_t r = (uint32_t)wave; r < R; r += kW) {
             const RayScratch rs = image(r);
             const uint32_t n = n0 + r;
             const RayWeights rw = ray_weights(rs, S, a.trunc, a.sc_factor, lane);
@@ -201,6 +210,13 @@ __global__ __launch_bounds__(256, NARUTO_RENDER_PACKED_MINWAVES) void k_render_f
         }
         __syncthreads();                             // the images are reused by the next group
     }
+}
+// rays per group of the eight-wave form: what the LDS next to the weight images (exact mode's: the larger) and eight slabs takes, at most 32
+inline uint32_t render_packed8_rays(uint32_t S) {
+    const size_t fixed = sizeof(FwdLdsExact) + 8u * sizeof(FwdSlab) + 1024u;
+    const size_t room = (size_t)160u * 1024u > fixed ? (size_t)160u * 1024u - fixed : 0u;
+    const uint32_t r = (uint32_t)(room / ((size_t)kRayFields * S * sizeof(float)));
+    return r > 32u ? 32u : r;
 }
 
 }  // namespace naruto

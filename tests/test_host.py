@@ -256,7 +256,7 @@ def test_no_kernel_spills_to_scratch(built_lib):
     hot = [k for k in res if re.match(r"k_(query_|render_|hash_scatter_|bin_|loss_|sample_|composite_|bwd_finish|adam_)", k)]
     for must in ("k_query_fwd<true,256,false>", "k_query_fwd<true,128,false>", "k_query_fwd<true,256,true>", "k_query_fwd_loss<false,true>", "k_query_fwd_loss<true,true>", "k_query_fwd_loss<false,false>", "k_query_fwd_loss<true,false>",
                  "k_query_fwd_loss_packed<false,8>", "k_query_fwd_loss_packed<true,8>", "k_query_bwd", "k_query_bwd_bf", "k_render_fwd<false>",
-                 "k_render_fwd_packed<false>", "k_render_fwd_packed<true>", "k_hash_scatter_lds", "k_bin_count", "k_bin_fill<1024>", "k_bin_fill<512>", "k_bin_apply",
+                 "k_render_fwd_packed<false,256>", "k_render_fwd_packed<true,256>", "k_render_fwd_packed<false,512>", "k_render_fwd_packed<true,512>", "k_hash_scatter_lds", "k_bin_count", "k_bin_fill<1024>", "k_bin_fill<512>", "k_bin_apply",
                  "k_loss_bwd_fused", "k_bwd_finish"):
         assert must in res, f"{must} not found in the code object (have: {sorted(res)[:8]} ...)"
     assert len(hot) >= 30
@@ -265,7 +265,8 @@ def test_no_kernel_spills_to_scratch(built_lib):
     # the occupancy each hot kernel was written for: registers per lane within the budget of its waves per SIMD (512 / waves)
     budget = {"k_query_fwd<true,256,false>": 256, "k_query_fwd<true,128,false>": 256, "k_query_fwd<true,256,true>": 256, "k_query_fwd_loss<false,true>": 256, "k_query_fwd_loss<true,true>": 256, "k_query_fwd_loss<false,false>": 256, "k_query_fwd_loss<true,false>": 256,
               "k_query_fwd_loss_packed<false,8>": 256, "k_query_fwd_loss_packed<true,8>": 256, "k_bin_fill<1024>": 128, "k_query_fwd_bf<true,256,false>": 256,
-              "k_render_fwd_packed<false>": 256, "k_render_fwd_packed<true>": 256, "k_hash_scatter_lds": 128, "k_query_bwd": 512, "k_query_bwd_bf": 512}
+              "k_render_fwd_packed<false,256>": 256, "k_render_fwd_packed<true,256>": 256, "k_render_fwd_packed<false,512>": 256, "k_render_fwd_packed<true,512>": 256,
+              "k_hash_scatter_lds": 128, "k_query_bwd": 512, "k_query_bwd_bf": 512}
     for k, b in budget.items():
         assert res[k]["vgpr_count"] <= b, (k, res[k])            # .vgpr_count is the unified total (architectural + accumulation registers)
     # Spilled SCALAR registers (round 5): they live in lanes of a vector register -- v_writelane / v_readlane around the code that needs the

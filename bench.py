@@ -66,6 +66,12 @@ WORKLOADS = {
 }
 
 
+# what "f32" means on this path since round 5: every value is fp32 in memory and in the reference's sense; the MLP forward's products are formed
+# from EXACT three-way bf16 splits of the fp32 operands on the bf16 matrix pipe (six partial products, fp32 accumulation: one fp32 rounding
+# per product, tests/test_gpu_parity.py::test_x3_chain_against_the_fp32_chain bounds the two chains at full size), the backward runs fp32 MFMA
+DTYPE_F32 = "f32 (MLP forward products as exact bf16x3 splits on the bf16 MFMA, fp32 accumulate; backward fp32 MFMA; everything else fp32)"
+
+
 def workload(name: str):
     if name not in WORKLOADS:
         raise SystemExit(f"unknown workload {name}; choose from {sorted(WORKLOADS)}")
@@ -480,7 +486,7 @@ def run_eval(args, dev):
     out = {
         "metric": "rendered rays/sec (eval render), Replica office_0", "value": round(n_rays * args.steps / dt, 1), "unit": "rays/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.mlp == "fp32" else "bf16 (MLP operands; fp32 accumulate, fp32 elsewhere)", "data": "synthetic",
+        "dtype": DTYPE_F32 if args.mlp == "fp32" else "bf16 (MLP operands; fp32 accumulate, fp32 elsewhere)", "data": "synthetic",
         "config": {"workload": f"{args.workload} = BASELINE {WORKLOADS[args.workload][2]}: office_0 bbox, {n_rays} rays x {S_tot} samples, uncertainty grid on, "
                                f"eval-mode render_rays in one launch (naruto_render_fwd), MLP {args.mlp}", "rays_per_gpu": n_rays, "samples_per_ray": S_tot},
         "roofline": {"bound": "hbm", "achieved": round(alg / k_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / k_ms / 1e6 / HBM_PEAK_GBS, 4),
@@ -608,7 +614,7 @@ def run_ba_iter(args, dev):
     ms = res["graph"]
     out = {"metric": "mapping-iter ms (one global_BA iteration end to end), Replica office_0", "value": round(ms, 4), "unit": "ms", "n_gpus": 1, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(ms, 4), "mapping_iter_ms": round(ms, 4), "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32" if args.mlp == "fp32" else "bf16 (MLP operands; fp32 accumulate, fp32 elsewhere)", "data": "synthetic",
+           "dtype": DTYPE_F32 if args.mlp == "fp32" else "bf16 (MLP operands; fp32 accumulate, fp32 elsewhere)", "data": "synthetic",
            "rays_per_s": round(n_train / ms * 1e3, 1),
            "config": {"workload": f"{args.workload} = BASELINE {WORKLOADS[args.workload][2]}: office_0 bbox, {n_kf} keyframes x {R} stored rays, {Hh} x {Ww} current frame, "
                                   f"mapping.sample 2048, active_ray {'on (4x oversampled batch of ' + str(ba.sample_num + n_cur) + ' rays, K = 500)' if args.active_ray else 'off'}, "
@@ -697,7 +703,7 @@ def main():
         S_tot = trc["n_samples_d"] + trc["n_range_d"]
         out = {"metric": "rendered rays/sec (train step), Replica office_0", "value": d["rays_per_s"], "unit": "rays/s", "n_gpus": 1, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": d["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32" if args.mlp == "fp32" else "bf16 (MLP operands; fp32 accumulate, fp32 elsewhere)", "data": "synthetic",
+               "dtype": DTYPE_F32 if args.mlp == "fp32" else "bf16 (MLP operands; fp32 accumulate, fp32 elsewhere)", "data": "synthetic",
                "config": {"workload": f"{args.workload} = BASELINE {WORKLOADS[args.workload][2]}: {n_workload} rays x {S_tot} samples, one global_BA iteration of the "
                                       "reference's UNCHANGED loop body (coslam.py:361-399: model.forward, get_loss_from_ret with Co-SLAM's torch smoothness, "
                                       "loss.backward(retain_graph=True), torch.optim.Adam, uncertainty-grid Adam every 5th) around NarutoFieldHIP, eager launches",
@@ -817,7 +823,7 @@ def main():
             "metric": "rendered rays/sec (train step), Replica office_0",
             "value": round(n_total * args.steps / dt, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "f32" if args.mlp == "fp32" else "bf16 (MLP operands; fp32 accumulate, fp32 elsewhere)", "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPE_F32 if args.mlp == "fp32" else "bf16 (MLP operands; fp32 accumulate, fp32 elsewhere)", "data": "synthetic",
             "prewarm": {"untimed_steps_before_the_timed_region": args.warmup + 8 + n_prewarm, "target_ms": PREWARM_MS},
             "ms_per_step_median_of_5_chunks": None if ms_chunks is None else round(ms_chunks, 4),
             "graph_launches": (f"one hipGraph per {chain_n} iterations (= one global_BA call, mapping.iters); the remainder of K and --no-chain: one per iteration"
@@ -950,6 +956,30 @@ def main():
             except Exception as e:                               # informational: never fail the bench line over it
                 out["roofline_gather"]["random_line_roof"] = {"error": repr(e)[:200]}
             out["roofline"] = roof
+            # Round 6: when the iteration's dominant launch is its forward, `roofline` is THAT launch -- the depth-ordered walk /
+            # short-ray kernel the timed step runs (depth sampling, field query over the samples some consumer can see, loss stage, lattice encode),
+            # timed alone with HIP events in the iteration's launch shape, SURVEY 8(d)'s 1 056 B per sample it EVALUATES + 64 B per ray -- and
+            # the flat all-samples launch of the same arithmetic stays in `roofline_gather`.
+            if roof["kernel"].startswith("k_query_fwd") and it.get("evaluated_samples") is not None:
+                S_it = int(it["samples"]) // int(n_rays)
+                k_it = "k_query_fwd_loss_short" if S_it <= 64 else "k_query_fwd_loss"
+                iprof, isrc = pmc_profile(args.workload, k_it)
+                roof_it = {"bound": "hbm", "achieved": it["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(it["GBps"] / HBM_PEAK_GBS, 4),
+                           "traffic": iprof.get("traffic_bytes"), "kernel": k_it,
+                           "launch": "as launched by the timed step (naruto_debug_train_query_fwd: the same launch, alone)",
+                           "kernel_ms": it["ms"], "alg_bytes": it["alg_bytes"], "evaluated_samples": it["evaluated_samples"], "samples": it["samples"],
+                           "alg_bytes_all_samples": roof["alg_bytes"], "frac_all_samples_flat_launch": roof["frac"], "flat_launch_kernel_ms": roof["kernel_ms"]}
+                if iprof.get("traffic_bytes") is not None:
+                    roof_it["traffic_source"] = f"profiles/{isrc}"
+                    roof_it["traffic_GBps"] = round(iprof["traffic_bytes"] / it["ms"] / 1e6, 1)
+                    roof_it["traffic_frac"] = round(iprof["traffic_bytes"] / it["ms"] / 1e6 / HBM_PEAK_GBS, 4)
+                if iprof.get("tcc_req") is not None and "random_line_roof" in roof and "lines_per_s" in roof["random_line_roof"]:
+                    rr_it = dict(roof["random_line_roof"])
+                    rr_it["l2_requests_per_launch_pmc"] = int(iprof["tcc_req"])
+                    rr_it["frac_l2_requests"] = round(iprof["tcc_req"] / (it["ms"] * 1e-3) / rr_it["lines_per_s"], 4)
+                    rr_it["l2_requests_source"] = f"profiles/{isrc} (TCC_REQ_sum)"
+                    roof_it["random_line_roof"] = rr_it
+                out["roofline"] = roof_it
             if sc_it is not None and "active_samples" in sc_it:
                 # the same figure with the backward's share (3168 B minus the forward's 1056 B per sample) charged only for the samples the
                 # backward actually processes (the compacted list: non-zero loss gradient), not for every sample of the batch: the honest

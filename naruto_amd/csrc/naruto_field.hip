@@ -324,14 +324,6 @@ __device__ __forceinline__ bool ee_lane_live(const EeState& st, const EarlyExit&
     return !(z > lim + 1e-5f * fabsf(lim) + 1e-6f);
 }
 
-// What is known of that limit BEFORE any network output (round 6): it is at least measured depth + truncation, so a sample up to there is
-// needed whatever the sdf turns out to be; a ray without a measured depth gives nothing away.  (Used by the round-6 experiments that fetched these
-// samples ahead of the network's output; the shipped walk does not call it.)
-__device__ __forceinline__ bool ee_apriori_live(const EarlyExit& ee, float td, float z) {
-    if (!(td > 0.0f)) return true;
-    return !(z > td + 2.0f * ee.trunc_sc);
-}
-
 // One 64-point tile of the forward: hash gather (lane half hh fetches the corners with x offset hh of points 0..31, then 32..63),
 // OneBlob, both MLPs.  x, y, z: THIS lane's point (lane = point within the tile); mA / mB: feat_save rows of point j / j + 32.
 // Results: out.rgb / out.sdf for this lane's point; geo (optional) [M,15]: the sdf-net's geometric features of both halves.

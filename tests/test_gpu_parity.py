@@ -2907,6 +2907,50 @@ def test_configs2_eval_render_at_full_size(gpu):
     assert float(got["uncert_map"].min()) > 0
 
 
+def test_x3_chain_against_the_fp32_chain(gpu):
+    """What the bench line's dtype "f32 (... exact bf16x3 splits on the bf16 MFMA ...)" claims, at full size: the exact mode's
+    matrix phase as six bf16 products of exactly split fp32 operands (fwd_mlp_tile_x3, round 5) is fp32-grade arithmetic -- compared here
+    against the fp32 matrix-instruction chain (fwd_mlp_tile) on the SAME 8192 x 43 = 352 256 samples: the eval render of all 8192 rays in one
+    call runs the eight-wave kernel (x3 chain), the same rays in calls of 2048 the four-wave kernel (fp32 MFMA chain; naruto_render_fwd picks by
+    ray count).  far = 3 m keeps every sample inside OneBlob's closed-form range, so both take the same OneBlob form and what is left IS the two
+    chains' distance: each rounds a handful of times per output, in different places."""
+    cfg = H.office_cfg(16, perturb=1.0)
+    cfg["cam"]["far"] = 3.0
+    ora = H.make_oracle(cfg, 0.2, 29).eval()
+    m = H.make_hip_from_oracle(cfg, ora, gpu).eval()
+    N, S_tot = 8192, 43
+    rays = syn.random_rays(N, cfg["mapping"]["bound"], seed=29, zero_depth_frac=0.05)
+    ro, rd, td = (torch.from_numpy(rays[k]).to(gpu) for k in ("rays_o", "rays_d", "target_d"))
+    rand = torch.rand(N, S_tot, generator=torch.Generator().manual_seed(7)).to(gpu)
+    with torch.no_grad():
+        whole = m.render_rays(ro, rd, target_d=td, rand=rand)["raw"]
+        parts = torch.cat([m.render_rays(ro[i:i + 2048], rd[i:i + 2048], target_d=td[i:i + 2048], rand=rand[i:i + 2048])["raw"] for i in range(0, N, 2048)], 0)
+        want = ora.render_rays(ro.cpu(), rd.cpu(), target_d=td.cpu(), rand=rand.cpu())["raw"]
+    assert whole.shape == parts.shape == (N, S_tot, 5)
+    assert torch.isfinite(whole).all() and torch.isfinite(parts).all()
+    for c, name in enumerate(("r", "g", "b", "sdf")):
+        a, b = whole[..., c].double(), parts[..., c].double()
+        scale = float(b.abs().max())
+        d = float((a - b).abs().max())
+        # measured (tools/x3_chain_stats.py, MI355X): max 6.0e-8 absolute = 2.9e-7 ... 4.3e-7 of the channel's largest magnitude (0.12 ... 0.20), mean
+        # 6e-9; both chains 4.2e-7 ... 1.7e-6 from the CPU oracle, within 2 % of each other
+        assert d <= 5e-7 * scale, f"raw[...,{name}]: x3 chain vs fp32 chain {d:.3e} (scale {scale:.3e})"
+        # ... and both sit equally close to the fp64-free CPU oracle (its own fp32 rounding is of the same size)
+        da, db = float((a - want[..., c].double().to(gpu)).abs().max()), float((b - want[..., c].double().to(gpu)).abs().max())
+        assert da <= TOL_OUT and db <= TOL_OUT and da <= 2.0 * db + 1e-7 * scale, (name, da, db)
+    assert bool((whole[..., :4] != parts[..., :4]).any()), "the two calls were meant to run DIFFERENT matrix chains"
+    assert torch.equal(whole[..., 4], parts[..., 4])        # the uncertainty channel never sees the MLP
+    # non-finite operands: the exact split of +-inf is (inf, NaN, NaN) -- the x3 chain answers NaN where the fp32 chain answers +-inf (or NaN, for
+    # inf * 0).  Either way the output is NON-FINITE in both chains at the same samples, which is all any consumer (the reference's
+    # `assert uncert_map.min() > 0`, a NaN loss) can see of a diverged network; documented in DESIGN.md section 4, pinned here.
+    with torch.no_grad():
+        m.decoder.sdf_net.model[0].weight[3, 5] = float("inf")
+        bad_whole = m.render_rays(ro, rd, target_d=td, rand=rand)["raw"]
+        bad_parts = torch.cat([m.render_rays(ro[i:i + 2048], rd[i:i + 2048], target_d=td[i:i + 2048], rand=rand[i:i + 2048])["raw"] for i in range(0, N, 2048)], 0)
+    assert torch.equal(torch.isfinite(bad_whole), torch.isfinite(bad_parts))
+    assert not torch.isfinite(bad_whole[..., 3]).any() and torch.isfinite(bad_whole[..., 4]).all()
+
+
 def test_configs2_map_volumes_on_the_full_lattice(gpu):
     """BASELINE configs[2], planner query path (ii): get_map_volumes (coslam_utils.py:58-97) on the FULL [49,56,35] lattice of office_0
     at 0.1 m -- 96 040 points through query_sdf(return_uncert=True) + the post-processing kernel -- against the oracle's restatement

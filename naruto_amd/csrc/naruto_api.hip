@@ -960,8 +960,6 @@ int launch_train_query(const NarutoField* f, const NarutoParams* p, const Naruto
         ee.target_d = t->target_d;
         ee.trunc_sc = f->desc.trunc * f->desc.sc_factor;
         ee.tiles_per_ray = pl.tpr;
-        static const uint32_t stagger = getenv("NARUTO_DEBUG_WALK_STAGGER") ? (uint32_t)atoi(getenv("NARUTO_DEBUG_WALK_STAGGER")) : 0u;
-        ee.stagger = stagger;
         blocks = (N + 3u) / 4u;
         if (blocks > cu_count(f) * 4u) blocks = cu_count(f) * 4u;
     }

@@ -269,7 +269,6 @@ struct EarlyExit {
     const float* target_d;
     float trunc_sc;
     uint32_t tiles_per_ray;
-    uint32_t stagger;            // experiment (NARUTO_DEBUG_WALK_STAGGER): low 8 bits = s_sleep(127) loops half of the walk's workgroups wait before their first tile; bit 8: which half
 };
 
 // state of one ray's front-to-back walk (wave-uniform): first sign change seen, its depth, the last sample so far
@@ -312,6 +311,43 @@ __device__ __forceinline__ bool ee_after_tile(EeState& st, const EarlyExit& ee, 
         }
     }
     return false;
+}
+
+// (round 6) the same with the sample depth and the ray's measured depth handed over in registers -- the walk holds both; ee_after_tile's two
+// global loads sat on the critical path of every tile
+__device__ __forceinline__ bool ee_after_tile_r(EeState& st, float trunc_sc, float td, float zs, uint32_t tq, uint32_t next_begin, uint32_t ray_end,
+                                                float sdf, int lane, float* __restrict__ raw) {
+    if (!st.found) {
+        if (tq > 0u && st.prev_sdf * lane_f32(sdf, 0) < 0.0f) {          // the pair straddling the tile boundary
+            st.found = true;
+            st.zfirst = st.prev_z;
+        } else {
+            const float nb = __shfl_down(sdf, 1, 64);
+            const uint32_t first = wave_min_u32((lane < 63 && sdf * nb < 0.0f) ? (uint32_t)lane : 0xFFFFFFFFu);
+            if (first != 0xFFFFFFFFu) {
+                st.found = true;
+                st.zfirst = __shfl(zs, (int)first, 64);
+            }
+        }
+    }
+    const float z_last = lane_f32(zs, 63);
+    st.prev_sdf = lane_f32(sdf, 63);
+    st.prev_z = z_last;
+    if (st.found) {
+        const float lim = fmaxf(st.zfirst, td) + trunc_sc;
+        if (z_last > lim + 1e-5f * fabsf(lim) + 1e-6f) {
+            if (raw != nullptr) {
+                for (uint32_t k = next_begin * 5u + lane; k < ray_end * 5u; k += 64u) raw[k] = 0.0f;
+            }
+            return true;
+        }
+    }
+    return false;
+}
+__device__ __forceinline__ bool ee_lane_live_r(const EeState& st, float trunc_sc, float td, float z) {
+    if (!st.found) return true;
+    const float lim = fmaxf(st.zfirst, td) + trunc_sc;
+    return !(z > lim + 1e-5f * fabsf(lim) + 1e-6f);
 }
 
 // Within a tile that IS evaluated: once the ray's first sign change is known (st.found), a sample beyond
@@ -576,41 +612,58 @@ __device__ __forceinline__ void fwd_gather_tile(const LevelTab& lt, const float2
 #define NARUTO_WALK_HALF 1
 #endif
 constexpr bool kWalkHalf = NARUTO_WALK_HALF != 0;
-// gather phase of a tile whose live lanes all lie in [0, 32): points 0..31 only (lane half hh fetches their corners with x offset hh), features
-// -> slab half 0 + feat_save rows mA; slab half 1 is not written (fwd_mlp_tile_x3<.., true> does not read it)
-__device__ __forceinline__ void fwd_gather_tile_half(const LevelTab& lt, const float2* __restrict__ table, float x, float y, float z, float* __restrict__ feat_save,
-                                                     uint32_t M, uint32_t mA, int lane, FwdSlab& sl, bool live) {
+// gather phase of a tile BEHIND a ray's first (the chip's memory path is idle by then: what such a tile costs is its chain of dependent round
+// trips, not lines).  HALF: the live lanes all lie in [0, 32) -- points 0..31 only (lane half hh fetches their corners with x offset hh), eight
+// levels in flight, features -> slab half 0 + feat_save rows mA; slab half 1 is not written (fwd_mlp_tile_x3<.., true> does not read it).
+// Otherwise both halves as fwd_gather_tile<true>, but FOUR levels in flight instead of two.
+template <bool HALF>
+__device__ __forceinline__ void fwd_gather_tile_deep(const LevelTab& lt, const float2* __restrict__ table, float x, float y, float z, float* __restrict__ feat_save,
+                                                     uint32_t M, uint32_t mA, uint32_t mB, int lane, FwdSlab& sl, bool live) {
     const uint32_t hh = (uint32_t)lane >> 5;
     float la = live ? 1.0f : 0.0f, lb = la;
     swap32(la, lb);
-    const bool liveA = la != 0.0f;
+    const bool liveA = la != 0.0f, liveB = lb != 0.0f;
     float xa = x, xb = x, ya = y, yb = y, za = z, zb = z;
-    swap32(xa, xb); swap32(ya, yb); swap32(za, zb);        // xa = x of points (0..31 | 0..31)
-    constexpr int kDepth = 8;                               // levels in flight
-    HalfCorners ha[kDepth];
-    float2 va[kDepth][4];
+    swap32(xa, xb); swap32(ya, yb); swap32(za, zb);        // xa = x of points (0..31 | 0..31), xb = (32..63 | 32..63)
+    constexpr int kDepth = HALF ? 8 : 4;                    // levels in flight
+    constexpr int kStep = kDepth / 2;                       // slots are refilled in groups of kStep
+    HalfCorners ha[kDepth], hb[HALF ? 1 : kDepth];
+    float2 va[kDepth][4], vb[HALF ? 1 : kDepth][4];
     auto issue = [&](auto tc) {
         constexpr int T = decltype(tc)::value;
         int Tr = T;
         asm volatile("" : "+s"(Tr));
         ha[T % kDepth] = hash_level_half_index(lt, Tr, xa, ya, za, hh);
         hash_level_half_load_sel<true>(lt, Tr, table, ha[T % kDepth], va[T % kDepth], liveA);
+        if constexpr (!HALF) {
+            hb[T % kDepth] = hash_level_half_index(lt, Tr, xb, yb, zb, hh);
+            hash_level_half_load_sel<true>(lt, Tr, table, hb[T % kDepth], vb[T % kDepth], liveB);
+        }
     };
     static_for<0, kDepth>([&](auto tc) { issue(tc); });
     static_for<0, kLevels>([&](auto tc) {
         constexpr int T = decltype(tc)::value;
-        const float2 pa = hash_level_half_blend(ha[T % kDepth], va[T % kDepth]);
-        float ua = pa.x, wa = pa.y;
-        swap32(ua, wa);
-        float b0 = ua + wa;
-        b0 = liveA ? b0 : 0.0f;
-        if (feat_save != nullptr) {
-            char* __restrict__ fs = reinterpret_cast<char*>(feat_save + (size_t)T * M * 2u);
-            if (liveA) *reinterpret_cast<float*>(fs + ((mA * 2u + hh) << 2)) = b0;
+        char* __restrict__ fs = reinterpret_cast<char*>(feat_save + (size_t)T * M * 2u);
+        {
+            const float2 pa = hash_level_half_blend(ha[T % kDepth], va[T % kDepth]);
+            float ua = pa.x, wa = pa.y;
+            swap32(ua, wa);
+            float b0 = ua + wa;
+            b0 = liveA ? b0 : 0.0f;
+            if (feat_save != nullptr && liveA) *reinterpret_cast<float*>(fs + ((mA * 2u + hh) << 2)) = b0;
+            sl.feat[T][0][lane] = b0;
         }
-        sl.feat[T][0][lane] = b0;
-        // (in groups of four: the slots of levels T - 3 .. T are free again)
-        if constexpr (T % 4 == 3 && T + kDepth - 3 < kLevels) static_for<T + kDepth - 3, T + kDepth + 1>([&](auto uc) { issue(uc); });
+        if constexpr (!HALF) {
+            const float2 pb = hash_level_half_blend(hb[T % kDepth], vb[T % kDepth]);
+            float ub = pb.x, wb = pb.y;
+            swap32(ub, wb);
+            float b1 = ub + wb;
+            b1 = liveB ? b1 : 0.0f;
+            if (feat_save != nullptr && liveB) *reinterpret_cast<float*>(fs + ((mB * 2u + hh) << 2)) = b1;
+            sl.feat[T][1][lane] = b1;
+        }
+        // (the slots of levels T - kStep + 1 .. T are free again)
+        if constexpr (T % kStep == kStep - 1 && T + kDepth - kStep + 1 < kLevels) static_for<T + kDepth - kStep + 1, T + kDepth + 1>([&](auto uc) { issue(uc); });
     });
 }
 

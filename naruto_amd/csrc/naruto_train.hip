@@ -129,7 +129,8 @@ __device__ __forceinline__ void loss_stage_no_ray(int lane, float* __restrict__ 
     }
 }
 // the four rays' terms (after a barrier) -> this group's row of the sums, fixed order; one coherent store per slot
-__device__ __forceinline__ void loss_stage_row(const LossStageArgs& a, const float (*terms)[10], uint32_t group) {
+template <int LD>
+__device__ __forceinline__ void loss_stage_row(const LossStageArgs& a, const float (*terms)[LD], uint32_t group) {
     if (threadIdx.x < 10) {
         const int k = threadIdx.x;
         double v = (double)terms[0][k];
@@ -201,7 +202,6 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
     __shared__ Lds L;
     __shared__ FwdSlab slabs[SPLIT ? kRaysPerBlock : 1];
     __shared__ double red[4];
-    __shared__ float terms[kRaysPerBlock][10];
     extern __shared__ float ray_lds[];
     if (blockIdx.x >= n_fwd_blocks) {
         bool encode = false;
@@ -215,6 +215,10 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
     // twice per ray; from LDS a field costs one broadcast read where it is used.
     __shared__ LossStageArgs a_s;
     __shared__ WalkExtra wx_s;
+    // per ray (wave): [0..6] origin, direction, measured depth -- read by every tile --, [12..15] the targets {r, g, b, depth} for the loss stage, which
+    // leaves its ten terms in [0..9] (the ray constants are dead by then); 256 B instead of 160 + 176: this kernel's LDS is budgeted to the byte
+    // (two workgroups per CU at S = 128)
+    __shared__ float ray_c[kRaysPerBlock][16];
     if (threadIdx.x == 0) { a_s = a; wx_s = wx; }
     if constexpr (SPLIT && BF) stage_fwd_weights_bf_via_lds<256>(L, reinterpret_cast<float*>(slabs), p, threadIdx.x);
     else if constexpr (SPLIT) stage_fwd_exact<256, sizeof(slabs)>(L, slabs, p, threadIdx.x);
@@ -222,10 +226,6 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
     else stage_fwd_weights<256>(L, p, threadIdx.x);
     __syncthreads();
     stamp(1);
-    if (ee.stagger != 0u) {
-        const bool late = (ee.stagger & 256u) ? (blockIdx.x & 1u) != 0u : blockIdx.x >= n_fwd_blocks / 2u;
-        if (late) for (uint32_t i = 0; i < (ee.stagger & 255u); ++i) __builtin_amdgcn_s_sleep(127);
-    }
     // the wave index as a SCALAR: everything derived from it (the ray, its tiles, the wave's LDS image) then lives in SGPRs instead of
     // vector registers -- what took this kernel from 9 spilled registers (40 bytes of scratch, reloaded inside the tile loop) to none
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -237,11 +237,30 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
     for (uint32_t group = blockIdx.x; group < n_groups; group += n_fwd_blocks) {          // uniform over the workgroup: barriers inside
         const uint32_t task = group * (uint32_t)kRaysPerBlock + (uint32_t)wave;
         if (task < a.n_rays) {
+            // Round 6: everything the ray needs from memory besides the table is requested HERE, once, and consumed from registers / the
+            // wave's LDS image -- the ray itself, its measured depth (early termination), its targets (loss stage), its depths (sampled into
+            // the image, or fetched).  Before, every tile re-read its depths and the ray from global memory (the depths right after
+            // writing them) and ee_after_tile / the loss stage fetched the measured depth again: two to three L2 round trips on the
+            // critical path of every tile, one more in front of the loss stage.  Same arithmetic on the same numbers: same bits.
+            // (through LDS, one lane each: as wave-uniform scalar loads they would sit in seven more scalar registers across the tile loop --
+            // this kernel spills those -- and as vector registers the loads would be issued by all 64 lanes)
+            if (lane < 11) {
+                float v;
+                if (lane < 3) v = ps.rays_o[3 * task + lane];
+                else if (lane < 6) v = ps.rays_d[3 * task + lane - 3];
+                else if (lane == 6) v = ee.target_d[task];
+                else if (lane < 10) v = a_s.target_rgb[3 * (size_t)task + lane - 7];
+                else v = a_s.target_d[task];
+                ray_c[wave][lane < 7 ? lane : lane + 5] = v;
+            }
+            bool sampled = false;
             if constexpr (SPLIT) if (wx.on) {
                 const SampleArgs& sa = wx_s.sa;
-                sample_z_ray(task, sa.target_d, sa.near_, sa.far_, sa.nu, sa.nr, sa.range_d, sa.rand, sa.rng, sa.z_vals, rs.c0, rs.c1, lane);
-                __threadfence_block();
+                sample_z_ray(task, sa.target_d, sa.near_, sa.far_, sa.nu, sa.nr, sa.range_d, sa.rand, sa.rng, sa.z_vals, rs.c0, rs.c1, lane, rs.z);
+                sampled = true;
             }
+            if (!sampled) for (uint32_t s = lane; s < S; s += 64u) rs.z[s] = ps.z_vals[(size_t)task * S + s];
+            wave_lds_sync();
             if (group == blockIdx.x) stamp(2);
             EeState ees{false, 0.0f, 0.0f, 0.0f};
             const uint32_t ray0 = task * S;                              // the ray's first sample in the point list
@@ -253,20 +272,25 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
                 const bool valid = s < S;
                 const uint32_t t0 = ray0 + tq * 64u;
                 const uint32_t m = valid ? t0 + (uint32_t)lane : ray0 + S - 1u;
-                float x, y, z;
-                load_point(ps, bt, m, x, y, z);
-                const float zv = ps.z_vals[m];
-                const bool live = valid && ((tq > 0u && kEeLaneSkip) ? ee_lane_live(ees, ee, task, zv) : true);
+                const float zv = rs.z[valid ? s : S - 1u];
+                const float* __restrict__ rc = ray_c[wave];
+                const float td_ee = rc[6];
+                // load_point's arithmetic with the depth from the image
+                const float x = __fdiv_rn(__fsub_rn(__fadd_rn(rc[0], __fmul_rn(rc[3], zv)), bt.bmin[0]), bt.bext[0]);
+                const float y = __fdiv_rn(__fsub_rn(__fadd_rn(rc[1], __fmul_rn(rc[4], zv)), bt.bmin[1]), bt.bext[1]);
+                const float z = __fdiv_rn(__fsub_rn(__fadd_rn(rc[2], __fmul_rn(rc[5], zv)), bt.bmin[2]), bt.bext[2]);
+                const bool live = valid && ((tq > 0u && kEeLaneSkip) ? ee_lane_live_r(ees, ee.trunc_sc, td_ee, zv) : true);
                 const float u = live ? uncert_sample(ut, p.uncert_grid, x, y, z) : 0.0f;
                 FwdTileOut to;
                 const bool live_out = live;
                 if constexpr (SPLIT) {                       // the tile in two phases (fwd_tile_split / fwd_tile_split_bf), with a stamp between them
                     // round 6: a tile behind the first whose live lanes (a prefix: depths are sorted) end within its first 32 points runs as a HALF
-                    // tile -- A points only, eight levels' gathers in flight, the A matrix chains (fwd_gather_tile_half)
+                    // tile -- A points only, eight levels' gathers in flight, the A matrix chains (fwd_gather_tile_deep<true>).  (A third unrolled gather -- both halves, four levels in flight, for
+                    // the full tiles behind the first -- was measured: the kernel's code outgrows the instruction cache, 60 -> 89 us.)
                     bool half = false;
                     if constexpr (kWalkHalf && !BF && kExactX3) half = tq > 0u && !__any(live && lane >= 32);
                     if constexpr (NARUTO_FWD_GATHER_PRIO != 0) __builtin_amdgcn_s_setprio(NARUTO_FWD_GATHER_PRIO);
-                    if (half) fwd_gather_tile_half(lt, table, x, y, z, feat_save, M, t0 + (uint32_t)j, lane, slabs[wave], live);
+                    if (half) fwd_gather_tile_deep<true>(lt, table, x, y, z, feat_save, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, slabs[wave], live);
                     else fwd_gather_tile<true>(lt, table, x, y, z, feat_save, M, t0 + (uint32_t)j, t0 + (uint32_t)j + 32u, lane, slabs[wave], live);
                     if constexpr (NARUTO_FWD_GATHER_PRIO != 0) __builtin_amdgcn_s_setprio(0);
                     if (tq == 0u && group == blockIdx.x) stamp(3);
@@ -285,28 +309,26 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss(LevelTab lt, UncertTa
                     float* o = raw + (size_t)m * 5;
                     o[0] = to.rgb[0]; o[1] = to.rgb[1]; o[2] = to.rgb[2]; o[3] = to.sdf; o[4] = u_out;
                     rs.c0[s] = to.rgb[0]; rs.c1[s] = to.rgb[1]; rs.c2[s] = to.rgb[2]; rs.sdf[s] = to.sdf; rs.u[s] = u_out;
-                    rs.z[s] = zv;
                 }
                 if (tq == 0u && group == blockIdx.x) stamp(4);
-                if (tq + 1u < tpr && ee_after_tile(ees, ee, ps, m, tq, t0 + 64u, ray0 + S, task, to.sdf, lane, raw)) { ++tq; break; }
+                if (tq + 1u < tpr && ee_after_tile_r(ees, ee.trunc_sc, td_ee, zv, tq, t0 + 64u, ray0 + S, to.sdf, lane, raw)) { ++tq; break; }
             }
-            // tiles that were not evaluated: raw is zeros there (ee_after_tile wrote them), the image gets the same
+            // tiles that were not evaluated: raw is zeros there (ee_after_tile wrote them), the image gets the same (its depths are in place)
             for (uint32_t s = tq * 64u + (uint32_t)lane; s < S; s += 64u) {
                 rs.c0[s] = 0.0f; rs.c1[s] = 0.0f; rs.c2[s] = 0.0f; rs.sdf[s] = 0.0f; rs.u[s] = 0.0f;
-                rs.z[s] = ps.z_vals[(size_t)task * S + s];
             }
             wave_lds_sync();
             if (group == blockIdx.x) {
                 stamp(5);
                 if (timeline != nullptr && lane == 0) timeline[((size_t)blockIdx.x * 4u + (size_t)wave) * 8u + 7u] = tq;
             }
-            loss_stage_ray(a_s, rs, task, lane, terms[wave]);
+            loss_stage_ray(a_s, rs, task, lane, ray_c[wave], ray_c[wave] + 12);
             if (group == blockIdx.x) stamp(6);
         } else {
-            loss_stage_no_ray(lane, terms[wave]);
+            loss_stage_no_ray(lane, ray_c[wave]);
         }
         __syncthreads();
-        loss_stage_row(a_s, terms, group);
+        loss_stage_row(a_s, ray_c, group);
         __syncthreads();                                   // terms are rewritten by the next group
     }
 }

@@ -12,6 +12,7 @@
 #include "naruto_render.hip"
 #include "naruto_rays.hip"
 #include "naruto_train.hip"
+#include "naruto_sorted.hip"
 #include "naruto_renderfused.hip"
 #include "naruto_planner.hip"
 #include "naruto_mesh.hip"
@@ -682,7 +683,10 @@ BwdWs bwd_ws(const NarutoField* f, void* workspace, uint32_t cap) {
 int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, const NarutoPoints* pts, const float* feat_save,
                    const float* d_raw, const float* d_geo, const uint32_t* active_idx, const uint32_t* n_active, const NarutoExtraPoints* extra,
                    uint32_t flags, const NarutoGrads* g, void* workspace, void* stream, uint32_t n_front, const uint32_t* n_list_dev,
-                   const AdamFuse* adam = nullptr, const void* w_img = nullptr, const TvLate* tv_late = nullptr, const AssembleArgs* next = nullptr) {
+                   const AdamFuse* adam = nullptr, const void* w_img = nullptr, const TvLate* tv_late = nullptr, const AssembleArgs* next = nullptr,
+                   bool feat_sample_major = false) {
+    // (feat_sample_major: feat_save is [M][16][2] -- the Morton-ordered forward of the large tables wrote it, see naruto_sorted.hip)
+    const uint32_t feat_M = feat_sample_major ? 1u : M, feat_mul = feat_sample_major ? (uint32_t)kLevels : 1u;
     if ((active_idx == nullptr) != (n_active == nullptr)) return fail(NARUTO_ERR_INVALID, "query_bwd: active_idx and n_active go together");
     if (n_front > 0 && (extra != nullptr || n_list_dev == nullptr)) return fail(NARUTO_ERR_INVALID, "query_bwd: front list excludes extra points");
     const uint32_t E = n_front > 0 ? n_front : ((extra != nullptr && g != nullptr && g->table != nullptr) ? extra->n : 0u);
@@ -726,10 +730,10 @@ int query_bwd_impl(const NarutoField* f, const NarutoParams* p, uint32_t M, cons
     if (!phase_mlp) { /* the point list, d_feat and the wgrad partials are those of the preceding MLP-only call */ }
     else if (bf)
         hipLaunchKernelGGL(k_query_bwd_bf, dim3(blocks), dim3(256), kBwdBfLdsBytes, (hipStream_t)stream, f->lt, f->ut, f->bt, *p, ps, M, cap, feat_save, d_raw,
-                           d_geo, d_feat, x_list, g->uncert_grid, partials, active_idx, n_active, n_front, unc_atomic, w_img);
+                           d_geo, d_feat, x_list, g->uncert_grid, partials, active_idx, n_active, n_front, unc_atomic, w_img, feat_M, feat_mul);
     else
         hipLaunchKernelGGL(k_query_bwd, dim3(blocks), dim3(64 * kBwdWaves), sizeof(BwdLds), (hipStream_t)stream, f->lt, f->ut, f->bt, *p, ps, M, cap, feat_save, d_raw,
-                           d_geo, d_feat, x_list, g->uncert_grid, partials, active_idx, n_active, n_front, unc_atomic, w_img);
+                           d_geo, d_feat, x_list, g->uncert_grid, partials, active_idx, n_active, n_front, unc_atomic, w_img, feat_M, feat_mul);
     if (int rc = check_launch("query_bwd")) return rc;
     if (adam != nullptr) {
         if (!phase_mlp || !phase_table) return fail(NARUTO_ERR_INVALID, "query_bwd: the fused optimiser runs the backward in one piece");
@@ -817,9 +821,11 @@ int naruto_query_bwd(const NarutoField* f, const NarutoParams* p, uint32_t M, co
 namespace {
 struct TrainWs {
     float* terms; float* tv_feat; double* tv_partial; void* bwd; double* fold; uint32_t* block_sums; void* w_img; float* w10;
+    uint32_t* sort;               // the Morton-ordered forward's buffers (naruto_sorted.hip): count | cursor | base [3][kSortCells], n_list + totals [320], cells | list | list2 [3][M], pts [M] float4
     uint32_t n3, n_tv_blocks;
     size_t total;
 };
+inline size_t sort_ws_words(size_t M) { return 3u * (size_t)kSortCells + 320u + 7u * ((M + 63u) / 64u * 64u); }
 TrainWs train_ws(const NarutoField* f, const NarutoTrainStep* t) {
     TrainWs w{};
     const uint32_t S = t->n_samples_d + t->n_range_d;
@@ -839,6 +845,7 @@ TrainWs train_ws(const NarutoField* f, const NarutoTrainStep* t) {
     w.w_img = base + off;                                 off += al(bwd_weight_image_bytes());
     w.w10 = reinterpret_cast<float*>(base + off);         off += al(16u * sizeof(float));          // gathered loss_weight_parts
     w.bwd = base + off;                                   off += al(naruto_query_bwd_workspace(f, (uint32_t)(M + w.n3)));
+    w.sort = reinterpret_cast<uint32_t*>(base + off);     off += al(sort_ws_words(M) * sizeof(uint32_t));     // (every plan: the plan is not known here, and it is 12 B per sample)
     w.total = off;
     return w;
 }
@@ -875,7 +882,9 @@ int train_check(const NarutoField* f, const NarutoParams* p, const NarutoTrainSt
 //   Packed  k_query_fwd_loss_packed (see launch_train_query)
 //   Short   S <= 64 (round 5): a workgroup packs 256 / S rays into its four waves' tiles (k_query_fwd_loss_short), loss stage inside, one row
 //           of loss partials per workgroup -- the shipped 32 + 11 sampling in five launches without a second round of workgroups
-enum class FwdForm { Flat, Walk, Packed, Short };
+//   Sorted  tables no cache holds (round 6): the flat field query in Morton order of the samples a consumer can see (naruto_sorted.hip), loss stage
+//           in its own launch; feat_save sample-major
+enum class FwdForm { Flat, Walk, Packed, Short, Sorted };
 struct TrainFwdPlan {
     FwdForm form;
     bool fused;         // the loss stage rides in the field query's launch
@@ -898,6 +907,14 @@ TrainFwdPlan train_fwd_plan(const NarutoField* f, const NarutoTrainStep* t, bool
     const bool can_fuse = with_loss && !no_fuse && ray_scratch_bytes(S) <= kFwdLossMaxRayLds;
     bool packed_on = packed_mode == 2 || ((packed_mode == 1 || packed_mode == 3) && !exact);
     if (packed_on && packed_mode == 1) packed_on = (size_t)f->n_entries * 2u * sizeof(float) > ((size_t)64u << 20);
+    // NARUTO_FWD_SORTED: 1 (default) the Morton-ordered forward for tables of more than 64 MB -- where every gather is an HBM line --, 2 for
+    // every table (tests), 0 never (the packed forward as in round 4 / 5)
+    static const int sorted_mode = getenv("NARUTO_FWD_SORTED") == nullptr ? 1 : atoi(getenv("NARUTO_FWD_SORTED"));
+    const bool big_table = (size_t)f->n_entries * 2u * sizeof(float) > ((size_t)64u << 20);
+    if (with_loss && kFwdSplit && (sorted_mode == 2 || (sorted_mode == 1 && big_table && packed_mode == 1)) && (uint64_t)N * S < 0x0FFFFFFFull) {
+        pl.form = FwdForm::Sorted;
+        return pl;
+    }
     if (packed_on && with_loss && !no_fuse && kFwdSplit && S <= 4095u && N >= 1u) {
         pl.form = FwdForm::Packed;          // (falls back to the flat launch inside launch_train_query if not even one row fits the LDS)
         pl.fused = true;
@@ -975,6 +992,32 @@ int launch_train_query(const NarutoField* f, const NarutoParams* p, const Naruto
     // NARUTO_FWD_PACKED: 0 never, 1 (default) as above, 2 everywhere incl. S = 64 k, 3 wherever the walk cannot run.  Losses and gradients
     // agree with the other launch shapes to the distance between OneBlob's closed and dense forms, ~1e-6 (which form a point gets depends on
     // the tile it shares).  NARUTO_PACK_ONE_PASS=1: every sample in the first pass (measured: 0.200 / 0.180 ms at the two batches above).
+    if (pl.form == FwdForm::Sorted) {
+        const TrainWs w = train_ws(f, t);
+        const size_t Mp = ((size_t)M + 63u) / 64u * 64u;
+        SortArgs sa{};
+        sa.M = M; sa.S = S; sa.target_d = t->target_d; sa.trunc_sc = f->desc.trunc * f->desc.sc_factor;
+        sa.count = w.sort; sa.cursor = w.sort + kSortCells; sa.base = w.sort + 2u * (size_t)kSortCells; sa.n_list = w.sort + 3u * (size_t)kSortCells;
+        sa.cells = sa.n_list + 320; sa.list = sa.cells + Mp; sa.list2 = sa.list + Mp; sa.pts = reinterpret_cast<float4*>(sa.list2 + Mp);
+        hipLaunchKernelGGL(k_sort_zero, dim3(2u * kSortCells / 4u / 256u), dim3(256), 0, st, reinterpret_cast<uint4*>(sa.count), 2u * kSortCells / 4u);
+        const bool bfm = f->desc.mlp_mode == NARUTO_MLP_BF16;
+        const uint32_t mblocks = (M + 255u) / 256u;
+        hipLaunchKernelGGL(k_sort_count, dim3(mblocks), dim3(256), 0, st, sa, ps, f->bt, t->raw);
+        hipLaunchKernelGGL(k_sort_sum, dim3(256), dim3(256), 0, st, sa, sa.n_list + 8);          // (the totals: 256 words behind the two list lengths)
+        hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, st, sa, sa.n_list + 8);
+        hipLaunchKernelGGL(k_sort_fill, dim3(mblocks), dim3(256), 0, st, sa, ps, f->bt);
+        if (int rc = check_launch("sort_count / scan / fill")) return rc;
+        const uint32_t qblocks = cu_count(f);
+#define NARUTO_LAUNCH_LIST(LISTV, PTSV, NV) do { \
+            if (bfm) hipLaunchKernelGGL(k_query_fwd_list<true>, dim3(qblocks), dim3(512), 0, st, f->lt, f->ut, f->bt, *p, ps, LISTV, PTSV, NV, t->raw, t->feat_save); \
+            else hipLaunchKernelGGL(k_query_fwd_list<false>, dim3(qblocks), dim3(512), 0, st, f->lt, f->ut, f->bt, *p, ps, LISTV, PTSV, NV, t->raw, t->feat_save); } while (0)
+        NARUTO_LAUNCH_LIST(sa.list, sa.pts, sa.n_list);
+        if (int rc = check_launch("query_fwd_list")) return rc;
+        hipLaunchKernelGGL(k_sort_more, dim3((N + 255u) / 256u), dim3(256), 0, st, sa, N, t->z_vals, t->raw);
+        NARUTO_LAUNCH_LIST(sa.list2, static_cast<const float4*>(nullptr), sa.n_list + 1);
+#undef NARUTO_LAUNCH_LIST
+        return check_launch("sort_more / query_fwd_list");          // (*fused stays false: the caller launches the loss stage)
+    }
     if (pl.form == FwdForm::Packed) {
         // workgroup shape: 8 waves x 1 per CU, or 4 waves x 2 per CU (NARUTO_PACK_WAVES); rows (of four rays) a workgroup holds at a time: as many as
         // the LDS next to the weights, the feature slabs and the tiles' points takes, at most three
@@ -1364,11 +1407,12 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
     const bool late = moved;
     if (late) { tvl.tv_partial = w.tv_partial; tvl.n_tv_blocks = w.n_tv_blocks; tvl.inv_p3 = tv_args(t).inv_p3; tvl.losses = t->losses; tvl.loss_weights = t->loss_weights; }
     int rc;
+    const bool feat_sm = train_fwd_plan(f, t, true, false).form == FwdForm::Sorted;      // the layout the forward of this plan left feat_save in
     if (n_front > 0)
         rc = query_bwd_impl(f, p, M, &pts, t->feat_save, t->d_raw, nullptr, t->active_idx, t->n_active, nullptr, flags, g, w.bwd, stream, n_front, bw.n_total, ad, w_img,
-                            (late && ad != nullptr) ? &tvl : nullptr, next);
+                            (late && ad != nullptr) ? &tvl : nullptr, next, feat_sm);
     else        // no smoothness term: the workspace was sized for cap = M + n3 with n3 = 0
-        rc = query_bwd_impl(f, p, M, &pts, t->feat_save, t->d_raw, nullptr, t->active_idx, t->n_active, nullptr, flags, g, w.bwd, stream, 0u, nullptr, ad, w_img, nullptr, next);
+        rc = query_bwd_impl(f, p, M, &pts, t->feat_save, t->d_raw, nullptr, t->active_idx, t->n_active, nullptr, flags, g, w.bwd, stream, 0u, nullptr, ad, w_img, nullptr, next, feat_sm);
     if (rc != NARUTO_OK) return rc;
     if (late && ad == nullptr) {                                 // no optimiser in the backward: the value gets a (tiny) launch of its own
         hipLaunchKernelGGL(k_tv_late, dim3(1), dim3(256), 0, st, tvl);

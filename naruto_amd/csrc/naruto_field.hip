@@ -2305,7 +2305,9 @@ __global__ __launch_bounds__(64 * kBwdWaves) void k_query_bwd(LevelTab lt, Uncer
                                                    const float* __restrict__ d_geo, float* __restrict__ d_feat, float* __restrict__ x_out,
                                                    float* __restrict__ d_uncert_grid, float* __restrict__ partials,
                                                    const uint32_t* __restrict__ active_idx, const uint32_t* __restrict__ n_active, uint32_t list_off, int unc_atomic,
-                                                   const void* __restrict__ w_img) {
+                                                   const void* __restrict__ w_img, uint32_t feat_M, uint32_t feat_mul) {
+    // feat_save[(T * feat_M + m * feat_mul) * 2 + f]: level-major (feat_M = M, feat_mul = 1) or, behind the Morton-ordered forward of the large
+    // tables (naruto_sorted.hip), sample-major (feat_M = 1, feat_mul = 16)
     // list_off: position of this launch's first point in the scatter's point list (the smoothness lattice sits in front)
     // w_img: the weight part of BwdLds prepared in global memory, or NULL (stage it here)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -2356,7 +2358,7 @@ __global__ __launch_bounds__(64 * kBwdWaves) void k_query_bwd(LevelTab lt, Uncer
 #pragma unroll
         for (int q = 0; q < 5; ++q) t.g[q] = g[q];
 #pragma unroll
-        for (int T = 0; T < kLevels; ++T) t.feat[T] = feat_save[((size_t)T * M + t.m) * 2 + hh];
+        for (int T = 0; T < kLevels; ++T) t.feat[T] = feat_save[((size_t)T * feat_M + (size_t)t.m * feat_mul) * 2 + hh];
         return t;
     };
     const uint32_t tile_stride = gridDim.x * (uint32_t)kBwdWaves;
@@ -2789,7 +2791,7 @@ __global__ __launch_bounds__(256, NARUTO_BWD_BF_MINWAVES) void k_query_bwd_bf(Le
                                                       const float* __restrict__ d_geo, float* __restrict__ d_feat, float* __restrict__ x_out,
                                                       float* __restrict__ d_uncert_grid, float* __restrict__ partials,
                                                       const uint32_t* __restrict__ active_idx, const uint32_t* __restrict__ n_active, uint32_t list_off, int unc_atomic,
-                                                      const void* __restrict__ w_img) {
+                                                      const void* __restrict__ w_img, uint32_t feat_M, uint32_t feat_mul) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     BwdLdsBf& L = *reinterpret_cast<BwdLdsBf*>(smem_raw);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2825,8 +2827,8 @@ __global__ __launch_bounds__(256, NARUTO_BWD_BF_MINWAVES) void k_query_bwd_bf(Le
         float ftA[kLevels], ftB[kLevels];
 #pragma unroll
         for (int T = 0; T < kLevels; ++T) {
-            ftA[T] = feat_save[((size_t)T * M + mA) * 2 + hh];
-            ftB[T] = feat_save[((size_t)T * M + mB) * 2 + hh];
+            ftA[T] = feat_save[((size_t)T * feat_M + (size_t)mA * feat_mul) * 2 + hh];
+            ftB[T] = feat_save[((size_t)T * feat_M + (size_t)mB * feat_mul) * 2 + hh];
         }
         float x, y, z;
         load_point(ps, bt, m, x, y, z);

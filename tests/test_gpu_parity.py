@@ -1637,6 +1637,112 @@ def test_packed_forward_equals_the_flat_one(gpu, tmp_path):
             assert d <= 2e-5 * scale, f"S = {tag}: {k} differs by {d:.3e} at scale {scale:.3e}"
 
 
+def test_sorted_forward_equals_the_flat_one(gpu, tmp_path):
+    """Round 6: the Morton-ordered training forward of the tables no cache holds (naruto_sorted.hip: the samples needed whatever the network says, counting-
+    sorted by the cell of their position, evaluated in that order; the rest of each ray's band in a second pass; feat_save sample-major, read by the
+    backward through its row multiplier) -- forced onto a small table by NARUTO_FWD_SORTED=2 and compared with the flat field query over every sample
+    (NARUTO_FWD_SORTED=0, NARUTO_FWD_PACKED=0): same losses, rendered maps, sums and every gradient, at the distance between OneBlob's closed and dense
+    forms (a point's form depends on the tile it shares).  43 and 128 samples per ray, a batch smaller than a tile, one of several thousand rays; both
+    MLP modes."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for tag, n_samples_d, n_rays, bf in (("43", 32, 333, False), ("43_one_ray", 32, 1, False), ("43_many", 32, 4100, False), ("128", 117, 333, False), ("43_bf16", 32, 333, True)):
+        script = tmp_path / f"iteration_sorted_{tag}.py"
+        text = _KNOB_SCRIPT.replace("n_samples_d=117", f"n_samples_d={n_samples_d}").replace("N = 333", f"N = {n_rays}")
+        if bf:
+            text = text.replace('tr, cam = cfg["training"], cfg["cam"]', 'cfg["decoder"]["mlp_precision"] = "bf16"\ntr, cam = cfg["training"], cfg["cam"]')
+        script.write_text(text)
+        res = []
+        for k, env in enumerate(({"NARUTO_FWD_SORTED": "2"}, {"NARUTO_FWD_SORTED": "0", "NARUTO_FWD_PACKED": "0"})):
+            out = tmp_path / f"sorted_{tag}_{k}.npz"
+            e = dict(os.environ)
+            e.update(env)
+            subprocess.run([sys.executable, str(script), root, str(out)], check=True, env=e, timeout=600)
+            res.append(dict(np.load(out)))
+        a, b = res
+        assert float(np.abs(b["g_table"]).max()) > 0
+        for k in a:
+            scale = float(np.abs(b[k]).max()) + 1e-30
+            d = float(np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)).max())
+            assert d <= 2e-5 * scale, f"S = {tag}: {k} differs by {d:.3e} at scale {scale:.3e}"
+
+
+_FULL_T22_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import bench
+from naruto_amd import ops
+from naruto_amd.field import NarutoFieldHIP
+gpu = torch.device("cuda", 0)
+cfg, N = bench.workload("unit1024_T22_131072x43")
+tr, cam = cfg["training"], cfg["cam"]
+torch.manual_seed(3)
+m = NarutoFieldHIP(cfg, torch.tensor(cfg["mapping"]["bound"], dtype=torch.float32)).to(gpu)
+m.get_uncert_grid(0.1)
+with torch.no_grad():
+    m.embed_fn.params.uniform_(-0.3, 0.3)           # a field with structure: sign changes on most rays
+rays = bench.bench_rays(cfg, N)
+w = torch.tensor([tr["rgb_weight"], tr["depth_weight"], tr["sdf_weight"], tr["fs_weight"], 0.0, tr["uncert_weight"], 0.0, 0.0, 0.1, 0.0])
+ts = ops.TrainStep(m._handle(), m._params(), torch.zeros_like(m.uncert_grid), N, n_samples_d=tr["n_samples_d"], n_range_d=tr["n_range_d"],
+                   near=cam["near"], far=cam["far"], range_d=tr["range_d"], depth_trunc=cam["depth_trunc"], rgb_missing=tr["rgb_missing"],
+                   perturb=True, loss_weights=w.to(gpu), smooth=(12, 0.1, 0.05), device_rng=True, seed=5)
+args = [torch.from_numpy(rays[k]).to(gpu).contiguous() for k in ("rays_o", "rays_d", "target_rgb")] + [torch.from_numpy(rays["target_d"]).to(gpu).reshape(-1).contiguous()]
+losses = ts.run(*args).clone()
+torch.cuda.synchronize()
+S = tr["n_samples_d"] + tr["n_range_d"]
+raw = ts.raw.reshape(N, S, 5)
+z = ts.z_vals.reshape(N, S)
+ev = raw.abs().sum(-1) > 0
+# size-independent properties of ANY correct forward of this path: what is evaluated is a PREFIX of every ray (depths are sorted), it reaches at least
+# to measured depth + truncation, and nothing is evaluated behind max(first sign change, measured depth) + truncation + one sample
+first_gap = (~ev).float().argmax(1)
+n_ev = ev.sum(1)
+prefix_ok = bool(((n_ev == first_gap) | (n_ev == S)).all())
+td = args[3].reshape(-1, 1)
+tsc = float(cfg["training"]["trunc"])
+need = (~(td > 0)) | (z <= td + tsc)
+covers = bool((ev | ~need).all())
+g = ts.grads["table"]
+idx = torch.arange(0, g.numel(), 9973, device=gpu)
+out = {"losses": losses.cpu().numpy(), "rgb": ts.rgb.cpu().numpy(), "depth": ts.depth.cpu().numpy(), "sums": ts.sums.cpu().numpy()[:10],
+       "g_table_probe": g.reshape(-1)[idx].cpu().numpy(), "g_table_abs_sum": np.array([float(g.double().abs().sum())]),
+       "g_sdf_w0": ts.grads["sdf_w0"].cpu().numpy(), "g_col_w1": ts.grads["col_w1"].cpu().numpy(), "g_uncert_grid": ts.grads["uncert_grid"].cpu().numpy(),
+       "n_eval": np.array([int(ev.sum())]), "n_active": np.array([int(ts.n_active.item())]), "prefix_ok": np.array([prefix_ok]), "covers": np.array([covers])}
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_configs4_at_its_full_per_gpu_size(gpu, tmp_path):
+    """BASELINE configs[4] at the FULL size of one GPU's shard -- 131 072 rays x 43 samples, T = 2^22 (281 MB table), 5.6 M samples: too large for the CPU
+    oracle in a test, so (i) size-independent properties of the band every forward of this path must respect (evaluated samples form a prefix of their
+    ray, reaching at least to measured depth + truncation) and (ii) the two independent implementations against each other -- the Morton-ordered forward
+    (round 6, the default here) and the packed forward (round 4; NARUTO_FWD_SORTED=0), which share neither the launch structure nor the order of
+    evaluation nor the layout of the saved features: losses, rendered maps, loss sums, weight / uncertainty-grid gradients and a strided probe of the table
+    gradient (the binned scatter's path) agree to OneBlob's closed-vs-dense distance."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "t22_full.py"
+    script.write_text(_FULL_T22_SCRIPT)
+    res = []
+    for k, env in enumerate(({"NARUTO_FWD_SORTED": "1"}, {"NARUTO_FWD_SORTED": "0"})):
+        out = tmp_path / f"t22_full_{k}.npz"
+        e = dict(os.environ)
+        e.update(env)
+        subprocess.run([sys.executable, str(script), root, str(out)], check=True, env=e, timeout=900)
+        res.append(dict(np.load(out)))
+    a, b = res
+    for r in res:
+        assert bool(r["prefix_ok"][0]) and bool(r["covers"][0])
+        assert np.isfinite(r["losses"]).all() and 0 < int(r["n_active"][0]) <= int(r["n_eval"][0]) <= 131072 * 43
+    assert int(a["n_active"][0]) == int(b["n_active"][0]), "the backward's list (what can receive a cotangent) does not depend on the forward's form"
+    for k in a:
+        if k in ("n_eval", "n_active", "prefix_ok", "covers"):
+            continue
+        scale = float(np.abs(b[k]).max()) + 1e-30
+        d = float(np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)).max())
+        assert d <= 5e-5 * scale, f"{k} differs by {d:.3e} at scale {scale:.3e}"
+
+
 def test_short_and_partial_walk_forwards_equal_the_flat_one(gpu, tmp_path):
     """Round 5: sample counts that are not a multiple of 64 get the five-launch iteration too -- S <= 64 (the shipped 32 + 11) through
     k_query_fwd_loss_short (a workgroup packs 256 / S rays into its four waves' tiles, samples the depths itself, loss stage inside, one

@@ -379,6 +379,7 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss_short(LevelTab lt, Un
     // What the depth sampling and the loss stage wait for from memory -- the rays' measured depths and colours, the jitter key -- is
     // requested in front of the weight staging (into LDS: tgt), so that it is there when it is needed instead of costing each ray a trip.
     __shared__ float tgt[kShortMaxRays][4];
+    __shared__ float rayc[kShortMaxRays][8];            // round 6: the rays themselves too (origin, direction): a tile's lanes read them from here
     const bool use_rng = wx.on != 0u && wx.sa.rand == nullptr && wx.sa.rng != nullptr;
     const uint64_t key_pre = use_rng ? rng_key(wx.sa.rng) : 0ull;
     auto fetch_targets = [&](uint32_t ray_first) {
@@ -387,6 +388,11 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss_short(LevelTab lt, Un
             float v = 0.0f;
             if (n < a.n_rays) v = c == 3u ? a.target_d[n] : a.target_rgb[3 * (size_t)n + c];
             tgt[r][c] = v;
+        } else if (threadIdx.x >= 64u && threadIdx.x < 64u + 8u * R) {
+            const uint32_t q = threadIdx.x - 64u, r = q >> 3, c = q & 7u, n = ray_first + r;
+            float v = 0.0f;
+            if (n < a.n_rays && c < 6u) v = c < 3u ? ps.rays_o[3 * n + c] : ps.rays_d[3 * n + c - 3u];
+            rayc[r][c] = v;
         }
     };
     fetch_targets(blockIdx.x * R);
@@ -430,9 +436,10 @@ __global__ __launch_bounds__(256, 2) void k_query_fwd_loss_short(LevelTab lt, Un
         if ((uint32_t)wave * 64u < n_here * S) {           // wave-uniform: a tile with at least one sample
             const float zv = rs.z[s];
             // load_point's arithmetic with the depth from the image
-            const float px = __fadd_rn(ps.rays_o[3 * n + 0], __fmul_rn(ps.rays_d[3 * n + 0], zv));
-            const float py = __fadd_rn(ps.rays_o[3 * n + 1], __fmul_rn(ps.rays_d[3 * n + 1], zv));
-            const float pz = __fadd_rn(ps.rays_o[3 * n + 2], __fmul_rn(ps.rays_d[3 * n + 2], zv));
+            const float* __restrict__ rc = rayc[r];
+            const float px = __fadd_rn(rc[0], __fmul_rn(rc[3], zv));
+            const float py = __fadd_rn(rc[1], __fmul_rn(rc[4], zv));
+            const float pz = __fadd_rn(rc[2], __fmul_rn(rc[5], zv));
             const float x = __fdiv_rn(__fsub_rn(px, bt.bmin[0]), bt.bext[0]);
             const float y = __fdiv_rn(__fsub_rn(py, bt.bmin[1]), bt.bext[1]);
             const float z = __fdiv_rn(__fsub_rn(pz, bt.bmin[2]), bt.bext[2]);

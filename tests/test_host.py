@@ -277,6 +277,8 @@ def test_no_kernel_spills_to_scratch(built_lib):
     # level loop is unrolled per level; a workgroup runs one sixteenth of it), spread evenly over the level units' code whatever the new role's
     # own form (inlined, its own function, its uniform values through LDS, its queue in static or dynamic LDS: all measured, 307 each time, 435 as
     # a function); the level units' workgroups did not slow down (hashed 49 -> 46 us, profiles/r05_scatter_timeline.txt).
+    # Round 6, the evidence the review asked for (profiles/r06_scatter_sgpr_spill_roles.txt, tools/scatter_sgpr_ab.sh: both builds, per workgroup type, three
+    # batch sizes): dense-level units 2 - 3 % slower with 307 than with 127, hashed units 5 - 6 % faster, the launch 51.2 vs 57.7 / 95.2 vs 91.8 / 1302 vs 1390 us.
     # k_query_fwd_loss<false,true> (round 6): 104 -> 132 with the HALF tile -- a second instantiation of the gather and of the x3 matrix phase in the tile
     # loop (the count is static spill SITES, per instantiation) -- while the kernel went 62.7 -> 60.4 us and every phase of its per-wave timeline
     # (tools/walk_timeline.py, profiles/r06_walk_timeline_*.txt) is as long or shorter than before; the ray constants and PointSrc went to LDS to

@@ -27,7 +27,7 @@ step()
 torch.cuda.synchronize()
 lib.naruto_debug_fwd_timeline(None)
 t = buf.cpu().numpy().reshape(n_wg, 8)
-t = t[t[:, 4] > 0]                     # (the forward's workgroups stamp other slots: only rows a scatter workgroup tagged)
+t = t[(t[:, 4] > 0) & (t[:, 4] < (1 << 24))]       # only rows a scatter workgroup tagged (the forward's waves leave time stamps -- huge numbers -- in the same buffer)
 t0 = t[:, 0].min()
 f = lambda a: (a.astype(np.float64) - t0) / 100.0
 st = tr._train_steps[next(iter(tr._train_steps))] if hasattr(tr, "_train_steps") else None

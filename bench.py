@@ -963,7 +963,17 @@ def main():
             if roof["kernel"].startswith("k_query_fwd") and it.get("evaluated_samples") is not None:
                 S_it = int(it["samples"]) // int(n_rays)
                 k_it = "k_query_fwd_loss_short" if S_it <= 64 else "k_query_fwd_loss"
+                n_table_bytes = int(tr.model.embed_fn.params.numel()) * 4
+                sorted_env = os.environ.get("NARUTO_FWD_SORTED", "1")
+                if sorted_env == "2" or (sorted_env == "1" and (n_table_bytes > (64 << 20) or (int(it["samples"]) >= 4000000 and S_it <= 64))):
+                    k_it = "k_query_fwd_list"          # the Morton-ordered forward (naruto_sorted.hip): sort launches + two list passes, timed together
                 iprof, isrc = pmc_profile(args.workload, k_it)
+                if k_it == "k_query_fwd_list" and iprof:
+                    # two launches of this kernel per iteration (first list, second list: same grid, so the PMC table averages them): per ITERATION = 2 x
+                    iprof = dict(iprof)
+                    for kk in ("traffic_bytes", "fetch_bytes", "write_bytes", "tcc_req"):
+                        if iprof.get(kk) is not None:
+                            iprof[kk] = 2 * iprof[kk]
                 roof_it = {"bound": "hbm", "achieved": it["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(it["GBps"] / HBM_PEAK_GBS, 4),
                            "traffic": iprof.get("traffic_bytes"), "kernel": k_it,
                            "launch": "as launched by the timed step (naruto_debug_train_query_fwd: the same launch, alone)",

@@ -15,6 +15,7 @@ import re
 import sys
 
 NAMES = {"k_query_fwd<color>": ["k_query_fwdILb1"], "k_query_bwd": ["k_query_bwd"],
+         "k_query_fwd_loss": ["k_query_fwd_lossI"], "k_query_fwd_loss_short": ["k_query_fwd_loss_shortI"], "k_query_fwd_list": ["k_query_fwd_listI"],
          "k_hash_scatter+reduce+k_wgrad_reduce": ["k_hash_scatter_lds", "k_scatter_reduce", "k_hash_scatter_atomic", "k_bwd_post", "k_wgrad_reduce", "k_bin_count",
                                                   "k_bin_colscan", "k_bin_start", "k_bin_fill", "k_bin_apply"],
          "k_hash_scatter_lds": ["k_hash_scatter_lds"], "k_bin_fill": ["k_bin_fill"], "k_bin_apply": ["k_bin_apply"], "k_bin_count": ["k_bin_count"], "k_bwd_finish": ["k_bwd_finish"], "k_tv_encode": ["k_tv_encode"],

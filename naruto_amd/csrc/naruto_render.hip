@@ -424,16 +424,28 @@ struct LossArgs {
 
 // one wave = ray n (ray_lds: the workgroup's dynamic LDS); la.sums may point into LDS
 // LOADED: the caller has filled the wave's LDS image already (load_ray)
+// the part of the composite backward that needs nothing but the ray: its weights and composited outputs (k_loss_bwd_fused runs it while the loss
+// stage's rows are still on their way, round 6)
+struct CompositeFwd { RayWeights rw; RayOut o; };
+__device__ __forceinline__ CompositeFwd composite_bwd_prepare(float* ray_lds, uint32_t n, int lane, int wave, uint32_t S, float trunc, float sc_factor) {
+#pragma clang fp contract(off)
+    const RayScratch rs = ray_scratch(ray_lds, wave, S);
+    CompositeFwd c;
+    c.rw = ray_weights(rs, S, trunc, sc_factor, lane);
+    c.o = ray_composite(rs, c.rw, n, S, 0, nullptr, lane);             // rgb WITHOUT the white background term
+    return c;
+}
 template <bool LOSS, bool LOADED = false>
 __device__ __forceinline__ void composite_bwd_ray(float* ray_lds, uint32_t n, int lane, int wave, uint32_t S, float trunc, float sc_factor, int white_bkgd,
                                                   const float* __restrict__ raw, const float* __restrict__ z_vals, const CompositeCot& cot, const LossArgs& la,
-                                                  float* __restrict__ d_raw, int accumulate, uint32_t* __restrict__ ray_count) {
+                                                  float* __restrict__ d_raw, int accumulate, uint32_t* __restrict__ ray_count, const CompositeFwd* pre = nullptr) {
     // inlined into two kernels (k_composite_bwd, k_loss_bwd_fused) that must produce the same bits: only the fmaf()s written below fuse
 #pragma clang fp contract(off)
     const RayScratch rs = ray_scratch(ray_lds, wave, S);
     if constexpr (!LOADED) load_ray(rs, raw, z_vals, n, S, lane);
-    const RayWeights rw = ray_weights(rs, S, trunc, sc_factor, lane);
-    const RayOut o = ray_composite(rs, rw, n, S, 0, nullptr, lane);     // rgb WITHOUT the white background term
+    const CompositeFwd cf = pre != nullptr ? *pre : composite_bwd_prepare(ray_lds, n, lane, wave, S, trunc, sc_factor);
+    const RayWeights rw = cf.rw;
+    const RayOut o = cf.o;
 
     float g_rgb[3] = {0.0f, 0.0f, 0.0f}, g_depth = 0.0f, g_acc = 0.0f, g_var = 0.0f, g_unc = 0.0f, g_disp = 0.0f;
     float td = 0.0f, dm = 0.0f, c_fs = 0.0f, c_sdf = 0.0f;

@@ -982,6 +982,9 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_bwd_fused(FusedBwdA
     const uint32_t r0 = blockIdx.x * kRaysPerBlock, n = r0 + wave;
     // Every load of this workgroup that depends on nothing goes out first -- the counts of the rays before it, the loss stage's rows, its
     // rays' raw values and depths (into the LDS image) -- so that they share ONE trip to memory instead of three behind one another.
+    // (round 6: the ray image FIRST -- its loads are the only ones the wave then has to wait for before it starts on the ray's own part of the composite
+    // backward; the counts and the loss stage's rows, requested right behind, arrive meanwhile)
+    if (n < a.n_rays) load_ray(ray_scratch(ray_lds, wave, a.S), a.raw, a.z_vals, n, a.S, lane);
     constexpr int kCountLoads = (int)(kFusedTailMaxRays / 256u);
     uint32_t cv[kCountLoads];
 #pragma unroll
@@ -992,7 +995,9 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_bwd_fused(FusedBwdA
     const uint32_t c = n < a.n_rays ? a.ray_count[n] : 0u;
     double pv[4][10];
     if (!a.sums_given) wg_partial_load<0xD6u>(a.partials, a.n_rows, 0u, pv);          // slots 1, 2, 4, 6, 7 (at most 1 024 rows here)
-    if (n < a.n_rays) load_ray(ray_scratch(ray_lds, wave, a.S), a.raw, a.z_vals, n, a.S, lane);
+    // the ray's own part of the composite backward (weights, composited outputs) while the counts and the loss stage's rows are still arriving
+    CompositeFwd cf{};
+    if (n < a.n_rays) cf = composite_bwd_prepare(ray_lds, n, lane, wave, a.S, a.trunc, a.sc_factor);
     // list offset: the counts of the rays before this workgroup's (integer sums: any order)
     uint32_t s = 0;
 #pragma unroll
@@ -1023,7 +1028,7 @@ __global__ __launch_bounds__(64 * kRaysPerBlock) void k_loss_bwd_fused(FusedBwdA
     LossArgs la = a.la;
     la.sums = s_sums;
     const CompositeCot cot{};
-    composite_bwd_ray<true, true>(ray_lds, n, lane, wave, a.S, a.trunc, a.sc_factor, a.white_bkgd, a.raw, a.z_vals, cot, la, a.d_raw, 0, nullptr);
+    composite_bwd_ray<true, true>(ray_lds, n, lane, wave, a.S, a.trunc, a.sc_factor, a.white_bkgd, a.raw, a.z_vals, cot, la, a.d_raw, 0, nullptr, &cf);
 }
 
 // loss weights handed over as separate device scalars (autograd's cotangents of an unchanged caller's scalar losses) -> one vector

@@ -21,7 +21,7 @@ for f in dropin_kernel_trace dropin_torch_profiler_swap_only dropin_torch_profil
   [ -s $G/${TAG}_$f.txt ] && grep -v "amdgpu.ids\|UserWarning\|_warn_once\|ROCTracer" $G/${TAG}_$f.txt | cut -c1-220 > $P/${TAG}_$f.txt
 done
 for f in sq_counters_sq sq_counters_2048x43_sq; do [ -s $G/${TAG}_$f.txt ] && cp $G/${TAG}_$f.txt $P/${TAG}_${f%_sq}.txt; done
-for f in fwd_timeline_2048x43 fwd_timeline_ba fwd_timeline_2048x128_packed_everywhere trained_step trained_step_flat accuracy_study short_timeline scatter_timeline fwd_lab; do
+for f in fwd_timeline_2048x43 fwd_timeline_ba fwd_timeline_2048x128_packed_everywhere trained_step trained_step_flat accuracy_study short_timeline scatter_timeline fwd_lab walk_timeline x3_chain_stats t22_band_stats_sorted1 t22_band_stats_sorted0; do
   [ -s $G/${TAG}_$f.txt ] && grep -v "amdgpu.ids\|UserWarning\|_warn_once\|ROCTracer" $G/${TAG}_$f.txt | cut -c1-260 > $P/${TAG}_$f.txt
 done
 [ -s $G/${TAG}_accuracy_study.json ] && cp $G/${TAG}_accuracy_study.json $P/

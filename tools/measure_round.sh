@@ -55,3 +55,8 @@ timeout 300 python tools/short_timeline.py 2148 > gpurun_out/${TAG}_short_timeli
 timeout 300 python tools/scatter_timeline.py > gpurun_out/${TAG}_scatter_timeline.txt 2>&1
 [ -x tools/fwd_lab ] && timeout 300 tools/fwd_lab > gpurun_out/${TAG}_fwd_lab.txt 2>&1
 git -C $R rev-parse HEAD > gpurun_out/${TAG}_commit.txt 2>/dev/null || true
+# round 6: per-wave timeline of the depth-ordered walk (trained state), the x3-vs-fp32 chain distance, what each large-table forward evaluates
+cd $R
+timeout 300 python tools/walk_timeline.py office0_2048x128 fp32 600 > gpurun_out/${TAG}_walk_timeline.txt 2>&1
+timeout 300 python tools/x3_chain_stats.py > gpurun_out/${TAG}_x3_chain_stats.txt 2>&1
+for v in 1 0; do NARUTO_FWD_SORTED=$v timeout 300 python tools/t22_band_stats.py 131072 150 > gpurun_out/${TAG}_t22_band_stats_sorted$v.txt 2>&1; done

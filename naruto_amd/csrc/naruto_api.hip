@@ -1166,6 +1166,24 @@ size_t naruto_train_workspace(const NarutoField* f, const NarutoTrainStep* t) {
     return train_ws(f, &c).total;
 }
 
+// (advisor, round 5) NARUTO_TRAIN_FWD_SUMS_TV_LATER and NARUTO_TRAIN_BWD_TV_MOVED must be paired: a forward that LEFT the smoothness term to the backward,
+// followed by a backward that is not told so, would silently drop the term (no value, stale cotangents on the front list).  The last forwards' decisions are
+// remembered per training workspace (host side, a handful of entries) and naruto_train_backward refuses the mismatch.
+namespace {
+struct TvLeft { const void* ws; bool left; };
+TvLeft g_tv_left[16] = {};
+int g_tv_left_next = 0;
+void note_tv_left(const void* ws, bool left) {
+    for (auto& e : g_tv_left) if (e.ws == ws) { e.left = left; return; }
+    g_tv_left[g_tv_left_next] = TvLeft{ws, left};
+    g_tv_left_next = (g_tv_left_next + 1) % 16;
+}
+bool tv_was_left(const void* ws) {
+    for (const auto& e : g_tv_left) if (e.ws == ws) return e.left;
+    return false;
+}
+}  // namespace
+
 int naruto_train_forward(const NarutoField* f, const NarutoParams* p, const NarutoTrainStep* t, int finalize, void* stream) {
     if (int rc = train_check(f, p, t, "train_forward")) return rc;
     const hipStream_t st = (hipStream_t)stream;
@@ -1181,6 +1199,7 @@ int naruto_train_forward(const NarutoField* f, const NarutoParams* p, const Naru
     // (the smoothness term is left to the backward: the single-process deferred tail, or the data-parallel SUMS_TV_LATER form)
     const bool deferred_ = (finalize == NARUTO_TRAIN_FWD_DEFER_TAIL || finalize == NARUTO_TRAIN_FWD_SUMS_TV_LATER) && tail_rides_in_backward(t);
     WalkExtra wx{};
+    note_tv_left(t->workspace, finalize == NARUTO_TRAIN_FWD_SUMS_TV_LATER && tv_moved(f, t, deferred_));
     if (tv_moved(f, t, deferred_)) {
         wx.on = 1u;
         wx.tv_groups = tv_tail_groups();
@@ -1348,6 +1367,9 @@ int naruto_train_backward(const NarutoField* f, const NarutoParams* p, const Nar
     const bool moved = (flags & (NARUTO_TRAIN_BWD_DEFERRED_TAIL | NARUTO_TRAIN_BWD_TV_MOVED)) != 0u && deferred && tv_moved(f, t, true);
     if ((flags & NARUTO_TRAIN_BWD_TV_MOVED) != 0u && !sums_given && !table_only)
         return fail(NARUTO_ERR_INVALID, "train_backward: NARUTO_TRAIN_BWD_TV_MOVED belongs to NARUTO_TRAIN_BWD_SUMS_GIVEN (a forward with NARUTO_TRAIN_FWD_SUMS_TV_LATER)");
+    if (sums_given && !table_only && (flags & NARUTO_TRAIN_BWD_TV_MOVED) == 0u && tv_was_left(t_in->workspace))
+        return fail(NARUTO_ERR_INVALID, "train_backward: the forward on this workspace ran with NARUTO_TRAIN_FWD_SUMS_TV_LATER (it left the smoothness term to the "
+                                        "backward): pass NARUTO_TRAIN_BWD_TV_MOVED with NARUTO_TRAIN_BWD_SUMS_GIVEN, or the term is dropped");
     if (deferred) {
         const bool smooth_d = t->smooth_points != 0 && (g->table != nullptr || opt != nullptr);
         const BwdWs bwd = bwd_ws(f, w.bwd, list_cap(M + w.n3));

@@ -507,7 +507,13 @@ class MappingTrainer:
                     self.model.note_min_uncert(self.model.min_uncert_running())
                     self.model.check_asserts()
                 return st['ret'][0], st['loss'][0]
-            which = 2 if (first and len(self._graphs) > 2 and not uncert_step) else (1 if uncert_step else 0)      # (2: capture(first_prologue=...))
+            if first and uncert_step and len(self._graphs) > 2:
+                # (advisor, round 5) the graph with the FIRST iteration's prologue has no uncertainty-step twin: replaying graph 1 here would train on
+                # whatever the previous call's last launch prefetched.  The reference never asks for it (global_BA steps the grid after iterations
+                # 5, 10, ...: coslam.py:397-399), so it is an error rather than a fourth captured graph.
+                raise RuntimeError("MappingTrainer.step(first=True, uncert_step=True): no graph was captured for a call's first iteration with an "
+                                   "uncertainty-grid step; the first iteration of a global_BA call is never one")
+            which = 2 if (first and len(self._graphs) > 2) else (1 if uncert_step else 0)      # (2: capture(first_prologue=...))
             self._graphs[which].replay()
             ret = st['ret'][which]
             # the reference's in-line ``assert uncert_map.min() > 0`` (scene_rep.py:280) as a deferred check: every replay folds its

@@ -18,7 +18,7 @@ for m in fp32 bf16; do timeout 600 python bench.py --workload office0_8192x43_ev
 for w in office0_2048x43 office0_8192x43 mp3d_2048x256 unit1024_131072x43; do
   timeout 600 python bench.py --workload $w --no-cpu-baseline --no-mapping-iter --steps 20 > gpurun_out/${TAG}_bench_$w.json 2> /dev/null; cut -c1-160 gpurun_out/${TAG}_bench_$w.json; echo
 done
-for m in fp32 bf16; do timeout 900 python bench.py --workload unit1024_T22_131072x43 --mlp $m --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${TAG}_bench_T22_$m.json 2> /dev/null; cut -c1-160 gpurun_out/${TAG}_bench_T22_$m.json; echo; done
+for m in fp32 bf16; do timeout 900 python bench.py --workload unit1024_T22_131072x43 --mlp $m --steps 60 --warmup 60 --no-cpu-baseline > gpurun_out/${TAG}_bench_T22_$m.json 2> /dev/null; cut -c1-160 gpurun_out/${TAG}_bench_T22_$m.json; echo; done
 timeout 600 python tools/bf16_error_study.py > gpurun_out/${TAG}_bf16_error_study.txt 2>&1
 bash tools/profile_round.sh $TAG office0_2048x128 30 > gpurun_out/${TAG}_prof_default.log 2>&1; tail -12 gpurun_out/${TAG}_prof_default.log
 bash tools/profile_round.sh $TAG unit1024_T22_131072x43 8 > gpurun_out/${TAG}_prof_T22.log 2>&1; tail -10 gpurun_out/${TAG}_prof_T22.log

@@ -433,6 +433,10 @@ typedef struct NarutoTrainStep {
                                                          index); the counter advances once per forward.        */
     const float *loss_weights;                        /* [10] device: d(total)/d(losses[i]); slots 4,6,7,9 ignored */
     float *z_vals, *raw, *feat_save;                  /* [N,S] [N,S,5] [16][N*S][2]                           */
+                                                      /* feat_save is PRIVATE to the forward / backward pair of one step: level-major as
+                                                       * written above, or sample-major [N*S][16][2] where the forward runs in Morton
+                                                       * order of the samples (tables > 64 MB, batches >= 4 M samples; round 6).  Same
+                                                       * size either way; naruto_train_backward knows which from the same launch plan.  */
     float *rgb, *depth, *uncert_map;                  /* [N,3] [N] [N] (any may be NULL)                      */
     double *sums;                                     /* [NARUTO_LOSS_NSUMS]                                  */
     float *losses;                                    /* [10]                                                 */

@@ -7,7 +7,7 @@
 // repeat inside an L2 window.  The packed forward (k_query_fwd_loss_packed, round 4) wins by NOT evaluating what no consumer can see; this
 // form does both:
 //
-//   k_sort_count   one thread per sample: needed whatever the network says?  (z <= measured depth + 2 truncations; every sample of a ray
+//   k_sort_count   one thread per sample: needed whatever the network says?  (z <= measured depth + truncation; every sample of a ray
 //                  without a depth) -> its cell (18-bit Morton code of the position, 64 cells per axis), one count per cell; the raw
 //                  rows of everything else are written as zeros
 //   k_sort_sum / k_sort_scan    exclusive prefix of the 262 144 cell counts
@@ -18,7 +18,7 @@
 //                  saved features addressed by SAMPLE: feat_save is sample-major here ([M][16][2]: one 128-byte row per sample, written
 //                  whole), which k_query_bwd reads through its row multiplier
 //   k_sort_more    one thread per ray: first sign change among what was evaluated -> the ray's band end, exactly as the walk / packed
-//                  forward find it; samples inside the band that were not needed a priori (first sign change behind depth + 2 truncations,
+//                  forward find it; samples inside the band that were not needed a priori (first sign change behind depth + truncation,
 //                  or none) go to a second list
 //   k_query_fwd_list   again, over the second list (empty once the network has learnt its depths)
 //

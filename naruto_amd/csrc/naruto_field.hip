@@ -812,7 +812,9 @@ __device__ __forceinline__ void stage_fwd_weights_x3_via_lds(FwdLdsX3& L, float*
 }
 // the matrix phase of a tile (fwd_mlp_tile's counterpart): hash part of the B operands from the slab
 // HALF (round 6): the tile's B points (32..63) are dead -- only the A chains run; the B lanes' outputs are unspecified (the caller writes zeros)
-template <bool COLOR, bool HALF = false>
+// LANE_BLOB (round 6): OneBlob's form (closed / dense: 1e-6 apart) chosen per LANE instead of per tile -- a sample's outputs then depend on the sample alone,
+// whatever tile it shares: the Morton-ordered forward, whose tiles are composed by atomics, stays bitwise reproducible
+template <bool COLOR, bool HALF = false, bool LANE_BLOB = false>
 __device__ __forceinline__ void fwd_mlp_tile_x3(const FwdLdsX3& L, const FwdSlab& sl, float x, float y, float z, float* __restrict__ geo, uint32_t M, uint32_t mA, uint32_t mB,
                                                 int lane, FwdTileOut& out) {
     const int hh = lane >> 5;
@@ -826,7 +828,8 @@ __device__ __forceinline__ void fwd_mlp_tile_x3(const FwdLdsX3& L, const FwdSlab
         hA = mfma16x3(w, pack8x3(fa), hA);
         if constexpr (!HALF) hB = mfma16x3(w, pack8x3(fb), hB);
     }
-    const bool blob_fast = __all(oneblob_sparse_ok(x) && oneblob_sparse_ok(y) && oneblob_sparse_ok(z));
+    const bool lane_ok = oneblob_sparse_ok(x) && oneblob_sparse_ok(y) && oneblob_sparse_ok(z);
+    const bool blob_fast = LANE_BLOB ? lane_ok : (bool)__all(lane_ok);
     static_for<0, 3>([&](auto dc) {
         constexpr int D = decltype(dc)::value;
         float e[kBins];
@@ -1061,11 +1064,12 @@ __device__ __forceinline__ u32x4_t pack8_acc(const f32x16& a, int r0) {
 }
 
 // the rest of a bf16 tile once the hash part of sdf layer 0 sits in hA / hB: OneBlob K blocks, sdf layer 1, the colour net
-template <bool COLOR>
+template <bool COLOR, bool LANE_BLOB = false>
 __device__ __forceinline__ void fwd_tail_bf(const FwdLdsBf& L, f32x16& hA, f32x16& hB, f32x16& cA, f32x16& cB, float x, float y, float z, float* __restrict__ geo, uint32_t M,
                                             uint32_t mA, uint32_t mB, int lane, FwdTileOut& out) {
     const int hh = lane >> 5;
-        const bool blob_fast = __all(oneblob_sparse_ok(x) && oneblob_sparse_ok(y) && oneblob_sparse_ok(z));
+        const bool lane_ok = oneblob_sparse_ok(x) && oneblob_sparse_ok(y) && oneblob_sparse_ok(z);
+        const bool blob_fast = LANE_BLOB ? lane_ok : (bool)__all(lane_ok);
         static_for<0, 3>([&](auto dc) {
             constexpr int D = decltype(dc)::value;
             float e[kBins];
@@ -1181,7 +1185,7 @@ __device__ __forceinline__ void fwd_tile_bf(const FwdLdsBf& L, const LevelTab& l
 }
 
 // the bf16 mode's matrix phase: the two hash K blocks from the slab, then the tail
-template <bool COLOR>
+template <bool COLOR, bool LANE_BLOB = false>
 __device__ __forceinline__ void fwd_mlp_tile_bf(const FwdLdsBf& L, const FwdSlab& sl, float x, float y, float z, float* __restrict__ geo, uint32_t M, uint32_t mA, uint32_t mB,
                                                 int lane, FwdTileOut& out) {
     f32x16 hA = zero16(), hB = zero16(), cA = zero16(), cB = zero16();
@@ -1194,7 +1198,7 @@ __device__ __forceinline__ void fwd_mlp_tile_bf(const FwdLdsBf& L, const FwdSlab
         hA = mfma16(w, pack8(fa), hA);
         hB = mfma16(w, pack8(fb), hB);
     }
-    fwd_tail_bf<COLOR>(L, hA, hB, cA, cB, x, y, z, geo, M, mA, mB, lane, out);
+    fwd_tail_bf<COLOR, LANE_BLOB>(L, hA, hB, cA, cB, x, y, z, geo, M, mA, mB, lane, out);
 }
 // phase-split form of a FULL bf16 tile (see fwd_tile_split): the same gather phase, then the two hash K blocks from the slab
 template <bool COLOR, bool MASK>

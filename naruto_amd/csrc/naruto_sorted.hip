@@ -188,8 +188,9 @@ __global__ __launch_bounds__(512, 1) void k_query_fwd_list(LevelTab lt, UncertTa
                 if ((uint32_t)pt < n_here) feat_save[(size_t)mp * 32u + (uint32_t)fl] = v;
             }
         }
-        if constexpr (BF) fwd_mlp_tile_bf<true>(L, slabs[wave], x, y, z, nullptr, 0u, 0u, 0u, lane, to);
-        else if constexpr (kExactX3) fwd_mlp_tile_x3<true>(L, slabs[wave], x, y, z, nullptr, 0u, 0u, 0u, lane, to);
+        // (OneBlob's form per LANE: the tiles here are composed by the counting sort's atomics, and a sample's bits must not depend on its neighbours)
+        if constexpr (BF) fwd_mlp_tile_bf<true, true>(L, slabs[wave], x, y, z, nullptr, 0u, 0u, 0u, lane, to);
+        else if constexpr (kExactX3) fwd_mlp_tile_x3<true, false, true>(L, slabs[wave], x, y, z, nullptr, 0u, 0u, 0u, lane, to);
         else fwd_mlp_tile<true>(L, slabs[wave], x, y, z, nullptr, 0u, 0u, 0u, lane, to);
         if (valid) {
             float* __restrict__ o = raw + (size_t)m * 5;

@@ -1003,7 +1003,7 @@ int launch_train_query(const NarutoField* f, const NarutoParams* p, const Naruto
         sa.cells = sa.n_list + 320; sa.list = sa.cells + Mp; sa.list2 = sa.list + Mp; sa.pts = reinterpret_cast<float4*>(sa.list2 + Mp);
         hipLaunchKernelGGL(k_sort_zero, dim3(2u * kSortCells / 4u / 256u), dim3(256), 0, st, reinterpret_cast<uint4*>(sa.count), 2u * kSortCells / 4u);
         const bool bfm = f->desc.mlp_mode == NARUTO_MLP_BF16;
-        const uint32_t mblocks = (M + 255u) / 256u;
+        const uint32_t mblocks = (M + 256u * kSortPer - 1u) / (256u * kSortPer);
         hipLaunchKernelGGL(k_sort_count, dim3(mblocks), dim3(256), 0, st, sa, ps, f->bt, t->raw);
         hipLaunchKernelGGL(k_sort_sum, dim3(256), dim3(256), 0, st, sa, sa.n_list + 8);          // (the totals: 256 words behind the two list lengths)
         hipLaunchKernelGGL(k_sort_scan, dim3(256), dim3(256), 0, st, sa, sa.n_list + 8);

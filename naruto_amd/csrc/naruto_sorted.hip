@@ -32,6 +32,7 @@ namespace naruto {
 constexpr uint32_t kSortBits = 6;                                  // per axis
 constexpr uint32_t kSortCells = 1u << (3u * kSortBits);            // 262 144
 constexpr uint32_t kSortNone = 0xFFFFFFFFu;
+constexpr uint32_t kSortPer = 8;                                   // 256-sample pieces per workgroup of k_sort_count / k_sort_fill
 
 __device__ __forceinline__ uint32_t spread3_6(uint32_t v) {        // 6 bits -> every third bit
     v &= 0x3Fu;
@@ -71,23 +72,46 @@ __global__ __launch_bounds__(256) void k_sort_zero(uint4* __restrict__ p, uint32
     if (i < n4) p[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
+// Runs of consecutive lanes with the same cell (neighbouring samples of a ray are 1 / 43 apart, a cell is 1 / 64 wide: every other lane continues its
+// predecessor's cell) share ONE atomic: the run's first lane adds the run's length.  -> this lane's rank inside its run, the run's length (valid in its first
+// lane), whether this lane leads a run.  Lanes with cell == kSortNone form runs too; the caller skips them.
+__device__ __forceinline__ void cell_runs(uint32_t cell, int lane, uint32_t& rank, uint32_t& len, bool& leads) {
+    const uint32_t prev = (uint32_t)__shfl_up((int)cell, 1, 64);
+    leads = lane == 0 || prev != cell;
+    const unsigned long long heads = __ballot(leads);
+    const unsigned long long below = heads & ((2ull << lane) - 1ull);                  // heads at or below this lane (lane 63: the shift wraps to all ones)
+    const int head = 63 - __builtin_clzll(below);
+    const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1)) << (lane + 1);
+    const int next = above != 0ull ? __builtin_ctzll(above) : 64;
+    rank = (uint32_t)(lane - head);
+    len = (uint32_t)(next - head);
+}
+
 __global__ __launch_bounds__(256) void k_sort_count(SortArgs a, PointSrc ps, BoxTab bt, float* __restrict__ raw) {
-    const uint32_t m = blockIdx.x * 256u + threadIdx.x;
-    if (m >= a.M) return;
+    // (kSortPer consecutive 256-sample pieces per workgroup: at one sample per thread the launch is 22 016 tiny workgroups and bound by their dispatch)
+#pragma unroll 1
+    for (uint32_t piece = 0; piece < kSortPer; ++piece) {
+    const uint32_t m_raw = (blockIdx.x * kSortPer + piece) * 256u + threadIdx.x;
+    const bool in = m_raw < a.M;
+    const uint32_t m = in ? m_raw : a.M - 1u;                  // (whole waves stay: the run detection shuffles)
     const uint32_t n = m / a.S;
     const float zv = ps.z_vals[m];
-    const bool listed = sort_apriori(a.target_d[n], zv, a.trunc_sc);
+    const bool listed = in && sort_apriori(a.target_d[n], zv, a.trunc_sc);
     uint32_t cell = kSortNone;
     if (listed) {
         float x, y, z;
         load_point(ps, bt, m, x, y, z);
         cell = morton_cell(x, y, z);
-        atomicAdd(a.count + cell, 1u);
-    } else {
+    } else if (in) {
         float* __restrict__ o = raw + (size_t)m * 5;
         o[0] = 0.0f; o[1] = 0.0f; o[2] = 0.0f; o[3] = 0.0f; o[4] = 0.0f;
     }
-    a.cells[m] = cell;
+    uint32_t rank, len;
+    bool leads;
+    cell_runs(cell, (int)(threadIdx.x & 63u), rank, len, leads);
+    if (leads && cell != kSortNone) atomicAdd(a.count + cell, len);
+    if (in) a.cells[m] = cell;
+    }
 }
 
 // exclusive prefix of the cell counts in two launches of 256 workgroups (1 024 cells each, coalesced): the workgroups' totals, then every workgroup adds up
@@ -125,17 +149,29 @@ __global__ __launch_bounds__(256) void k_sort_scan(SortArgs a, const uint32_t* _
 }
 
 __global__ __launch_bounds__(256) void k_sort_fill(SortArgs a, PointSrc ps, BoxTab bt) {
-    const uint32_t m = blockIdx.x * 256u + threadIdx.x;
-    if (m >= a.M) return;
-    const uint32_t cell = a.cells[m];
-    if (cell == kSortNone) return;
-    const uint32_t pos = a.base[cell] + atomicAdd(a.cursor + cell, 1u);
+#pragma unroll 1
+    for (uint32_t piece = 0; piece < kSortPer; ++piece) {
+    const uint32_t m_raw = (blockIdx.x * kSortPer + piece) * 256u + threadIdx.x;
+    const bool in = m_raw < a.M;
+    const uint32_t m = in ? m_raw : a.M - 1u;
+    const uint32_t cell = in ? a.cells[m] : kSortNone;
+    // one returning atomic per run of equal cells (cell_runs): the run's first lane reserves the run's places, the others take theirs by rank
+    const int lane = (int)(threadIdx.x & 63u);
+    uint32_t rank, len;
+    bool leads;
+    cell_runs(cell, lane, rank, len, leads);
+    uint32_t first = 0u;
+    if (leads && cell != kSortNone) first = a.base[cell] + atomicAdd(a.cursor + cell, len);
+    first = (uint32_t)__shfl((int)first, lane - (int)rank, 64);
+    if (cell == kSortNone) continue;
+    const uint32_t pos = first + rank;
     a.list[pos] = m;
     // the sample's normalised position rides along (one 16-byte entry in list order): the query reads it coalesced instead of fetching the ray and the
     // depth of 64 unrelated samples per tile
     float x, y, z;
     load_point(ps, bt, m, x, y, z);
     a.pts[pos] = make_float4(x, y, z, __uint_as_float(m));
+    }
 }
 
 // The flat field query over a list of sample indices (n_dev entries): persistent eight-wave workgroups, the two-phase tile of k_query_fwd.

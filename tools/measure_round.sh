@@ -21,7 +21,7 @@ done
 for m in fp32 bf16; do timeout 900 python bench.py --workload unit1024_T22_131072x43 --mlp $m --steps 60 --warmup 60 --no-cpu-baseline > gpurun_out/${TAG}_bench_T22_$m.json 2> /dev/null; cut -c1-160 gpurun_out/${TAG}_bench_T22_$m.json; echo; done
 timeout 600 python tools/bf16_error_study.py > gpurun_out/${TAG}_bf16_error_study.txt 2>&1
 bash tools/profile_round.sh $TAG office0_2048x128 30 > gpurun_out/${TAG}_prof_default.log 2>&1; tail -12 gpurun_out/${TAG}_prof_default.log
-bash tools/profile_round.sh $TAG unit1024_T22_131072x43 8 > gpurun_out/${TAG}_prof_T22.log 2>&1; tail -10 gpurun_out/${TAG}_prof_T22.log
+PMC_WARMUP=100 bash tools/profile_round.sh $TAG unit1024_T22_131072x43 8 > gpurun_out/${TAG}_prof_T22.log 2>&1; tail -10 gpurun_out/${TAG}_prof_T22.log
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace -d $R/gpurun_out/${TAG}_ktbf -o kt -- python $R/bench.py --mlp bf16 --no-cpu-baseline --steps 30 > /dev/null 2> $R/gpurun_out/${TAG}_ktbf.log
 python $R/tools/prof_summary.py $(find $R/gpurun_out/${TAG}_ktbf -name "*.db" | head -1) > $R/gpurun_out/${TAG}_office0_2048x128_bf16_kernel_trace.txt; rm -rf $R/gpurun_out/${TAG}_ktbf

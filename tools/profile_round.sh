@@ -17,7 +17,7 @@ timeout 900 rocprofv3 --kernel-trace -d ${P}_kt -o kt -- python $R/bench.py --wo
 python $R/tools/prof_summary.py $(find ${P}_kt -name "*.db" | head -1) > ${P}_kernel_trace.txt
 rm -rf ${P}_kt
 for c in FETCH_SIZE WRITE_SIZE TCC_REQ_sum; do
-  timeout 900 rocprofv3 --kernel-trace --pmc $c -d ${P}_pmc_$c -o pmc -- python $R/bench.py --workload $W --no-graph --no-cpu-baseline --no-dropin --no-mapping-iter --steps 6 --warmup 2 > /dev/null 2> ${P}_pmc_$c.log
+  timeout 900 rocprofv3 --kernel-trace --pmc $c -d ${P}_pmc_$c -o pmc -- python $R/bench.py --workload $W --no-graph --no-cpu-baseline --no-dropin --no-mapping-iter --steps 6 --warmup ${PMC_WARMUP:-2} > /dev/null 2> ${P}_pmc_$c.log
   python $R/tools/prof_summary.py $(find ${P}_pmc_$c -name "*.db" | head -1) > ${P}_pmc_$c.txt
   rm -rf ${P}_pmc_$c
 done
